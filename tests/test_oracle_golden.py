@@ -1,0 +1,123 @@
+"""Pin the CPU oracle against golden vectors produced by the real reference
+(tools/make_goldens.py, run in the build container against /root/reference)."""
+import numpy as np
+import pytest
+import torch
+
+from musicfpaugment_amd import synth
+from musicfpaugment_amd.training.weights import formula_state_dict
+from oracle import audfprint as oa
+from oracle import dejavu as od
+from oracle import metrics as om
+from oracle import stft as ostft
+from oracle import unet as ou
+
+
+def unpack(bits, shape):
+    n = int(np.prod(shape))
+    return np.unpackbits(bits)[:n].reshape(shape).astype(bool)
+
+
+def test_g1_spectrogram(golden):
+    g = golden("g1_spectrogram")
+    wav = synth.batch(2, seed=int(g["seed"]), n=int(g["n"]))
+    assert synth.digest(wav) == str(g["wav_digest"]), "synthetic generator drifted"
+    spec = ostft.spectrogram(wav)
+    assert spec.dtype == np.float64 and spec.shape == g["spectrogram"].shape
+    np.testing.assert_allclose(spec, g["spectrogram"], rtol=0, atol=1e-13)
+    cplx = ostft.stft_audfprint(wav[0])
+    np.testing.assert_allclose(cplx, g["stft0"], rtol=0, atol=1e-11)
+    assert ostft.n_frames(64000) == 251 and ostft.n_frames(8000) == 32
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_g3_find_peaks_full_clips(golden, i):
+    g = golden("g3_audfprint_peaks")
+    d = synth.clip(int(g["seeds"][i]), tonal=bool(g["tonal"][i]))
+    assert synth.digest(d) == str(g[f"wav_digest{i}"])
+    assert oa.a_dec() == float(g[f"a_dec{i}"]) == 0.9951323690285719
+    sg = ostft.magnitude(d)
+    sg = sg / sg.max()
+    filt = oa.preprocess(sg)
+    np.testing.assert_allclose(filt[::8, ::8], g[f"filt_sub{i}"], rtol=0, atol=1e-9)
+    table = oa.gauss_table(256, oa.F_SD)
+    fwd = oa.fwd_prune(filt, oa.a_dec(), table)
+    assert np.array_equal(fwd.astype(bool), unpack(g[f"fwdmask{i}"], (256, 251)))
+    pklist, mask, spec = oa.find_peaks(d)
+    assert mask.dtype == np.float32 and mask.shape == (256, 251)
+    assert np.array_equal(mask.astype(bool), unpack(g[f"mask{i}"], (256, 251)))
+    assert np.array_equal(np.array(pklist, dtype=np.int32).reshape(-1, 2), g[f"pklist{i}"])
+    np.testing.assert_allclose(spec[::8, ::8], g[f"spec_sub{i}"], rtol=0, atol=1e-13)
+
+
+def test_g3_strict_known_answer(golden):
+    """Filtered log-spectrogram shipped in full: the pruner must reproduce the reference mask exactly."""
+    g = golden("g3_audfprint_peaks")
+    filt = g["short_filtered"]
+    mask = oa.peaks_from_filtered(filt)
+    assert np.array_equal(mask.astype(bool), unpack(g["short_mask"], filt.shape))
+    assert np.array_equal(np.array(oa.pklist_from_mask(mask), dtype=np.int32).reshape(-1, 2), g["short_pklist"])
+    # and the pre-processing chain is bit-identical on this machine image
+    assert np.array_equal(oa.preprocess(g["short_sgram"]), filt)
+
+
+def test_g3_empty_input():
+    pk, m = oa.find_peaks(np.zeros(0, dtype=np.float32))
+    assert pk == [] and m.size == 0
+
+
+def test_g3b_float32_unet_path(golden):
+    g = golden("g3b_audfprint_peaks_unet")
+    spec = g["spec"]
+    assert spec.dtype == np.float32
+    pklist, mask, spec_out = oa.find_peaks_from_sgram(spec)
+    assert np.array_equal(mask.astype(bool), unpack(g["mask"], tuple(g["mask_shape"])))
+    assert np.array_equal(np.array(pklist, dtype=np.int32).reshape(-1, 2), g["pklist"])
+    assert spec_out.dtype == np.float32
+
+
+def test_g4_dejavu(golden):
+    g = golden("g4_dejavu_peaks")
+    coords, mask = od.get_2d_peaks(g["arr"], amp_min=50)
+    assert np.array_equal(np.array(coords, dtype=np.int32).reshape(-1, 2), g["coords"])
+    assert mask.dtype == np.float64 and np.array_equal(mask.astype(np.uint8), g["mask"])
+    coords0, mask0 = od.get_2d_peaks(np.zeros((30, 30)), amp_min=-1)
+    assert np.array_equal(np.array(coords0, dtype=np.int32).reshape(-1, 2), g["zeros_coords"])
+    assert np.array_equal(mask0.astype(np.uint8), g["zeros_mask"])
+    d = synth.clip(int(g["full_seed"]))
+    assert synth.digest(d) == str(g["full_wav_digest"])
+    coords_f, mask_f, spec_f = od.fingerprint_peaks(d.astype(np.float64) * 32767.0)
+    assert mask_f.shape == tuple(g["full_shape"]) == (257, 249)
+    assert np.array_equal(np.array(coords_f, dtype=np.int32).reshape(-1, 2), g["full_coords"])
+    np.testing.assert_allclose(spec_f[::8, ::8], g["full_spec_sub"], rtol=1e-12, atol=0)
+
+
+def test_g5_metrics(golden):
+    g = golden("g5_metrics")
+    pred, gt, prf = g["pred"].astype(np.float32), g["gt"].astype(np.float32), g["prf"]
+    for k in range(3):
+        got = [om.precision(pred[k:k + 1], gt[k:k + 1]), om.recall(pred[k:k + 1], gt[k:k + 1]),
+               om.f1score(pred[k:k + 1], gt[k:k + 1])]
+        assert got == list(prf[k])
+    got = [om.precision(pred, gt), om.recall(pred, gt), om.f1score(pred, gt)]
+    assert got == list(prf[3])
+    c = om.counts(pred, gt)
+    assert c[:, 0].sum() / c[:, 1].sum() == prf[3][0] and c[:, 2].sum() / c[:, 3].sum() == prf[3][1]
+    assert list(prf[2]) == [0.0, 0.0, 0.0]
+
+
+def test_g6_unet_forward(golden):
+    g = golden("g6_unet_forward")
+    sd = formula_state_dict(int(g["weight_seed"]))
+    with torch.no_grad():
+        y = ou.forward(torch.from_numpy(g["x"]), sd)
+    assert ou.relative_l1(y, torch.from_numpy(g["y"])) < 1e-5
+    wav8 = synth.batch(1, seed=int(g["seed8"]))
+    assert synth.digest(wav8) == str(g["x8_digest"])
+    x8 = torch.from_numpy(ostft.spectrogram(wav8)).float().unsqueeze(1)
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        y8 = ou.forward(x8, sd)
+    sub = torch.from_numpy(g["y8_sub"])
+    assert ou.relative_l1(y8[0, 0, ::4, ::4], sub) < 1e-5
+    assert abs(float(y8.double().abs().sum()) - float(g["y8_abs_sum"])) < 1e-5 * float(g["y8_abs_sum"])

@@ -1,0 +1,72 @@
+"""The oracle restates third-party arithmetic the reference calls on this path
+(scipy lfilter / maximum_filter / binary_erosion, numpy pairwise mean,
+matplotlib mlab.specgram).  Cross-check the restatements against the libraries."""
+import numpy as np
+import pytest
+
+from oracle import audfprint as oa
+from oracle import dejavu as od
+from oracle import stft as ostft
+
+
+def test_highpass_is_scipy_lfilter_bit_exact():
+    scipy_signal = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(37, 251)) * 5
+    want = np.array([scipy_signal.lfilter([1, -1], [1, -(0.98 ** 1)], r) for r in x])
+    assert np.array_equal(oa.highpass(x), want)
+    x32 = x.astype(np.float32)
+    want32 = np.array([scipy_signal.lfilter([1, -1], [1, -(0.98 ** 1)], r) for r in x32])
+    assert want32.dtype == np.float64 and np.array_equal(oa.highpass(x32), want32)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [5, 8, 127, 128, 129, 1000, 8192, 8193, 257 * 32, 20000, 257 * 251])
+def test_numpy_sum_restatement(dtype, n):
+    rng = np.random.default_rng(n)
+    a = rng.normal(size=n).astype(dtype)
+    assert oa.numpy_sum(a) == np.add.reduce(a)
+    if n <= 8192:
+        assert oa.pairwise_sum(a) == np.add.reduce(a)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_mean_follows_memory_order(dtype):
+    rng = np.random.default_rng(3)
+    c = rng.normal(size=(257, 251)).astype(dtype)          # C order: bin-major (UNet output layout)
+    f = np.asfortranarray(c)                               # F order: frame-major (stft(...).transpose() layout)
+    assert np.mean(c) == oa.numpy_mean(c) and np.mean(f) == oa.numpy_mean(f)
+    assert oa.numpy_mean(f) == oa.numpy_mean(np.ascontiguousarray(c.T))
+    # the layouts the reference produces: |stft| keeps the transposed layout through abs / divide / maximum / log
+    from oracle import stft as ostft_
+    m = ostft_.magnitude(rng.normal(size=4000).astype(np.float32))
+    lg = np.log(np.maximum(m / m.max(), 1e-6))
+    assert lg.flags["F_CONTIGUOUS"] and not lg.flags["C_CONTIGUOUS"]
+
+
+def test_max_filter_and_erosion_match_scipy():
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(1)
+    for shape in [(64, 48), (257, 249), (21, 9), (5, 40)]:
+        a = np.round(rng.normal(size=shape) * 4)          # many exact ties
+        a[rng.random(shape) < 0.3] = 0.0
+        fp = np.ones((21, 21), dtype=bool)
+        assert np.array_equal(od.maximum_filter_square(a, 10), ndi.maximum_filter(a, footprint=fp))
+        assert np.array_equal(od.erode_square(a == 0, 10), ndi.binary_erosion(a == 0, structure=fp, border_value=1))
+
+
+def test_specgram_matches_mlab():
+    mlab = pytest.importorskip("matplotlib.mlab")
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=8000) * 32767
+    want = mlab.specgram(x, NFFT=512, Fs=8000, window=mlab.window_hanning, noverlap=256)[0]
+    got = ostft.specgram_psd(x)
+    assert got.shape == want.shape == (257, 30)
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+def test_locmax_edges():
+    v = np.array([3.0, 3.0, 1.0, 2.0, 2.0, 5.0])
+    # ties: a plateau's LAST cell is the peak (>= on the left, strict on the right)
+    assert oa.locmax(v).tolist() == [False, True, False, False, False, True]
+    assert oa.locmax(np.array([1.0])).tolist() == [True]

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (deezer/musicFPaugment).
+
+Build-container only: needs /root/reference (read-only) and is never run on the
+GPU box.  The reference is imported unmodified with import-time stubs for the
+packages it imports but this path never calls (librosa, torchaudio, julius,
+nnAudio, torchmetrics, GPUtil/tensorflow via training.utils) and with
+``torch.load`` patched during import so the module-level checkpoint loads in
+afp/audfprint/peak_extractor.py:24-37 and afp/dejavu/fingerprint.py:27-31 get a
+formula state_dict instead of the unpublished checkpoint.  Nothing of the
+reference is copied: only numeric inputs/outputs are written.
+
+Usage:  python tools/make_goldens.py            (writes tests/golden/)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from musicfpaugment_amd import synth  # noqa: E402
+from musicfpaugment_amd.training.weights import formula_state_dict  # noqa: E402
+
+
+def import_reference():
+    import torch
+
+    sys.path.insert(0, REF)
+    sys.path.insert(1, os.path.join(REF, "afp"))
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    stub("librosa")
+    stub("librosa.display")
+    sys.modules["librosa"].display = sys.modules["librosa.display"]
+
+    class _Resample:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+
+    ta = stub("torchaudio")
+    ta.transforms = stub("torchaudio.transforms", Resample=_Resample)
+    stub("julius")
+    stub("nnAudio")
+    stub("nnAudio.features")
+
+    class _PSNR:
+        def __init__(self, **k):
+            pass
+
+    stub("torchmetrics", PeakSignalNoiseRatio=_PSNR)
+    import training  # noqa: F401  (reference namespace package)
+
+    stub("training.utils", set_gpus=lambda *a, **k: "cpu")
+    from training.model import Demucs
+    from training.unet import UNet
+
+    unet_sd = formula_state_dict(0)
+    demucs_sd = Demucs().state_dict()
+    orig = torch.load
+    torch.load = lambda path, *a, **k: {"model_state_dict": unet_sd if "unet" in path else demucs_sd}
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            import afp.audfprint.peak_extractor as pe
+            import dejavu.fingerprint as fp
+    finally:
+        torch.load = orig
+    import testing.metrics as tm
+    from testing.parameters import afp_settings
+    from training.visualisation import spectrogram
+
+    return dict(pe=pe, fp=fp, tm=tm, spectrogram=spectrogram, UNet=UNet, afp_settings=afp_settings)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    import scipy.signal
+    import torch
+
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    pe, fp, tm = ref["pe"], ref["fp"], ref["tm"]
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    versions = np.array([f"torch {torch.__version__}", f"numpy {np.__version__}",
+                         f"scipy {__import__('scipy').__version__}",
+                         f"matplotlib {__import__('matplotlib').__version__}"])
+
+    # ---- G1 / G2: spectrogram() and audfprint stft on two 1-second clips -------------------
+    wav = synth.batch(2, seed=1000, n=8000, tonal=True)
+    spec = ref["spectrogram"](torch.from_numpy(wav)).numpy()
+    assert spec.dtype == np.float64 and spec.shape == (2, 257, 32)
+    win = np.hanning(514)[1:-1]
+    import afp.audfprint.stft as rstft
+
+    cplx = rstft.stft(wav[0], n_fft=512, hop_length=256, window=win)
+    save("g1_spectrogram", seed=1000, n=8000, wav_digest=synth.digest(wav), spectrogram=spec,
+         stft0=cplx, versions=versions)
+
+    # ---- G3: find_peaks without denoising on full 8-second clips ---------------------------
+    analyzer = pe.Audfprint_peaks(ref["afp_settings"]["audfprint"])
+    seeds = [59, 60, 2059]
+    tonal = [True, True, False]
+    g3 = {}
+    for i, (s, t) in enumerate(zip(seeds, tonal)):
+        d = synth.clip(s, tonal=t)
+        pklist, mask, spec_i = analyzer.find_peaks(d)
+        # intermediate stages with the reference's own calls (peak_extractor.py:259-301)
+        sg = np.abs(rstft.stft(d, n_fft=512, hop_length=256, window=win))
+        sg /= np.max(sg)
+        lg = np.log(np.maximum(sg, np.max(sg) / 1e6))
+        lg = lg - np.mean(lg)
+        filt = np.array([scipy.signal.lfilter([1, -1], [1, -(0.98 ** 1)], r) for r in lg])[:-1, ]
+        adec = 1 - 0.01 * (analyzer.density * np.sqrt(analyzer.n_hop / 352.8) / 35)
+        fwd = analyzer._decaying_threshold_fwd_prune(filt, adec)
+        g3[f"pklist{i}"] = np.array(pklist, dtype=np.int32).reshape(-1, 2)
+        g3[f"mask{i}"] = np.packbits(mask.astype(bool))
+        g3[f"fwdmask{i}"] = np.packbits(fwd.astype(bool))
+        g3[f"spec_sub{i}"] = spec_i[::8, ::8].copy()
+        g3[f"filt_sub{i}"] = filt[::8, ::8].copy()
+        g3[f"wav_digest{i}"] = synth.digest(d)
+        g3[f"a_dec{i}"] = adec
+        print(f"  clip seed {s} tonal {t}: {len(pklist)} peaks (fwd {int(fwd.sum())})")
+    # a short clip whose filtered log-spectrogram ships in full (strict-entry known answer)
+    d = synth.clip(77, n=8000)
+    pklist, mask, _ = analyzer.find_peaks(d)
+    sg = np.abs(rstft.stft(d, n_fft=512, hop_length=256, window=win))
+    sg /= np.max(sg)
+    lg = np.log(np.maximum(sg, np.max(sg) / 1e6))
+    lg = lg - np.mean(lg)
+    filt = np.array([scipy.signal.lfilter([1, -1], [1, -(0.98 ** 1)], r) for r in lg])[:-1, ]
+    g3.update(short_sgram=sg, short_filtered=filt, short_pklist=np.array(pklist, dtype=np.int32).reshape(-1, 2),
+              short_mask=np.packbits(mask.astype(bool)), short_seed=77)
+    e_pk, e_mask = analyzer.find_peaks(np.zeros(0, dtype=np.float32))
+    assert e_pk == [] and e_mask.size == 0
+    save("g3_audfprint_peaks", seeds=np.array(seeds), tonal=np.array(tonal), mask_shape=np.array([256, 251]),
+         versions=versions, **g3)
+
+    # ---- G3b: find_peaks WITH the UNet (float32 spectrogram path) on a 1-second clip ------
+    analyzer_dn = pe.Audfprint_peaks(ref["afp_settings"]["audfprint"], denoising=True, denoising_model="unet")
+    d = synth.clip(4242, n=8000)
+    pklist, mask, spec_dn = analyzer_dn.find_peaks(d)
+    assert spec_dn.dtype == np.float32
+    save("g3b_audfprint_peaks_unet", seed=4242, n=8000, wav_digest=synth.digest(d), unet_seed=0,
+         spec=spec_dn, pklist=np.array(pklist, dtype=np.int32).reshape(-1, 2),
+         mask=np.packbits(mask.astype(bool)), mask_shape=np.array(mask.shape), versions=versions)
+
+    # ---- G4: get_2D_peaks ---------------------------------------------------------------------
+    rng = np.random.default_rng(4)
+    a = rng.normal(0.0, 30.0, size=(64, 48))
+    a[5:9, 7:12] = 80.0                      # plateau: every cell of it ties with the max
+    a[0, 0] = 120.0                          # corner peak
+    a[63, 20] = 95.0                         # border peak
+    a[30, 47] = 90.0
+    a[40:64, 24:48] = 0.0                    # exact-zero background (erosion term)
+    a[50, 36] = 70.0
+    coords, mask = fp.get_2D_peaks(a.copy(), plot=False, amp_min=50)
+    b = np.zeros((30, 30))                   # all-zero array: eroded background cancels local maxima
+    coords_b, mask_b = fp.get_2D_peaks(b.copy(), plot=False, amp_min=-1)
+    d = synth.clip(61, tonal=True)
+    _, mask_full, specgram_full = fp.fingerprint((d.astype(np.float64) * 32767.0), get_masks=True)
+    f_idx, t_idx = np.nonzero(mask_full)
+    save("g4_dejavu_peaks", arr=a, coords=np.array(coords, dtype=np.int32).reshape(-1, 2), mask=mask.astype(np.uint8),
+         zeros_coords=np.array(coords_b, dtype=np.int32).reshape(-1, 2), zeros_mask=mask_b.astype(np.uint8),
+         full_seed=61, full_wav_digest=synth.digest(d), full_shape=np.array(mask_full.shape),
+         full_coords=np.stack([f_idx, t_idx], axis=1).astype(np.int32), full_spec_sub=specgram_full[::8, ::8].copy(),
+         versions=versions)
+    print(f"  dejavu: {len(coords)} peaks on the 64x48 case, {len(f_idx)} on the full clip")
+
+    # ---- G5: Precision / Recall / F1 -----------------------------------------------------------
+    rng = np.random.default_rng(5)
+    pred = (rng.random((3, 40, 30)) < 0.06).astype(np.float32)
+    gt = (rng.random((3, 40, 30)) < 0.06).astype(np.float32)
+    gt[0] = np.where(rng.random((40, 30)) < 0.5, pred[0], gt[0])
+    for m in (pred, gt):
+        m[0, 0, 0] = 1
+        m[0, 0, 7] = 1
+        m[0, 9, 0] = 1
+        m[0, 39, 29] = 1
+        m[0, 39, 3] = 1
+        m[0, 12, 29] = 1
+    pred[0, 1, 1] = 1
+    gt[0, 1, 8] = 1
+    pred[2] = 0                               # empty prediction -> precision 0, recall 0
+    res = []
+    for k in range(3):
+        p_, g_ = torch.from_numpy(pred[k:k + 1]), torch.from_numpy(gt[k:k + 1])
+        res.append([tm.Precision()(p_, g_), tm.Recall()(p_, g_), tm.F1score()(p_, g_)])
+    p_, g_ = torch.from_numpy(pred), torch.from_numpy(gt)
+    res.append([tm.Precision()(p_, g_), tm.Recall()(p_, g_), tm.F1score()(p_, g_)])
+    save("g5_metrics", pred=pred.astype(np.uint8), gt=gt.astype(np.uint8), prf=np.array(res, dtype=np.float64),
+         versions=versions)
+
+    # ---- G6: UNet eval forward with formula weights -------------------------------------------
+    net = ref["UNet"](1, 1, rate=0.05)
+    net.load_state_dict(formula_state_dict(0))
+    net.eval()
+    wav = synth.batch(2, seed=300, n=8000)
+    x = ref["spectrogram"](torch.from_numpy(wav)).float().unsqueeze(1)       # (2,1,257,32)
+    with torch.no_grad():
+        y = net(x)
+    wav8 = synth.batch(1, seed=301)
+    x8 = ref["spectrogram"](torch.from_numpy(wav8)).float().unsqueeze(1)      # (1,1,257,251)
+    with torch.no_grad():
+        y8 = net(x8)
+    save("g6_unet_forward", weight_seed=0, x=x.numpy(), y=y.numpy(), seed8=301, x8_digest=synth.digest(wav8),
+         y8_sub=y8.numpy()[0, 0, ::4, ::4].copy(), y8_abs_sum=float(y8.double().abs().sum()),
+         y8_sum=float(y8.double().sum()), versions=versions)
+
+    # ---- G7: one UNet training step (train.py:257-317, spec branch), dropout 0 ---------------
+    net = ref["UNet"](1, 1, rate=0.0)
+    net.load_state_dict(formula_state_dict(1))
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    clean = synth.batch(2, seed=500, n=8000)
+    aug = (0.7 * clean + 0.3 * synth.batch(2, seed=600, n=8000, tonal=False)).astype(np.float32)
+    clean_spec = ref["spectrogram"](torch.from_numpy(clean))
+    aug_spec = ref["spectrogram"](torch.from_numpy(aug))
+    pred = net(aug_spec.unsqueeze(1).float()).squeeze(1)
+    loss = torch.nn.L1Loss()(pred, clean_spec)
+    opt.zero_grad()
+    loss.backward()
+    names = [n for n, _ in net.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) for _, p in net.named_parameters()])
+    ghead = np.stack([p.grad.flatten()[:4].double().numpy() for _, p in net.named_parameters()
+                      if p.numel() >= 4])
+    opt.step()
+    whead = np.stack([p.detach().flatten()[:4].double().numpy() for _, p in net.named_parameters() if p.numel() >= 4])
+    sd = net.state_dict()
+    rm = np.concatenate([sd[k].numpy()[:4] for k in sd if k.endswith("running_mean")])
+    rv = np.concatenate([sd[k].numpy()[:4] for k in sd if k.endswith("running_var")])
+    save("g7_unet_train_step", weight_seed=1, clean_seed=500, noise_seed=600, n=8000, loss=float(loss),
+         loss_dtype=str(loss.dtype), names=np.array(names), grad_norm=gnorm, grad_head=ghead, weight_head=whead,
+         running_mean_head=rm, running_var_head=rv, pred_sub=pred.detach().numpy()[:, ::4, ::4].copy(),
+         versions=versions)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
