@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the musicFPaugment hot path on MI355X.
+
+Metric (BASELINE.json): 8 s / 8 kHz clips per second through STFT + UNet + peak-pick.
+One "step" = one pass of the whole chain (fused STFT-magnitude -> UNet eval forward on fp32 MFMA
+-> Audfprint log/high-pass + forward/backward pruning) over a batch of synthetic clips that is
+already resident in HBM.  N GPUs = N processes, each with its own batch (weak scaling; clips are
+independent, no data-path collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the MFMA implicit-GEMM
+convolutions of the UNet): algorithmic FLOPs / HIP-event time of those launches inside the timed
+region.  `cpu_baseline` times the CPU oracle (the numpy/torch-CPU restatement of the reference)
+on a bounded sample of the same workload on this box's host cores (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+CLIP_SAMPLES = 64000
+
+
+def cpu_baseline(n_clips: int, seed: int):
+    """The oracle chain (reference algorithms on the CPU) on `n_clips` clips: clips/s on the host cores."""
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.training.weights import formula_state_dict
+    from oracle import audfprint as oa
+    from oracle import stft as ostft
+    from oracle import unet as ou
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = formula_state_dict(0)
+    wav = synth.batch(n_clips, seed=seed)
+
+    def one(w):
+        sg = ostft.magnitude(w)
+        sg = sg / sg.max()
+        with torch.no_grad():
+            den = ou.forward(torch.from_numpy(sg).float()[None, None], sd)[0, 0].numpy()
+        return oa.find_peaks_from_sgram(den)[1]
+
+    one(wav[0])                                   # warm-up (thread pools, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    for w in wav:
+        one(w)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_clips / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n_clips} synthetic 8 s clips, per clip like the reference: numpy STFT -> torch-CPU fp32 UNet "
+                      f"forward (batch 1) -> log/high-pass + fwd/bwd prune; {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--cpu-clips", type=int, default=12, help="clips of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+
+    from musicfpaugment_amd import ops_unet, synth
+    from musicfpaugment_amd.pipeline import UNET_MFMA_GFLOP_PER_CLIP, HotPath
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict
+
+    B = args.clips
+    net = None
+    if not args.no_unet:
+        net = UNet(1, 1, rate=0.05)
+        net.load_state_dict(formula_state_dict(0))
+        net = net.to(dev).eval()
+    hot = HotPath(net, device=dev)
+
+    # synthetic clips of SURVEY.md §8d: 32 distinct generated clips per rank, tiled to B with a sign/gain variation
+    base = synth.batch(min(B, 32), seed=synth.BASE_SEED + 1000 * rank)
+    reps = (B + len(base) - 1) // len(base)
+    gains = (1.0 - 0.5 * np.arange(reps) / max(reps, 1)).astype(np.float32)
+    wav = np.concatenate([base * g for g in gains])[:B]
+    wav = torch.from_numpy(np.ascontiguousarray(wav)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mask, npeaks = hot(wav)
+    barrier()
+    timer = ops_unet.KernelTimer()
+    ops_unet.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mask, npeaks = hot(wav)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops_unet.set_timer(None)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    total_peaks = int(npeaks.sum().item())
+
+    if rank == 0:
+        clips = world * B * args.steps
+        out = {
+            "metric": "8s/8kHz clips/sec (STFT+UNet+peak-pick)" if net is not None else "8s/8kHz clips/sec (STFT+peak-pick, no UNet)",
+            "value": round(clips / dt_max, 3),
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "STFT(512/256,f64) -> UNet(1,1) eval forward (fp32 MFMA, formula weights) -> "
+                                   "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms",
+                       "clips_per_gpu_per_step": B, "peaks_last_step_rank0": total_peaks,
+                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
+        }
+        if net is not None and timer.launches():
+            conv_ms = timer.total_ms()
+            flops = UNET_MFMA_GFLOP_PER_CLIP * 1e9 * B * args.steps
+            achieved = flops / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "conv_mfma_kernel (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                               "launches": timer.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+        if world == 1 and args.cpu_clips > 0 and net is not None:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_clips, synth.BASE_SEED)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

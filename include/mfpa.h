@@ -1,0 +1,185 @@
+/*
+ * mfpa.h -- C ABI of libmfpa.so, the MI355X (gfx950) implementation of the
+ * musicFPaugment hot path:
+ *
+ *   waveform -> STFT magnitude -> [UNet denoiser] -> spectral-peak picking -> peak-mask metrics
+ *
+ * The reference (deezer/musicFPaugment) is pure Python and has no FFI of its own;
+ * each entry point below names the reference function (file:line under the
+ * reference tree) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add at those call sites.
+ *
+ * Conventions
+ *  - every function returns 0 on success, MFPA_EINVAL for a shape/argument error,
+ *    or MFPA_EHIP - hipError_t for a HIP runtime failure; nothing aborts or throws;
+ *  - all pointers are DEVICE pointers owned by the caller (e.g. torch allocations),
+ *    all arrays dense row-major; the library allocates nothing;
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream) with no host synchronisation, so calls can be captured in a hipGraph;
+ *  - functions are re-entrant; one process drives one GPU (multi-GPU = one process
+ *    per GPU, sharding clips across ranks).
+ */
+#ifndef MFPA_H
+#define MFPA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFPA_OK 0
+#define MFPA_EINVAL (-22)
+#define MFPA_EHIP (-1000) /* result is MFPA_EHIP - hipError_t */
+
+#define MFPA_F32 0
+#define MFPA_F64 1
+
+#define MFPA_N_FFT 512
+#define MFPA_N_HOP 256
+#define MFPA_N_BINS 257
+
+/* ABI version: bumps when a signature changes. */
+int mfpa_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * STFT tables (HOST function, no GPU work): fills out[MFPA_STFT_TABLE_LEN] doubles on the host
+ * from a 512-point window -- [0,512) the window, then the FFT twiddles.  The caller uploads the
+ * array once and passes the device pointer as `tables` below (the window is an argument of the
+ * reference's stft too, afp/audfprint/stft.py:15-19; the library itself keeps no state).
+ */
+#define MFPA_STFT_TABLE_LEN 1288
+int mfpa_stft_tables(const double* window512, double* out);
+
+/* STFT magnitude.  Replaces torch.stft + abs in training/visualisation.py:20-28 and
+ * np.abs(stft.stft(...)) in afp/audfprint/peak_extractor.py:259-261 (afp/audfprint/stft.py:15-62).
+ *   wav      (B, T_w) float32, T_w > 256
+ *   tables   device copy of mfpa_stft_tables(np.hanning(514)[1:-1]) for both reference call sites
+ *   mag      (B, 257, n_frames) float32 or float64 (out_dtype), n_frames = 1 + T_w / 256;
+ *            centre / reflect padding, one-sided, unnormalised, computed in float64
+ *   clip_max (B) float64, may be NULL: max float64 magnitude of each clip
+ */
+int mfpa_stft_mag(const float* wav, int B, int T_w, const double* tables,
+                  void* mag, int out_dtype, double* clip_max, void* stream);
+
+/* Number of STFT frames for T_w samples (1 + T_w / 256). */
+int mfpa_stft_frames(int T_w);
+
+/* mlab.specgram power spectrogram, afp/dejavu/fingerprint.py:60-66: no padding, frames at
+ * multiples of 256 while a full frame fits ((T_w - 256) / 256 frames), one-sided PSD with bins
+ * 1..255 doubled; samples are multiplied by scale_in first (dejavu.py:109 feeds x * 32767).
+ * The common factor 1/(Fs*sum(w^2)) is NOT applied: the reference divides by the maximum
+ * immediately (fingerprint.py:68).
+ *   tables   device copy of mfpa_stft_tables(np.hanning(512))
+ *   psd (B, 257, n_frames) float64, clip_max (B) float64 may be NULL. */
+int mfpa_specgram_psd(const float* wav, int B, int T_w, double scale_in, const double* tables,
+                      double* psd, double* clip_max, void* stream);
+int mfpa_specgram_frames(int T_w);
+
+/* In-place division by a maximum.  per_clip = 0: one max over the whole batch
+ * (torch.max(specgram), training/visualisation.py:29); per_clip = 1: each clip by its own
+ * (sgram /= np.max(sgram), peak_extractor.py:263; arr2D /= arr2D.max(), fingerprint.py:68).
+ *   data (B, n) dtype, clip_max (B) float64 as produced by mfpa_stft_mag. */
+int mfpa_normalize(void* data, int dtype, int B, long long n, const double* clip_max,
+                   int per_clip, void* stream);
+
+/* data (B, n) float64 -> out (B, n) float32 (the `.float()` of training/train.py:272). */
+int mfpa_f64_to_f32(const double* in, float* out, long long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Audfprint peak picker = everything of Audfprint_peaks.find_peaks after the optional UNet,
+ * afp/audfprint/peak_extractor.py:271-311.
+ *
+ * Stage 1, mfpa_audfprint_prepare: log(max(s, max/1e6)) - mean, per-bin 1-pole high-pass
+ * (scipy lfilter([1,-1],[1,-0.98])), Nyquist bin dropped  (peak_extractor.py:272-290).
+ *   spec       (B, F, T) float32 or float64 (dtype), F = bins + 1 (257)
+ *   denom      (B) float64 or NULL: if given, s = spec / denom[b] first (fuses the
+ *              per-clip normalisation of peak_extractor.py:263)
+ *   mean_order 0: numpy sums the spectrogram bin-major (C order: the UNet output),
+ *              1: frame-major (the un-denoised |stft| array, which is a transposed view)
+ *              -- the pairwise summation tree of np.mean is reproduced in that order
+ *   log_input  1: `spec` already holds log(max(s, max/1e6)) computed by the caller
+ *              (strict mode: everything downstream is IEEE add/mul/compare -> bit-exact)
+ *   filtered   (B, T, F-1) float64, FRAME-major workspace consumed by mfpa_audfprint_prune
+ *   scratch    (B, F*T) float64 workspace
+ */
+int mfpa_audfprint_prepare(const void* spec, int dtype, int B, int F, int T, const double* denom,
+                           int mean_order, int log_input, double pole,
+                           double* filtered, double* scratch, void* stream);
+
+/* Stage 2, mfpa_audfprint_prune: forward decaying-threshold pass then backward pruning
+ * (_decaying_threshold_fwd_prune / _bwd_prune_peaks, peak_extractor.py:173-234).
+ *   filtered (B, T, R) float64 frame-major, R = 256 bins (R % 4 == 0, R <= 256)
+ *   gauss    (2R+1) float64: exp(-0.5*((j-R)/f_sd)^2), the table of peak_extractor.py:163-165
+ *   a_dec    threshold decay per frame (peak_extractor.py:295)
+ *   maxpks   peaks kept per frame (<= 8; reference 5)
+ *   mask     (B, R, T) uint8 in {0,1} -- peaks_mask of find_peaks, bin-major like the reference
+ *   npeaks   (B) int32
+ */
+int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const double* gauss,
+                         double a_dec, int maxpks, uint8_t* mask, int32_t* npeaks, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dejavu picker.  mfpa_dejavu_prepare: arr = scale*ln(max(a, max/1e6)) - mean with
+ * a = psd / denom (fingerprint.py:68,78-79; scale = 10; mean_order as for mfpa_audfprint_prepare:
+ * mlab.specgram hands back a frame-major array, so the reference sums with mean_order = 1).  mfpa_localmax2d: get_2D_peaks,
+ * afp/dejavu/fingerprint.py:94-171: (2r+1)^2 maximum filter with scipy 'reflect' borders,
+ * equality test, XOR with the eroded exact-zero background (border_value 1), amp > amp_min.
+ *   arr  (B, F, T) float64;  mask (B, F, T) uint8;  npeaks (B) int32
+ */
+int mfpa_dejavu_prepare(const double* psd, int B, int F, int T, const double* denom, double scale,
+                        int mean_order, double* arr, void* stream);
+int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double amp_min,
+                    uint8_t* mask, int32_t* npeaks, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Peak-mask metrics, testing/metrics.py:10-192.  For 0/1 masks (B, N1, N2), N1,N2 >= 2:
+ *   counts (B, 4) int64 = [hits_precision, n_predicted, hits_recall, n_ground_truth] per clip,
+ * where a peak (i, j) of one mask is looked up in the other at (i + [i==0], j + [j==0])
+ * (the reference's low-border quirk).  Precision = sum hits_p / sum n_p, etc.
+ */
+int mfpa_peak_metrics(const uint8_t* predicted, const uint8_t* gt, int B, int N1, int N2,
+                      int64_t* counts, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * UNet denoiser building blocks, training/unet.py:8-108.  Activations are NHWC float32
+ * ("pixels x channels": H = frequency bins, W = frames); with C = 1 at both ends of the
+ * network this is byte-identical to the reference's NCHW (B,1,257,T) tensors.
+ */
+
+/* 3x3 convolution, padding 1, no bias, fused per-channel affine (folded eval BatchNorm) + ReLU
+ * (DoubleConv halves, unet.py:16-21).  The input may be the channel-concatenation of two
+ * tensors [x0 | x1] where x1 has its own extent (H1, W1) <= (H, W) and is zero-padded at the
+ * bottom/right (Up.forward, unet.py:56-63); pass x1 = NULL, C1 = 0 for a plain conv.
+ *   x0 (B,H,W,C0)  x1 (B,H1,W1,C1)  w (9, Cout, C0+C1): [tap = ky*3+kx][Cout][Cin]  scale/shift (Cout)
+ *   y  (B,H,W,Cout);  relu: 0/1;  scale/shift may be NULL (identity).
+ * C0, C1 multiples of 32; Cout a multiple of 64.  precision: 0 = float32 MFMA (exact fp32 products). */
+int mfpa_conv3x3_bn_relu(const float* x0, int C0, const float* x1, int C1, int H1, int W1,
+                         int B, int H, int W, const float* w, int Cout,
+                         const float* scale, const float* shift, int relu, int precision,
+                         float* y, void* stream);
+
+/* First layer: 3x3 conv from ONE input channel (inc.double_conv.0, unet.py:86) fused with the
+ * spectrogram normalisation: x = (float)(spec / denom) when spec64 != NULL, else x32 as is.
+ *   w (9, Cout), y (B,H,W,Cout). */
+int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip,
+                            int B, int H, int W, const float* w, int Cout,
+                            const float* scale, const float* shift, float* y, void* stream);
+
+/* MaxPool2d(2), floor (unet.py:34).  x (B,H,W,C) -> y (B,H/2,W/2,C). */
+int mfpa_maxpool2(const float* x, int B, int H, int W, int C, float* y, void* stream);
+
+/* ConvTranspose2d(k=2, s=2) + bias (unet.py:51-53).  x (B,H,W,Cin), w (4, Cout, Cin): [tap = dy*2+dx][Cout][Cin],
+ * y (B,2H,2W,Cout). */
+int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
+                  int Cout, int precision, float* y, void* stream);
+
+/* OutConv 1x1 + bias to ONE class (unet.py:68-74).  x (B*H*W, C), w (C), y (B*H*W). */
+int mfpa_conv1x1_out(const float* x, long long npix, int C, const float* w, float bias, float* y,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFPA_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libmfpa.so (the C ABI declared in include/mfpa.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this
+module raises.  torch is imported first so that the HIP runtime already mapped by
+PyTorch-ROCm (SONAME libamdhip64.so.7) is the one libmfpa.so binds to -- kernels
+are then enqueued on torch's current stream and operate on torch allocations.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_longlong, c_void_p
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfpa.so")
+
+EINVAL = -22
+EHIP = -1000
+F32, F64 = 0, 1
+STFT_TABLE_LEN = 1288
+ABI_VERSION = 1
+
+
+class MfpaError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "mfpa_version": ([], c_int),
+    "mfpa_stft_tables": ([c_void_p, c_void_p], c_int),
+    "mfpa_stft_frames": ([c_int], c_int),
+    "mfpa_specgram_frames": ([c_int], c_int),
+    "mfpa_stft_mag": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_specgram_psd": ([c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_normalize": ([c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p], c_int),
+    "mfpa_f64_to_f32": ([c_void_p, c_void_p, c_longlong, c_void_p], c_int),
+    "mfpa_audfprint_prepare": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_double,
+                                c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_audfprint_prune": ([c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p,
+                              c_void_p], c_int),
+    "mfpa_dejavu_prepare": ([c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_localmax2d": ([c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_peak_metrics": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_conv3x3_bn_relu": ([c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                              c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_conv3x3_c1_bn_relu": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_maxpool2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_convT2x2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                       c_void_p], c_int),
+    "mfpa_conv1x1_out": ([c_void_p, c_longlong, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/mfpa.h declares (used by the CPU-side ABI test)."""
+    return sorted(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfpaError(
+                f"{LIB_PATH} is missing: build it with `python -m musicfpaugment_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise MfpaError(f"libmfpa.so does not export {name}; rebuild it") from e
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if handle.mfpa_version() != ABI_VERSION:
+            raise MfpaError(f"libmfpa.so ABI {handle.mfpa_version()} != expected {ABI_VERSION}; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == EINVAL:
+        raise ValueError(f"{what}: invalid argument (MFPA_EINVAL)")
+    if rc <= EHIP:
+        raise MfpaError(f"{what}: HIP error {EHIP - rc}")
+    raise MfpaError(f"{what}: error {rc}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous CUDA(HIP) tensor, or 0 for None."""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise MfpaError("libmfpa operates on GPU tensors only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise MfpaError("libmfpa needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t, name="input"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise MfpaError(f"{name} must be a tensor on the MI355X (got {type(t).__name__}"
+                        f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); no CPU fallback")

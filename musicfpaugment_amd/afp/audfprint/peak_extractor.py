@@ -1,0 +1,77 @@
+"""Audfprint peak extraction on MI355X -- mirror of afp/audfprint/peak_extractor.py:76-311.
+
+``Audfprint_peaks(params, denoising, denoising_model)`` keeps the reference's constructor and
+``find_peaks(d) -> (pklist, peaks_mask, spec)`` contract (empty input -> ``([], np.array([]))``,
+peak_extractor.py:253-254).  Unlike the reference, importing this module loads no checkpoint and
+needs no NVIDIA GPU: the denoiser is passed in (``unet=``).  ``find_peaks_batch`` is the batched,
+sync-free form the benchmark uses; ``find_peaks`` wraps it for one clip.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...constants import afp_settings
+
+
+class Audfprint_peaks(object):
+    def __init__(self, params: Optional[Dict[str, Any]] = None, denoising: bool = False, denoising_model=None,
+                 unet=None, device="cuda") -> None:
+        params = afp_settings["audfprint"] if params is None else params
+        self.density = params["density"]
+        self.target_sr = params["samplerate"]
+        self.n_fft = params["n_fft"]
+        self.n_hop = params["n_hop"]
+        self.shifts = params["shifts"]
+        self.f_sd = params["freq-sd"]
+        self.maxpksperframe = params["pks-per-frame"]
+        self.maxpairsperpeak = 3
+        self.mindt = 2
+        self.targetdt = 63
+        self.targetdf = 31
+        self.denoising = denoising
+        self.denoising_model = denoising_model
+        self.device = torch.device(device)
+        if self.n_fft != 512 or self.n_hop != 256:
+            raise NotImplementedError("the HIP STFT is built for n_fft 512 / hop 256 (testing/parameters.py:24-25)")
+        if self.denoising:
+            assert self.denoising_model in ["demucs", "unet"]
+            if self.denoising_model == "demucs":
+                raise NotImplementedError("Demucs waveform denoising is a next-tier row (SURVEY.md §8f-2)")
+            if unet is None:
+                raise ValueError("denoising=True needs the UNet instance (unet=...): this module loads no checkpoint")
+            self.unet = unet.to(self.device).eval()
+        else:
+            self.unet = None
+
+    # ------------------------------------------------------------------ batched device path
+    def find_peaks_batch(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(B, T) float32 on the GPU -> (mask (B,256,nF) uint8, npeaks (B,) int32, spec (B,257,nF)).
+
+        STFT -> per-clip /max -> [UNet] -> log/mean/high-pass -> forward + backward pruning; no host sync.
+        spec is float64 without denoising and float32 with it, like the reference's third return value.
+        """
+        mag, cmax = ops.stft_mag(wav, torch.float64)
+        a_dec = ops.audfprint_a_dec(self.density, self.n_hop)
+        if self.unet is not None:
+            spec = self.unet.denoise_spectrogram(mag, cmax, per_clip=True)        # float32 (B,257,nF)
+            filtered = ops.audfprint_prepare(spec, None, mean_order=0)            # C-contiguous in the reference
+        else:
+            spec = ops.normalize_(mag, cmax, per_clip=True)
+            filtered = ops.audfprint_prepare(spec, None, mean_order=1)            # |stft| is a transposed view there
+        mask, npeaks = ops.audfprint_prune(filtered, a_dec, self.maxpksperframe, float(self.f_sd))
+        return mask, npeaks, spec
+
+    # ------------------------------------------------------------------ reference call surface
+    def find_peaks(self, d) -> Tuple[List[Tuple[int, int]], np.ndarray, np.ndarray]:
+        if len(d) == 0:
+            return [], np.array([])
+        x = torch.as_tensor(np.asarray(d) if not isinstance(d, torch.Tensor) else d).to(self.device, torch.float32)
+        mask, _, spec = self.find_peaks_batch(x.reshape(1, -1))
+        m = mask[0]
+        cols, bins = torch.nonzero(m.t(), as_tuple=True)                          # column-major ascending (:305-309)
+        pklist = list(zip(cols.tolist(), bins.tolist()))
+        return pklist, m.to(torch.float32).cpu().numpy(), spec[0].cpu().numpy()

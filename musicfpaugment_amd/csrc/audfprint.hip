@@ -1,0 +1,348 @@
+// Audfprint spectral-peak picker for MI355X (gfx950): everything of Audfprint_peaks.find_peaks
+// after the optional UNet (afp/audfprint/peak_extractor.py:271-311 of the reference).
+//
+// Compiled with -ffp-contract=off: every float64 value that takes part in a comparison is
+// produced by the same un-fused IEEE add / multiply sequence numpy and scipy execute, so for a
+// given log-spectrogram the peak set is bit-identical to the reference's by construction.
+//
+//   prepare : log(max(s, max/1e6)) - mean   (np.mean's pairwise-summation tree reproduced
+//             in the array's memory order), scipy lfilter([1,-1],[1,-0.98]) per bin, output
+//             written FRAME-major so the pruner reads whole spectrum columns coalesced.
+//   prune   : forward decaying-threshold pass + backward pruning.  The scan over frames is
+//             inherently sequential (each column's threshold depends on every earlier peak), so
+//             one 64-lane wavefront owns a clip: 4 bins per lane, threshold in registers,
+//             per-frame top-k by wavefront arg-max (value desc, bin desc), columns prefetched
+//             4 frames ahead.  Latency-bound by design; parallelism comes from clips.
+#include "mfpa_common.h"
+#include "mfpa_npsum.h"
+
+namespace {
+
+using namespace mfpa_np;
+constexpr int PREP_THREADS = 512;
+constexpr int TT = 16;  // frames per transpose tile
+
+// TIn: dtype of the spectrogram (and of the log / mean arithmetic, as numpy keeps it).
+template <typename TIn>
+__global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __restrict__ spec, int F, int T,
+                                                               const double* __restrict__ denom, int mean_order,
+                                                               int log_input, double pole,
+                                                               double* __restrict__ filtered,
+                                                               double* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = F - 1;
+  double* tile_in = reinterpret_cast<double*>(smem);   // [R][TT+1]
+  double* tile_out = tile_in + R * (TT + 1);           // [TT][R]
+  TIn* heap = reinterpret_cast<TIn*>(tile_out + TT * R);  // [chunks][HEAP]
+  __shared__ double red[PREP_THREADS / 64];
+  __shared__ double bcast[2];
+
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = F * T;
+  const TIn* x = spec + (size_t)b * N;
+  double* L = scratch + (size_t)b * N;
+  const bool has_den = denom != nullptr;
+  const double den = has_den ? denom[b] : 1.0;
+
+  bool do_log = false;
+  TIn floor_v = 0;
+  if (!log_input) {
+    // pass A: max of the (normalised) spectrogram
+    TIn m = -INFINITY;
+    for (int i = tid; i < N; i += PREP_THREADS) {
+      TIn s = has_den ? (TIn)((double)x[i] / den) : x[i];
+      m = s > m ? s : m;
+    }
+    double md = mfpa_wave_max((double)m);
+    if ((tid & 63) == 0) red[tid >> 6] = md;
+    __syncthreads();
+    if (tid == 0) {
+      double mm = red[0];
+      for (int w = 1; w < PREP_THREADS / 64; ++w) mm = fmax(mm, red[w]);
+      bcast[0] = mm;
+    }
+    __syncthreads();
+    const TIn smax = (TIn)bcast[0];
+    do_log = smax > (TIn)0;                  // peak_extractor.py:274
+    floor_v = smax / (TIn)1e6;               // np.max(sgram) / 1e6 in the array's dtype
+  }
+  // pass B: log values (kept in the spectrogram's dtype, stored widened) in the input's bin-major layout
+  for (int i = tid; i < N; i += PREP_THREADS) {
+    TIn s = has_den ? (TIn)((double)x[i] / den) : x[i];
+    if (do_log) {
+      s = s > floor_v ? s : floor_v;
+      s = (TIn)log((double)s);
+    }
+    L[i] = (double)s;
+  }
+  __syncthreads();
+
+  TIn mean = 0;
+  if (do_log || log_input) {
+    // numpy mean: chunked pairwise sum in the array's memory order, one divide in the array's dtype
+    const TIn total = block_numpy_sum<TIn>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
+    mean = (TIn)(total / (TIn)N);
+  }
+
+  // pass C: x - mean, then y[n] = x[n] + z; z = -x[n] - (-pole) * y[n]  (scipy lfilter, DF-II transposed)
+  double z = 0.0;
+  const double npole = -pole;
+  double* outp = filtered + (size_t)b * T * R;
+  for (int t0 = 0; t0 < T; t0 += TT) {
+    const int nt = min(TT, T - t0);
+    for (int e = tid; e < R * TT; e += PREP_THREADS) {
+      const int r = e / TT, tt = e % TT;
+      if (tt < nt) tile_in[r * (TT + 1) + tt] = L[(size_t)r * T + t0 + tt];
+    }
+    __syncthreads();
+    if (tid < R) {
+      for (int tt = 0; tt < nt; ++tt) {
+        const TIn lv = (TIn)tile_in[tid * (TT + 1) + tt];
+        const double xn = (double)(TIn)(lv - mean);
+        const double yn = xn + z;
+        z = -xn - npole * yn;
+        tile_out[tt * R + tid] = yn;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < R * nt; e += PREP_THREADS) outp[(size_t)t0 * R + e] = tile_out[e];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- prune
+constexpr int MAXP = 8;
+
+struct Best {
+  double v;
+  int p;
+};
+
+// lexicographic max on (value, bin); p < 0 means "none"
+__device__ __forceinline__ Best best_of(Best a, Best b) {
+  const bool take_b = (a.p < 0) || (b.p >= 0 && (b.v > a.v || (b.v == a.v && b.p > a.p)));
+  return take_b ? b : a;
+}
+
+__device__ __forceinline__ Best wave_best(Best x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best y{__shfl_xor(x.v, o), __shfl_xor(x.p, o)};
+    x = best_of(x, y);
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ filtered, int R, int T,
+                                                   const double* __restrict__ gauss, double a_dec, int maxpks,
+                                                   uint8_t* __restrict__ mask, int32_t* __restrict__ npeaks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* G = reinterpret_cast<double*>(smem);               // [2R+1]
+  double* lv = G + (2 * R + 2);                              // [T][MAXP] peak values
+  short* lb = reinterpret_cast<short*>(lv + (size_t)T * MAXP);  // [T][MAXP] peak bins (-1 = pruned)
+  short* ln = lb + (size_t)T * MAXP;                         // [T] peaks recorded per frame
+
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const double* S = filtered + (size_t)b * T * R;
+  const int k0 = 4 * lane;
+  const bool own = k0 < R;  // R % 4 == 0: a lane owns 4 bins or none
+
+  for (int i = lane; i < 2 * R + 1; i += 64) G[i] = gauss[i];
+  for (int i = lane; i < T; i += 64) ln[i] = 0;
+  __syncthreads();
+
+  auto load_col = [&](int c, double (&v)[4]) {
+    if (own && c < T) {
+      const double2 a = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0);
+      const double2 d = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0 + 2);
+      v[0] = a.x; v[1] = a.y; v[2] = d.x; v[3] = d.y;
+    } else {
+      v[0] = v[1] = v[2] = v[3] = 0.0;
+    }
+  };
+  // locmax flags of a column held 4 bins per lane (peak_extractor.py:61-73)
+  auto locmax4 = [&](const double (&v)[4], bool (&pk)[4]) {
+    const double left = __shfl_up(v[3], 1);     // bin k0-1
+    const double right = __shfl_down(v[0], 1);  // bin k0+4
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = k0 + s;
+      const double lft = (s == 0) ? left : v[s - 1];
+      const double rgt = (s == 3) ? right : v[s + 1];
+      const bool ge_prev = (k == 0) || (v[s] >= lft);
+      const bool nxt_ge = (k < R - 1) && (rgt >= v[s]);
+      pk[s] = own && ge_prev && !nxt_ge;
+    }
+  };
+  double th[4];
+  // th[k] = max(th[k], val * G[k - p + R]) for this lane's bins
+  auto raise = [&](double val, int p) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (own) {
+        const double g = val * G[R - p + k0 + s];
+        th[s] = g > th[s] ? g : th[s];
+      }
+    }
+  };
+  // spreadpeaksinvector(vec, f_sd): zeros raised by every local maximum of vec
+  auto spread_init = [&](const double (&v)[4]) {
+    bool pk[4];
+    locmax4(v, pk);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) th[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      unsigned long long m = __ballot(pk[s]);
+      while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const double val = __shfl(v[s], src);
+        raise(val, 4 * src + s);
+      }
+    }
+  };
+
+  // ---- forward pass (peak_extractor.py:173-204)
+  {
+    double v10[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int n10 = T < 10 ? T : 10;
+    for (int c = 0; c < n10; ++c) {
+      double v[4];
+      load_col(c, v);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v10[s] = v[s] > v10[s] ? v[s] : v10[s];
+    }
+    spread_init(v10);
+  }
+  double cur[4][4], nxt[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_col(q, cur[q]);
+  for (int c0 = 0; c0 < T; c0 += 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_col(c0 + 4 + q, nxt[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q;
+      if (c < T) {
+        bool cand[4];
+        locmax4(cur[q], cand);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cand[s] = cand[s] && (cur[q][s] > th[s]);  // against the pre-update threshold
+        int cnt = 0;
+        while (cnt < maxpks) {
+          Best mine{0.0, -1};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            if (cand[s]) mine = best_of(mine, Best{cur[q][s], k0 + s});
+          if (__ballot(mine.p >= 0) == 0ull) break;
+          const Best w = wave_best(mine);
+          raise(w.v, w.p);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            if (k0 + s == w.p) cand[s] = false;
+          if (lane == 0) {
+            lv[(size_t)c * MAXP + cnt] = w.v;
+            lb[(size_t)c * MAXP + cnt] = (short)w.p;
+          }
+          ++cnt;
+        }
+        if (lane == 0) ln[c] = (short)cnt;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) th[s] = th[s] * a_dec;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) cur[q][s] = nxt[q][s];
+  }
+  __syncthreads();
+
+  // ---- backward pass (peak_extractor.py:206-234)
+  {
+    double v[4];
+    load_col(T - 1, v);
+    spread_init(v);
+  }
+  for (int c = T - 1; c >= 0; --c) {
+    const int n = ln[c];
+    for (int i = 0; i < n; ++i) {
+      const double val = lv[(size_t)c * MAXP + i];
+      const int p = lb[(size_t)c * MAXP + i];
+      const int s_sel = p & 3;
+      const double mine = s_sel == 0 ? th[0] : (s_sel == 1 ? th[1] : (s_sel == 2 ? th[2] : th[3]));
+      const double thp = __shfl(mine, p >> 2);
+      if (val >= thp) {
+        raise(val, p);
+        if (c + 1 < T) {  // delete any following peak in the same bin
+          if (lane < ln[c + 1] && lb[(size_t)(c + 1) * MAXP + lane] == (short)p) lb[(size_t)(c + 1) * MAXP + lane] = -1;
+        }
+      } else if (lane == 0) {
+        lb[(size_t)c * MAXP + i] = -1;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) th[s] = a_dec * th[s];
+  }
+  __syncthreads();
+
+  // ---- emit: mask (R, T) uint8 was zeroed by the host-side memset on the same stream
+  uint8_t* M = mask + (size_t)b * R * T;
+  int count = 0;
+  for (int e = lane; e < T * MAXP; e += 64) {
+    const int c = e / MAXP, i = e % MAXP;
+    if (i < ln[c]) {
+      const int p = lb[e];
+      if (p >= 0) {
+        M[(size_t)p * T + c] = 1;
+        ++count;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+  if (lane == 0) npeaks[b] = count;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfpa_audfprint_prepare(const void* spec, int dtype, int B, int F, int T, const double* denom, int mean_order,
+                           int log_input, double pole, double* filtered, double* scratch, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!spec || !filtered || !scratch || B < 0 || F < 2 || T < 1) return MFPA_EINVAL;
+  if (dtype != MFPA_F32 && dtype != MFPA_F64) return MFPA_EINVAL;
+  if (F - 1 > 256) return MFPA_EINVAL;
+  const long long N = (long long)F * T;
+  if ((N + NPY_BUFSIZE - 1) / NPY_BUFSIZE > MAX_CHUNKS) return MFPA_EINVAL;
+  const int R = F - 1;
+  const int nchunks = (int)((N + NPY_BUFSIZE - 1) / NPY_BUFSIZE);
+  const size_t lds = sizeof(double) * ((size_t)R * (TT + 1) + (size_t)TT * R) + sizeof(double) * (size_t)nchunks * HEAP;
+  hipStream_t s = mfpa_stream(stream);
+  if (dtype == MFPA_F64)
+    hipLaunchKernelGGL(prepare_kernel<double>, dim3(B), dim3(PREP_THREADS), lds, s, (const double*)spec, F, T, denom,
+                       mean_order, log_input, pole, filtered, scratch);
+  else
+    hipLaunchKernelGGL(prepare_kernel<float>, dim3(B), dim3(PREP_THREADS), lds, s, (const float*)spec, F, T, denom,
+                       mean_order, log_input, pole, filtered, scratch);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const double* gauss, double a_dec, int maxpks,
+                         uint8_t* mask, int32_t* npeaks, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!filtered || !gauss || !mask || !npeaks || B < 0) return MFPA_EINVAL;
+  if (R < 4 || R > 256 || (R % 4) != 0 || T < 1 || T > 1500 || maxpks < 1 || maxpks > MAXP) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  MFPA_HIP(hipMemsetAsync(mask, 0, (size_t)B * R * T, s));
+  const size_t lds = sizeof(double) * (2 * R + 2) + (size_t)T * MAXP * (sizeof(double) + sizeof(short)) + sizeof(short) * T;
+  hipLaunchKernelGGL(prune_kernel, dim3(B), dim3(64), lds, s, filtered, R, T, gauss, a_dec, maxpks, mask, npeaks);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // extern "C"

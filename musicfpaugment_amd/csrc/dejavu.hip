@@ -1,0 +1,165 @@
+// Dejavu 2-D local-maximum peak picker for MI355X (gfx950).
+//
+//   prepare   : arr = scale * ln(max(a, max(a)/1e6)) - mean, a = psd / denom
+//               (afp/dejavu/fingerprint.py:68,78-79); np.mean's summation order reproduced.
+//   localmax2d: get_2D_peaks (fingerprint.py:94-171): (2r+1)^2 maximum filter with scipy
+//               'reflect' borders, (filtered == value), XOR with the erosion of the exact-zero
+//               background (border_value 1), amplitude > amp_min.  Only comparisons: bit-exact
+//               by construction for a given arr.
+//
+// localmax2d tiles the (F, T) plane: a workgroup stages its tile plus a radius-wide halo in LDS
+// (values with reflected indices for the maximum, a background flag with the constant-1 border
+// for the erosion), then runs the separable row pass and column pass out of LDS.
+// Compiled with -ffp-contract=off (the pre-processing feeds exact comparisons).
+#include "mfpa_common.h"
+#include "mfpa_npsum.h"
+
+namespace {
+
+using namespace mfpa_np;
+constexpr int PREP_THREADS = 512;
+
+__global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const double* __restrict__ psd, int F, int T,
+                                                                      const double* __restrict__ denom, double scale,
+                                                                      int mean_order, double* __restrict__ arr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* heap = reinterpret_cast<double*>(smem);
+  __shared__ double red[PREP_THREADS / 64];
+  __shared__ double bcast[2];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int N = F * T;
+  const double* x = psd + (size_t)b * N;
+  double* L = arr + (size_t)b * N;
+  const bool has_den = denom != nullptr;
+  const double den = has_den ? denom[b] : 1.0;
+
+  double m = -INFINITY;
+  for (int i = tid; i < N; i += PREP_THREADS) {
+    const double s = has_den ? x[i] / den : x[i];
+    m = s > m ? s : m;
+  }
+  m = mfpa_wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = red[0];
+    for (int w = 1; w < PREP_THREADS / 64; ++w) mm = fmax(mm, red[w]);
+    bcast[0] = mm;
+  }
+  __syncthreads();
+  const double floor_v = bcast[0] / 1e6;
+  for (int i = tid; i < N; i += PREP_THREADS) {
+    double s = has_den ? x[i] / den : x[i];
+    s = s > floor_v ? s : floor_v;
+    L[i] = scale * log(s);
+  }
+  __syncthreads();
+  const double total = block_numpy_sum<double>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
+  const double mean = total / (double)N;
+  for (int i = tid; i < N; i += PREP_THREADS) L[i] = L[i] - mean;
+}
+
+constexpr int TH = 32, TW = 64, LM_THREADS = 256;
+
+__device__ __forceinline__ int reflect_index(int i, int n) {  // scipy.ndimage mode='reflect'
+  const int period = 2 * n;
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - 1 - i : i;
+}
+
+__global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __restrict__ arr, int F, int T, int r,
+                                                                double amp_min, uint8_t* __restrict__ mask,
+                                                                int32_t* __restrict__ npeaks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HH = TH + 2 * r, HW = TW + 2 * r;
+  double* A = reinterpret_cast<double*>(smem);     // [HH][HW] values, reflected
+  double* Hm = A + HH * HW;                        // [HH][TW] row-pass maxima
+  uint8_t* Bg = reinterpret_cast<uint8_t*>(Hm + HH * TW);  // [HH][HW] background flag (out of bounds = 1)
+  uint8_t* Hb = Bg + HH * HW;                      // [HH][TW] row-pass AND
+
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int i0 = blockIdx.y * TH, j0 = blockIdx.x * TW;
+  const double* X = arr + (size_t)b * F * T;
+
+  for (int e = tid; e < HH * HW; e += LM_THREADS) {
+    const int hi = e / HW, hj = e % HW;
+    const int gi = i0 - r + hi, gj = j0 - r + hj;
+    const double v = X[(size_t)reflect_index(gi, F) * T + reflect_index(gj, T)];
+    A[e] = v;
+    const bool inside = gi >= 0 && gi < F && gj >= 0 && gj < T;
+    Bg[e] = inside ? (uint8_t)(v == 0.0) : (uint8_t)1;
+  }
+  __syncthreads();
+  for (int e = tid; e < HH * TW; e += LM_THREADS) {
+    const int hi = e / TW, j = e % TW;
+    const double* row = A + hi * HW + j;
+    const uint8_t* brow = Bg + hi * HW + j;
+    double m = row[0];
+    uint8_t bg = brow[0];
+    for (int d = 1; d <= 2 * r; ++d) {
+      m = row[d] > m ? row[d] : m;
+      bg &= brow[d];
+    }
+    Hm[e] = m;
+    Hb[e] = bg;
+  }
+  __syncthreads();
+  int count = 0;
+  for (int e = tid; e < TH * TW; e += LM_THREADS) {
+    const int i = e / TW, j = e % TW;
+    const int gi = i0 + i, gj = j0 + j;
+    if (gi < F && gj < T) {
+      double m = Hm[i * TW + j];
+      uint8_t bg = Hb[i * TW + j];
+      for (int d = 1; d <= 2 * r; ++d) {
+        const double v = Hm[(i + d) * TW + j];
+        m = v > m ? v : m;
+        bg &= Hb[(i + d) * TW + j];
+      }
+      const double val = A[(i + r) * HW + j + r];
+      const bool local_max = (m == val);
+      const bool detected = local_max != (bg != 0);
+      const bool keep = detected && (val > amp_min);
+      mask[((size_t)b * F + gi) * T + gj] = keep ? 1 : 0;
+      count += keep ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+  if ((tid & 63) == 0 && count) atomicAdd(npeaks + b, count);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfpa_dejavu_prepare(const double* psd, int B, int F, int T, const double* denom, double scale, int mean_order,
+                        double* arr, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!psd || !arr || B < 0 || F < 1 || T < 1) return MFPA_EINVAL;
+  const long long N = (long long)F * T;
+  const long long nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
+  if (nchunks > MAX_CHUNKS) return MFPA_EINVAL;
+  hipLaunchKernelGGL(dejavu_prepare_kernel, dim3(B), dim3(PREP_THREADS), sizeof(double) * nchunks * HEAP,
+                     mfpa_stream(stream), psd, F, T, denom, scale, mean_order, arr);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double amp_min, uint8_t* mask,
+                    int32_t* npeaks, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!arr || !mask || !npeaks || B < 0 || F < 1 || T < 1 || radius < 0 || radius > 16) return MFPA_EINVAL;
+  if (B > 65535) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  MFPA_HIP(hipMemsetAsync(npeaks, 0, sizeof(int32_t) * B, s));
+  const int HH = TH + 2 * radius, HW = TW + 2 * radius;
+  const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)HH * TW) + (size_t)HH * HW + (size_t)HH * TW;
+  dim3 grid((T + TW - 1) / TW, (F + TH - 1) / TH, B);
+  hipLaunchKernelGGL(localmax2d_kernel, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Shared helpers for the libmfpa HIP sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfpa.h"
+
+#define MFPA_WAVE 64
+
+#define MFPA_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return MFPA_EHIP - (int)e__;       \
+  } while (0)
+
+#define MFPA_HIP(call)                                        \
+  do {                                                        \
+    hipError_t e__ = (call);                                  \
+    if (e__ != hipSuccess) return MFPA_EHIP - (int)e__;       \
+  } while (0)
+
+static inline hipStream_t mfpa_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ double mfpa_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Non-negative doubles order like their bit patterns: max via integer atomic.
+__device__ __forceinline__ void mfpa_atomic_max_nonneg(double* addr, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(addr),
+            static_cast<unsigned long long>(__double_as_longlong(v)));
+}

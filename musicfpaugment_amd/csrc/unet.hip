@@ -1,0 +1,412 @@
+// UNet denoiser kernels for MI355X (gfx950), training/unet.py:8-108 of the reference.
+//
+// Activations are NHWC float32 (H = frequency bins, W = frames).  The 3x3 convolutions and the
+// 2x2 transposed convolutions are implicit GEMMs on the matrix cores with float32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- the reference is fp32):
+//
+//   M = output pixels of a PHxPW patch (128 per workgroup), N = output channels (64/128 per
+//   workgroup), K = taps x input channels, walked in chunks of 32 channels.
+//
+// LDS im2col staging: per 32-channel chunk the workgroup stages the patch PLUS its one-pixel
+// halo once ((PH+2)x(PW+2) pixels x 32 channels) and all nine taps read their shifted A
+// fragments out of that tile, so the input is fetched 1.4-1.6x instead of 9x.  Both operands
+// sit in LDS K-contiguous with rows padded to 36 floats: a lane's fragment for four consecutive
+// MFMA k-steps is one conflict-free ds_read_b128.  Zero padding of the convolution, ragged
+// patch edges and the decoder's pad+concat (Up.forward, unet.py:56-63) are all folded into
+// the halo loader; the folded BatchNorm affine + ReLU run in the epilogue on the accumulators.
+// Global loads of the next tap's weights (and next chunk's halo) are issued before the MFMA
+// block of the current tap and written to LDS after it, so they overlap the matrix work.
+#include "mfpa_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 32;        // channels per K chunk
+constexpr int LDK = KC + 4;   // padded LDS row (floats): 144 B -> conflict-free b128 fragment reads
+constexpr int CONV_THREADS = 256;
+
+struct ConvArgs {
+  const float* x0;  // (B,H,W,C0)
+  const float* x1;  // (B,H1,W1,C1) or null
+  const float* w;   // [taps][Cout][Cin], Cin contiguous
+  const float* scale;
+  const float* shift;
+  float* y;
+  int C0, C1, H1, W1, oy1, ox1;
+  int B, H, W, Cout, relu;
+  int tiles_x, tiles_y;
+};
+
+// MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).  MODE 1: 2x2 stride-2 transposed conv: one tap per
+// workgroup column (blockIdx.y = tap * (Cout/BN) + n-tile), output scattered to (2y+dy, 2x+dx).
+template <int BN, int PH, int PW, int MODE>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int HALO = (MODE == 0) ? 1 : 0;
+  constexpr int TAPS = (MODE == 0) ? 9 : 1;
+  constexpr int HPW = PW + 2 * HALO, HPH = PH + 2 * HALO;
+  constexpr int HP = HPW * HPH;                       // halo-tile pixels
+  constexpr int BM = PH * PW;                         // 128
+  static_assert(BM == 128, "workgroup tile is 128 pixels");
+  constexpr int NT = BN / 64;                         // 32-wide n tiles per wave (2x2 wave grid)
+  constexpr int MT = 2;
+  constexpr int A_F4 = (HP * (KC / 4) + CONV_THREADS - 1) / CONV_THREADS;
+  constexpr int B_F4 = BN * (KC / 4) / CONV_THREADS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);         // [HP][LDK]
+  float* Bs = As + HP * LDK;                          // [BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+  const int b = bx;
+  const int n_tiles = a.Cout / BN;
+  const int n_tile = (MODE == 0) ? blockIdx.y : blockIdx.y % n_tiles;
+  const int ct_tap = (MODE == 0) ? 0 : blockIdx.y / n_tiles;
+  const int n0 = n_tile * BN;
+  const int y0 = ty * PH, x0p = tx * PW;
+  const int Cin = a.C0 + a.C1;
+  const int nchunks = Cin / KC;
+
+  f32x4 areg[A_F4];
+  f32x4 breg[B_F4];
+
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * KC;
+    const bool from0 = c0 < a.C0;
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) {
+      const int idx = tid + it * CONV_THREADS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < HP * (KC / 4)) {
+        const int pix = idx / (KC / 4), q = idx % (KC / 4);
+        const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+          if (from0) {
+            v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
+          } else {
+            const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+            if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
+              v = *reinterpret_cast<const f32x4*>(a.x1 + (((size_t)b * a.H1 + y1) * a.W1 + x1) * a.C1 + (c0 - a.C0) + 4 * q);
+          }
+        }
+      }
+      areg[it] = v;
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) {
+      const int idx = tid + it * CONV_THREADS;
+      if (idx < HP * (KC / 4)) {
+        const int pix = idx / (KC / 4), q = idx % (KC / 4);
+        *reinterpret_cast<f32x4*>(As + pix * LDK + 4 * q) = areg[it];
+      }
+    }
+  };
+  auto load_b = [&](int chunk, int tap) {
+    const int wt = (MODE == 0) ? tap : ct_tap;
+    const float* wbase = a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC;
+#pragma unroll
+    for (int it = 0; it < B_F4; ++it) {
+      const int idx = tid + it * CONV_THREADS;
+      const int n = idx / (KC / 4), q = idx % (KC / 4);
+      breg[it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * Cin + 4 * q);
+    }
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int it = 0; it < B_F4; ++it) {
+      const int idx = tid + it * CONV_THREADS;
+      const int n = idx / (KC / 4), q = idx % (KC / 4);
+      *reinterpret_cast<f32x4*>(Bs + n * LDK + 4 * q) = breg[it];
+    }
+  };
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  int a_base[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = wm * 64 + mt * 32 + li;
+    a_base[mt] = ((m / PW) * HPW + (m % PW)) * LDK + 4 * lh;
+  }
+  int b_base[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b_base[nt] = (wn * (NT * 32) + nt * 32 + li) * LDK + 4 * lh;
+
+  load_a(0);
+  load_b(0, 0);
+  store_a();
+  store_b();
+  __syncthreads();
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const bool last = (chunk == nchunks - 1) && (tap == TAPS - 1);
+      const bool new_chunk = (tap == TAPS - 1);
+      if (!last) {
+        load_b(new_chunk ? chunk + 1 : chunk, new_chunk ? 0 : tap + 1);
+        if (new_chunk) load_a(chunk + 1);
+      }
+      const int tap_off = (MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0;
+#pragma unroll
+      for (int s = 0; s < KC / 8; ++s) {
+        f32x4 af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(As + a_base[mt] + tap_off + 8 * s);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4*>(Bs + b_base[nt] + 8 * s);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].x, bf[nt].x, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].y, bf[nt].y, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].z, bf[nt].z, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].w, bf[nt].w, acc[mt][nt], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+      if (!last) {
+        store_b();
+        if (new_chunk) store_a();
+      }
+      __syncthreads();
+    }
+  }
+
+  // epilogue: y = relu(acc * scale[n] + shift[n]); D[row = pixel][col = channel]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn * (NT * 32) + nt * 32 + li;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = y0 + m / PW, gx = x0p + m % PW;
+        if (gy < a.H && gx < a.W) {
+          float v = acc[mt][nt][r] * sc + sh;
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          if (MODE == 0) {
+            a.y[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + n] = v;
+          } else {
+            const int oy = 2 * gy + (ct_tap >> 1), ox = 2 * gx + (ct_tap & 1);
+            a.y[(((size_t)b * (2 * a.H) + oy) * (2 * a.W) + ox) * a.Cout + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// First layer: 1 input channel -> Cout (multiple of 4), fused spectrogram normalisation.
+// 16 lanes per pixel x 4 channels per lane... generalised: Cout/4 lanes per pixel.
+__global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x32, const double* __restrict__ spec64,
+                                                         const double* __restrict__ denom, int per_clip, int B, int H,
+                                                         int W, const float* __restrict__ w, int Cout,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float* __restrict__ y) {
+  const int lanes_per_pix = Cout / 4;
+  const int pix_per_block = 256 / lanes_per_pix;
+  const int sub = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
+  float4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(w + (size_t)t * Cout + 4 * sub);
+  const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + 4 * sub) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+  double gden = 1.0;
+  if (spec64 && denom && !per_clip) {
+    gden = 0.0;
+    for (int i = 0; i < B; ++i) gden = fmax(gden, denom[i]);
+  }
+  const long long npix = (long long)B * H * W;
+  for (long long p = (long long)blockIdx.x * pix_per_block + pl; p < npix; p += (long long)gridDim.x * pix_per_block) {
+    const int gx = (int)(p % W);
+    const int gy = (int)((p / W) % H);
+    const int b = (int)(p / ((long long)W * H));
+    const double den = (spec64 && denom) ? (per_clip ? denom[b] : gden) : 1.0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const size_t o = ((size_t)b * H + yy) * W + xx;
+        v = spec64 ? (float)(spec64[o] / den) : x32[o];
+      }
+      acc.x += v * wt[t].x;
+      acc.y += v * wt[t].y;
+      acc.z += v * wt[t].z;
+      acc.w += v * wt[t].w;
+    }
+    float4 o4;
+    o4.x = fmaxf(acc.x * sc.x + sh.x, 0.f);
+    o4.y = fmaxf(acc.y * sc.y + sh.y, 0.f);
+    o4.z = fmaxf(acc.z * sc.z + sh.z, 0.f);
+    o4.w = fmaxf(acc.w * sc.w + sh.w, 0.f);
+    *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ x, int B, int H, int W, int C,
+                                                       float* __restrict__ y) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const long long total = (long long)B * Ho * Wo * C4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c4 = (int)(e % C4);
+    long long p = e / C4;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const float* base = x + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * c4;
+    const float4 v00 = *reinterpret_cast<const float4*>(base);
+    const float4 v01 = *reinterpret_cast<const float4*>(base + C);
+    const float4 v10 = *reinterpret_cast<const float4*>(base + (size_t)W * C);
+    const float4 v11 = *reinterpret_cast<const float4*>(base + (size_t)W * C + C);
+    float4 o;
+    o.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+    o.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+    o.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+    o.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+    *reinterpret_cast<float4*>(y + (size_t)e * 4) = o;
+  }
+}
+
+// OutConv 1x1 to one class: C/4 lanes per pixel, float4 per lane, shuffle reduce.
+__global__ __launch_bounds__(256) void conv1x1_out_kernel(const float* __restrict__ x, long long npix, int C,
+                                                          const float* __restrict__ w, float bias, float* __restrict__ y) {
+  const int lpp = C / 4;  // lanes per pixel (power of two <= 64)
+  const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
+  const float4 wv = *reinterpret_cast<const float4*>(w + 4 * sub);
+  const long long iters = (npix + (long long)gridDim.x * ppb - 1) / ((long long)gridDim.x * ppb);
+  for (long long it = 0; it < iters; ++it) {
+    const long long p = (it * gridDim.x + blockIdx.x) * ppb + pl;
+    float s = 0.f;
+    if (p < npix) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * C + 4 * sub);
+      s = v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+    }
+    for (int o = lpp >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (sub == 0 && p < npix) y[p] = s + bias;
+  }
+}
+
+template <int BN, int PH, int PW, int MODE>
+int launch_conv(const ConvArgs& a, int grid_y, hipStream_t s) {
+  constexpr int HALO = (MODE == 0) ? 1 : 0;
+  constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
+  const size_t lds = sizeof(float) * ((size_t)HP * LDK + (size_t)BN * LDK);
+  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)grid_y);
+  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, MODE>), grid, dim3(CONV_THREADS), lds, s, a);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+template <int MODE>
+int dispatch_conv(ConvArgs& a, hipStream_t s) {
+  const bool wide = a.W > 16;  // 4x32 patches for wide planes, 8x16 for the 16x15 bottleneck
+  const int taps_y = (MODE == 0) ? 1 : 4;
+  if (wide) {
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 3) / 4;
+  } else {
+    a.tiles_x = (a.W + 15) / 16;
+    a.tiles_y = (a.H + 7) / 8;
+  }
+  if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
+  if (a.Cout % 128 == 0) {
+    const int gy = taps_y * (a.Cout / 128);
+    return wide ? launch_conv<128, 4, 32, MODE>(a, gy, s) : launch_conv<128, 8, 16, MODE>(a, gy, s);
+  }
+  const int gy = taps_y * (a.Cout / 64);
+  return wide ? launch_conv<64, 4, 32, MODE>(a, gy, s) : launch_conv<64, 8, 16, MODE>(a, gy, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfpa_conv3x3_bn_relu(const float* x0, int C0, const float* x1, int C1, int H1, int W1, int B, int H, int W,
+                         const float* w, int Cout, const float* scale, const float* shift, int relu, int precision,
+                         float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x0 || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
+  if (C0 < KC || C0 % KC || C1 < 0 || C1 % KC || Cout < 64 || Cout % 64) return MFPA_EINVAL;
+  if (C1 > 0 && (!x1 || H1 < 1 || W1 < 1 || H1 > H || W1 > W)) return MFPA_EINVAL;
+  if (precision != 0) return MFPA_EINVAL;
+  ConvArgs a{};
+  a.x0 = x0; a.x1 = C1 ? x1 : nullptr; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
+  a.C0 = C0; a.C1 = C1; a.H1 = C1 ? H1 : 0; a.W1 = C1 ? W1 : 0;
+  a.oy1 = C1 ? (H - H1) / 2 : 0;  // F.pad(x1, [dx//2, dx-dx//2, dy//2, dy-dy//2]), unet.py:59-62
+  a.ox1 = C1 ? (W - W1) / 2 : 0;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+  return dispatch_conv<0>(a, mfpa_stream(stream));
+}
+
+int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                  int precision, float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
+  if (Cin < KC || Cin % KC || Cout < 64 || Cout % 64 || precision != 0) return MFPA_EINVAL;
+  ConvArgs a{};
+  a.x0 = x; a.w = w; a.scale = nullptr; a.shift = bias; a.y = y;
+  a.C0 = Cin; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 0;
+  return dispatch_conv<1>(a, mfpa_stream(stream));
+}
+
+int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,
+                            int W, const float* w, int Cout, const float* scale, const float* shift, float* y,
+                            void* stream) {
+  if (B == 0) return MFPA_OK;
+  if ((!x32 && !spec64) || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
+  if (Cout % 4 || Cout < 4 || Cout > 1024 || (256 % (Cout / 4)) != 0) return MFPA_EINVAL;
+  const long long npix = (long long)B * H * W;
+  const int ppb = 256 / (Cout / 4);
+  long long blocks = (npix + ppb - 1) / ppb;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x32, spec64, denom,
+                     per_clip, B, H, W, w, Cout, scale, shift, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_maxpool2(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !y || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x, B, H, W, C, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_conv1x1_out(const float* x, long long npix, int C, const float* w, float bias, float* y, void* stream) {
+  if (!x || !w || !y || npix < 0 || C < 4 || C > 256 || (C & (C - 1)) != 0) return MFPA_EINVAL;
+  if (npix == 0) return MFPA_OK;
+  const int ppb = 256 / (C / 4);
+  long long blocks = (npix + ppb - 1) / ppb;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(conv1x1_out_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x, npix, C, w, bias, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // extern "C"

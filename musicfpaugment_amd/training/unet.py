@@ -1,0 +1,139 @@
+"""UNet spectrogram denoiser on MI355X -- host-side mirror of the reference's training/unet.py.
+
+Same constructor, same module tree (hence the same 118 state_dict keys: published
+checkpoints ``{"model_state_dict": ...}`` load unchanged), same ``forward((B,1,F,T)) ->
+(B,1,F,T)`` contract.  The torch ``nn`` layers below are parameter containers only: forward
+never calls them.  It runs the hand-written gfx950 kernels of libmfpa.so (csrc/unet.hip):
+NHWC activations, float32 MFMA implicit-GEMM convolutions with the eval-mode BatchNorm
+folded into a per-channel affine + ReLU epilogue, pad + concat folded into the decoder
+convolutions' loaders.  There is no PyTorch/CPU fallback.
+
+Reference: training/unet.py:8-25 DoubleConv, :28-38 Down, :41-65 Up, :68-74 OutConv,
+:77-108 UNet.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops_unet as K
+from .._lib import MfpaError, require_gpu
+
+
+class DoubleConv(nn.Module):
+    """(convolution => [BN] => ReLU) * 2 -- parameter container (training/unet.py:8-25)."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        if not mid_channels:
+            mid_channels = out_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+        )
+
+
+class Down(nn.Module):
+    """MaxPool2d(2) then DoubleConv (training/unet.py:28-38)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(in_channels, out_channels))
+
+
+class Up(nn.Module):
+    """ConvTranspose2d(k2, s2) then pad + concat + DoubleConv (training/unet.py:41-65)."""
+
+    def __init__(self, in_channels, out_channels, bilinear=False):
+        super().__init__()
+        if bilinear:
+            raise NotImplementedError("bilinear=True is never used by the reference's experiments "
+                                      "(training/train.py:646 builds UNet(1, 1, rate=0.05)); not built")
+        self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+        self.conv = DoubleConv(in_channels, out_channels)
+
+
+class OutConv(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+
+class UNet(nn.Module):
+    def __init__(self, n_channels, n_classes, rate=0, bilinear=False):
+        super().__init__()
+        if n_channels != 1 or n_classes != 1:
+            raise NotImplementedError("the hot path is the 1-channel spectrogram denoiser UNet(1, 1, ...)")
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.bilinear = bilinear
+        self.dropout = nn.Dropout(rate)
+
+        self.inc = DoubleConv(n_channels, 64)
+        self.down1 = Down(64, 128)
+        self.down2 = Down(128, 256)
+        self.down3 = Down(256, 512)
+        self.down4 = Down(512, 1024)
+        self.up1 = Up(1024, 512, bilinear)
+        self.up2 = Up(512, 256, bilinear)
+        self.up3 = Up(256, 128, bilinear)
+        self.up4 = Up(128, 64, bilinear)
+        self.outc = OutConv(64, n_classes)
+
+        self.max_clips_per_pass = 64       # activations of one pass: ~0.12 GB per 8 s clip
+        self._packed: Optional[Dict[str, torch.Tensor]] = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ packed weights
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def packed_weights(self) -> Dict[str, torch.Tensor]:
+        """Kernel-layout weights ([tap][Cout][Cin]) + folded eval BatchNorm; rebuilt when parameters change."""
+        key = self._weights_key()
+        if self._packed is None or key != self._packed_key:
+            self._packed = K.pack_unet_weights(self.state_dict())
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        require_gpu(x, "UNet input")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError("expected (B, 1, F, T)")
+        if self.training:
+            raise NotImplementedError(
+                "UNet training-mode forward (BatchNorm batch statistics, Dropout) runs through "
+                "musicfpaugment_amd.training.train.Trainer's HIP step; call .eval() for inference")
+        if x.dtype != torch.float32:
+            raise TypeError("UNet input must be float32 (the reference casts with .float(), training/train.py:272)")
+        pw = self.packed_weights()
+        B = x.shape[0]
+        outs: List[torch.Tensor] = []
+        for s in range(0, B, self.max_clips_per_pass):
+            xs = x[s:s + self.max_clips_per_pass].contiguous()
+            outs.append(K.unet_forward_eval(pw, x32=xs.view(xs.shape[0], xs.shape[2], xs.shape[3])))
+        y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        return y.view(B, 1, x.shape[2], x.shape[3])
+
+    def denoise_spectrogram(self, spec64: torch.Tensor, clip_max: torch.Tensor, per_clip: bool) -> torch.Tensor:
+        """Fused entry for the pipeline: raw float64 |STFT| (B,F,T) + maxima -> denoised (B,F,T) float32.
+        The normalise + .float() step (peak_extractor.py:263-265 / train.py:272) runs inside the first conv."""
+        require_gpu(spec64, "spectrogram")
+        if self.training:
+            raise MfpaError("denoise_spectrogram is the inference path; call .eval()")
+        pw = self.packed_weights()
+        B = spec64.shape[0]
+        if not per_clip:
+            clip_max = clip_max.max().expand(B).contiguous()
+        outs = []
+        for s in range(0, B, self.max_clips_per_pass):
+            e = min(B, s + self.max_clips_per_pass)
+            outs.append(K.unet_forward_eval(pw, spec64=spec64[s:e], denom=clip_max[s:e].contiguous()))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)

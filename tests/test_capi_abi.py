@@ -1,0 +1,79 @@
+"""CPU-side checks of the drop-in boundary: libmfpa.so loads, exports every symbol include/mfpa.h declares,
+host-only entry points work, and the product package refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from musicfpaugment_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from musicfpaugment_amd.csrc.build import build
+        build(verbose=False)
+    return _lib
+
+
+def test_header_and_library_agree(lib):
+    header = open(os.path.join(ROOT, "include", "mfpa.h")).read()
+    declared = sorted(set(re.findall(r"^int\s+(mfpa_\w+)\s*\(", header, flags=re.M)))
+    assert declared == lib.exported_symbols(), "include/mfpa.h and the ctypes signature table diverged"
+    handle = lib.lib()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.mfpa_version() == lib.ABI_VERSION
+    m = re.search(r"#define MFPA_STFT_TABLE_LEN (\d+)", header)
+    assert int(m.group(1)) == lib.STFT_TABLE_LEN
+
+
+def test_host_only_entry_points(lib):
+    h = lib.lib()
+    assert h.mfpa_stft_frames(64000) == 251 and h.mfpa_stft_frames(24000) == 94 and h.mfpa_specgram_frames(64000) == 249
+    win = np.hanning(514)[1:-1]
+    out = np.empty(lib.STFT_TABLE_LEN)
+    assert h.mfpa_stft_tables(win.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0
+    np.testing.assert_array_equal(out[:512], win)
+    m = np.arange(256)
+    np.testing.assert_allclose(out[512:1024:2], np.cos(2 * np.pi * m / 256), atol=3e-16)
+    np.testing.assert_allclose(out[513:1024:2], -np.sin(2 * np.pi * m / 256), atol=3e-16)
+    assert h.mfpa_stft_tables(None, None) == lib.EINVAL
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    h = lib.lib()
+    # invalid shapes are rejected on the host before any launch (works without a GPU)
+    assert h.mfpa_stft_mag(1, 2, 100, 1, 1, 0, None, None) == lib.EINVAL        # T_w <= 256
+    assert h.mfpa_stft_mag(None, 2, 8000, None, None, 0, None, None) == lib.EINVAL
+    assert h.mfpa_audfprint_prune(1, 1, 255, 10, 1, 0.99, 5, 1, 1, None) == lib.EINVAL   # R % 4
+    assert h.mfpa_audfprint_prune(1, 1, 256, 10, 1, 0.99, 9, 1, 1, None) == lib.EINVAL   # maxpks > 8
+    assert h.mfpa_peak_metrics(1, 1, 1, 1, 5, 1, None) == lib.EINVAL                      # N1 < 2
+    assert h.mfpa_conv3x3_bn_relu(1, 48, None, 0, 0, 0, 1, 8, 8, 1, 64, None, None, 1, 0, 1, None) == lib.EINVAL
+    assert h.mfpa_stft_mag(None, 0, 8000, None, None, 0, None, None) == 0      # empty batch is a no-op
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    from musicfpaugment_amd import ops
+    from musicfpaugment_amd._lib import MfpaError
+    from musicfpaugment_amd.training.unet import UNet
+    with pytest.raises(MfpaError):
+        ops.stft_mag(torch.zeros(1, 8000))
+    with pytest.raises(MfpaError):
+        UNet(1, 1).eval()(torch.zeros(1, 1, 257, 32))
+    with pytest.raises(MfpaError):
+        ops.peak_metrics_counts(torch.zeros(1, 4, 4, dtype=torch.uint8), torch.zeros(1, 4, 4, dtype=torch.uint8))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "musicfpaugment_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)

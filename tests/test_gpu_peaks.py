@@ -1,0 +1,165 @@
+"""GPU parity: peak pickers and peak-mask metrics vs the oracle -- bit-exact index sets."""
+import numpy as np
+import pytest
+import torch
+
+from musicfpaugment_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from musicfpaugment_amd import ops as _ops
+    return _ops
+
+
+def unpack(bits, shape):
+    return np.unpackbits(bits)[: int(np.prod(shape))].reshape(shape).astype(np.uint8)
+
+
+def test_prune_strict_golden(ops, golden):
+    """Reference's own filtered log-spectrogram in, reference's own mask out (known answer)."""
+    g = golden("g3_audfprint_peaks")
+    filt = g["short_filtered"]                                   # (256, 32) float64
+    fm = torch.from_numpy(np.ascontiguousarray(filt.T))[None].cuda()   # frame-major (1, T, 256)
+    mask, npk = ops.audfprint_prune(fm)
+    want = unpack(g["short_mask"], filt.shape)
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), want)
+    assert int(npk[0]) == int(want.sum()) == len(g["short_pklist"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_prepare_strict_log_input_bit_exact(ops, dtype, order):
+    """log_input=1: mean + high-pass on the device must equal numpy/scipy bit for bit."""
+    from oracle import audfprint as oa
+    rng = np.random.default_rng(5)
+    lg = np.log(np.maximum(rng.random((3, 257, 251)), 1e-6)).astype(dtype)
+    got = ops.audfprint_prepare(torch.from_numpy(lg).cuda(), mean_order=int(order == "F"), log_input=True)
+    for b in range(3):
+        flat = np.ascontiguousarray(lg[b] if order == "C" else lg[b].T).reshape(-1)
+        mean = dtype(oa.numpy_sum(flat) / dtype(flat.size))
+        want = oa.highpass(lg[b] - mean)[:-1]
+        np.testing.assert_array_equal(got[b].cpu().numpy().T, want)
+
+
+def _oracle_masks(sgrams, order):
+    from oracle import audfprint as oa
+    return np.stack([oa.peaks_from_filtered(oa.preprocess(s, order)) for s in sgrams]).astype(np.uint8)
+
+
+def test_audfprint_full_clips_float64(ops, golden):
+    """|STFT| -> normalise -> log/mean/high-pass -> prune, all on the device, vs the oracle and the goldens."""
+    from oracle import stft as ostft
+    g = golden("g3_audfprint_peaks")
+    seeds = [int(s) for s in g["seeds"]] + list(range(700, 713))
+    tonal = [bool(t) for t in g["tonal"]] + [k % 2 == 0 for k in range(13)]
+    wav = np.stack([synth.clip(s, tonal=t) for s, t in zip(seeds, tonal)])
+    mag, cmax = ops.stft_mag(torch.from_numpy(wav).cuda(), torch.float64)
+    filtered = ops.audfprint_prepare(mag, denom=cmax, mean_order=1)
+    mask, npk = ops.audfprint_prune(filtered)
+    got = mask.cpu().numpy()
+    for i in range(3):      # golden masks from the real reference
+        np.testing.assert_array_equal(got[i], unpack(g[f"mask{i}"], (256, 251)))
+    # same spectrogram (the device's) through the oracle: bit-exact index sets
+    m = mag.cpu().numpy()
+    sg = m / m.reshape(len(seeds), -1).max(axis=1)[:, None, None]
+    want = _oracle_masks(sg, "F")
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(npk.cpu().numpy(), want.reshape(len(seeds), -1).sum(axis=1))
+    # and against the oracle's own STFT
+    want2 = np.stack([(lambda r: r[1])(__import__("oracle.audfprint", fromlist=["x"]).find_peaks(w)) for w in wav[:4]])
+    np.testing.assert_array_equal(got[:4], want2.astype(np.uint8))
+
+
+def test_audfprint_float32_spectrogram_path(ops, golden):
+    """float32 (UNet-output-like) spectrograms: log and mean are float32 in the reference."""
+    g = golden("g3b_audfprint_peaks_unet")
+    spec = g["spec"]                                              # (257, 32) float32 from the real reference UNet
+    rng = np.random.default_rng(11)
+    extra = (rng.random((6, 257, 251)) ** 4).astype(np.float32)
+    extra[1] -= 0.05                                              # UNet outputs can be negative (floored at max/1e6)
+    filt = ops.audfprint_prepare(torch.from_numpy(spec[None]).cuda(), mean_order=0)
+    mask, _ = ops.audfprint_prune(filt)
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), unpack(g["mask"], tuple(g["mask_shape"])))
+    filt = ops.audfprint_prepare(torch.from_numpy(extra).cuda(), mean_order=0)
+    mask, _ = ops.audfprint_prune(filt)
+    want = _oracle_masks(extra, "C")
+    mism = [(mask[b].cpu().numpy() != want[b]).sum() for b in range(len(extra))]
+    assert sum(mism) == 0, f"float32 path peak flips per clip: {mism}"
+
+
+def test_audfprint_edge_cases(ops):
+    from oracle import audfprint as oa
+    # all-zero clip: max <= 0 -> log/mean skipped (peak_extractor.py:272-280), ragged T, tiny T
+    z = torch.zeros((1, 257, 40), dtype=torch.float64, device="cuda")
+    mask, npk = ops.audfprint_prune(ops.audfprint_prepare(z))
+    want = oa.peaks_from_filtered(oa.preprocess(np.zeros((257, 40))))
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), want.astype(np.uint8))
+    rng = np.random.default_rng(2)
+    for T in (1, 3, 9, 17, 130):
+        s = rng.random((2, 257, T))
+        mask, _ = ops.audfprint_prune(ops.audfprint_prepare(torch.from_numpy(s).cuda(), mean_order=0))
+        np.testing.assert_array_equal(mask.cpu().numpy(), _oracle_masks(s, "C"))
+    with pytest.raises(ValueError):
+        ops.audfprint_prune(torch.zeros((1, 8, 255), dtype=torch.float64, device="cuda"))
+    m, n = ops.audfprint_prune(torch.zeros((0, 8, 256), dtype=torch.float64, device="cuda"))
+    assert m.shape == (0, 256, 8)
+
+
+def test_dejavu_golden_and_oracle(ops, golden):
+    from oracle import dejavu as od
+    g = golden("g4_dejavu_peaks")
+    arr = torch.from_numpy(g["arr"])[None].cuda()
+    mask, npk = ops.localmax2d(arr, 10, 50.0)
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), g["mask"])
+    assert int(npk[0]) == len(g["coords"])
+    z = torch.zeros((1, 30, 30), dtype=torch.float64, device="cuda")
+    mask, npk = ops.localmax2d(z, 10, -1.0)
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), g["zeros_mask"])
+    # random arrays with ties / zeros, several shapes (tile edges, smaller than the window)
+    rng = np.random.default_rng(3)
+    for shape in [(257, 249), (64, 48), (33, 65), (7, 5), (21, 130)]:
+        a = np.round(rng.normal(size=(2,) + shape) * 40)
+        a[rng.random(a.shape) < 0.2] = 0.0
+        mask, npk = ops.localmax2d(torch.from_numpy(a).cuda(), 10, 50.0)
+        for b in range(2):
+            coords, want = od.get_2d_peaks(a[b], 50)
+            np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
+            assert int(npk[b]) == len(coords)
+
+
+def test_dejavu_full_pipeline(ops, golden):
+    from oracle import dejavu as od
+    g = golden("g4_dejavu_peaks")
+    seeds = [int(g["full_seed"]), 62, 63, 64]
+    wav = np.stack([synth.clip(s) for s in seeds])
+    psd, cmax = ops.specgram_psd(torch.from_numpy(wav).cuda(), scale_in=32767.0)
+    arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=1)
+    mask, npk = ops.localmax2d(arr, 10, 50.0)
+    f_idx, t_idx = np.nonzero(mask[0].cpu().numpy())
+    np.testing.assert_array_equal(np.stack([f_idx, t_idx], axis=1), g["full_coords"])
+    for b, w in enumerate(wav):
+        coords, want, _ = od.fingerprint_peaks(w.astype(np.float64) * 32767.0)
+        np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
+
+
+def test_peak_metrics(ops, golden):
+    from oracle import metrics as om
+    g = golden("g5_metrics")
+    pred, gt = torch.from_numpy(g["pred"]).cuda(), torch.from_numpy(g["gt"]).cuda()
+    c = ops.peak_metrics_counts(pred, gt).cpu().numpy()
+    np.testing.assert_array_equal(c, om.counts(g["pred"], g["gt"]))
+    for k in range(3):
+        p = c[k, 0] / c[k, 1] if c[k, 1] else 0.0
+        r = c[k, 2] / c[k, 3] if c[k, 3] else 0.0
+        assert [p, r] == list(g["prf"][k][:2])
+    rng = np.random.default_rng(9)
+    a = (rng.random((5, 251, 256)) < 0.02).astype(np.uint8)
+    b = (rng.random((5, 251, 256)) < 0.02).astype(np.uint8)
+    b[:2] |= a[:2] & (rng.random((2, 251, 256)) < 0.7)
+    a[:, 0, :] |= rng.random((5, 256)) < 0.1
+    a[:, :, 0] |= rng.random((5, 251)) < 0.1
+    c = ops.peak_metrics_counts(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(c, om.counts(a, b))

@@ -1,0 +1,118 @@
+"""GPU parity: UNet eval forward on float32 MFMA vs the torch-CPU fp32 oracle (tolerance: relative L1 <= 1e-4,
+BASELINE.json) and the golden outputs of the real reference module."""
+import numpy as np
+import pytest
+import torch
+
+from musicfpaugment_amd import synth
+from musicfpaugment_amd.training.weights import formula_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def net():
+    from musicfpaugment_amd.training.unet import UNet
+    m = UNet(1, 1, rate=0.05)
+    m.load_state_dict(formula_state_dict(0))
+    return m.cuda().eval()
+
+
+def test_state_dict_keys_match_reference_inventory(net):
+    from musicfpaugment_amd.training.weights import state_dict_shapes
+    sd = net.state_dict()
+    shapes = state_dict_shapes()
+    assert list(sd.keys()) == list(shapes.keys()) and len(sd) == 118
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+
+
+def test_building_blocks_vs_torch(net):
+    """Each kernel against the plain torch fp32 op on ragged shapes (odd extents, tile tails)."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_unet as K
+    from oracle.unet import relative_l1
+    g = torch.Generator().manual_seed(1)
+    for (B, H, W, C0, C1, Cout) in [(2, 9, 37, 64, 0, 64), (1, 16, 15, 512, 0, 1024), (2, 33, 31, 64, 64, 128),
+                                   (1, 5, 70, 32, 0, 128), (1, 13, 16, 96, 32, 64)]:
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))
+        sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+        if C1:
+            x1 = torch.randn(B, C1, H - 1, W - 1, generator=g)
+            xin = torch.cat([x0, F.pad(x1, [0, 1, 0, 1])], dim=1)
+        else:
+            x1, xin = None, x0
+        want = F.relu(F.conv2d(xin, w, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+        got = K.conv3x3_bn_relu(x0.permute(0, 2, 3, 1).contiguous().cuda(), K.pack_conv3x3(w).cuda(), sc.cuda(), sh.cuda(),
+                                x1=None if x1 is None else x1.permute(0, 2, 3, 1).contiguous().cuda())
+        assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-5, (B, H, W, C0, C1, Cout)
+    for (B, H, W, Cin) in [(2, 16, 15, 1024), (1, 7, 33, 128)]:
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cin, Cin // 2, 2, 2, generator=g) / np.sqrt(Cin)
+        bias = torch.randn(Cin // 2, generator=g)
+        want = F.conv_transpose2d(x, w, bias, stride=2)
+        got = K.convT2x2(x.permute(0, 2, 3, 1).contiguous().cuda(), K.pack_convT2x2(w).cuda(), bias.cuda())
+        assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-5
+    x = torch.randn(2, 64, 257, 251, generator=g)
+    got = K.maxpool2(x.permute(0, 2, 3, 1).contiguous().cuda())
+    assert torch.equal(got.cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 2))
+    wv, b0 = torch.randn(64, generator=g), 0.3
+    got = K.conv1x1_out(x.permute(0, 2, 3, 1).contiguous().cuda(), wv.cuda(), b0)
+    want = F.conv2d(x, wv.view(1, 64, 1, 1), torch.tensor([b0]))[:, 0]
+    assert relative_l1(got.cpu(), want) < 1e-5
+    x1c = torch.rand(2, 1, 30, 45, generator=g)
+    w1 = torch.randn(64, 1, 3, 3, generator=g)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    want = F.relu(F.conv2d(x1c, w1, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    got = K.conv3x3_c1_bn_relu(w1.permute(2, 3, 1, 0).reshape(9, 64).contiguous().cuda(), sc.cuda(), sh.cuda(),
+                               x32=x1c[:, 0].contiguous().cuda())
+    assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-5
+
+
+def test_forward_golden_reference_module(net, golden):
+    from oracle.unet import relative_l1
+    g = golden("g6_unet_forward")
+    y = net(torch.from_numpy(g["x"]).cuda())
+    assert y.shape == g["y"].shape and y.dtype == torch.float32
+    assert relative_l1(y.cpu(), torch.from_numpy(g["y"])) <= TOL
+    from oracle import stft as ostft
+    wav8 = synth.batch(1, seed=int(g["seed8"]))
+    x8 = torch.from_numpy(ostft.spectrogram(wav8)).float().unsqueeze(1)
+    y8 = net(x8.cuda()).cpu()
+    assert relative_l1(y8[0, 0, ::4, ::4], torch.from_numpy(g["y8_sub"])) <= TOL
+    assert abs(float(y8.double().abs().sum()) - float(g["y8_abs_sum"])) <= TOL * float(g["y8_abs_sum"])
+
+
+def test_forward_vs_oracle_batch_and_fused_entry(net):
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    from musicfpaugment_amd import ops
+    wav = synth.batch(3, seed=900, n=24000)                       # the reference's 3 s training length: 257 x 94
+    sd = formula_state_dict(0)
+    spec = ostft.spectrogram(wav)
+    x = torch.from_numpy(spec).float().unsqueeze(1)
+    with torch.no_grad():
+        want = ou.forward(x, sd)
+    got = net(x.cuda()).cpu()
+    assert ou.relative_l1(got, want) <= TOL
+    # fused entry: raw float64 |STFT| + maxima straight from the STFT kernel
+    mag, cmax = ops.stft_mag(torch.from_numpy(wav).cuda(), torch.float64)
+    got2 = net.denoise_spectrogram(mag, cmax, per_clip=False).cpu()
+    assert ou.relative_l1(got2.unsqueeze(1), want) <= TOL
+    net.max_clips_per_pass = 2                                     # sub-batching must not change results
+    got3 = net(x.cuda()).cpu()
+    net.max_clips_per_pass = 64
+    assert torch.equal(got3, got)
+
+
+def test_train_mode_and_cpu_inputs_fail_loudly(net):
+    from musicfpaugment_amd._lib import MfpaError
+    with pytest.raises(MfpaError):
+        net(torch.zeros(1, 1, 257, 32))
+    net.train()
+    try:
+        with pytest.raises(NotImplementedError):
+            net(torch.zeros(1, 1, 257, 32, device="cuda"))
+    finally:
+        net.eval()
