@@ -160,12 +160,33 @@ int mfpa_conv3x3_bn_relu(const float* x0, int C0, const float* x1, int C1, int H
                          const float* scale, const float* shift, int relu, int precision,
                          float* y, void* stream);
 
+/* General form of the MFMA implicit-GEMM convolution (same kernel as the two entry points above
+ * and below), used by the training step: forward with the previous layer's BatchNorm + ReLU applied
+ * to source 0 ON LOAD, input gradients (a 3x3 conv of dz with transposed, flipped weights; mode 2 for
+ * the transposed conv), cropped outputs.  training/unet.py:8-65, training/train.py:314-316 (backward).
+ *   mode 0: 3x3 conv pad 1;  1: ConvTranspose2d(k2,s2) forward (y is (B,2H,2W,Cout));
+ *        2: ConvTranspose2d input gradient (x0 is (B,2H,2W,C0), y is (B,H,W,Cout), w (4,Cout,C0))
+ *   in_scale0/in_shift0 (C0) or NULL: x0 <- relu(x0*scale+shift) per channel when loaded
+ *   x1 (B,H1,W1,C1) zero-padded to (H,W) like mfpa_conv3x3_bn_relu (mode 0 only)
+ *   yH,yW: output extent (0 = H,W): pixels beyond are not stored, y is (B,yH,yW,Cout)  (modes 0, 2)
+ */
+typedef struct mfpa_conv_desc {
+  const float* x0; const float* in_scale0; const float* in_shift0;
+  const float* x1;
+  const float* w; const float* out_scale; const float* out_shift;
+  float* y;
+  int C0, C1, H1, W1;
+  int B, H, W, Cout, relu;
+  int yH, yW, mode;
+} mfpa_conv_desc;
+int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
+
 /* First layer: 3x3 conv from ONE input channel (inc.double_conv.0, unet.py:86) fused with the
  * spectrogram normalisation: x = (float)(spec / denom) when spec64 != NULL, else x32 as is.
  *   w (9, Cout), y (B,H,W,Cout). */
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip,
                             int B, int H, int W, const float* w, int Cout,
-                            const float* scale, const float* shift, float* y, void* stream);
+                            const float* scale, const float* shift, int relu, float* y, void* stream);
 
 /* MaxPool2d(2), floor (unet.py:34).  x (B,H,W,C) -> y (B,H/2,W/2,C). */
 int mfpa_maxpool2(const float* x, int B, int H, int W, int C, float* y, void* stream);
@@ -178,6 +199,73 @@ int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, 
 /* OutConv 1x1 + bias to ONE class (unet.py:68-74).  x (B*H*W, C), w (C), y (B*H*W). */
 int mfpa_conv1x1_out(const float* x, long long npix, int C, const float* w, float bias, float* y,
                      void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * UNet training step, training/train.py:257-317 (spec branch): forward in train mode, L1 loss,
+ * backward, Adam.  A layer's BatchNorm+ReLU output is never materialised: convolutions write the raw
+ * output z, mfpa_bn_stats reduces the batch statistics into per-channel (scale, shift), and consumers
+ * apply relu(z*scale+shift) on load (mfpa_conv_mfma's in_scale0/in_shift0).  Reductions are two-stage
+ * float64 and deterministic.  `workspace`: at least mfpa_red_blocks() * max(2*C, 65) doubles.
+ */
+int mfpa_red_blocks(void);
+
+/* nn.BatchNorm2d in train mode (unet.py:17,20): z (npix, C) -> mean, invstd (biased var, eps),
+ * scale = gamma*invstd, shift = beta - mean*scale; running_mean/var (momentum, unbiased var) updated
+ * in place when non-NULL. */
+int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, const float* beta, float eps,
+                  float momentum, float* mean, float* invstd, float* scale, float* shift,
+                  float* running_mean, float* running_var, double* workspace, void* stream);
+
+/* BatchNorm+ReLU backward: dy (gradient w.r.t. relu(bn(z))) is overwritten with the gradient w.r.t. z;
+ * dgamma, dbeta (C) are produced; coef is a (3, C) scratch. */
+int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     float* dgamma, float* dbeta, float* coef, double* workspace, void* stream);
+
+/* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
+int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);
+
+/* p = MaxPool2d(2)(relu(z*scale+shift)) (unet.py:34) and its backward: dy += route(dp) to the window's
+ * first maximum. */
+int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* scale, const float* shift,
+                      float* p, void* stream);
+int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const float* scale,
+                          const float* shift, const float* dp, float* dy, void* stream);
+
+/* Weight gradient on MFMA, ACCUMULATED into dw (zero it first):
+ *   mode 0: dw[tap][co][ci] += sum_p dz[p][co] * xin[p + tap][ci]          (3x3 conv; dw (9,Cout,C0+C1))
+ *   mode 1: dw[tap][co][ci] += sum_p dz[2y+dy,2x+dx][co] * xin[y,x][ci]    (transposed conv; dw (4,Cout,C0))
+ * xin = [x0 (affine+ReLU on load if in_scale0) | x1 zero-padded] exactly as the forward saw it.
+ * C0, C1, Cout multiples of 64. */
+typedef struct mfpa_wgrad_desc {
+  const float* dz; const float* x0; const float* in_scale0; const float* in_shift0; const float* x1;
+  float* dw;
+  int C0, C1, H1, W1;
+  int B, H, W, Cout, mode;
+} mfpa_wgrad_desc;
+int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream);
+
+/* First layer (1 input channel): dw[tap][co] += sum_p dz[p][co] * x[p + tap]; x as in
+ * mfpa_conv3x3_c1_bn_relu (per-clip denominators). */
+int mfpa_wgrad_c1(const float* dz, const float* x32, const double* spec64, const double* denom, int B, int H,
+                  int W, int Cout, float* dw, void* stream);
+
+/* OutConv in training: pred[p] = sum_c relu(z[p][c]*scale[c]+shift[c]) * w[c] + bias[0];
+ * backward: dy[p][c] = dpred[p]*w[c], dwb = [C weight gradients, bias gradient]. */
+int mfpa_outconv_fwd(const float* z, long long npix, int C, const float* scale, const float* shift,
+                     const float* w, const float* bias, float* pred, void* stream);
+int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, const float* scale,
+                     const float* shift, const float* w, float* dy, float* dwb, double* workspace, void* stream);
+
+/* nn.L1Loss(mean) of float32 pred against the float64 target (train.py:280): loss[0] (float64) and,
+ * if dpred != NULL, dpred = sign(pred - target) / n. */
+int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dpred, double* loss,
+                 double* workspace, void* stream);
+
+/* torch.optim.Adam step (train.py:661: lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay) on flat
+ * arrays; g is multiplied by grad_scale first (1/world_size after a SUM all-reduce). step >= 1. */
+int mfpa_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MfpaError(RuntimeError):
@@ -46,12 +46,48 @@ _SIGNATURES = {
     "mfpa_conv3x3_bn_relu": ([c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_conv3x3_c1_bn_relu": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_maxpool2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_convT2x2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                        c_void_p], c_int),
     "mfpa_conv1x1_out": ([c_void_p, c_longlong, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
+    "mfpa_conv_mfma": ([c_void_p, c_void_p], c_int),
+    "mfpa_red_blocks": ([], c_int),
+    "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_maxpool2_bwd_add": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p], c_int),
+    "mfpa_wgrad_mfma": ([c_void_p, c_void_p], c_int),
+    "mfpa_wgrad_c1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_outconv_fwd": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+                         c_int),
+    "mfpa_outconv_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p], c_int),
+    "mfpa_l1_loss": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_adam_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int,
+                        c_float, c_void_p], c_int),
 }
+
+
+class ConvDesc(ctypes.Structure):
+    """mfpa_conv_desc of include/mfpa.h."""
+    _fields_ = [("x0", c_void_p), ("in_scale0", c_void_p), ("in_shift0", c_void_p), ("x1", c_void_p),
+                ("w", c_void_p), ("out_scale", c_void_p), ("out_shift", c_void_p), ("y", c_void_p),
+                ("C0", c_int), ("C1", c_int), ("H1", c_int), ("W1", c_int),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("relu", c_int),
+                ("yH", c_int), ("yW", c_int), ("mode", c_int)]
+
+
+class WgradDesc(ctypes.Structure):
+    """mfpa_wgrad_desc of include/mfpa.h."""
+    _fields_ = [("dz", c_void_p), ("x0", c_void_p), ("in_scale0", c_void_p), ("in_shift0", c_void_p),
+                ("x1", c_void_p), ("dw", c_void_p),
+                ("C0", c_int), ("C1", c_int), ("H1", c_int), ("W1", c_int),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("mode", c_int)]
 
 _lib = None
 

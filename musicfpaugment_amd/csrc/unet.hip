@@ -28,23 +28,29 @@ constexpr int LDK = KC + 4;   // padded LDS row (floats): 144 B -> conflict-free
 constexpr int CONV_THREADS = 256;
 
 struct ConvArgs {
-  const float* x0;  // (B,H,W,C0)
-  const float* x1;  // (B,H1,W1,C1) or null
-  const float* w;   // [taps][Cout][Cin], Cin contiguous
-  const float* scale;
+  const float* x0;         // source 0: (B,H,W,C0) [mode 2: (B,2H,2W,C0)]
+  const float* in_scale0;  // optional per-channel affine + ReLU applied to source 0 ON LOAD (training: the
+  const float* in_shift0;  //   previous layer's BatchNorm+ReLU is never materialised); null = plain
+  const float* x1;         // source 1: (B,H1,W1,C1) or null, zero-padded to (H,W) at offset (oy1,ox1)
+  const float* w;          // [taps][Cout][Cin], Cin contiguous
+  const float* scale;      // epilogue per-output-channel affine (null = identity)
   const float* shift;
   float* y;
   int C0, C1, H1, W1, oy1, ox1;
   int B, H, W, Cout, relu;
+  int yH, yW;              // output extent (crop): pixels with gy >= yH or gx >= yW are not stored
   int tiles_x, tiles_y;
 };
 
-// MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).  MODE 1: 2x2 stride-2 transposed conv: one tap per
-// workgroup column (blockIdx.y = tap * (Cout/BN) + n-tile), output scattered to (2y+dy, 2x+dx).
+// MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).
+// MODE 1: 2x2 stride-2 transposed conv forward: one tap per workgroup column
+//         (blockIdx.y = tap * (Cout/BN) + n-tile), output scattered to (2y+dy, 2x+dx).
+// MODE 2: transposed-conv input gradient: 4 taps, A gathered from the (2H,2W) tensor at (2y+dy, 2x+dx).
 template <int BN, int PH, int PW, int MODE>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
-  constexpr int TAPS = (MODE == 0) ? 9 : 1;
+  constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 2 ? 4 : 1);
+  constexpr bool A_PER_TAP = (MODE == 2);               // A tile changes with the tap
   constexpr int HPW = PW + 2 * HALO, HPH = PH + 2 * HALO;
   constexpr int HP = HPW * HPH;                       // halo-tile pixels
   constexpr int BM = PH * PW;                         // 128
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
   const int ty = bx % a.tiles_y; bx /= a.tiles_y;
   const int b = bx;
   const int n_tiles = a.Cout / BN;
-  const int n_tile = (MODE == 0) ? blockIdx.y : blockIdx.y % n_tiles;
-  const int ct_tap = (MODE == 0) ? 0 : blockIdx.y / n_tiles;
+  const int n_tile = (MODE == 1) ? blockIdx.y % n_tiles : blockIdx.y;
+  const int ct_tap = (MODE == 1) ? blockIdx.y / n_tiles : 0;
   const int n0 = n_tile * BN;
   const int y0 = ty * PH, x0p = tx * PW;
   const int Cin = a.C0 + a.C1;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
   f32x4 areg[A_F4];
   f32x4 breg[B_F4];
 
-  auto load_a = [&](int chunk) {
+  auto load_a = [&](int chunk, int tap) {
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
 #pragma unroll
@@ -89,7 +95,21 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
         const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
           if (from0) {
-            v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
+            if (MODE == 2) {
+              const int sy = 2 * gy + (tap >> 1), sx = 2 * gx + (tap & 1);
+              v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * (2 * a.H) + sy) * (2 * a.W) + sx) * a.C0 + c0 + 4 * q);
+            } else {
+              v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
+            }
+            if (a.in_scale0) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * q);
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * q);
+              v = v * sc + sh;
+              v.x = v.x > 0.f ? v.x : 0.f;
+              v.y = v.y > 0.f ? v.y : 0.f;
+              v.z = v.z > 0.f ? v.z : 0.f;
+              v.w = v.w > 0.f ? v.w : 0.f;
+            }
           } else {
             const int y1 = gy - a.oy1, x1 = gx - a.ox1;
             if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
@@ -111,7 +131,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
     }
   };
   auto load_b = [&](int chunk, int tap) {
-    const int wt = (MODE == 0) ? tap : ct_tap;
+    const int wt = (MODE == 1) ? ct_tap : tap;
     const float* wbase = a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC;
 #pragma unroll
     for (int it = 0; it < B_F4; ++it) {
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) b_base[nt] = (wn * (NT * 32) + nt * 32 + li) * LDK + 4 * lh;
 
-  load_a(0);
+  load_a(0, 0);
   load_b(0, 0);
   store_a();
   store_b();
@@ -158,9 +178,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
     for (int tap = 0; tap < TAPS; ++tap) {
       const bool last = (chunk == nchunks - 1) && (tap == TAPS - 1);
       const bool new_chunk = (tap == TAPS - 1);
+      const int nchunk = new_chunk ? chunk + 1 : chunk, ntap = new_chunk ? 0 : tap + 1;
       if (!last) {
-        load_b(new_chunk ? chunk + 1 : chunk, new_chunk ? 0 : tap + 1);
-        if (new_chunk) load_a(chunk + 1);
+        load_b(nchunk, ntap);
+        if (new_chunk || A_PER_TAP) load_a(nchunk, ntap);
       }
       const int tap_off = (MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0;
 #pragma unroll
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
       __syncthreads();
       if (!last) {
         store_b();
-        if (new_chunk) store_a();
+        if (new_chunk || A_PER_TAP) store_a();
       }
       __syncthreads();
     }
@@ -201,11 +222,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
       for (int r = 0; r < 16; ++r) {
         const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gy = y0 + m / PW, gx = x0p + m % PW;
-        if (gy < a.H && gx < a.W) {
+        if (gy < a.yH && gx < a.yW) {
           float v = acc[mt][nt][r] * sc + sh;
           if (a.relu) v = v > 0.f ? v : 0.f;
-          if (MODE == 0) {
-            a.y[(((size_t)b * a.H + gy) * a.W + gx) * a.Cout + n] = v;
+          if (MODE != 1) {
+            a.y[(((size_t)b * a.yH + gy) * a.yW + gx) * a.Cout + n] = v;
           } else {
             const int oy = 2 * gy + (ct_tap >> 1), ox = 2 * gx + (ct_tap & 1);
             a.y[(((size_t)b * (2 * a.H) + oy) * (2 * a.W) + ox) * a.Cout + n] = v;
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
                                                          const double* __restrict__ denom, int per_clip, int B, int H,
                                                          int W, const float* __restrict__ w, int Cout,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         float* __restrict__ y) {
+                                                         int relu, float* __restrict__ y) {
   const int lanes_per_pix = Cout / 4;
   const int pix_per_block = 256 / lanes_per_pix;
   const int sub = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
@@ -257,10 +278,16 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
       acc.w += v * wt[t].w;
     }
     float4 o4;
-    o4.x = fmaxf(acc.x * sc.x + sh.x, 0.f);
-    o4.y = fmaxf(acc.y * sc.y + sh.y, 0.f);
-    o4.z = fmaxf(acc.z * sc.z + sh.z, 0.f);
-    o4.w = fmaxf(acc.w * sc.w + sh.w, 0.f);
+    o4.x = acc.x * sc.x + sh.x;
+    o4.y = acc.y * sc.y + sh.y;
+    o4.z = acc.z * sc.z + sh.z;
+    o4.w = acc.w * sc.w + sh.w;
+    if (relu) {
+      o4.x = fmaxf(o4.x, 0.f);
+      o4.y = fmaxf(o4.y, 0.f);
+      o4.z = fmaxf(o4.z, 0.f);
+      o4.w = fmaxf(o4.w, 0.f);
+    }
     *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
   }
 }
@@ -322,7 +349,7 @@ int launch_conv(const ConvArgs& a, int grid_y, hipStream_t s) {
 template <int MODE>
 int dispatch_conv(ConvArgs& a, hipStream_t s) {
   const bool wide = a.W > 16;  // 4x32 patches for wide planes, 8x16 for the 16x15 bottleneck
-  const int taps_y = (MODE == 0) ? 1 : 4;
+  const int taps_y = (MODE == 1) ? 4 : 1;
   if (wide) {
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + 3) / 4;
@@ -356,7 +383,7 @@ int mfpa_conv3x3_bn_relu(const float* x0, int C0, const float* x1, int C1, int H
   a.C0 = C0; a.C1 = C1; a.H1 = C1 ? H1 : 0; a.W1 = C1 ? W1 : 0;
   a.oy1 = C1 ? (H - H1) / 2 : 0;  // F.pad(x1, [dx//2, dx-dx//2, dy//2, dy-dy//2]), unet.py:59-62
   a.ox1 = C1 ? (W - W1) / 2 : 0;
-  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu; a.yH = H; a.yW = W;
   return dispatch_conv<0>(a, mfpa_stream(stream));
 }
 
@@ -367,12 +394,36 @@ int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, 
   if (Cin < KC || Cin % KC || Cout < 64 || Cout % 64 || precision != 0) return MFPA_EINVAL;
   ConvArgs a{};
   a.x0 = x; a.w = w; a.scale = nullptr; a.shift = bias; a.y = y;
-  a.C0 = Cin; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 0;
+  a.C0 = Cin; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 0; a.yH = H; a.yW = W;
   return dispatch_conv<1>(a, mfpa_stream(stream));
 }
 
+int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
+  if (!d) return MFPA_EINVAL;
+  if (d->B == 0) return MFPA_OK;
+  if (!d->x0 || !d->w || !d->y || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
+  if (d->C0 < KC || d->C0 % KC || d->C1 < 0 || d->C1 % KC || d->Cout < 64 || d->Cout % 64) return MFPA_EINVAL;
+  if (d->mode < 0 || d->mode > 2) return MFPA_EINVAL;
+  if (d->C1 > 0 && (d->mode != 0 || !d->x1 || d->H1 < 1 || d->W1 < 1 || d->H1 > d->H || d->W1 > d->W)) return MFPA_EINVAL;
+  if ((d->in_scale0 == nullptr) != (d->in_shift0 == nullptr)) return MFPA_EINVAL;
+  ConvArgs a{};
+  a.x0 = d->x0; a.in_scale0 = d->in_scale0; a.in_shift0 = d->in_shift0;
+  a.x1 = d->C1 ? d->x1 : nullptr; a.w = d->w; a.scale = d->out_scale; a.shift = d->out_shift; a.y = d->y;
+  a.C0 = d->C0; a.C1 = d->C1; a.H1 = d->C1 ? d->H1 : 0; a.W1 = d->C1 ? d->W1 : 0;
+  a.oy1 = d->C1 ? (d->H - d->H1) / 2 : 0;
+  a.ox1 = d->C1 ? (d->W - d->W1) / 2 : 0;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.relu = d->relu;
+  a.yH = (d->mode != 1 && d->yH > 0) ? d->yH : d->H;
+  a.yW = (d->mode != 1 && d->yW > 0) ? d->yW : d->W;
+  if (a.yH > d->H || a.yW > d->W) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  if (d->mode == 0) return dispatch_conv<0>(a, s);
+  if (d->mode == 1) return dispatch_conv<1>(a, s);
+  return dispatch_conv<2>(a, s);
+}
+
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,
-                            int W, const float* w, int Cout, const float* scale, const float* shift, float* y,
+                            int W, const float* w, int Cout, const float* scale, const float* shift, int relu, float* y,
                             void* stream) {
   if (B == 0) return MFPA_OK;
   if ((!x32 && !spec64) || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
@@ -382,7 +433,7 @@ int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double
   long long blocks = (npix + ppb - 1) / ppb;
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x32, spec64, denom,
-                     per_clip, B, H, W, w, Cout, scale, shift, y);
+                     per_clip, B, H, W, w, Cout, scale, shift, relu, y);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

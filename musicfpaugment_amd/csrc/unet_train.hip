@@ -1,0 +1,735 @@
+// Training-step kernels of the UNet denoiser for MI355X (gfx950): the pieces of
+// Trainer.train_epoch's spec branch (training/train.py:257-317 of the reference) that are not the
+// convolution itself (csrc/unet.hip):
+//
+//   BatchNorm batch statistics + running-stat update, BN/ReLU/max-pool forward glue,
+//   BN/ReLU backward (reduce + apply), max-pool backward, weight gradients on MFMA,
+//   bias / OutConv gradients, L1 loss forward+backward, fused Adam.
+//
+// Design: a layer's BatchNorm+ReLU output is never materialised.  The convolution writes its raw
+// output z, one bandwidth pass reduces the batch statistics into a per-channel (scale, shift),
+// and every consumer (next conv, transposed conv, pool, weight-gradient kernel) applies
+// relu(z*scale+shift) while loading.  Reductions are two-stage float64 (per-workgroup partials,
+// then one finishing workgroup) so they are deterministic and independent of the grid.
+#include "mfpa_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RED_BLOCKS = 1024;
+
+// ------------------------------------------------------------------ per-channel sums over pixels
+// partial[(blk*C + c)*NV + v]: NV float64 sums per channel.  MODE 0: {sum z, sum z^2} (BN statistics);
+// MODE 1: {sum g, sum g*xhat} with g = dy*[z*scale+shift > 0], xhat = (z-mean)*invstd (BN backward);
+// MODE 2: {sum x} (bias gradient).
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                          long long npix, int C, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          double* __restrict__ partial) {
+  constexpr int NV = (MODE == 2) ? 1 : 2;
+  const int C4 = C / 4;
+  const int lanes = C4 < 256 ? C4 : 256;          // lanes across channel quads
+  const int rows = 256 / lanes;                   // pixels in flight per block
+  const int cq0 = threadIdx.x % lanes, prow = threadIdx.x / lanes;
+  __shared__ double sh[256 * 8];
+  for (int cq = cq0; cq < C4; cq += lanes) {
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    f32x4 sc = {0, 0, 0, 0}, sf = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+    if (MODE == 1) {
+      sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
+      sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
+      mu = *reinterpret_cast<const f32x4*>(mean + 4 * cq);
+      is = *reinterpret_cast<const f32x4*>(invstd + 4 * cq);
+    }
+    for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)p * C + 4 * cq);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s0[k] += (double)v[k];
+          s1[k] += (double)v[k] * (double)v[k];
+        }
+      } else if (MODE == 1) {
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * cq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float g = (zz[k] * sc[k] + sf[k] > 0.f) ? v[k] : 0.f;
+          const float xh = (zz[k] - mu[k]) * is[k];
+          s0[k] += (double)g;
+          s1[k] += (double)g * (double)xh;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s0[k] += (double)v[k];
+      }
+    }
+    // combine the `rows` pixel-rows of this block for channel quad cq
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sh[threadIdx.x * 8 + k] = s0[k];
+      sh[threadIdx.x * 8 + 4 + k] = s1[k];
+    }
+    __syncthreads();
+    if (prow == 0) {
+      for (int r = 1; r < rows; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s0[k] += sh[(r * lanes + cq0) * 8 + k];
+          s1[k] += sh[(r * lanes + cq0) * 8 + 4 + k];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double* dst = partial + ((size_t)blockIdx.x * C + 4 * cq + k) * NV;
+        dst[0] = s0[k];
+        if (NV == 2) dst[1] = s1[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// BN statistics finish: mean, biased var -> invstd, fused (scale, shift); running stats with momentum
+// (unbiased variance), exactly nn.BatchNorm2d in train mode (training/unet.py:17,20).
+__global__ void bn_stats_finish_kernel(const double* __restrict__ partial, int nblk, int C, double count, float eps,
+                                       float momentum, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ mean,
+                                       float* __restrict__ invstd, float* __restrict__ scale,
+                                       float* __restrict__ shift, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[((size_t)b * C + c) * 2];
+    ss += partial[((size_t)b * C + c) * 2 + 1];
+  }
+  const double m = s / count;
+  double var = ss / count - m * m;
+  if (var < 0) var = 0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  mean[c] = (float)m;
+  invstd[c] = (float)is;
+  const float sc = gamma[c] * (float)is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  if (running_mean) {
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+// BN backward finish: dgamma = sum g*xhat, dbeta = sum g; coefficients so that
+// dz = ka*g - kb - kc*xhat  with ka = gamma*invstd, kb = ka*dbeta/N, kc = ka*dgamma/N.
+__global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int nblk, int C, double count,
+                                     const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     float* __restrict__ coef /* [3][C] */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0, sgx = 0;
+  for (int b = 0; b < nblk; ++b) {
+    sg += partial[((size_t)b * C + c) * 2];
+    sgx += partial[((size_t)b * C + c) * 2 + 1];
+  }
+  dgamma[c] = (float)sgx;
+  dbeta[c] = (float)sg;
+  const double ka = (double)gamma[c] * (double)invstd[c];
+  coef[c] = (float)ka;
+  coef[C + c] = (float)(ka * sg / count);
+  coef[2 * C + c] = (float)(ka * sgx / count);
+}
+
+__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+
+// dy <- dz in place (BatchNorm + ReLU backward), all per-channel constants precomputed.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ z,
+                                                           long long npix, int C, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef) {
+  const int C4 = C / 4;
+  const long long total = npix * C4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int cq = (int)(e % C4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * cq);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + 4 * cq);
+    const f32x4 ka = *reinterpret_cast<const f32x4*>(coef + 4 * cq);
+    const f32x4 kb = *reinterpret_cast<const f32x4*>(coef + C + 4 * cq);
+    const f32x4 kc = *reinterpret_cast<const f32x4*>(coef + 2 * C + 4 * cq);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + e * 4);
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + e * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = (zz[k] * sc[k] + sf[k] > 0.f) ? g[k] : 0.f;
+      const float xh = (zz[k] - mu[k]) * is[k];
+      o[k] = ka[k] * gg - kb[k] - kc[k] * xh;
+    }
+    *reinterpret_cast<f32x4*>(dy + e * 4) = o;
+  }
+}
+
+// p = maxpool2(relu(z*scale+shift)), floor (unet.py:34 after the BN+ReLU of the DoubleConv).
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ z, int B, int H, int W, int C,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ p) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const long long total = (long long)B * Ho * Wo * C4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int cq = (int)(e % C4);
+    long long q = e / C4;
+    const int xo = (int)(q % Wo); q /= Wo;
+    const int yo = (int)(q % Ho);
+    const int b = (int)(q / Ho);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
+    const float* base = z + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * cq;
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};   // relu output is >= 0
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)(t >> 1) * W + (t & 1)) * C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float y = v[k] * sc[k] + sf[k];
+        m[k] = y > m[k] ? y : m[k];
+      }
+    }
+    *reinterpret_cast<f32x4*>(p + e * 4) = m;
+  }
+}
+
+// dy_full += route(dp): the gradient of a pooled cell goes to the first maximum of its 2x2 window of
+// y = relu(z*scale+shift) (scan order (0,0),(0,1),(1,0),(1,1), strict >), as torch's max_pool2d backward.
+__global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ z, int B, int H, int W, int C,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ dp, float* __restrict__ dy) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const long long total = (long long)B * Ho * Wo * C4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int cq = (int)(e % C4);
+    long long q = e / C4;
+    const int xo = (int)(q % Wo); q /= Wo;
+    const int yo = (int)(q % Ho);
+    const int b = (int)(q / Ho);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
+    const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * cq;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dp + e * 4);
+    float best[4];
+    int arg[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + base + ((size_t)(t >> 1) * W + (t & 1)) * C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float y = v[k] * sc[k] + sf[k];
+        y = y > 0.f ? y : 0.f;
+        if (t == 0 || y > best[k]) {
+          best[k] = y;
+          arg[k] = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float* d = dy + base + ((size_t)(t >> 1) * W + (t & 1)) * C;
+      f32x4 cur = *reinterpret_cast<f32x4*>(d);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] += (arg[k] == t) ? g[k] : 0.f;
+      *reinterpret_cast<f32x4*>(d) = cur;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weight gradient on MFMA
+// dW[tap][co][ci] += sum over pixels of dz[p][co] * xin[p + tap][ci]   (MODE 0, 3x3 conv, 9 taps)
+// dW[tap][co][ci] += sum over pixels of dup[2y+dy, 2x+dx][co] * xin[y,x][ci]   (MODE 1, transposed conv, 4 taps)
+// GEMM per tap: M = 64 output channels, N = 64 input channels, K = pixels.  A workgroup owns one 64x64
+// (co, ci) tile for ALL taps and walks 4x32-pixel patches (grid-strided over the batch): per patch the
+// dz tile and the haloed xin tile are staged in LDS pixel-major (the natural NHWC order, so no transpose:
+// MFMA lanes read 32 consecutive channels of one pixel with ds_read_b32); each wave keeps one 32x32
+// accumulator per tap (9 x 16 VGPRs) and the A fragment of a k-step is reused by all taps.  Partial sums
+// are added to dW with one float atomic per element per workgroup (256-B contiguous segments).
+struct WgradArgs {
+  const float* dz;        // MODE 0: (B,H,W,Cout);  MODE 1: (B,2H,2W,Cout)
+  const float* x0;        // (B,H,W,C0)
+  const float* in_scale0; // optional affine+ReLU on load for x0
+  const float* in_shift0;
+  const float* x1;        // (B,H1,W1,C1) zero-padded (MODE 0 only)
+  float* dw;              // [taps][Cout][C0+C1]
+  int C0, C1, H1, W1, oy1, ox1;
+  int B, H, W, Cout;
+  int tiles_x, tiles_y;
+};
+
+constexpr int WG_PH = 4, WG_PW = 32, WG_PIX = 128, WG_T = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgradArgs a) {
+  constexpr int HALO = (MODE == 0) ? 1 : 0;
+  constexpr int TAPS = (MODE == 0) ? 9 : 4;
+  constexpr int HPW = WG_PW + 2 * HALO, HPH = WG_PH + 2 * HALO, HP = HPW * HPH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ds = reinterpret_cast<float*>(smem);   // [128][64]  dz tile (pixel-major)
+  float* Xs = Ds + WG_PIX * WG_T;               // [HP][64]   xin tile with halo (pixel-major)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cot = wave & 1, cit = wave >> 1;
+  const int co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T;
+  const int Cin = a.C0 + a.C1;
+  const bool from0 = ci0 < a.C0;
+  const long long npatch = (long long)a.B * a.tiles_x * a.tiles_y;
+
+  floatx16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (long long patch = blockIdx.z; patch < npatch; patch += gridDim.z) {
+    long long q = patch;
+    const int tx = (int)(q % a.tiles_x); q /= a.tiles_x;
+    const int ty = (int)(q % a.tiles_y);
+    const int b = (int)(q / a.tiles_y);
+    const int y0 = ty * WG_PH, x0p = tx * WG_PW;
+    __syncthreads();   // previous patch's fragment reads are done
+    // stage xin (+halo): HP pixels x 64 channels
+    for (int idx = tid; idx < HP * (WG_T / 4); idx += 256) {
+      const int pix = idx / (WG_T / 4), c4 = idx % (WG_T / 4);
+      const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        if (from0) {
+          v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4);
+          if (a.in_scale0) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + ci0 + 4 * c4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + ci0 + 4 * c4);
+            v = v * sc + sh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+          }
+        } else {
+          const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+          if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
+            v = *reinterpret_cast<const f32x4*>(a.x1 + (((size_t)b * a.H1 + y1) * a.W1 + x1) * a.C1 + (ci0 - a.C0) + 4 * c4);
+        }
+      }
+      *reinterpret_cast<f32x4*>(Xs + pix * WG_T + 4 * c4) = v;
+    }
+    for (int tap = 0; tap < (MODE == 0 ? 1 : TAPS); ++tap) {
+      if (MODE == 1 && tap > 0) __syncthreads();
+      // stage dz: 128 pixels x 64 channels (MODE 1: the tap's strided view of the upsampled gradient)
+      for (int idx = tid; idx < WG_PIX * (WG_T / 4); idx += 256) {
+        const int pix = idx / (WG_T / 4), c4 = idx % (WG_T / 4);
+        const int gy = y0 + pix / WG_PW, gx = x0p + pix % WG_PW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy < a.H && gx < a.W) {
+          if (MODE == 0)
+            v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
+          else
+            v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)b * (2 * a.H) + 2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout + co0 + 4 * c4);
+        }
+        *reinterpret_cast<f32x4*>(Ds + pix * WG_T + 4 * c4) = v;
+      }
+      __syncthreads();
+      const float* Ap = Ds + cot * 32 + li;
+      const float* Bp = Xs + cit * 32 + li;
+#pragma unroll 4
+      for (int k0 = 0; k0 < WG_PIX; k0 += 2) {
+        const int m = k0 + lh;
+        const float av = Ap[m * WG_T];
+        const int hb = ((m / WG_PW) * HPW + (m % WG_PW)) * WG_T;
+        if (MODE == 0) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const float bv = Bp[hb + ((t / 3) * HPW + (t % 3)) * WG_T];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+          }
+        } else {
+          const float bv = Bp[hb];
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t)
+            if (t == tap) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[row = co][col = ci]
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int ci = ci0 + cit * 32 + li;
+      atomicAdd(a.dw + ((size_t)t * a.Cout + co) * Cin + ci, acc[t][r]);
+    }
+}
+
+// First layer weight gradient (1 input channel): dW[tap][co] += sum_p dz[p][co] * x[p + tap].
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const float* __restrict__ dz, const float* __restrict__ x32,
+                                                       const double* __restrict__ spec64,
+                                                       const double* __restrict__ denom, int B, int H, int W, int Cout,
+                                                       float* __restrict__ dw) {
+  const int lanes = Cout / 4, rows = 256 / lanes;
+  const int cq = threadIdx.x % lanes, prow = threadIdx.x / lanes;
+  float acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[t][k] = 0.f;
+  const long long npix = (long long)B * H * W;
+  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
+    const int gx = (int)(p % W), gy = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (size_t)p * Cout + 4 * cq);
+    const double den = (spec64 && denom) ? denom[b] : 1.0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const size_t o = ((size_t)b * H + yy) * W + xx;
+        v = spec64 ? (float)(spec64[o] / den) : x32[o];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[t][k] += g[k] * v;
+    }
+  }
+  __shared__ float sh[256 * 36];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[threadIdx.x * 36 + t * 4 + k] = acc[t][k];
+  __syncthreads();
+  if (prow == 0) {
+    for (int r = 1; r < rows; ++r)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t][k] += sh[(r * lanes + cq) * 36 + t * 4 + k];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(dw + (size_t)t * Cout + 4 * cq + k, acc[t][k]);
+  }
+}
+
+// ------------------------------------------------------------------ OutConv (1x1 -> 1 class) in training
+// pred[p] = sum_c relu(z[p][c]*scale[c]+shift[c]) * w[c] + bias
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ z, long long npix, int C,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ pred) {
+  const int lpp = C / 4, sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * sub);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * sub);
+  const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * sub);
+  const float b0 = bias[0];
+  const long long iters = (npix + (long long)gridDim.x * ppb - 1) / ((long long)gridDim.x * ppb);
+  for (long long it = 0; it < iters; ++it) {
+    const long long p = (it * gridDim.x + blockIdx.x) * ppb + pl;
+    float s = 0.f;
+    if (p < npix) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * sub);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float y = v[k] * sc[k] + sf[k];
+        s += (y > 0.f ? y : 0.f) * wv[k];
+      }
+    }
+    for (int o = lpp >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (sub == 0 && p < npix) pred[p] = s + b0;
+  }
+}
+
+// dy[p][c] = dpred[p]*w[c];  partial[blk][c] = sum_p dpred[p]*y[p][c] (c < C), partial[blk][C] = sum_p dpred[p]
+__global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpred,
+                                                          long long npix, int C, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ w,
+                                                          float* __restrict__ dy, double* __restrict__ partial) {
+  const int lpp = C / 4, sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
+  const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * sub);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * sub);
+  const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * sub);
+  double sw[4] = {0, 0, 0, 0}, sb = 0;
+  for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
+    const float g = dpred[p];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * sub);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float y = v[k] * sc[k] + sf[k];
+      sw[k] += (double)g * (double)(y > 0.f ? y : 0.f);
+      o[k] = g * wv[k];
+    }
+    *reinterpret_cast<f32x4*>(dy + (size_t)p * C + 4 * sub) = o;
+    if (sub == 0) sb += (double)g;
+  }
+  __shared__ double sh[256 * 5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[threadIdx.x * 5 + k] = sw[k];
+  sh[threadIdx.x * 5 + 4] = sb;
+  __syncthreads();
+  if (pl == 0) {
+    for (int r = 1; r < ppb; ++r) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sw[k] += sh[(r * lpp + sub) * 5 + k];
+      if (sub == 0) sb += sh[(r * lpp) * 5 + 4];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) partial[(size_t)blockIdx.x * (C + 1) + 4 * sub + k] = sw[k];
+    if (sub == 0) partial[(size_t)blockIdx.x * (C + 1) + C] = sb;
+  }
+}
+
+// ------------------------------------------------------------------ L1 loss (mean), float32 pred vs float64 target
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred, const double* __restrict__ target,
+                                                 long long n, float* __restrict__ dpred, double* __restrict__ partial) {
+  double s = 0;
+  const float inv = (float)(1.0 / (double)n);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double d = (double)pred[i] - target[i];
+    s += fabs(d);
+    if (dpred) dpred[i] = d > 0 ? inv : (d < 0 ? -inv : 0.f);
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ void l1_finish_kernel(const double* __restrict__ partial, int nblk, long long n, double* __restrict__ loss) {
+  __shared__ double sh[256];
+  double s = 0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = sh[0] / (double)n;
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam, no weight decay, no amsgrad)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float grad_scale) {
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+inline int grid_for(long long work, int per_block = 256, int cap = 256 * 16) {
+  long long b = (work + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfpa_red_blocks(void) { return RED_BLOCKS; }
+
+int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, const float* beta, float eps,
+                  float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                  float* running_var, double* workspace, void* stream) {
+  if (npix == 0) return MFPA_OK;
+  if (!z || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace) return MFPA_EINVAL;
+  if (npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
+  const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
+                     nullptr, nullptr, workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, (double)npix,
+                     eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                     float* coef, double* workspace, void* stream) {
+  if (npix == 0) return MFPA_OK;
+  if (!dy || !z || !gamma || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace) return MFPA_EINVAL;
+  if (npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
+  const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, z, npix, C, scale, shift, mean, invstd,
+                     workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, (double)npix,
+                     gamma, invstd, dgamma, dbeta, coef);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
+                     mean, invstd, coef);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream) {
+  if (npix == 0) return MFPA_OK;
+  if (!x || !out || !workspace || npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
+  const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(nblk), dim3(256), 0, s, x, nullptr, npix, C, nullptr, nullptr, nullptr,
+                     nullptr, workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, out);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, float* p,
+                      void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!z || !scale || !shift || !p || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(total)), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C, scale,
+                     shift, p);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const float* scale, const float* shift,
+                          const float* dp, float* dy, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!z || !scale || !shift || !dp || !dy || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(grid_for(total)), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
+                     scale, shift, dp, dy);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
+  if (!d) return MFPA_EINVAL;
+  if (d->B == 0) return MFPA_OK;
+  if (!d->dz || !d->x0 || !d->dw || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
+  if (d->C0 < 64 || d->C0 % 64 || d->C1 < 0 || d->C1 % 64 || d->Cout < 64 || d->Cout % 64) return MFPA_EINVAL;
+  if (d->mode != 0 && d->mode != 1) return MFPA_EINVAL;
+  if (d->C1 > 0 && (d->mode != 0 || !d->x1 || d->H1 < 1 || d->W1 < 1 || d->H1 > d->H || d->W1 > d->W)) return MFPA_EINVAL;
+  if ((d->in_scale0 == nullptr) != (d->in_shift0 == nullptr)) return MFPA_EINVAL;
+  WgradArgs a{};
+  a.dz = d->dz; a.x0 = d->x0; a.in_scale0 = d->in_scale0; a.in_shift0 = d->in_shift0;
+  a.x1 = d->C1 ? d->x1 : nullptr; a.dw = d->dw;
+  a.C0 = d->C0; a.C1 = d->C1; a.H1 = d->C1 ? d->H1 : 0; a.W1 = d->C1 ? d->W1 : 0;
+  a.oy1 = d->C1 ? (d->H - d->H1) / 2 : 0;
+  a.ox1 = d->C1 ? (d->W - d->W1) / 2 : 0;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.tiles_x = (d->W + WG_PW - 1) / WG_PW;
+  a.tiles_y = (d->H + WG_PH - 1) / WG_PH;
+  const long long npatch = (long long)a.B * a.tiles_x * a.tiles_y;
+  const int tiles = (d->Cout / WG_T) * ((d->C0 + d->C1) / WG_T);
+  long long split = (2048 + tiles - 1) / tiles;   // ~2048 workgroups in flight in total
+  if (split > npatch) split = npatch;
+  if (split < 1) split = 1;
+  if (split > 65535) split = 65535;
+  dim3 grid(d->Cout / WG_T, (d->C0 + d->C1) / WG_T, (unsigned)split);
+  hipStream_t s = mfpa_stream(stream);
+  if (d->mode == 0) {
+    const size_t lds = sizeof(float) * ((size_t)WG_PIX * WG_T + (size_t)(WG_PH + 2) * (WG_PW + 2) * WG_T);
+    hipLaunchKernelGGL(wgrad_mfma_kernel<0>, grid, dim3(256), lds, s, a);
+  } else {
+    const size_t lds = sizeof(float) * ((size_t)WG_PIX * WG_T + (size_t)WG_PH * WG_PW * WG_T);
+    hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
+  }
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_wgrad_c1(const float* dz, const float* x32, const double* spec64, const double* denom, int B, int H, int W,
+                  int Cout, float* dw, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!dz || (!x32 && !spec64) || !dw || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
+  if (Cout % 4 || Cout < 4 || Cout > 1024 || (256 % (Cout / 4)) != 0) return MFPA_EINVAL;
+  const long long npix = (long long)B * H * W;
+  const int rows = 256 / (Cout / 4);
+  hipLaunchKernelGGL(wgrad_c1_kernel, dim3(grid_for(npix, rows * 16, 2048)), dim3(256), 0, mfpa_stream(stream), dz, x32,
+                     spec64, denom, B, H, W, Cout, dw);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_outconv_fwd(const float* z, long long npix, int C, const float* scale, const float* shift, const float* w,
+                     const float* bias, float* pred, void* stream) {
+  if (npix == 0) return MFPA_OK;
+  if (!z || !scale || !shift || !w || !bias || !pred || npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
+  hipLaunchKernelGGL(outconv_fwd_kernel, dim3(grid_for(npix, 256 / (C / 4), 256 * 32)), dim3(256), 0,
+                     mfpa_stream(stream), z, npix, C, scale, shift, w, bias, pred);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, const float* scale, const float* shift,
+                     const float* w, float* dy, float* dwb, double* workspace, void* stream) {
+  if (npix == 0) return MFPA_OK;
+  if (!z || !dpred || !scale || !shift || !w || !dy || !dwb || !workspace) return MFPA_EINVAL;
+  if (npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int nblk = grid_for(npix, (256 / (C / 4)) * 16, RED_BLOCKS);
+  hipLaunchKernelGGL(outconv_bwd_kernel, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, dy, workspace);
+  MFPA_CHECK_LAUNCH();
+  // finish: column sums of the (nblk, C+1) partial matrix: C weight gradients then the bias gradient
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dpred, double* loss, double* workspace,
+                 void* stream) {
+  if (!pred || !target || !loss || !workspace || n <= 0) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int nblk = grid_for(n, 256 * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(l1_kernel, dim3(nblk), dim3(256), 0, s, pred, target, n, dpred, workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, s, workspace, nblk, n, loss);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, void* stream) {
+  if (n == 0) return MFPA_OK;
+  if (!p || !g || !m || !v || n < 0 || step < 1) return MFPA_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256 * 4, 256 * 16)), dim3(256), 0, mfpa_stream(stream), p, g, m, v, n,
+                     lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,388 @@
+"""UNet training step on MI355X: forward (train mode) + L1 + backward + Adam over the C ABI.
+
+Reference: Trainer.train_epoch, spec branch, training/train.py:257-317 -- spectrogram(clean),
+spectrogram(aug), pred = UNet(aug.float()), L1Loss(pred, clean_f64), zero_grad / backward / Adam.step.
+
+torch autograd is not used.  The engine owns ONE flat float32 buffer of all 31,036,481 parameters in
+kernel layout (conv weights [tap][Cout][Cin]) laid out in the order the backward pass finishes them
+(outc, up4 ... up1, down4 ... inc), with matching flat gradient / Adam-moment buffers: gradients of a
+block form a contiguous bucket that can be all-reduced (RCCL) while earlier layers are still in
+backward, and Adam is one fused launch over the whole buffer.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ._lib import ConvDesc, WgradDesc, check, lib, ptr, stream
+from . import ops_unet as K
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+ENC = K.ENC
+DEC = K.DEC
+ENC_CH = [(1, 64), (64, 128), (128, 256), (256, 512), (512, 1024)]
+DEC_CH = [(1024, 512), (512, 256), (256, 128), (128, 64)]
+
+
+# ----------------------------------------------------------------------------- thin kernel wrappers
+class Stats:
+    """Per-channel batch statistics of one BatchNorm layer: mean, invstd and the fused scale/shift."""
+
+    def __init__(self, C, device):
+        buf = torch.empty((4, C), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
+              relu=False, out_hw: Optional[Tuple[int, int]] = None):
+    """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output."""
+    B = x0.shape[0]
+    if mode == 2:
+        H, W = x0.shape[1] // 2, x0.shape[2] // 2
+    else:
+        H, W = x0.shape[1], x0.shape[2]
+    C0 = x0.shape[3]
+    C1 = 0 if x1 is None else x1.shape[3]
+    if mode == 1:
+        oh, ow = 2 * H, 2 * W
+    else:
+        oh, ow = out_hw if out_hw is not None else (H, W)
+    y = torch.empty((B, oh, ow, Cout), dtype=torch.float32, device=x0.device)
+    d = ConvDesc(x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
+                 in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), w=ptr(w),
+                 out_scale=ptr(out_scale), out_shift=ptr(out_shift), y=ptr(y), C0=C0, C1=C1,
+                 H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
+                 B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
+                 mode=mode)
+    t0 = K._TIMER.start() if K._TIMER is not None else None
+    check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
+    if t0 is not None:
+        K._TIMER.stop(t0)
+    return y
+
+
+def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None):
+    B, H, W, C0 = x0.shape
+    d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
+                  in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), dw=ptr(dw), C0=C0,
+                  C1=0 if x1 is None else x1.shape[3], H1=0 if x1 is None else x1.shape[1],
+                  W1=0 if x1 is None else x1.shape[2], B=B, H=H, W=W, Cout=Cout, mode=mode)
+    t0 = K._TIMER.start() if K._TIMER is not None else None
+    check(lib().mfpa_wgrad_mfma(ctypes.byref(d), stream()), "mfpa_wgrad_mfma")
+    if t0 is not None:
+        K._TIMER.stop(t0)
+
+
+def _npix(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+# ----------------------------------------------------------------------------- the engine
+class UNetTrainEngine:
+    """Owns kernel-layout master parameters, gradients and Adam moments of a UNet(1, 1) and runs train steps."""
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.module = module
+        self.device = next(module.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("the training engine runs on the MI355X only")
+        rate = module.dropout.p
+        if rate != 0:
+            raise NotImplementedError("Dropout(rate>0) in the HIP training step is not built yet "
+                                      "(reference trains with rate 0.05, training/train.py:646); use rate=0")
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.group = process_group
+        self._layout()
+        self.load_from_module()
+        self.workspace = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device=self.device)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ flat layout (backward completion order)
+    def _layout(self):
+        segs: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            n = 1
+            for s in shape:
+                n *= s
+            segs[name] = (off, tuple(shape))
+            off += n
+
+        def dconv(prefix, cin, cout, first=False):
+            # reverse order inside the block too: second conv finishes first
+            add(prefix + ".3.w", (9, cout, cout)); add(prefix + ".4.g", (cout,)); add(prefix + ".4.b", (cout,))
+            add(prefix + ".0.w", (9, cout) if first else (9, cout, cin)); add(prefix + ".1.g", (cout,)); add(prefix + ".1.b", (cout,))
+
+        self.buckets: List[Tuple[str, int, int]] = []
+        start = off
+        add("outc.wb", (65,))                       # 64 weights + bias
+        for name, (cin, cout) in zip(reversed(DEC), reversed(DEC_CH)):      # up4, up3, up2, up1
+            dconv(name + ".conv.double_conv", cin, cout)
+            add(name + ".up.w", (4, cin // 2, cin)); add(name + ".up.b", (cin // 2,))
+            self.buckets.append((name, start, off)); start = off
+        for name, (cin, cout) in zip(reversed(ENC), reversed(ENC_CH)):      # down4 ... inc
+            dconv(name, cin, cout, first=(cin == 1))
+            self.buckets.append((name, start, off)); start = off
+        self.segs, self.n_params = segs, off
+        dev = self.device
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.P = {k: self.flat_p[o:o + self._n(s)].view(s) for k, (o, s) in segs.items()}
+        self.G = {k: self.flat_g[o:o + self._n(s)].view(s) for k, (o, s) in segs.items()}
+        self.running: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def _n(shape):
+        n = 1
+        for s in shape:
+            n *= s
+        return n
+
+    # ------------------------------------------------------------------ module <-> engine
+    def _bn_names(self, prefix):
+        return [(prefix + ".1", prefix + ".1.g", prefix + ".1.b"), (prefix + ".4", prefix + ".4.g", prefix + ".4.b")]
+
+    def load_from_module(self):
+        sd = self.module.state_dict()
+        with torch.no_grad():
+            for i, p in enumerate(ENC + [d + ".conv.double_conv" for d in DEC]):
+                w0 = sd[p + ".0.weight"].float()
+                if w0.shape[1] == 1:
+                    self.P[p + ".0.w"].copy_(w0.permute(2, 3, 1, 0).reshape(9, w0.shape[0]))
+                else:
+                    self.P[p + ".0.w"].copy_(K.pack_conv3x3(w0))
+                self.P[p + ".3.w"].copy_(K.pack_conv3x3(sd[p + ".3.weight"]))
+                for bn, g, b in self._bn_names(p):
+                    self.P[g].copy_(sd[bn + ".weight"]); self.P[b].copy_(sd[bn + ".bias"])
+                    self.running[bn + ".running_mean"] = sd[bn + ".running_mean"].float().clone()
+                    self.running[bn + ".running_var"] = sd[bn + ".running_var"].float().clone()
+            for d in DEC:
+                self.P[d + ".up.w"].copy_(K.pack_convT2x2(sd[d + ".up.weight"]))
+                self.P[d + ".up.b"].copy_(sd[d + ".up.bias"])
+            self.P["outc.wb"][:64].copy_(sd["outc.conv.weight"].reshape(-1))
+            self.P["outc.wb"][64:].copy_(sd["outc.conv.bias"].reshape(-1))
+
+    def sync_to_module(self):
+        """Write the master parameters / running statistics back into the nn.Module (reference key layout)."""
+        m = self.module
+        sd = m.state_dict()
+        with torch.no_grad():
+            for p in ENC + [d + ".conv.double_conv" for d in DEC]:
+                w0 = self.P[p + ".0.w"]
+                if w0.dim() == 2:
+                    sd[p + ".0.weight"].copy_(w0.view(3, 3, 1, -1).permute(3, 2, 0, 1))
+                else:
+                    sd[p + ".0.weight"].copy_(w0.view(3, 3, w0.shape[1], w0.shape[2]).permute(2, 3, 0, 1))
+                w3 = self.P[p + ".3.w"]
+                sd[p + ".3.weight"].copy_(w3.view(3, 3, w3.shape[1], w3.shape[2]).permute(2, 3, 0, 1))
+                for bn, g, b in self._bn_names(p):
+                    sd[bn + ".weight"].copy_(self.P[g]); sd[bn + ".bias"].copy_(self.P[b])
+                    sd[bn + ".running_mean"].copy_(self.running[bn + ".running_mean"])
+                    sd[bn + ".running_var"].copy_(self.running[bn + ".running_var"])
+                    sd[bn + ".num_batches_tracked"].fill_(self.step_count)
+            for d in DEC:
+                wu = self.P[d + ".up.w"]
+                sd[d + ".up.weight"].copy_(wu.view(2, 2, wu.shape[1], wu.shape[2]).permute(3, 2, 0, 1))
+                sd[d + ".up.bias"].copy_(self.P[d + ".up.b"])
+            sd["outc.conv.weight"].copy_(self.P["outc.wb"][:64].view(1, 64, 1, 1))
+            sd["outc.conv.bias"].copy_(self.P["outc.wb"][64:])
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        """Gradients re-laid-out under the reference's parameter names (tests / inspection)."""
+        out = {}
+        for p in ENC + [d + ".conv.double_conv" for d in DEC]:
+            g0 = self.G[p + ".0.w"]
+            out[p + ".0.weight"] = (g0.view(3, 3, 1, -1).permute(3, 2, 0, 1) if g0.dim() == 2
+                                    else g0.view(3, 3, g0.shape[1], g0.shape[2]).permute(2, 3, 0, 1)).contiguous()
+            g3 = self.G[p + ".3.w"]
+            out[p + ".3.weight"] = g3.view(3, 3, g3.shape[1], g3.shape[2]).permute(2, 3, 0, 1).contiguous()
+            for bn, g, b in self._bn_names(p):
+                out[bn + ".weight"] = self.G[g]; out[bn + ".bias"] = self.G[b]
+        for d in DEC:
+            gu = self.G[d + ".up.w"]
+            out[d + ".up.weight"] = gu.view(2, 2, gu.shape[1], gu.shape[2]).permute(3, 2, 0, 1).contiguous()
+            out[d + ".up.bias"] = self.G[d + ".up.b"]
+        out["outc.conv.weight"] = self.G["outc.wb"][:64].view(1, 64, 1, 1)
+        out["outc.conv.bias"] = self.G["outc.wb"][64:]
+        return out
+
+    # ------------------------------------------------------------------ kernels with engine state
+    def _bn_stats(self, z, bn, g, b) -> Stats:
+        C = z.shape[-1]
+        st = Stats(C, z.device)
+        check(lib().mfpa_bn_stats(ptr(z), _npix(z), C, ptr(self.P[g]), ptr(self.P[b]), BN_EPS, BN_MOMENTUM, ptr(st.mean),
+                                  ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(self.running[bn + ".running_mean"]),
+                                  ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
+        return st
+
+    def _bn_relu_bwd(self, dy, z, st: Stats, g, b):
+        C = z.shape[-1]
+        coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
+        check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
+                                     ptr(st.mean), ptr(st.invstd), ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
+                                     ptr(self.workspace), stream()), "mfpa_bn_relu_bwd")
+        return dy
+
+    # ------------------------------------------------------------------ forward (train mode)
+    def _dconv_fwd(self, prefix, src0, aff0: Optional[Stats], src1=None, first_input=None):
+        cout = self.P[prefix + ".3.w"].shape[1]
+        if first_input is not None:
+            x32, spec64, denom = first_input
+            z0 = K.conv3x3_c1_bn_relu(self.P[prefix + ".0.w"], None, None, x32=x32, spec64=spec64, denom=denom,
+                                      per_clip=True, relu=False)
+        else:
+            z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1)
+        st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b")
+        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0)
+        st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b")
+        return dict(prefix=prefix, src0=src0, aff0=aff0, src1=src1, first_input=first_input, z0=z0, st0=st0, z3=z3, st3=st3)
+
+    def forward(self, x32=None, spec64=None, denom=None):
+        """Train-mode forward.  Input (B,F,T): float32 spectrogram, or raw float64 |STFT| + per-clip denominators
+        (the divide + .float() of train.py:264-272 is fused into the first conv).  Returns pred (B,F,T) float32."""
+        recs = {}
+        r = self._dconv_fwd(ENC[0], None, None, first_input=(x32, spec64, denom))
+        recs["inc"] = r
+        prev = r
+        for name in ENC[1:]:
+            z, st = prev["z3"], prev["st3"]
+            B, H, W, C = z.shape
+            p = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=z.device)
+            check(lib().mfpa_bn_relu_pool(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(p), stream()),
+                  "mfpa_bn_relu_pool")
+            r = self._dconv_fwd(name, p, None)
+            recs[name] = r
+            prev = r
+        skips = [recs[ENC[3]], recs[ENC[2]], recs[ENC[1]], recs["inc"]]
+        for name, skip in zip(DEC, skips):
+            u = conv_mfma(prev["z3"], self.P[name + ".up.w"], self.P[name + ".up.w"].shape[1], mode=1,
+                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"])
+            if skip["z3"].shape[1] - u.shape[1] > 1 or skip["z3"].shape[2] - u.shape[2] > 1:
+                raise NotImplementedError("skip/upsample size difference > 1 (needs top/left padding offsets)")
+            r = self._dconv_fwd(name + ".conv.double_conv", skip["z3"], skip["st3"], src1=u)
+            r["up_in"], r["up_name"], r["u"] = prev, name, u
+            recs[name] = r
+            prev = r
+        z, st = prev["z3"], prev["st3"]
+        pred = torch.empty(z.shape[:3], dtype=torch.float32, device=z.device)
+        wb = self.P["outc.wb"]
+        check(lib().mfpa_outconv_fwd(ptr(z), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(wb), ptr(wb[64:]),
+                                     ptr(pred), stream()), "mfpa_outconv_fwd")
+        self._recs = recs
+        return pred
+
+    # ------------------------------------------------------------------ backward
+    def _dconv_bwd(self, r, dy, need_input_grad=True):
+        """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1)."""
+        prefix = r["prefix"]
+        cout = r["z3"].shape[-1]
+        dz3 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b")
+        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"])
+        wt3 = self.P[prefix + ".3.w"].flip(0).transpose(1, 2).contiguous()          # [tap'][ci][co]
+        dmid = conv_mfma(dz3, wt3, cout)
+        del dz3
+        dz0 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b")
+        if r["first_input"] is not None:
+            x32, spec64, denom = r["first_input"]
+            B, H, W, C = dz0.shape
+            check(lib().mfpa_wgrad_c1(ptr(dz0), ptr(x32), ptr(spec64), ptr(denom), B, H, W, C, ptr(self.G[prefix + ".0.w"]),
+                                      stream()), "mfpa_wgrad_c1")
+            return None, None
+        wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"])
+        if not need_input_grad:
+            return None, None
+        w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
+        wt0 = w0.flip(0).transpose(1, 2)                                            # (9, cin, cout) view
+        c0 = r["src0"].shape[-1]
+        d0 = conv_mfma(dz0, wt0[:, :c0].contiguous(), c0)
+        d1 = None
+        if r["src1"] is not None:
+            c1 = r["src1"].shape[-1]
+            d1 = conv_mfma(dz0, wt0[:, c0:].contiguous(), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]))
+        return d0, d1
+
+    def backward(self, dpred):
+        recs = self._recs
+        self.flat_g.zero_()
+        last = recs[DEC[-1]]
+        z, st = last["z3"], last["st3"]
+        dy = torch.empty_like(z)
+        wb = self.P["outc.wb"]
+        check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(wb), ptr(dy),
+                                     ptr(self.G["outc.wb"]), ptr(self.workspace), stream()), "mfpa_outconv_bwd")
+        handles = []
+        dskip = {}
+        enc_of_dec = {DEC[0]: ENC[3], DEC[1]: ENC[2], DEC[2]: ENC[1], DEC[3]: ENC[0]}
+        for name in reversed(DEC):                                                  # up4 ... up1
+            r = recs[name]
+            d_skip, d_u = self._dconv_bwd(r, dy)
+            dskip[enc_of_dec[name]] = d_skip
+            # transposed conv: bias, weight and input gradients
+            cout = d_u.shape[-1]
+            check(lib().mfpa_colsum(ptr(d_u), _npix(d_u), cout, ptr(self.G[name + ".up.b"]), ptr(self.workspace),
+                                    stream()), "mfpa_colsum")
+            prev = r["up_in"]
+            wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"])
+            wt = self.P[name + ".up.w"].transpose(1, 2).contiguous()                # (4, cin, cout)
+            dy = conv_mfma(d_u, wt, wt.shape[1], mode=2)
+            handles.append(self._reduce_bucket(name))
+        for i in range(len(ENC) - 1, -1, -1):                                       # down4 ... inc
+            name = ENC[i]
+            r = recs[name if i else "inc"]
+            d_p, _ = self._dconv_bwd(r, dy)
+            if i:
+                below = recs[ENC[i - 1] if i - 1 else "inc"]
+                dy = dskip[ENC[i - 1]]
+                z, st = below["z3"], below["st3"]
+                B, H, W, C = z.shape
+                check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
+                                                  stream()), "mfpa_maxpool2_bwd_add")
+            handles.append(self._reduce_bucket(name))
+        for h in handles:
+            if h is not None:
+                h.wait()
+        self._recs = None
+
+    def _reduce_bucket(self, name):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return None
+        for bname, s, e in self.buckets:
+            if bname == name:
+                return dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    # ------------------------------------------------------------------ loss / optimiser / step
+    def l1_loss(self, pred, target64, want_grad=True):
+        n = pred.numel()
+        dpred = torch.empty_like(pred) if want_grad else None
+        check(lib().mfpa_l1_loss(ptr(pred), ptr(target64), n, ptr(dpred), ptr(self.loss), ptr(self.workspace), stream()),
+              "mfpa_l1_loss")
+        return self.loss, dpred
+
+    def optimizer_step(self):
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        self.step_count += 1
+        check(lib().mfpa_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), self.n_params,
+                                   self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world,
+                                   stream()), "mfpa_adam_step")
+
+    def train_step(self, aug_spec64, aug_denom, clean_spec64):
+        """One optimisation step on spectrograms: aug_spec64 raw float64 |STFT| (B,F,T) with its normaliser
+        aug_denom (B,), clean_spec64 the normalised float64 target.  Returns the loss (device float64 scalar)."""
+        pred = self.forward(spec64=aug_spec64, denom=aug_denom)
+        loss, dpred = self.l1_loss(pred, clean_spec64)
+        self.backward(dpred)
+        self.optimizer_step()
+        return loss

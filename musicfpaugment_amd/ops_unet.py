@@ -111,13 +111,13 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
     return y
 
 
-def conv3x3_c1_bn_relu(w, scale, shift, x32=None, spec64=None, denom=None, per_clip=True):
+def conv3x3_c1_bn_relu(w, scale, shift, x32=None, spec64=None, denom=None, per_clip=True, relu=True):
     src = x32 if x32 is not None else spec64
     B, H, W = src.shape
     Cout = w.shape[1]
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=src.device)
     check(lib().mfpa_conv3x3_c1_bn_relu(ptr(x32), ptr(spec64), ptr(denom), int(per_clip), B, H, W, ptr(w), Cout,
-                                        ptr(scale), ptr(shift), ptr(y), stream()), "mfpa_conv3x3_c1_bn_relu")
+                                        ptr(scale), ptr(shift), int(relu), ptr(y), stream()), "mfpa_conv3x3_c1_bn_relu")
     return y
 
 
