@@ -80,6 +80,75 @@ def cpu_baseline(budget_s: float, seed: int):
                       f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
 
 
+def bench_train(args, rank, world, dev, dist):
+    """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips (dropout 0), fp32 MFMA."""
+    from musicfpaugment_amd import ops, ops_unet, synth
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict
+
+    B = args.clips
+    net = UNet(1, 1, rate=0.0)
+    net.load_state_dict(formula_state_dict(0))
+    net = net.to(dev).train()
+    eng = UNetTrainEngine(net, lr=1e-3)
+    base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank)
+    noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False)
+    reps = (B + len(base) - 1) // len(base)
+    clean = np.concatenate([base] * reps)[:B]
+    aug = np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * reps)[:B]
+    clean, aug = torch.from_numpy(clean).to(dev), torch.from_numpy(aug).to(dev)
+
+    def step():
+        cm, cmax = ops.stft_mag(clean, torch.float64)
+        am, amax = ops.stft_mag(aug, torch.float64)
+        gmax_c, gmax_a = cmax.max(), amax.max()           # spectrogram(): one max over the (global) batch
+        if dist is not None:
+            dist.all_reduce(gmax_c, op=dist.ReduceOp.MAX)
+            dist.all_reduce(gmax_a, op=dist.ReduceOp.MAX)
+        ops.normalize_(cm, gmax_c.expand(B).contiguous(), per_clip=True)
+        return eng.train_step(am, gmax_a.expand(B).contiguous(), cm)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    timer = ops_unet.KernelTimer()
+    ops_unet.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops_unet.set_timer(None)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    if rank == 0:
+        mfma_gflop = 280.1 - 3 * 0.082               # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU)
+        conv_ms = timer.total_ms()
+        achieved = mfma_gflop * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "8s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
+            "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UNet(1,1,rate=0) train step, L1 + Adam(1e-3), 8 s clips 257x251, fp32 MFMA",
+                       "clips_per_gpu_per_step": B, "loss_last": float(loss),
+                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_mfma_kernel + wgrad_mfma_kernel", "launches": timer.launches(),
+                         "kernel_ms_per_step": round(conv_ms / args.steps, 3)}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +157,9 @@ def main():
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
+                         "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +178,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+
+    if args.mode == "train":
+        return bench_train(args, rank, world, dev, dist)
 
     from musicfpaugment_amd import ops_unet, synth
     from musicfpaugment_amd.pipeline import UNET_MFMA_GFLOP_PER_CLIP, HotPath

@@ -93,21 +93,33 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
   }
 }
 
+// Finish kernels: one 64-lane wavefront per channel sums the per-workgroup float64 partials (lane-strided, then a
+// fixed xor-shuffle tree: deterministic), lane 0 finalises.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 // BN statistics finish: mean, biased var -> invstd, fused (scale, shift); running stats with momentum
 // (unbiased variance), exactly nn.BatchNorm2d in train mode (training/unet.py:17,20).
-__global__ void bn_stats_finish_kernel(const double* __restrict__ partial, int nblk, int C, double count, float eps,
-                                       float momentum, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* __restrict__ mean,
-                                       float* __restrict__ invstd, float* __restrict__ scale,
-                                       float* __restrict__ shift, float* __restrict__ running_mean,
-                                       float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                              double count, float eps, float momentum,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ mean,
+                                                              float* __restrict__ invstd, float* __restrict__ scale,
+                                                              float* __restrict__ shift, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0, ss = 0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     s += partial[((size_t)b * C + c) * 2];
     ss += partial[((size_t)b * C + c) * 2 + 1];
   }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if (lane) return;
   const double m = s / count;
   double var = ss / count - m * m;
   if (var < 0) var = 0;
@@ -126,17 +138,20 @@ __global__ void bn_stats_finish_kernel(const double* __restrict__ partial, int n
 
 // BN backward finish: dgamma = sum g*xhat, dbeta = sum g; coefficients so that
 // dz = ka*g - kb - kc*xhat  with ka = gamma*invstd, kb = ka*dbeta/N, kc = ka*dgamma/N.
-__global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int nblk, int C, double count,
-                                     const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     float* __restrict__ coef /* [3][C] */) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                            double count, const float* __restrict__ gamma,
+                                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double sg = 0, sgx = 0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     sg += partial[((size_t)b * C + c) * 2];
     sgx += partial[((size_t)b * C + c) * 2 + 1];
   }
+  sg = wave_sum_d(sg);
+  sgx = wave_sum_d(sgx);
+  if (lane) return;
   dgamma[c] = (float)sgx;
   dbeta[c] = (float)sg;
   const double ka = (double)gamma[c] * (double)invstd[c];
@@ -145,12 +160,14 @@ __global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int nbl
   coef[2 * C + c] = (float)(ka * sgx / count);
 }
 
-__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                            float* __restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
-  out[c] = (float)s;
+  for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * C + c];
+  s = wave_sum_d(s);
+  if (lane == 0) out[c] = (float)s;
 }
 
 // dy <- dz in place (BatchNorm + ReLU backward), all per-channel constants precomputed.
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
 // dW[tap][co][ci] += sum over pixels of dz[p][co] * xin[p + tap][ci]   (MODE 0, 3x3 conv, 9 taps)
 // dW[tap][co][ci] += sum over pixels of dup[2y+dy, 2x+dx][co] * xin[y,x][ci]   (MODE 1, transposed conv, 4 taps)
 // GEMM per tap: M = 64 output channels, N = 64 input channels, K = pixels.  A workgroup owns one 64x64
-// (co, ci) tile for ALL taps and walks 4x32-pixel patches (grid-strided over the batch): per patch the
+// (co, ci) tile for ALL taps and walks 2x32-pixel patches (grid-strided over the batch): per patch the
 // dz tile and the haloed xin tile are staged in LDS pixel-major (the natural NHWC order, so no transpose:
 // MFMA lanes read 32 consecutive channels of one pixel with ds_read_b32); each wave keeps one 32x32
 // accumulator per tap (9 x 16 VGPRs) and the A fragment of a k-step is reused by all taps.  Partial sums
@@ -278,10 +295,10 @@ struct WgradArgs {
   int tiles_x, tiles_y;
 };
 
-constexpr int WG_PH = 4, WG_PW = 32, WG_PIX = 128, WG_T = 64;
+constexpr int WG_PH = 2, WG_PW = 32, WG_PIX = 64, WG_T = 64;
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int TAPS = (MODE == 0) ? 9 : 4;
   constexpr int HPW = WG_PW + 2 * HALO, HPH = WG_PH + 2 * HALO, HP = HPW * HPH;
@@ -571,7 +588,7 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
                      nullptr, nullptr, workspace);
   MFPA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, (double)npix,
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
@@ -589,7 +606,7 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, z, npix, C, scale, shift, mean, invstd,
                      workspace);
   MFPA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, (double)npix,
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
@@ -607,7 +624,7 @@ int mfpa_colsum(const float* x, long long npix, int C, float* out, double* works
   hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(nblk), dim3(256), 0, s, x, nullptr, npix, C, nullptr, nullptr, nullptr,
                      nullptr, workspace);
   MFPA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, out);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, out);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -703,7 +720,7 @@ int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, 
   hipLaunchKernelGGL(outconv_bwd_kernel, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, dy, workspace);
   MFPA_CHECK_LAUNCH();
   // finish: column sums of the (nblk, C+1) partial matrix: C weight gradients then the bias gradient
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

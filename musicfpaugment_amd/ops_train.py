@@ -82,6 +82,39 @@ def _npix(t):
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+def flat_layout():
+    """Segments {name: (offset, shape)} of the flat parameter buffer, the all-reduce buckets
+    [(block, start, end)] and the total element count.  Order = the order the backward pass finishes
+    gradients (outc, up4 ... up1, down4 ... inc; inside a DoubleConv the second conv first), so each bucket
+    is a contiguous slice that is complete -- and can be all-reduced -- while earlier layers are still in backward."""
+    segs: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+    off = 0
+
+    def add(name, shape):
+        nonlocal off
+        n = 1
+        for s in shape:
+            n *= s
+        segs[name] = (off, tuple(shape))
+        off += n
+
+    def dconv(prefix, cin, cout, first=False):
+        add(prefix + ".3.w", (9, cout, cout)); add(prefix + ".4.g", (cout,)); add(prefix + ".4.b", (cout,))
+        add(prefix + ".0.w", (9, cout) if first else (9, cout, cin)); add(prefix + ".1.g", (cout,)); add(prefix + ".1.b", (cout,))
+
+    buckets: List[Tuple[str, int, int]] = []
+    start = off
+    add("outc.wb", (65,))                       # 64 weights + bias
+    for name, (cin, cout) in zip(reversed(DEC), reversed(DEC_CH)):      # up4, up3, up2, up1
+        dconv(name + ".conv.double_conv", cin, cout)
+        add(name + ".up.w", (4, cin // 2, cin)); add(name + ".up.b", (cin // 2,))
+        buckets.append((name, start, off)); start = off
+    for name, (cin, cout) in zip(reversed(ENC), reversed(ENC_CH)):      # down4 ... inc
+        dconv(name, cin, cout, first=(cin == 1))
+        buckets.append((name, start, off)); start = off
+    return segs, buckets, off
+
+
 # ----------------------------------------------------------------------------- the engine
 class UNetTrainEngine:
     """Owns kernel-layout master parameters, gradients and Adam moments of a UNet(1, 1) and runs train steps."""
@@ -105,32 +138,7 @@ class UNetTrainEngine:
 
     # ------------------------------------------------------------------ flat layout (backward completion order)
     def _layout(self):
-        segs: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
-        off = 0
-
-        def add(name, shape):
-            nonlocal off
-            n = 1
-            for s in shape:
-                n *= s
-            segs[name] = (off, tuple(shape))
-            off += n
-
-        def dconv(prefix, cin, cout, first=False):
-            # reverse order inside the block too: second conv finishes first
-            add(prefix + ".3.w", (9, cout, cout)); add(prefix + ".4.g", (cout,)); add(prefix + ".4.b", (cout,))
-            add(prefix + ".0.w", (9, cout) if first else (9, cout, cin)); add(prefix + ".1.g", (cout,)); add(prefix + ".1.b", (cout,))
-
-        self.buckets: List[Tuple[str, int, int]] = []
-        start = off
-        add("outc.wb", (65,))                       # 64 weights + bias
-        for name, (cin, cout) in zip(reversed(DEC), reversed(DEC_CH)):      # up4, up3, up2, up1
-            dconv(name + ".conv.double_conv", cin, cout)
-            add(name + ".up.w", (4, cin // 2, cin)); add(name + ".up.b", (cin // 2,))
-            self.buckets.append((name, start, off)); start = off
-        for name, (cin, cout) in zip(reversed(ENC), reversed(ENC_CH)):      # down4 ... inc
-            dconv(name, cin, cout, first=(cin == 1))
-            self.buckets.append((name, start, off)); start = off
+        segs, self.buckets, off = flat_layout()
         self.segs, self.n_params = segs, off
         dev = self.device
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)

@@ -1,0 +1,186 @@
+"""UNet `Trainer` / `EarlyStopping` on MI355X -- mirror of the spec branch of the reference's training/train.py.
+
+Reference: Trainer.train_epoch (:245-359), validation_epoch (:361-468), EarlyStopping (:582-612),
+__main__ wiring (:645-667: UNet(1,1,rate), L1Loss, Adam(lr 1e-3, betas (0.9, 0.999)),
+ReduceLROnPlateau(min, factor 0.1, patience 10)).
+
+What is kept: constructor argument names, `train_epoch(epoch) -> {"loss": float}`,
+`validation_epoch() -> ({"loss": float}, {"psnr": float})`, the loop quirk (range(1, steps) iterations,
+loss divided by `steps`, train.py:257,341), checkpoint dictionaries with the reference's keys
+(`{"model_state_dict": ...}` for best, + optimizer/epoch for last, train.py:197-221).
+What is different: no tf.data / tensorboard / Progbar; the loaders are plain Python iterators yielding
+`(clean (B,T,1) or (B,T), augmented (B,T,1) or (B,T))` float32 tensors; the step itself runs through
+UNetTrainEngine (HIP kernels, no autograd); one process per GPU with RCCL gradient all-reduce when
+torch.distributed is initialised (the reference is single-GPU).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Iterator, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..constants import LEARNING_RATE, TRAIN_STEPS, VAL_STEPS
+from ..ops_train import UNetTrainEngine
+from .unet import UNet
+
+
+class EarlyStopping:
+    """training/train.py:582-612: stop after `patience` epochs without a `min_delta` improvement."""
+
+    def __init__(self, patience: int = 20, min_delta: float = 0.0):
+        self.patience, self.min_delta = patience, min_delta
+        self.counter = 0
+        self.best_loss: Optional[float] = None
+        self.early_stop = False
+
+    def __call__(self, val_loss: float) -> None:
+        if self.best_loss is None:
+            self.best_loss = val_loss
+        elif self.best_loss - val_loss > self.min_delta:
+            self.best_loss = val_loss
+            self.counter = 0
+        elif self.best_loss - val_loss < self.min_delta:
+            self.counter += 1
+            if self.counter >= self.patience:
+                self.early_stop = True
+
+
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode="min", factor, patience) on the engine's lr
+    (default relative threshold 1e-4, cooldown 0), as wired at train.py:662-666."""
+
+    def __init__(self, engine: UNetTrainEngine, factor: float = 0.1, patience: int = 10, threshold: float = 1e-4):
+        self.engine, self.factor, self.patience, self.threshold = engine, factor, patience, threshold
+        self.best = float("inf")
+        self.num_bad = 0
+
+    def step(self, metric: float) -> None:
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad = metric, 0
+        else:
+            self.num_bad += 1
+        if self.num_bad > self.patience:
+            self.engine.lr *= self.factor
+            self.num_bad = 0
+
+
+def _global_max(clip_max: torch.Tensor) -> torch.Tensor:
+    """spectrogram() divides by ONE max over the whole batch (visualisation.py:29); with the batch sharded over
+    ranks that is a scalar MAX all-reduce, so single-device results are reproduced."""
+    m = clip_max.max()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return m
+
+
+class Trainer:
+    def __init__(self, model: UNet, train_loader: Iterator, val_loader: Optional[Iterator] = None,
+                 learning_rate: float = LEARNING_RATE, train_steps: int = TRAIN_STEPS, val_steps: int = VAL_STEPS,
+                 device="cuda", ckpt_path: Optional[str] = None, input_type: str = "spec",
+                 scheduler_factor: float = 0.1, scheduler_patience: int = 10, early_stop_patience: int = 20):
+        if input_type != "spec":
+            raise NotImplementedError("input_type='audio' is the Demucs branch (next tier, SURVEY.md §8f-2)")
+        self.device = torch.device(device)
+        self.model = model.to(self.device)
+        self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+        self.scheduler = ReduceLROnPlateau(self.engine, scheduler_factor, scheduler_patience)
+        self.early_stopping = EarlyStopping(early_stop_patience)
+        self.train_loader_iter, self.val_loader_iter = train_loader, val_loader
+        self.train_steps, self.val_steps = train_steps, val_steps
+        self.ckpt_path = ckpt_path
+        self.epoch = 0
+        self.best_val_loss = float("inf")
+        self.losses: Dict[str, list] = {"train": [], "val": []}
+
+    # ------------------------------------------------------------------ one batch
+    def _specs(self, clean_audios: torch.Tensor, augmented_audios: torch.Tensor):
+        clean = clean_audios.to(self.device, torch.float32)
+        aug = augmented_audios.to(self.device, torch.float32)
+        clean = clean.squeeze(-1) if clean.dim() == 3 else clean          # (B,T,1) -> (B,T)   train.py:260
+        aug = aug.squeeze(-1) if aug.dim() == 3 else aug
+        cm, cmax = ops.stft_mag(clean.contiguous(), torch.float64)
+        am, amax = ops.stft_mag(aug.contiguous(), torch.float64)
+        B = cm.shape[0]
+        ops.normalize_(cm, _global_max(cmax).expand(B).contiguous(), per_clip=True)     # clean_specs, float64 target
+        return am, _global_max(amax).expand(B).contiguous(), cm
+
+    def train_step(self, clean_audios, augmented_audios) -> torch.Tensor:
+        am, aden, clean_spec = self._specs(clean_audios, augmented_audios)
+        return self.engine.train_step(am, aden, clean_spec)
+
+    # ------------------------------------------------------------------ epochs
+    def train_epoch(self, epoch: int) -> Dict[str, Any]:
+        self.model.train()
+        total = torch.zeros(1, dtype=torch.float64, device=self.device)
+        for _ in range(1, self.train_steps):                    # reference quirk: steps-1 iterations (train.py:257)
+            clean, aug = next(self.train_loader_iter)
+            total += self.train_step(clean, aug)                # loss stays on the device: no per-step .item() sync
+        return {"loss": float(total.item()) / self.train_steps}  # ... divided by steps (train.py:341)
+
+    @torch.no_grad()
+    def validation_epoch(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+        if self.val_loader_iter is None:
+            raise ValueError("no validation loader")
+        self.engine.sync_to_module()
+        self.model.eval()
+        total = torch.zeros(1, dtype=torch.float64, device=self.device)
+        psnr_total = 0.0
+        for _ in range(1, self.val_steps):
+            clean, aug = next(self.val_loader_iter)
+            am, aden, clean_spec = self._specs(clean, aug)
+            pred = self.model.denoise_spectrogram(am, aden, per_clip=True)
+            loss, _ = self.engine.l1_loss(pred, clean_spec, want_grad=False)
+            total += loss
+            mse = torch.mean((pred.double() - clean_spec) ** 2)
+            rng = clean_spec.max() - clean_spec.min()
+            psnr_total += float(10.0 * torch.log10(rng * rng / mse))
+        val_loss = float(total.item()) / self.val_steps
+        self.scheduler.step(val_loss)                           # train.py:462
+        self.model.train()
+        return {"loss": val_loss}, {"psnr": psnr_total / self.val_steps}
+
+    # ------------------------------------------------------------------ checkpoints (train.py:197-221, :130-161)
+    def save_checkpoint(self, val_loss: float) -> None:
+        if self.ckpt_path is None:
+            return
+        os.makedirs(self.ckpt_path, exist_ok=True)
+        self.engine.sync_to_module()
+        sd = self.model.state_dict()
+        torch.save({"epoch": self.epoch, "model_state_dict": sd,
+                    "optimizer_state_dict": {"exp_avg": self.engine.flat_m, "exp_avg_sq": self.engine.flat_v,
+                                             "step": self.engine.step_count, "lr": self.engine.lr},
+                    "losses": self.losses, "best_val_loss": self.best_val_loss},
+                   os.path.join(self.ckpt_path, "last_epoch.pt"))
+        if val_loss < self.best_val_loss:
+            self.best_val_loss = val_loss
+            torch.save({"model_state_dict": sd, "best_val_loss": val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
+
+    def load_checkpoint(self) -> bool:
+        path = None if self.ckpt_path is None else os.path.join(self.ckpt_path, "last_epoch.pt")
+        if path is None or not os.path.exists(path):
+            return False
+        ck = torch.load(path, map_location=self.device)
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.engine.load_from_module()
+        opt = ck["optimizer_state_dict"]
+        self.engine.flat_m.copy_(opt["exp_avg"]); self.engine.flat_v.copy_(opt["exp_avg_sq"])
+        self.engine.step_count, self.engine.lr = opt["step"], opt["lr"]
+        self.epoch, self.losses, self.best_val_loss = ck["epoch"], ck["losses"], ck["best_val_loss"]
+        return True
+
+    def training_loop(self, nb_epochs: int) -> None:
+        """train.py:171-243 without the logging side outputs."""
+        self.load_checkpoint()
+        while self.epoch < nb_epochs:
+            self.epoch += 1
+            self.losses["train"].append(self.train_epoch(self.epoch)["loss"])
+            if self.val_loader_iter is not None:
+                val, _ = self.validation_epoch()
+                self.losses["val"].append(val["loss"])
+                self.early_stopping(val["loss"])
+                self.save_checkpoint(val["loss"])
+                if self.early_stopping.early_stop:
+                    break

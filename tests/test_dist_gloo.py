@@ -40,3 +40,45 @@ def test_metric_counts_allreduce_gloo_world2():
     mp.spawn(_worker, args=(2, port, counts, ret), nprocs=2, join=True)
     want = counts.sum(axis=0).tolist()
     assert ret[0] == want and ret[1] == want
+
+
+def test_gradient_bucket_layout():
+    """The flat parameter buffer of the training engine: every reference parameter exactly once, buckets contiguous."""
+    from musicfpaugment_amd.ops_train import flat_layout
+    segs, buckets, n = flat_layout()
+    assert n == 31_036_481                                   # the reference UNet(1,1)'s parameter count
+    assert buckets[0][1] == 0 and buckets[-1][2] == n
+    assert all(a[2] == b[1] for a, b in zip(buckets, buckets[1:]))
+    assert [b[0] for b in buckets][:4] == ["up4", "up3", "up2", "up1"]
+    offs = sorted((o, int(np.prod(s))) for o, s in segs.values())
+    assert all(o + k == o2 for (o, k), (o2, _) in zip(offs, offs[1:]))
+
+
+def _allreduce_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from musicfpaugment_amd.ops_train import flat_layout
+    _, buckets, n = flat_layout()
+    n_small = 4096
+    g = torch.full((n_small,), float(rank + 1))
+    # the engine's pattern: async SUM all-reduce per bucket in backward order, wait, then scale by 1/world in Adam
+    cut = lambda v: v * n_small // n
+    handles = [dist.all_reduce(g[cut(s):cut(e)], op=dist.ReduceOp.SUM, async_op=True) for _, s, e in buckets
+               if cut(e) > cut(s)]
+    for h in handles:
+        h.wait()
+    m = torch.tensor([float(rank)])
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)                 # the spectrogram() global-max exchange
+    ret[rank] = (g.tolist(), float(m))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_pattern_gloo_world2():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_allreduce_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        g, m = ret[r]
+        assert set(g) == {3.0} and m == 1.0

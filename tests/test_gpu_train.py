@@ -143,3 +143,37 @@ def test_train_step_vs_oracle_autograd_and_loss_decreases():
     for _ in range(5):
         losses.append(float(eng.train_step(am, aug_den, clean_spec)))
     assert losses[-1] < losses[0], losses
+
+
+def test_trainer_mirror_epoch_and_checkpoint(tmp_path):
+    """Trainer.train_epoch / validation_epoch / checkpoints on a synthetic loader (reference: training/train.py:171-468)."""
+    from musicfpaugment_amd.training.train import EarlyStopping, Trainer
+    from musicfpaugment_amd.training.unet import UNet
+
+    def loader(seed):
+        k = 0
+        while True:
+            clean = synth.batch(2, seed=seed + 2 * (k % 2), n=8000)
+            noise = synth.batch(2, seed=seed + 100 + 2 * (k % 2), n=8000, tonal=False)
+            yield torch.from_numpy(clean)[:, :, None], torch.from_numpy((0.7 * clean + 0.3 * noise).astype(np.float32))[:, :, None]
+            k += 1
+
+    net = UNet(1, 1, rate=0.0)
+    net.load_state_dict(formula_state_dict(3))
+    tr = Trainer(net, loader(10), loader(10), learning_rate=1e-3, train_steps=5, val_steps=3, ckpt_path=str(tmp_path))
+    l1 = tr.train_epoch(1)["loss"]
+    l2 = tr.train_epoch(2)["loss"]
+    assert l2 < l1
+    val, met = tr.validation_epoch()
+    assert np.isfinite(val["loss"]) and np.isfinite(met["psnr"])
+    tr.save_checkpoint(val["loss"])
+    ck = torch.load(tmp_path / "best_epoch.pt")
+    assert list(ck["model_state_dict"].keys()) == list(formula_state_dict(3).keys())
+    net2 = UNet(1, 1, rate=0.0)
+    tr2 = Trainer(net2, loader(10), None, ckpt_path=str(tmp_path))
+    assert tr2.load_checkpoint() and tr2.engine.step_count == tr.engine.step_count
+    assert torch.equal(tr2.engine.flat_p, tr.engine.flat_p)
+    es = EarlyStopping(patience=2)
+    for v in (1.0, 1.1, 1.2):
+        es(v)
+    assert es.early_stop
