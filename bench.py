@@ -81,14 +81,15 @@ def cpu_baseline(budget_s: float, seed: int):
 
 
 def bench_train(args, rank, world, dev, dist):
-    """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips (dropout 0), fp32 MFMA."""
+    """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips, Dropout(0.05) as the reference
+    trains (training/train.py:646), fp32 MFMA."""
     from musicfpaugment_amd import ops, ops_unet, synth
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
     from musicfpaugment_amd.training.weights import formula_state_dict
 
     B = args.clips
-    net = UNet(1, 1, rate=0.0)
+    net = UNet(1, 1, rate=0.05)
     net.load_state_dict(formula_state_dict(0))
     net = net.to(dev).train()
     eng = UNetTrainEngine(net, lr=1e-3)
@@ -138,7 +139,7 @@ def bench_train(args, rank, world, dev, dist):
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UNet(1,1,rate=0) train step, L1 + Adam(1e-3), 8 s clips 257x251, fp32 MFMA",
+            "config": {"workload": "UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, fp32 MFMA",
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -178,6 +178,8 @@ typedef struct mfpa_conv_desc {
   int C0, C1, H1, W1;
   int B, H, W, Cout, relu;
   int yH, yW, mode;
+  unsigned drop_seed, drop_thresh; /* training Dropout on source 0 after the affine+ReLU: keep element idx iff */
+  float drop_scale;                /* hash(seed, idx) >= thresh (= rate * 2^32), scaled by 1/(1-rate); 0 = off  */
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 
@@ -220,17 +222,21 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
  * dgamma, dbeta (C) are produced; coef is a (3, C) scratch. */
 int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma,
                      const float* scale, const float* shift, const float* mean, const float* invstd,
-                     float* dgamma, float* dbeta, float* coef, double* workspace, void* stream);
+                     float* dgamma, float* dbeta, float* coef, double* workspace,
+                     unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
 
 /* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
 int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);
 
 /* p = MaxPool2d(2)(relu(z*scale+shift)) (unet.py:34) and its backward: dy += route(dp) to the window's
- * first maximum. */
+ * first maximum.  drop_*: the nn.Dropout (unet.py:83,99-103) that follows this DoubleConv in train mode, applied
+ * to relu(bn(z)) with the stateless mask of mfpa_conv_desc (thresh 0 = no dropout); mfpa_bn_relu_bwd applies the
+ * same mask to the incoming gradient. */
 int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* scale, const float* shift,
-                      float* p, void* stream);
+                      float* p, unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
 int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const float* scale,
-                          const float* shift, const float* dp, float* dy, void* stream);
+                          const float* shift, const float* dp, float* dy,
+                          unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
 
 /* Weight gradient on MFMA, ACCUMULATED into dw (zero it first):
  *   mode 0: dw[tap][co][ci] += sum_p dz[p][co] * xin[p + tap][ci]          (3x3 conv; dw (9,Cout,C0+C1))
@@ -242,6 +248,8 @@ typedef struct mfpa_wgrad_desc {
   float* dw;
   int C0, C1, H1, W1;
   int B, H, W, Cout, mode;
+  unsigned drop_seed, drop_thresh;
+  float drop_scale;
 } mfpa_wgrad_desc;
 int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream);
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_longlong, c_void_p
+from ctypes import c_double, c_float, c_int, c_longlong, c_uint, c_void_p
 
 import torch  # noqa: F401  (must precede the dlopen below)
 
@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MfpaError(RuntimeError):
@@ -56,11 +56,12 @@ _SIGNATURES = {
     "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
-    "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
+                           c_void_p], c_int),
     "mfpa_maxpool2_bwd_add": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p], c_int),
+                               c_uint, c_uint, c_float, c_void_p], c_int),
     "mfpa_wgrad_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_wgrad_c1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_outconv_fwd": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -79,7 +80,8 @@ class ConvDesc(ctypes.Structure):
                 ("w", c_void_p), ("out_scale", c_void_p), ("out_shift", c_void_p), ("y", c_void_p),
                 ("C0", c_int), ("C1", c_int), ("H1", c_int), ("W1", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("relu", c_int),
-                ("yH", c_int), ("yW", c_int), ("mode", c_int)]
+                ("yH", c_int), ("yW", c_int), ("mode", c_int),
+                ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -87,7 +89,8 @@ class WgradDesc(ctypes.Structure):
     _fields_ = [("dz", c_void_p), ("x0", c_void_p), ("in_scale0", c_void_p), ("in_shift0", c_void_p),
                 ("x1", c_void_p), ("dw", c_void_p),
                 ("C0", c_int), ("C1", c_int), ("H1", c_int), ("W1", c_int),
-                ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("mode", c_int)]
+                ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("mode", c_int),
+                ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float)]
 
 _lib = None
 

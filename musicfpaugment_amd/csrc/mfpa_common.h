@@ -32,3 +32,19 @@ __device__ __forceinline__ void mfpa_atomic_max_nonneg(double* addr, double v) {
   atomicMax(reinterpret_cast<unsigned long long*>(addr),
             static_cast<unsigned long long>(__double_as_longlong(v)));
 }
+
+// Counter-based dropout mask (training): keep element `idx` of a tensor iff hash(seed, idx) >= thresh, where
+// thresh = rate * 2^32.  Stateless, so the mask is recomputed wherever the dropped activation is consumed
+// (forward loaders and the backward pass) and never stored.  Mirrored in numpy by tests/test_gpu_train.py.
+__host__ __device__ __forceinline__ uint32_t mfpa_mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ bool mfpa_keep(uint32_t seed, uint32_t thresh, unsigned long long idx) {
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  return mfpa_mix32(mfpa_mix32(lo + seed) ^ (hi * 0x7F4A7C15u + seed)) >= thresh;
+}

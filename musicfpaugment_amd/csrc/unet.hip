@@ -40,6 +40,8 @@ struct ConvArgs {
   int B, H, W, Cout, relu;
   int yH, yW;              // output extent (crop): pixels with gy >= yH or gx >= yW are not stored
   int tiles_x, tiles_y;
+  unsigned drop_seed, drop_thresh;   // dropout on source 0 after the affine+ReLU (thresh 0 = off)
+  float drop_scale;
 };
 
 // MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).
@@ -109,6 +111,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
               v.y = v.y > 0.f ? v.y : 0.f;
               v.z = v.z > 0.f ? v.z : 0.f;
               v.w = v.w > 0.f ? v.w : 0.f;
+              if (a.drop_thresh) {
+                const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+              }
             }
           } else {
             const int y1 = gy - a.oy1, x1 = gx - a.ox1;
@@ -416,6 +423,8 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   a.yH = (d->mode != 1 && d->yH > 0) ? d->yH : d->H;
   a.yW = (d->mode != 1 && d->yW > 0) ? d->yW : d->W;
   if (a.yH > d->H || a.yW > d->W) return MFPA_EINVAL;
+  if (d->drop_thresh && (!d->in_scale0 || d->mode == 2)) return MFPA_EINVAL;
+  a.drop_seed = d->drop_seed; a.drop_thresh = d->drop_thresh; a.drop_scale = d->drop_scale;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s);
   if (d->mode == 1) return dispatch_conv<1>(a, s);

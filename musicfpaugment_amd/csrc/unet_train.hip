@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, unsigned drop_seed,
+                                                          unsigned drop_thresh, float drop_scale) {
   constexpr int NV = (MODE == 2) ? 1 : 2;
   const int C4 = C / 4;
   const int lanes = C4 < 256 ? C4 : 256;          // lanes across channel quads
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
         const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * cq);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float g = (zz[k] * sc[k] + sf[k] > 0.f) ? v[k] : 0.f;
+          float g = (zz[k] * sc[k] + sf[k] > 0.f) ? v[k] : 0.f;
+          if (drop_thresh) g = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)p * C + 4 * cq + k) ? g * drop_scale : 0.f;
           const float xh = (zz[k] - mu[k]) * is[k];
           s0[k] += (double)g;
           s1[k] += (double)g * (double)xh;
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
-                                                           const float* __restrict__ coef) {
+                                                           const float* __restrict__ coef, unsigned drop_seed,
+                                                           unsigned drop_thresh, float drop_scale) {
   const int C4 = C / 4;
   const long long total = npix * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gg = (zz[k] * sc[k] + sf[k] > 0.f) ? g[k] : 0.f;
+      float gg = (zz[k] * sc[k] + sf[k] > 0.f) ? g[k] : 0.f;
+      if (drop_thresh) gg = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)e * 4 + k) ? gg * drop_scale : 0.f;
       const float xh = (zz[k] - mu[k]) * is[k];
       o[k] = ka[k] * gg - kb[k] - kc[k] * xh;
     }
@@ -204,7 +208,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
 // p = maxpool2(relu(z*scale+shift)), floor (unet.py:34 after the BN+ReLU of the DoubleConv).
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ z, int B, int H, int W, int C,
                                                            const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, float* __restrict__ p) {
+                                                           const float* __restrict__ shift, float* __restrict__ p,
+                                                           unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const long long total = (long long)B * Ho * Wo * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -219,10 +224,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
     f32x4 m = {0.f, 0.f, 0.f, 0.f};   // relu output is >= 0
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)(t >> 1) * W + (t & 1)) * C);
+      const size_t off = ((size_t)(t >> 1) * W + (t & 1)) * C;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + off);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float y = v[k] * sc[k] + sf[k];
+        float y = v[k] * sc[k] + sf[k];
+        if (drop_thresh) y = (y > 0.f && mfpa_keep(drop_seed, drop_thresh, (unsigned long long)(base - z) + off + k)) ? y * drop_scale : 0.f;
         m[k] = y > m[k] ? y : m[k];
       }
     }
@@ -235,7 +242,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ z, int B, int H, int W, int C,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
-                                                              const float* __restrict__ dp, float* __restrict__ dy) {
+                                                              const float* __restrict__ dp, float* __restrict__ dy,
+                                                              unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const long long total = (long long)B * Ho * Wo * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
       for (int k = 0; k < 4; ++k) {
         float y = v[k] * sc[k] + sf[k];
         y = y > 0.f ? y : 0.f;
+        if (drop_thresh) y = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)base + ((size_t)(t >> 1) * W + (t & 1)) * C + k) ? y * drop_scale : 0.f;
         if (t == 0 || y > best[k]) {
           best[k] = y;
           arg[k] = t;
@@ -293,6 +302,8 @@ struct WgradArgs {
   int C0, C1, H1, W1, oy1, ox1;
   int B, H, W, Cout;
   int tiles_x, tiles_y;
+  unsigned drop_seed, drop_thresh;
+  float drop_scale;
 };
 
 constexpr int WG_PH = 2, WG_PW = 32, WG_PIX = 64, WG_T = 64;
@@ -341,6 +352,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
             v = v * sc + sh;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            if (a.drop_thresh) {
+              const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+            }
           }
         } else {
           const int y1 = gy - a.oy1, x1 = gx - a.ox1;
@@ -586,7 +602,7 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
-                     nullptr, nullptr, workspace);
+                     nullptr, nullptr, workspace, 0u, 0u, 1.f);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
@@ -596,7 +612,8 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
 
 int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                      const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                     float* coef, double* workspace, void* stream) {
+                     float* coef, double* workspace, unsigned drop_seed, unsigned drop_thresh, float drop_scale,
+                     void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!dy || !z || !gamma || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace) return MFPA_EINVAL;
   if (npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
@@ -604,13 +621,13 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, z, npix, C, scale, shift, mean, invstd,
-                     workspace);
+                     workspace, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
-                     mean, invstd, coef);
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -622,7 +639,7 @@ int mfpa_colsum(const float* x, long long npix, int C, float* out, double* works
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(nblk), dim3(256), 0, s, x, nullptr, npix, C, nullptr, nullptr, nullptr,
-                     nullptr, workspace);
+                     nullptr, workspace, 0u, 0u, 1.f);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, out);
   MFPA_CHECK_LAUNCH();
@@ -630,23 +647,24 @@ int mfpa_colsum(const float* x, long long npix, int C, float* out, double* works
 }
 
 int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, float* p,
-                      void* stream) {
+                      unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !p || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(total)), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C, scale,
-                     shift, p);
+                     shift, p, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
 int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const float* scale, const float* shift,
-                          const float* dp, float* dy, void* stream) {
+                          const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh, float drop_scale,
+                          void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !dp || !dy || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(grid_for(total)), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
-                     scale, shift, dp, dy);
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -666,6 +684,8 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
   a.oy1 = d->C1 ? (d->H - d->H1) / 2 : 0;
   a.ox1 = d->C1 ? (d->W - d->W1) / 2 : 0;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  if (d->drop_thresh && !d->in_scale0) return MFPA_EINVAL;
+  a.drop_seed = d->drop_seed; a.drop_thresh = d->drop_thresh; a.drop_scale = d->drop_scale;
   a.tiles_x = (d->W + WG_PW - 1) / WG_PW;
   a.tiles_y = (d->H + WG_PH - 1) / WG_PH;
   const long long npatch = (long long)a.B * a.tiles_x * a.tiles_y;

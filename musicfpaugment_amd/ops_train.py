@@ -36,6 +36,18 @@ class Stats:
     def __init__(self, C, device):
         buf = torch.empty((4, C), dtype=torch.float32, device=device)
         self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+        self.drop = (0, 0, 1.0)      # (seed, thresh = rate * 2^32, 1/(1-rate)) of the nn.Dropout that follows, if any
+
+
+def dropout_spec(seed: int, rate: float):
+    """Stateless dropout parameters of csrc/mfpa_common.h::mfpa_keep."""
+    if rate <= 0:
+        return (0, 0, 1.0)
+    return (seed & 0xFFFFFFFF, min(int(rate * 4294967296.0), 0xFFFFFFFF), 1.0 / (1.0 - rate))
+
+
+def _drop(st):
+    return st.drop if st is not None else (0, 0, 1.0)
 
 
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
@@ -58,7 +70,8 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  out_scale=ptr(out_scale), out_shift=ptr(out_shift), y=ptr(y), C0=C0, C1=C1,
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
-                 mode=mode)
+                 mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
+                 drop_scale=_drop(in_affine)[2])
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -71,7 +84,8 @@ def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
                   in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), dw=ptr(dw), C0=C0,
                   C1=0 if x1 is None else x1.shape[3], H1=0 if x1 is None else x1.shape[1],
-                  W1=0 if x1 is None else x1.shape[2], B=B, H=H, W=W, Cout=Cout, mode=mode)
+                  W1=0 if x1 is None else x1.shape[2], B=B, H=H, W=W, Cout=Cout, mode=mode,
+                  drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1], drop_scale=_drop(in_affine)[2])
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_wgrad_mfma(ctypes.byref(d), stream()), "mfpa_wgrad_mfma")
     if t0 is not None:
@@ -124,10 +138,8 @@ class UNetTrainEngine:
         self.device = next(module.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("the training engine runs on the MI355X only")
-        rate = module.dropout.p
-        if rate != 0:
-            raise NotImplementedError("Dropout(rate>0) in the HIP training step is not built yet "
-                                      "(reference trains with rate 0.05, training/train.py:646); use rate=0")
+        self.rate = float(module.dropout.p)        # nn.Dropout(rate) on x2..x5 and up1's output (unet.py:83,99-103)
+        self.drop_seed = 0x5EED
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.group = process_group
@@ -238,11 +250,12 @@ class UNetTrainEngine:
         coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
         check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                      ptr(st.mean), ptr(st.invstd), ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
-                                     ptr(self.workspace), stream()), "mfpa_bn_relu_bwd")
+                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], stream()),
+              "mfpa_bn_relu_bwd")
         return dy
 
     # ------------------------------------------------------------------ forward (train mode)
-    def _dconv_fwd(self, prefix, src0, aff0: Optional[Stats], src1=None, first_input=None):
+    def _dconv_fwd(self, prefix, src0, aff0: Optional[Stats], src1=None, first_input=None, drop_id=None):
         cout = self.P[prefix + ".3.w"].shape[1]
         if first_input is not None:
             x32, spec64, denom = first_input
@@ -253,6 +266,8 @@ class UNetTrainEngine:
         st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b")
         z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0)
         st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b")
+        if drop_id is not None and self.rate > 0:
+            st3.drop = dropout_spec(self.drop_seed + 16 * self.step_count + drop_id, self.rate)
         return dict(prefix=prefix, src0=src0, aff0=aff0, src1=src1, first_input=first_input, z0=z0, st0=st0, z3=z3, st3=st3)
 
     def forward(self, x32=None, spec64=None, denom=None):
@@ -262,13 +277,13 @@ class UNetTrainEngine:
         r = self._dconv_fwd(ENC[0], None, None, first_input=(x32, spec64, denom))
         recs["inc"] = r
         prev = r
-        for name in ENC[1:]:
+        for i, name in enumerate(ENC[1:]):
             z, st = prev["z3"], prev["st3"]
             B, H, W, C = z.shape
             p = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=z.device)
-            check(lib().mfpa_bn_relu_pool(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(p), stream()),
-                  "mfpa_bn_relu_pool")
-            r = self._dconv_fwd(name, p, None)
+            check(lib().mfpa_bn_relu_pool(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(p), st.drop[0], st.drop[1],
+                                          st.drop[2], stream()), "mfpa_bn_relu_pool")
+            r = self._dconv_fwd(name, p, None, drop_id=i)                 # x2..x5 = dropout(downN(...))
             recs[name] = r
             prev = r
         skips = [recs[ENC[3]], recs[ENC[2]], recs[ENC[1]], recs["inc"]]
@@ -277,7 +292,8 @@ class UNetTrainEngine:
                           in_affine=prev["st3"], out_shift=self.P[name + ".up.b"])
             if skip["z3"].shape[1] - u.shape[1] > 1 or skip["z3"].shape[2] - u.shape[2] > 1:
                 raise NotImplementedError("skip/upsample size difference > 1 (needs top/left padding offsets)")
-            r = self._dconv_fwd(name + ".conv.double_conv", skip["z3"], skip["st3"], src1=u)
+            r = self._dconv_fwd(name + ".conv.double_conv", skip["z3"], skip["st3"], src1=u,
+                                drop_id=4 if name == DEC[0] else None)  # x = dropout(up1(x5, x4))
             r["up_in"], r["up_name"], r["u"] = prev, name, u
             recs[name] = r
             prev = r
@@ -354,7 +370,7 @@ class UNetTrainEngine:
                 z, st = below["z3"], below["st3"]
                 B, H, W, C = z.shape
                 check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
-                                                  stream()), "mfpa_maxpool2_bwd_add")
+                                                  st.drop[0], st.drop[1], st.drop[2], stream()), "mfpa_maxpool2_bwd_add")
             handles.append(self._reduce_bucket(name))
         for h in handles:
             if h is not None:

@@ -109,8 +109,9 @@ class UNet(nn.Module):
             raise ValueError("expected (B, 1, F, T)")
         if self.training:
             raise NotImplementedError(
-                "UNet training-mode forward (BatchNorm batch statistics, Dropout) runs through "
-                "musicfpaugment_amd.training.train.Trainer's HIP step; call .eval() for inference")
+                "train-mode forward + backward run without autograd through musicfpaugment_amd.training.train.Trainer "
+                "(ops_train.UNetTrainEngine: BatchNorm batch statistics, Dropout, L1, backward, Adam as HIP kernels); "
+                "call .eval() for inference")
         if x.dtype != torch.float32:
             raise TypeError("UNet input must be float32 (the reference casts with .float(), training/train.py:272)")
         pw = self.packed_weights()

@@ -54,14 +54,18 @@ def up(x1, x2, sd, name, training=False, stats_out=None):
     return double_conv(torch.cat([x2, x1], dim=1), sd, name + ".conv.double_conv", training, stats_out)
 
 
-def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], training: bool = False, stats_out=None) -> torch.Tensor:
-    """UNet.forward, training/unet.py:97-108, dropout rate 0 (eval, or train with rate=0)."""
+def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], training: bool = False, stats_out=None,
+            dropout_masks=None) -> torch.Tensor:
+    """UNet.forward, training/unet.py:97-108.  nn.Dropout sits on x2..x5 and on up1's output (:99-103); it is the
+    identity in eval mode.  In training mode the five multiplicative masks (already scaled by 1/(1-rate)) are passed
+    explicitly as dropout_masks = [m2, m3, m4, m5, m_up1] (torch's own Philox stream cannot be reproduced elsewhere)."""
+    dm = dropout_masks if dropout_masks is not None else [1.0] * 5
     x1 = double_conv(x, sd, "inc.double_conv", training, stats_out)
-    x2 = down(x1, sd, "down1", training, stats_out)
-    x3 = down(x2, sd, "down2", training, stats_out)
-    x4 = down(x3, sd, "down3", training, stats_out)
-    x5 = down(x4, sd, "down4", training, stats_out)
-    y = up(x5, x4, sd, "up1", training, stats_out)
+    x2 = down(x1, sd, "down1", training, stats_out) * dm[0]
+    x3 = down(x2, sd, "down2", training, stats_out) * dm[1]
+    x4 = down(x3, sd, "down3", training, stats_out) * dm[2]
+    x5 = down(x4, sd, "down4", training, stats_out) * dm[3]
+    y = up(x5, x4, sd, "up1", training, stats_out) * dm[4]
     y = up(y, x3, sd, "up2", training, stats_out)
     y = up(y, x2, sd, "up3", training, stats_out)
     y = up(y, x1, sd, "up4", training, stats_out)

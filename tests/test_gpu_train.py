@@ -177,3 +177,51 @@ def test_trainer_mirror_epoch_and_checkpoint(tmp_path):
     for v in (1.0, 1.1, 1.2):
         es(v)
     assert es.early_stop
+
+
+def _host_keep_mask(seed, thresh, scale, shape_nhwc):
+    """numpy mirror of csrc/mfpa_common.h::mfpa_keep over an NHWC tensor -> NCHW multiplicative mask."""
+    n = int(np.prod(shape_nhwc))
+    idx = np.arange(n, dtype=np.uint64)
+    lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = synth._mix32(synth._mix32(lo + np.uint32(seed)) ^ (hi * np.uint32(0x7F4A7C15) + np.uint32(seed)))
+    keep = (h >= np.uint32(thresh)).astype(np.float32) * np.float32(scale)
+    return torch.from_numpy(keep.reshape(shape_nhwc)).permute(0, 3, 1, 2).contiguous()
+
+
+def test_train_step_with_dropout_matches_autograd_given_the_same_masks():
+    """Dropout(0.05) as the reference trains with (train.py:646).  torch's Philox stream cannot be reproduced, so the
+    device's stateless mask is regenerated on the host and fed to the oracle; everything else must then agree."""
+    from oracle import unet as ou
+    from musicfpaugment_amd.ops_train import UNetTrainEngine, dropout_spec
+    from musicfpaugment_amd.training.unet import UNet
+    sd = formula_state_dict(2)
+    net = UNet(1, 1, rate=0.05)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    eng = UNetTrainEngine(net, lr=1e-3)
+    am, aug_den, clean_spec = _g7_inputs()
+    B, F_, T_ = am.shape
+    shapes = [(B, F_ // 2, T_ // 2, 128), (B, F_ // 4, T_ // 4, 256), (B, F_ // 8, T_ // 8, 512), (B, F_ // 16, T_ // 16, 1024),
+              (B, F_ // 8, T_ // 8, 512)]
+    masks = [_host_keep_mask(*dropout_spec(eng.drop_seed + i, 0.05), shp) for i, shp in enumerate(shapes)]
+    kept = np.mean([float((m > 0).float().mean()) for m in masks])
+    assert abs(kept - 0.95) < 0.01
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    x = (am / aug_den[:, None, None]).float().cpu().unsqueeze(1)
+    pred_ref = ou.forward(x, params, training=True, dropout_masks=masks).squeeze(1)
+    loss_ref = F.l1_loss(pred_ref, clean_spec.cpu())
+    loss_ref.backward()
+    pred = eng.forward(spec64=am, denom=aug_den)
+    assert rel(pred, pred_ref.detach()) < 1e-4
+    loss, dpred = eng.l1_loss(pred, clean_spec)
+    eng.backward(dpred)
+    grads = eng.named_grads()
+    errs = sorted(rel(grads[k], params[k].grad) for k in grads)
+    assert errs[len(errs) // 2] < 5e-3 and errs[-1] < 2e-2, (errs[len(errs) // 2], errs[-1])
+    # and dropout really changes the result
+    net0 = UNet(1, 1, rate=0.0)
+    net0.load_state_dict(sd)
+    eng0 = UNetTrainEngine(net0.cuda().train())
+    assert rel(eng0.forward(spec64=am, denom=aug_den), pred) > 1e-3
