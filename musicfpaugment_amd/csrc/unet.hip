@@ -22,6 +22,8 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KC = 32;        // channels per K chunk
 constexpr int LDK = KC + 4;   // padded LDS row (floats): 144 B -> conflict-free b128 fragment reads
@@ -48,7 +50,13 @@ struct ConvArgs {
 // MODE 1: 2x2 stride-2 transposed conv forward: one tap per workgroup column
 //         (blockIdx.y = tap * (Cout/BN) + n-tile), output scattered to (2y+dy, 2x+dx).
 // MODE 2: transposed-conv input gradient: 4 taps, A gathered from the (2H,2W) tensor at (2y+dy, 2x+dx).
-template <int BN, int PH, int PW, int MODE>
+// PREC 0: v_mfma_f32_32x32x2_f32 (exact fp32 products).
+// PREC 1: "bf16x3" -- every fp32 operand is split x = hi + lo into two bf16 values and the product is
+//         hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 3 matrix instructions at 16x
+//         the fp32-MFMA rate, relative error ~2^-17 per product (UNet output: relative L1 ~2e-5, tolerance 1e-4).
+//         An LDS row is [32 hi bf16 | 32 lo bf16 | pad] = the same 144 bytes as 32 floats + pad; the weights are
+//         pre-split into that row format on the host, activations are split while they are staged.
+template <int BN, int PH, int PW, int MODE, int PREC>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 2 ? 4 : 1);
@@ -133,7 +141,19 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
       const int idx = tid + it * CONV_THREADS;
       if (idx < HP * (KC / 4)) {
         const int pix = idx / (KC / 4), q = idx % (KC / 4);
-        *reinterpret_cast<f32x4*>(As + pix * LDK + 4 * q) = areg[it];
+        if (PREC == 0) {
+          *reinterpret_cast<f32x4*>(As + pix * LDK + 4 * q) = areg[it];
+        } else {
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            hi[k] = (__bf16)areg[it][k];
+            lo[k] = (__bf16)(areg[it][k] - (float)hi[k]);
+          }
+          char* row = reinterpret_cast<char*>(As + pix * LDK);
+          *reinterpret_cast<bf16x4*>(row + 8 * q) = hi;
+          *reinterpret_cast<bf16x4*>(row + 64 + 8 * q) = lo;
+        }
       }
     }
   };
@@ -191,6 +211,32 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
         if (new_chunk || A_PER_TAP) load_a(nchunk, ntap);
       }
       const int tap_off = (MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0;
+      if (PREC == 1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const char* r = reinterpret_cast<const char*>(As + a_base[mt] + tap_off) + 32 * s;   // a_base already holds 16*lh bytes
+            ah[mt] = *reinterpret_cast<const bf16x8*>(r);
+            al[mt] = *reinterpret_cast<const bf16x8*>(r + 64);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const char* r = reinterpret_cast<const char*>(Bs + b_base[nt]) + 32 * s;
+            bh[nt] = *reinterpret_cast<const bf16x8*>(r);
+            bl[nt] = *reinterpret_cast<const bf16x8*>(r + 64);
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+      } else
 #pragma unroll
       for (int s = 0; s < KC / 8; ++s) {
         f32x4 af[MT], bf[NT];
@@ -342,19 +388,19 @@ __global__ __launch_bounds__(256) void conv1x1_out_kernel(const float* __restric
   }
 }
 
-template <int BN, int PH, int PW, int MODE>
+template <int BN, int PH, int PW, int MODE, int PREC>
 int launch_conv(const ConvArgs& a, int grid_y, hipStream_t s) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
   const size_t lds = sizeof(float) * ((size_t)HP * LDK + (size_t)BN * LDK);
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)grid_y);
-  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, MODE>), grid, dim3(CONV_THREADS), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, MODE, PREC>), grid, dim3(CONV_THREADS), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
-template <int MODE>
-int dispatch_conv(ConvArgs& a, hipStream_t s) {
+template <int MODE, int PREC>
+int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   const bool wide = a.W > 16;  // 4x32 patches for wide planes, 8x16 for the 16x15 bottleneck
   const int taps_y = (MODE == 1) ? 4 : 1;
   if (wide) {
@@ -367,10 +413,15 @@ int dispatch_conv(ConvArgs& a, hipStream_t s) {
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
   if (a.Cout % 128 == 0) {
     const int gy = taps_y * (a.Cout / 128);
-    return wide ? launch_conv<128, 4, 32, MODE>(a, gy, s) : launch_conv<128, 8, 16, MODE>(a, gy, s);
+    return wide ? launch_conv<128, 4, 32, MODE, PREC>(a, gy, s) : launch_conv<128, 8, 16, MODE, PREC>(a, gy, s);
   }
   const int gy = taps_y * (a.Cout / 64);
-  return wide ? launch_conv<64, 4, 32, MODE>(a, gy, s) : launch_conv<64, 8, 16, MODE>(a, gy, s);
+  return wide ? launch_conv<64, 4, 32, MODE, PREC>(a, gy, s) : launch_conv<64, 8, 16, MODE, PREC>(a, gy, s);
+}
+
+template <int MODE>
+int dispatch_conv(ConvArgs& a, hipStream_t s, int precision = 0) {
+  return precision ? dispatch_conv_p<MODE, 1>(a, s) : dispatch_conv_p<MODE, 0>(a, s);
 }
 
 }  // namespace
@@ -384,25 +435,25 @@ int mfpa_conv3x3_bn_relu(const float* x0, int C0, const float* x1, int C1, int H
   if (!x0 || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
   if (C0 < KC || C0 % KC || C1 < 0 || C1 % KC || Cout < 64 || Cout % 64) return MFPA_EINVAL;
   if (C1 > 0 && (!x1 || H1 < 1 || W1 < 1 || H1 > H || W1 > W)) return MFPA_EINVAL;
-  if (precision != 0) return MFPA_EINVAL;
+  if (precision != 0 && precision != 1) return MFPA_EINVAL;
   ConvArgs a{};
   a.x0 = x0; a.x1 = C1 ? x1 : nullptr; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
   a.C0 = C0; a.C1 = C1; a.H1 = C1 ? H1 : 0; a.W1 = C1 ? W1 : 0;
   a.oy1 = C1 ? (H - H1) / 2 : 0;  // F.pad(x1, [dx//2, dx-dx//2, dy//2, dy-dy//2]), unet.py:59-62
   a.ox1 = C1 ? (W - W1) / 2 : 0;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu; a.yH = H; a.yW = W;
-  return dispatch_conv<0>(a, mfpa_stream(stream));
+  return dispatch_conv<0>(a, mfpa_stream(stream), precision);
 }
 
 int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                   int precision, float* y, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!x || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
-  if (Cin < KC || Cin % KC || Cout < 64 || Cout % 64 || precision != 0) return MFPA_EINVAL;
+  if (Cin < KC || Cin % KC || Cout < 64 || Cout % 64 || (precision != 0 && precision != 1)) return MFPA_EINVAL;
   ConvArgs a{};
   a.x0 = x; a.w = w; a.scale = nullptr; a.shift = bias; a.y = y;
   a.C0 = Cin; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 0; a.yH = H; a.yW = W;
-  return dispatch_conv<1>(a, mfpa_stream(stream));
+  return dispatch_conv<1>(a, mfpa_stream(stream), precision);
 }
 
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {

@@ -35,8 +35,20 @@ def pack_convT2x2(w: torch.Tensor) -> torch.Tensor:
     return w.detach().float().permute(2, 3, 1, 0).reshape(4, co, ci).contiguous()
 
 
-def pack_unet_weights(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    pw: Dict[str, torch.Tensor] = {}
+def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """Kernel-layout fp32 weights [taps][Cout][Cin] -> the same-shaped float32 container whose every 32-channel
+    chunk (128 bytes) holds [32 bf16 hi | 32 bf16 lo] with w = hi + lo (+ O(2^-17 w)): the LDS row format of the
+    bf16x3 convolution (csrc/unet.hip, PREC 1)."""
+    t, co, ci = w.shape
+    w4 = w.reshape(t, co, ci // 32, 32)
+    hi = w4.to(torch.bfloat16)
+    lo = (w4 - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(t, co, ci)
+
+
+def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[str, torch.Tensor]:
+    """precision 0: fp32 MFMA weights; 1: additionally pre-split (bf16x3) copies under '<name>.w3'."""
+    pw: Dict[str, torch.Tensor] = {"precision": precision}
 
     def dconv(prefix, first_layer=False):
         w0 = sd[prefix + ".0.weight"]
@@ -57,6 +69,9 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     pw["outc.w"] = sd["outc.conv.weight"].detach().float().reshape(-1).contiguous()
     pw["outc.b"] = sd["outc.conv.bias"].detach().float().reshape(-1).contiguous()
     pw["outc.b_host"] = float(sd["outc.conv.bias"].detach().float().reshape(-1)[0].item())
+    if precision == 1:
+        for k in [k for k in pw if isinstance(pw[k], torch.Tensor) and pw[k].dim() == 3]:
+            pw[k + "3"] = split_bf16x3(pw[k])
     return pw
 
 
@@ -152,27 +167,33 @@ def conv1x1_out(x, w, bias: float):
 def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] = None,
                       spec64: Optional[torch.Tensor] = None, denom: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UNet.forward in eval mode (training/unet.py:97-108) on (B, F, T) -> (B, F, T) float32."""
+    prec = int(pw.get("precision", 0))
+    sfx = "3" if prec == 1 else ""
+
     def dconv(x, prefix, skip=None):
         if skip is None:
-            m = conv3x3_bn_relu(x, pw[prefix + ".0.w"], pw[prefix + ".0.scale"], pw[prefix + ".0.shift"])
+            m = conv3x3_bn_relu(x, pw[prefix + ".0.w" + sfx], pw[prefix + ".0.scale"], pw[prefix + ".0.shift"],
+                                precision=prec)
         else:  # decoder: channels = [skip | upsampled], upsampled zero-padded bottom/right to the skip extent
-            m = conv3x3_bn_relu(skip, pw[prefix + ".0.w"], pw[prefix + ".0.scale"], pw[prefix + ".0.shift"], x1=x)
-        return conv3x3_bn_relu(m, pw[prefix + ".3.w"], pw[prefix + ".3.scale"], pw[prefix + ".3.shift"])
+            m = conv3x3_bn_relu(skip, pw[prefix + ".0.w" + sfx], pw[prefix + ".0.scale"], pw[prefix + ".0.shift"], x1=x,
+                                precision=prec)
+        return conv3x3_bn_relu(m, pw[prefix + ".3.w" + sfx], pw[prefix + ".3.scale"], pw[prefix + ".3.shift"],
+                               precision=prec)
 
     p = ENC[0]
     m = conv3x3_c1_bn_relu(pw[p + ".0.w"], pw[p + ".0.scale"], pw[p + ".0.shift"], x32=x32, spec64=spec64, denom=denom)
-    x1 = conv3x3_bn_relu(m, pw[p + ".3.w"], pw[p + ".3.scale"], pw[p + ".3.shift"])
+    x1 = conv3x3_bn_relu(m, pw[p + ".3.w" + sfx], pw[p + ".3.scale"], pw[p + ".3.shift"], precision=prec)
     del m
     x2 = dconv(maxpool2(x1), ENC[1])
     x3 = dconv(maxpool2(x2), ENC[2])
     x4 = dconv(maxpool2(x3), ENC[3])
     x5 = dconv(maxpool2(x4), ENC[4])
-    y = dconv(convT2x2(x5, pw["up1.up.w"], pw["up1.up.b"]), "up1.conv.double_conv", skip=x4)
+    y = dconv(convT2x2(x5, pw["up1.up.w" + sfx], pw["up1.up.b"], precision=prec), "up1.conv.double_conv", skip=x4)
     del x5, x4
-    y = dconv(convT2x2(y, pw["up2.up.w"], pw["up2.up.b"]), "up2.conv.double_conv", skip=x3)
+    y = dconv(convT2x2(y, pw["up2.up.w" + sfx], pw["up2.up.b"], precision=prec), "up2.conv.double_conv", skip=x3)
     del x3
-    y = dconv(convT2x2(y, pw["up3.up.w"], pw["up3.up.b"]), "up3.conv.double_conv", skip=x2)
+    y = dconv(convT2x2(y, pw["up3.up.w" + sfx], pw["up3.up.b"], precision=prec), "up3.conv.double_conv", skip=x2)
     del x2
-    y = dconv(convT2x2(y, pw["up4.up.w"], pw["up4.up.b"]), "up4.conv.double_conv", skip=x1)
+    y = dconv(convT2x2(y, pw["up4.up.w" + sfx], pw["up4.up.b"], precision=prec), "up4.conv.double_conv", skip=x1)
     del x1
     return conv1x1_out(y, pw["outc.w"], pw["outc.b_host"])

@@ -87,6 +87,9 @@ class UNet(nn.Module):
         self.outc = OutConv(64, n_classes)
 
         self.max_clips_per_pass = 64       # activations of one pass: ~0.12 GB per 8 s clip
+        # inference arithmetic of the MFMA convolutions: 0 = fp32 MFMA (exact fp32 products, rel. L1 ~1e-6 vs the
+        # reference), 1 = bf16x3 split (3 bf16 MFMAs per product, rel. L1 ~2e-5; tolerance is 1e-4)
+        self.precision = 0
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
 
@@ -96,9 +99,9 @@ class UNet(nn.Module):
 
     def packed_weights(self) -> Dict[str, torch.Tensor]:
         """Kernel-layout weights ([tap][Cout][Cin]) + folded eval BatchNorm; rebuilt when parameters change."""
-        key = self._weights_key()
+        key = (self._weights_key(), self.precision)
         if self._packed is None or key != self._packed_key:
-            self._packed = K.pack_unet_weights(self.state_dict())
+            self._packed = K.pack_unet_weights(self.state_dict(), self.precision)
             self._packed_key = key
         return self._packed
 

@@ -116,3 +116,23 @@ def test_train_mode_and_cpu_inputs_fail_loudly(net):
             net(torch.zeros(1, 1, 257, 32, device="cuda"))
     finally:
         net.eval()
+
+
+def test_bf16x3_precision_meets_the_tolerance(net, golden):
+    """precision=1: every fp32 product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi).  Same 1e-4 gate as fp32."""
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    g = golden("g6_unet_forward")
+    net.precision = 1
+    try:
+        y = net(torch.from_numpy(g["x"]).cuda())
+        r1 = ou.relative_l1(y.cpu(), torch.from_numpy(g["y"]))
+        wav = synth.batch(2, seed=900, n=64000)
+        x = torch.from_numpy(ostft.spectrogram(wav)).float().unsqueeze(1)
+        with torch.no_grad():
+            want = ou.forward(x[:1], formula_state_dict(0))
+        r2 = ou.relative_l1(net(x.cuda())[:1].cpu(), want)
+    finally:
+        net.precision = 0
+    assert r1 <= TOL and r2 <= TOL, (r1, r2)
+    assert r1 > 1e-7          # it really is the split path
