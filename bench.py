@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
 
 
@@ -59,9 +60,11 @@ def cpu_baseline(budget_s: float, seed: int):
     for thr in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
         torch.set_num_threads(thr)
         one(wav[0])                               # warm-up at this thread count
-        t0 = time.perf_counter()
-        one(wav[1])
-        dt = time.perf_counter() - t0
+        dt = float("inf")
+        for k in (1, 2, 3):                       # best of three: the host is shared and noisy
+            t0 = time.perf_counter()
+            one(wav[k])
+            dt = min(dt, time.perf_counter() - t0)
         if best_t is None or dt < best_t:
             best_thr, best_t = thr, dt
         if dt > budget_s / 2:
@@ -158,6 +161,10 @@ def main():
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
+                         "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
+                         "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce)")
@@ -194,6 +201,7 @@ def main():
         net = UNet(1, 1, rate=0.05)
         net.load_state_dict(formula_state_dict(0))
         net = net.to(dev).eval()
+        net.precision = 1 if args.precision == "bf16x3" else 0
     hot = HotPath(net, device=dev)
 
     # synthetic clips of SURVEY.md §8d: 32 distinct generated clips per rank, tiled to B with a sign/gain variation
@@ -208,17 +216,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps):
+        timer = ops_unet.KernelTimer()
+        ops_unet.set_timer(timer)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = hot(wav)
+        barrier()
+        ops_unet.set_timer(None)
+        return time.perf_counter() - t0, timer, out
+
     for _ in range(args.warmup):
         mask, npeaks = hot(wav)
     barrier()
-    timer = ops_unet.KernelTimer()
-    ops_unet.set_timer(timer)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mask, npeaks = hot(wav)
-    barrier()
-    dt = time.perf_counter() - t0
-    ops_unet.set_timer(None)
+    dt, timer, (mask, npeaks) = timed(args.steps)
+    other = None
+    if net is not None and world == 1:        # the other arithmetic, same run, for the record (not the headline)
+        net.precision = 1 - net.precision
+        hot(wav)
+        barrier()
+        dt_o, timer_o, _ = timed(args.steps)
+        net.precision = 1 - net.precision
+        other = (dt_o, timer_o)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -239,21 +258,38 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "f32")
+                     if net is not None else "f64",
             "data": "synthetic",
-            "config": {"workload": "STFT(512/256,f64) -> UNet(1,1) eval forward (fp32 MFMA, formula weights) -> "
+            "config": {"workload": f"STFT(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights) -> "
                                    "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms",
                        "clips_per_gpu_per_step": B, "peaks_last_step_rank0": total_peaks,
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
         }
-        if net is not None and timer.launches():
-            conv_ms = timer.total_ms()
+        def roofline(tm, precision):
+            conv_ms = tm.total_ms()
             flops = UNET_MFMA_GFLOP_PER_CLIP * 1e9 * B * args.steps
-            achieved = flops / (conv_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "conv_mfma_kernel (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                               "launches": timer.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+            achieved = flops / (conv_ms * 1e-3) / 1e12        # ALGORITHMIC TFLOP/s of the MFMA conv launches
+            if precision == "fp32":
+                return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel": "conv_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                        "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+            return {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "mfma_flops_issued_per_algorithmic_flop": 3,
+                    "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                    "kernel": "conv_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 "
+                              "per fp32 product)",
+                    "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+
+        if net is not None and timer.launches():
+            out["roofline"] = roofline(timer, args.precision)
+        if other is not None:
+            oname = "fp32" if args.precision == "bf16x3" else "bf16x3"
+            out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),
+                                      "unit": "clips/s", "ms_per_step": round(1e3 * other[0] / args.steps, 3),
+                                      "roofline": roofline(other[1], oname)}
         if world == 1 and args.cpu_seconds > 0 and net is not None:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, synth.BASE_SEED)
         print(json.dumps(out), flush=True)

@@ -18,6 +18,9 @@
 // block of the current tap and written to LDS after it, so they overlap the matrix work.
 #include "mfpa_common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -27,7 +30,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KC = 32;        // channels per K chunk
 constexpr int LDK = KC + 4;   // padded LDS row (floats): 144 B -> conflict-free b128 fragment reads
-constexpr int CONV_THREADS = 256;
+
+__device__ __forceinline__ bool v_never(float v) { return v != 12345.678f; }  // keeps the accumulators live in the 'skip stores' experiment
 
 struct ConvArgs {
   const float* x0;         // source 0: (B,H,W,C0) [mode 2: (B,2H,2W,C0)]
@@ -44,6 +48,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   unsigned drop_seed, drop_thresh;   // dropout on source 0 after the affine+ReLU (thresh 0 = off)
   float drop_scale;
+  int dbg;                           // timing experiments only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA
 };
 
 // MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).
@@ -56,26 +61,36 @@ struct ConvArgs {
 //         the fp32-MFMA rate, relative error ~2^-17 per product (UNet output: relative L1 ~2e-5, tolerance 1e-4).
 //         An LDS row is [32 hi bf16 | 32 lo bf16 | pad] = the same 144 bytes as 32 floats + pad; the weights are
 //         pre-split into that row format on the host, activations are split while they are staged.
-template <int BN, int PH, int PW, int MODE, int PREC>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) {
+// WM x WN waves, each 64 pixels x (BN/WN) channels: the workgroup tile is (64*WM pixels) x BN channels.
+//
+// Pipeline per (chunk, tap) iteration `it`, with the weight tile double-buffered in LDS and two register sets:
+//     write B(it+1) registers -> Bs[(it+1)&1]   (loaded from L2/HBM during iteration it-1)
+//     issue global loads of B(it+2) -> the other register set; at tap 0 also of the NEXT chunk's halo tile
+//     MFMA block of iteration it from As / Bs[it&1]
+//     one barrier                                 (+ barrier, halo store, at a chunk's last tap)
+// so weight loads have two MFMA blocks to land, and the only exposed cost per iteration is the wave skew.
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int THREADS = 64 * WM * WN;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 2 ? 4 : 1);
   constexpr bool A_PER_TAP = (MODE == 2);               // A tile changes with the tap
   constexpr int HPW = PW + 2 * HALO, HPH = PH + 2 * HALO;
   constexpr int HP = HPW * HPH;                       // halo-tile pixels
-  constexpr int BM = PH * PW;                         // 128
-  static_assert(BM == 128, "workgroup tile is 128 pixels");
-  constexpr int NT = BN / 64;                         // 32-wide n tiles per wave (2x2 wave grid)
+  constexpr int BM = PH * PW;
+  static_assert(BM == 64 * WM, "workgroup tile is 64*WM pixels");
+  constexpr int NT = BN / (32 * WN);                  // 32-wide n tiles per wave
   constexpr int MT = 2;
-  constexpr int A_F4 = (HP * (KC / 4) + CONV_THREADS - 1) / CONV_THREADS;
-  constexpr int B_F4 = BN * (KC / 4) / CONV_THREADS;
+  constexpr int A_F4 = (HP * (KC / 4) + THREADS - 1) / THREADS;
+  constexpr int B_F4 = (BN * (KC / 4) + THREADS - 1) / THREADS;
+  constexpr bool B_EXACT = (BN * (KC / 4)) % THREADS == 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);         // [HP][LDK]
-  float* Bs = As + HP * LDK;                          // [BN][LDK]
+  float* Bs0 = As + HP * LDK;                         // [2][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   const int li = lane & 31, lh = lane >> 5;
 
   int bx = blockIdx.x;
@@ -89,16 +104,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
   const int y0 = ty * PH, x0p = tx * PW;
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / KC;
+  const int nit = nchunks * TAPS;
 
   f32x4 areg[A_F4];
-  f32x4 breg[B_F4];
+  f32x4 breg[2][B_F4];   // two register sets for the weight tile, always indexed with compile-time constants
 
-  auto load_a = [&](int chunk, int tap) {
+  auto load_a = [&](int chunk, int tap) __attribute__((always_inline)) {
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      const int idx = tid + it * CONV_THREADS;
+      const int idx = tid + it * THREADS;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (idx < HP * (KC / 4)) {
         const int pix = idx / (KC / 4), q = idx % (KC / 4);
@@ -135,10 +151,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
       areg[it] = v;
     }
   };
-  auto store_a = [&]() {
+  auto store_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      const int idx = tid + it * CONV_THREADS;
+      const int idx = tid + it * THREADS;
       if (idx < HP * (KC / 4)) {
         const int pix = idx / (KC / 4), q = idx % (KC / 4);
         if (PREC == 0) {
@@ -157,22 +173,29 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
       }
     }
   };
-  auto load_b = [&](int chunk, int tap) {
+  auto load_b = [&](int it_flat, auto SET) __attribute__((always_inline)) {
+    constexpr int set = decltype(SET)::value;
+    const int chunk = it_flat / TAPS, tap = it_flat % TAPS;
     const int wt = (MODE == 1) ? ct_tap : tap;
     const float* wbase = a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC;
 #pragma unroll
     for (int it = 0; it < B_F4; ++it) {
-      const int idx = tid + it * CONV_THREADS;
-      const int n = idx / (KC / 4), q = idx % (KC / 4);
-      breg[it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * Cin + 4 * q);
+      const int idx = tid + it * THREADS;
+      if (B_EXACT || idx < BN * (KC / 4)) {
+        const int n = idx / (KC / 4), q = idx % (KC / 4);
+        breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * Cin + 4 * q);
+      }
     }
   };
-  auto store_b = [&]() {
+  auto store_b = [&](auto SET, float* Bs) __attribute__((always_inline)) {
+    constexpr int set = decltype(SET)::value;
 #pragma unroll
     for (int it = 0; it < B_F4; ++it) {
-      const int idx = tid + it * CONV_THREADS;
-      const int n = idx / (KC / 4), q = idx % (KC / 4);
-      *reinterpret_cast<f32x4*>(Bs + n * LDK + 4 * q) = breg[it];
+      const int idx = tid + it * THREADS;
+      if (B_EXACT || idx < BN * (KC / 4)) {
+        const int n = idx / (KC / 4), q = idx % (KC / 4);
+        *reinterpret_cast<f32x4*>(Bs + n * LDK + 4 * q) = breg[set][it];
+      }
     }
   };
 
@@ -194,49 +217,34 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) b_base[nt] = (wn * (NT * 32) + nt * 32 + li) * LDK + 4 * lh;
 
-  load_a(0, 0);
-  load_b(0, 0);
-  store_a();
-  store_b();
-  __syncthreads();
-
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-#pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const bool last = (chunk == nchunks - 1) && (tap == TAPS - 1);
-      const bool new_chunk = (tap == TAPS - 1);
-      const int nchunk = new_chunk ? chunk + 1 : chunk, ntap = new_chunk ? 0 : tap + 1;
-      if (!last) {
-        load_b(nchunk, ntap);
-        if (new_chunk || A_PER_TAP) load_a(nchunk, ntap);
-      }
-      const int tap_off = (MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0;
-      if (PREC == 1) {
+  auto compute = [&](int tap, const float* Bs) __attribute__((always_inline)) {
+    const int tap_off = (MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0;
+    if (PREC == 1) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const char* r = reinterpret_cast<const char*>(As + a_base[mt] + tap_off) + 32 * s;   // a_base already holds 16*lh bytes
-            ah[mt] = *reinterpret_cast<const bf16x8*>(r);
-            al[mt] = *reinterpret_cast<const bf16x8*>(r + 64);
-          }
+        for (int mt = 0; mt < MT; ++mt) {
+          const char* r = reinterpret_cast<const char*>(As + a_base[mt] + tap_off) + 32 * s;
+          ah[mt] = *reinterpret_cast<const bf16x8*>(r);
+          al[mt] = *reinterpret_cast<const bf16x8*>(r + 64);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const char* r = reinterpret_cast<const char*>(Bs + b_base[nt]) + 32 * s;
+          bh[nt] = *reinterpret_cast<const bf16x8*>(r);
+          bl[nt] = *reinterpret_cast<const bf16x8*>(r + 64);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const char* r = reinterpret_cast<const char*>(Bs + b_base[nt]) + 32 * s;
-            bh[nt] = *reinterpret_cast<const bf16x8*>(r);
-            bl[nt] = *reinterpret_cast<const bf16x8*>(r + 64);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-            }
-        }
-      } else
+      }
+    } else {
 #pragma unroll
       for (int s = 0; s < KC / 8; ++s) {
         f32x4 af[MT], bf[NT];
@@ -254,13 +262,40 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].w, bf[nt].w, acc[mt][nt], 0, 0, 0);
           }
       }
-      __syncthreads();
-      if (!last) {
-        store_b();
-        if (new_chunk || A_PER_TAP) store_a();
-      }
-      __syncthreads();
     }
+  };
+
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  // one pipeline iteration; register set CUR holds B(it+1), the other set receives B(it+2)
+  auto step = [&](int it, auto CUR) __attribute__((always_inline)) {
+    constexpr int cur = decltype(CUR)::value;
+    const int tap = it % TAPS;
+    const bool chunk_end = (tap == TAPS - 1);
+    if (!(a.dbg & 1)) {
+      if (it + 1 < nit) store_b(CUR, Bs0 + ((it + 1) & 1) * (BN * LDK));
+      if (it + 2 < nit) load_b(it + 2, std::integral_constant<int, 1 - cur>{});
+    }
+    if (!A_PER_TAP && tap == 0 && it + TAPS < nit) load_a(it / TAPS + 1, 0);   // next chunk's halo, a whole chunk ahead
+    if (A_PER_TAP && it + 1 < nit) load_a((it + 1) / TAPS, (it + 1) % TAPS);
+    if (!(a.dbg & 8)) compute(tap, Bs0 + (it & 1) * (BN * LDK));
+    if ((chunk_end || A_PER_TAP) && it + 1 < nit) {
+      if (!(a.dbg & 2)) __syncthreads();            // every wave is done reading As
+      store_a();
+    }
+    if (!(a.dbg & 2)) __syncthreads();
+  };
+
+  load_a(0, 0);
+  load_b(0, Set0{});
+  store_a();
+  store_b(Set0{}, Bs0);
+  if (nit > 1) load_b(1, Set0{});
+  __syncthreads();
+
+  for (int it = 0; it < nit; it += 2) {
+    step(it, Set0{});
+    if (it + 1 < nit) step(it + 1, Set1{});
   }
 
   // epilogue: y = relu(acc * scale[n] + shift[n]); D[row = pixel][col = channel]
@@ -275,7 +310,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_mfma_kernel(ConvArgs a) 
       for (int r = 0; r < 16; ++r) {
         const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gy = y0 + m / PW, gx = x0p + m % PW;
-        if (gy < a.yH && gx < a.yW) {
+        if (gy < a.yH && gx < a.yW && !((a.dbg & 4) && v_never(acc[mt][nt][r]))) {
           float v = acc[mt][nt][r] * sc + sh;
           if (a.relu) v = v > 0.f ? v : 0.f;
           if (MODE != 1) {
@@ -388,35 +423,44 @@ __global__ __launch_bounds__(256) void conv1x1_out_kernel(const float* __restric
   }
 }
 
-template <int BN, int PH, int PW, int MODE, int PREC>
-int launch_conv(const ConvArgs& a, int grid_y, hipStream_t s) {
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC>
+int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
-  const size_t lds = sizeof(float) * ((size_t)HP * LDK + (size_t)BN * LDK);
-  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)grid_y);
-  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, MODE, PREC>), grid, dim3(CONV_THREADS), lds, s, a);
+  a.tiles_x = (a.W + PW - 1) / PW;
+  a.tiles_y = (a.H + PH - 1) / PH;
+  static const int dbg_env = getenv("MFPA_CONV_DBG") ? atoi(getenv("MFPA_CONV_DBG")) : 0;
+  a.dbg = dbg_env;
+  if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
+  const size_t lds = sizeof(float) * ((size_t)HP * LDK + 2 * (size_t)BN * LDK);
+  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(taps_y * (a.Cout / BN)));
+  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC>), grid, dim3(64 * WM * WN), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
+// Tile choice.  Waves always own 64 pixels x 64 channels.
+//   Cout % 128 == 0: 128-channel tiles; 8 waves on 8x32-pixel patches (256 x 128: half the weight traffic and
+//                    barriers per MFMA) when K = 9*Cin is long enough to amortise the prologue/epilogue of a
+//                    one-workgroup-per-CU kernel, else 4 waves on 4x32 patches (two workgroups per CU overlap).
+//   otherwise      : 64-channel tiles, 4 waves stacked along M on 8x32 patches (256 x 64).
+//   W <= 16 (the 16x15 bottleneck): 8x16 patches.
 template <int MODE, int PREC>
 int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
-  const bool wide = a.W > 16;  // 4x32 patches for wide planes, 8x16 for the 16x15 bottleneck
   const int taps_y = (MODE == 1) ? 4 : 1;
-  if (wide) {
-    a.tiles_x = (a.W + 31) / 32;
-    a.tiles_y = (a.H + 3) / 4;
-  } else {
-    a.tiles_x = (a.W + 15) / 16;
-    a.tiles_y = (a.H + 7) / 8;
+  const bool bn128 = (a.Cout % 128 == 0);
+  static const int wm_env = getenv("MFPA_CONV_WM") ? atoi(getenv("MFPA_CONV_WM")) : 0;   // experiments
+  const int cin = a.C0 + a.C1;
+  const bool big = (wm_env == 4) || (wm_env == 0 && cin >= 256);
+  if (a.W > 16 && a.H >= 8) {
+    if (!bn128) return launch_conv<64, 8, 32, 4, 1, MODE, PREC>(a, taps_y, s);
+    if (big) return launch_conv<128, 8, 32, 4, 2, MODE, PREC>(a, taps_y, s);
+    return launch_conv<128, 4, 32, 2, 2, MODE, PREC>(a, taps_y, s);
   }
-  if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  if (a.Cout % 128 == 0) {
-    const int gy = taps_y * (a.Cout / 128);
-    return wide ? launch_conv<128, 4, 32, MODE, PREC>(a, gy, s) : launch_conv<128, 8, 16, MODE, PREC>(a, gy, s);
+  if (a.W > 16) {
+    return bn128 ? launch_conv<128, 4, 32, 2, 2, MODE, PREC>(a, taps_y, s) : launch_conv<64, 4, 32, 2, 1, MODE, PREC>(a, taps_y, s);
   }
-  const int gy = taps_y * (a.Cout / 64);
-  return wide ? launch_conv<64, 4, 32, MODE, PREC>(a, gy, s) : launch_conv<64, 8, 16, MODE, PREC>(a, gy, s);
+  return bn128 ? launch_conv<128, 8, 16, 2, 2, MODE, PREC>(a, taps_y, s) : launch_conv<64, 8, 16, 2, 1, MODE, PREC>(a, taps_y, s);
 }
 
 template <int MODE>
