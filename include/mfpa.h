@@ -143,6 +143,29 @@ int mfpa_peak_metrics(const uint8_t* predicted, const uint8_t* gt, int B, int N1
                       int64_t* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Landmark pairing + hashing, the step after the pickers (next-tier row SURVEY.md §8f-1).  Integer only.
+ *
+ * mfpa_audfprint_landmarks: peaks2landmarks + landmarks2hashes + the duplicate removal of wavfile2hashes
+ * (afp/audfprint/peak_extractor.py:313-346, :40-58, :443-460) from the peak mask of mfpa_audfprint_prune.
+ *   mask (B,R,T) uint8 (<= 8 peaks per frame); cap = row capacity per clip (<= 8192)
+ *   landmarks (B,cap,4) int32 (col, bin1, bin2, dcol) in the reference's list order
+ *   hashes    (B,cap,2) int32 (time, hash) in the same order
+ *   uniq      (B,cap,2) int32 unique rows sorted by (time << 32) + hash
+ *   counts    (B,2) int32 = [n_landmarks, n_unique], or [-1,-1] when a clip overflows cap / 8 peaks per frame
+ *   reference constants: mindt 2, targetdt 63, targetdf 31, maxpairs 3 (peak_extractor.py:99-107)
+ *
+ * mfpa_dejavu_hashes: generate_hashes (afp/dejavu/fingerprint.py:174-213) from the mask of mfpa_localmax2d:
+ * peaks in (time, freq) order, each with its next fan-1 peaks, min_dt <= dt <= max_dt,
+ * SHA-1("f1|f2|dt") truncated to 10 bytes (= 20 hex digits).
+ *   digests (B,cap,10) uint8, t1 (B,cap) int32, counts (B) int32 (-1: more than peak_cap peaks or cap hashes)
+ */
+int mfpa_audfprint_landmarks(const uint8_t* mask, int B, int R, int T, int cap, int mindt, int targetdt,
+                             int targetdf, int maxpairs, int32_t* landmarks, int32_t* hashes, int32_t* uniq,
+                             int32_t* counts, void* stream);
+int mfpa_dejavu_hashes(const uint8_t* mask, int B, int F, int T, int cap, int peak_cap, int fan, int min_dt,
+                       int max_dt, uint8_t* digests, int32_t* t1, int32_t* counts, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * UNet denoiser building blocks, training/unet.py:8-108.  Activations are NHWC float32
  * ("pixels x channels": H = frequency bins, W = frames); with C = 1 at both ends of the
  * network this is byte-identical to the reference's NCHW (B,1,257,T) tensors.

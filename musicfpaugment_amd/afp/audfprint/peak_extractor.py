@@ -17,6 +17,19 @@ from ... import ops
 from ...constants import afp_settings
 
 
+def landmarks2hashes(landmarks_list) -> np.ndarray:
+    """[(time, bin1, bin2, dtime)] -> (n, 2) int32 (time, hash).  afp/audfprint/peak_extractor.py:40-58.
+    Pure bit packing of a host list (no device work needed); the batched device path packs hashes inside
+    mfpa_audfprint_landmarks."""
+    lm = np.array(landmarks_list, dtype=np.int64).reshape(-1, 4)
+    if lm.shape[0] == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    out = np.zeros((lm.shape[0], 2), dtype=np.int32)
+    out[:, 0] = lm[:, 0]
+    out[:, 1] = ((lm[:, 1] & 255) << 12) | (((lm[:, 2] - lm[:, 1]) & 63) << 6) | (lm[:, 3] & 63)
+    return out
+
+
 class Audfprint_peaks(object):
     def __init__(self, params: Optional[Dict[str, Any]] = None, denoising: bool = False, denoising_model=None,
                  unet=None, device="cuda") -> None:
@@ -75,3 +88,30 @@ class Audfprint_peaks(object):
         cols, bins = torch.nonzero(m.t(), as_tuple=True)                          # column-major ascending (:305-309)
         pklist = list(zip(cols.tolist(), bins.tolist()))
         return pklist, m.to(torch.float32).cpu().numpy(), spec[0].cpu().numpy()
+
+    # ------------------------------------------------------------------ landmarks / hashes (next-tier row §8f-1)
+    def hashes_batch(self, wav: torch.Tensor, cap: int = 4096):
+        """(B, T) float32 on the GPU -> (unique sorted (time, hash) rows (B, cap, 2) int32, counts (B,) int32):
+        wavfile2hashes with shifts = 1 (peak_extractor.py:426-460) for a whole batch, peaks never leaving the device."""
+        mask, _, _ = self.find_peaks_batch(wav)
+        _, _, uniq, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf,
+                                                     self.maxpairsperpeak)
+        return uniq, counts[:, 1].contiguous()
+
+    def peaks2landmarks(self, pklist: List[Tuple[int, int]]) -> List[Tuple[int, int, int, int]]:
+        """[(col, bin)] -> [(col, bin1, bin2, dcol)], peak_extractor.py:313-346, through the device kernel."""
+        if len(pklist) == 0:
+            return []
+        pk = np.asarray(pklist, dtype=np.int64).reshape(-1, 2)
+        T, R = int(pk[:, 0].max()) + 1, 256
+        if pk[:, 1].max() >= R:
+            raise ValueError("bins must be < 256 (they are packed into 8 bits, peak_extractor.py:54)")
+        mask = torch.zeros((1, R, T), dtype=torch.uint8)
+        mask[0, pk[:, 1], pk[:, 0]] = 1
+        cap = min(8192, max(16, 3 * len(pk)))
+        lm, _, _, counts = ops.audfprint_landmarks(mask.to(self.device), cap, self.mindt, self.targetdt, self.targetdf,
+                                                   self.maxpairsperpeak)
+        n = int(counts[0, 0])
+        if n < 0:
+            raise ValueError("more than 8 peaks in one frame or more than 8192 landmarks: outside the device kernel's limits")
+        return [tuple(r) for r in lm[0, :n].cpu().tolist()]

@@ -3,7 +3,7 @@
 ``get_2D_peaks(arr2D, plot=False, amp_min=50) -> (peak_coordinates, peak_mask)`` keeps the reference
 contract (coordinates [(freq, time)] in row-major order, mask float64).  ``fingerprint_peaks_batch``
 is the batched device path: mlab.specgram-style PSD -> /max -> 10 ln -> -mean -> 21x21 local maxima.
-Hash generation (generate_hashes, :174-213) is a next-tier row.
+`generate_hashes` / `fingerprint_batch` run the pairing + SHA-1 on the device (mfpa_dejavu_hashes).
 """
 from __future__ import annotations
 
@@ -38,3 +38,33 @@ def fingerprint_peaks_batch(wav: torch.Tensor, amp_min: float = afp_settings["de
     arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=1)
     mask, npeaks = ops.localmax2d(arr, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
     return mask, npeaks, ops.normalize_(psd, cmax, per_clip=True)
+
+
+def _hashes_to_list(dig: torch.Tensor, t1: torch.Tensor, n: int):
+    d = dig[:n].cpu().numpy()
+    return [(bytes(d[i]).hex(), int(t)) for i, t in enumerate(t1[:n].cpu().tolist())]
+
+
+def generate_hashes(peaks: List[Tuple[int, int]], fan_value: int = afp_settings["dejavu"]["fan_value"], device="cuda"):
+    """[(freq, time)] -> [(sha1("f1|f2|dt")[:20], t1)], afp/dejavu/fingerprint.py:174-213, on the device."""
+    if len(peaks) == 0:
+        return []
+    pk = np.asarray(peaks, dtype=np.int64).reshape(-1, 2)
+    F, T = int(pk[:, 0].max()) + 1, int(pk[:, 1].max()) + 1
+    mask = torch.zeros((1, F, T), dtype=torch.uint8)
+    mask[0, pk[:, 0], pk[:, 1]] = 1
+    cap = max(16, (fan_value - 1) * len(pk))
+    dig, t1, counts = ops.dejavu_hashes(mask.to(device), cap=cap, peak_cap=max(16, min(16384, len(pk))), fan_value=fan_value)
+    n = int(counts[0])
+    if n < 0:
+        raise ValueError("too many peaks for the device kernel (peak_cap 16384)")
+    return _hashes_to_list(dig[0], t1[0], n)
+
+
+def fingerprint_batch(wav: torch.Tensor, amp_min: float = afp_settings["dejavu"]["amp_min"],
+                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096):
+    """fingerprint(...) for a batch (afp/dejavu/fingerprint.py:34-91): (digests (B,cap,10) uint8, t1 (B,cap), counts (B,),
+    peak mask, normalised specgram), everything on the device."""
+    mask, _, spec = fingerprint_peaks_batch(wav, amp_min)
+    dig, t1, counts = ops.dejavu_hashes(mask, cap=cap, peak_cap=cap, fan_value=fan_value)
+    return dig, t1, counts, mask, spec

@@ -240,3 +240,43 @@ def peak_metrics_counts(predicted: torch.Tensor, gt: torch.Tensor) -> torch.Tens
     counts = torch.empty((B, 4), dtype=torch.int64, device=predicted.device)
     check(lib().mfpa_peak_metrics(ptr(predicted), ptr(gt), B, N1, N2, ptr(counts), stream()), "mfpa_peak_metrics")
     return counts
+
+
+# ----------------------------------------------------------------------------- landmarks / hashes
+def audfprint_landmarks(mask: torch.Tensor, cap: int = 4096, mindt: int = 2, targetdt: int = 63, targetdf: int = 31,
+                        maxpairs: int = 3):
+    """Peak masks (B, R, T) uint8 -> (landmarks (B,cap,4), hashes (B,cap,2), unique sorted hashes (B,cap,2),
+    counts (B,2) = [n_landmarks, n_unique]); all int32 on the device.  peak_extractor.py:313-346, :40-58, :443-460."""
+    require_gpu(mask, "mask")
+    if mask.dim() != 3 or mask.dtype != torch.uint8:
+        raise ValueError("mask must be (B, R, T) uint8")
+    mask = mask.contiguous()
+    B, R, T = mask.shape
+    if not (1 <= cap <= 8192) or R > 256:
+        raise ValueError("cap must be in [1, 8192] and R <= 256")
+    dev = mask.device
+    lm = torch.zeros((B, cap, 4), dtype=torch.int32, device=dev)
+    hs = torch.zeros((B, cap, 2), dtype=torch.int32, device=dev)
+    uq = torch.zeros((B, cap, 2), dtype=torch.int32, device=dev)
+    counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    check(lib().mfpa_audfprint_landmarks(ptr(mask), B, R, T, cap, mindt, targetdt, targetdf, maxpairs, ptr(lm), ptr(hs),
+                                         ptr(uq), ptr(counts), stream()), "mfpa_audfprint_landmarks")
+    return lm, hs, uq, counts
+
+
+def dejavu_hashes(mask: torch.Tensor, cap: int = 4096, peak_cap: int = 4096, fan_value: int = 3, min_dt: int = 0,
+                  max_dt: int = 200):
+    """Peak masks (B, F, T) uint8 -> (digests (B,cap,10) uint8 = sha1("f1|f2|dt")[:20 hex], t1 (B,cap) int32,
+    counts (B,) int32).  afp/dejavu/fingerprint.py:174-213."""
+    require_gpu(mask, "mask")
+    if mask.dim() != 3 or mask.dtype != torch.uint8:
+        raise ValueError("mask must be (B, F, T) uint8")
+    mask = mask.contiguous()
+    B, F, T = mask.shape
+    dev = mask.device
+    dig = torch.zeros((B, cap, 10), dtype=torch.uint8, device=dev)
+    t1 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    counts = torch.zeros((B,), dtype=torch.int32, device=dev)
+    check(lib().mfpa_dejavu_hashes(ptr(mask), B, F, T, cap, peak_cap, fan_value, min_dt, max_dt, ptr(dig), ptr(t1),
+                                   ptr(counts), stream()), "mfpa_dejavu_hashes")
+    return dig, t1, counts

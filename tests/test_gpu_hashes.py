@@ -1,0 +1,100 @@
+"""GPU parity: landmark pairing + hashing -- integer work, identical to the oracle / reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def unpack(bits, shape):
+    return np.unpackbits(bits)[: int(np.prod(shape))].reshape(shape).astype(np.uint8)
+
+
+def test_audfprint_landmarks_golden_and_random(golden):
+    from musicfpaugment_amd import ops
+    from oracle import hashes as oh
+    g = golden("g8_hashes")
+    masks = np.stack([unpack(g[f"aud_mask{i}"], (256, 251)) for i in range(2)])
+    rng = np.random.default_rng(0)
+    rnd = np.zeros((6, 256, 251), dtype=np.uint8)
+    for b in range(6):                                   # up to 5 peaks per frame, like the pruner's output
+        for c in range(251):
+            k = rng.integers(0, 6)
+            rnd[b, rng.choice(256, size=k, replace=False), c] = 1
+    rnd[4] = 0                                           # empty clip
+    rnd[5, :, 100:] = 0                                  # scols < T (peak_extractor.py:327)
+    allm = np.concatenate([masks, rnd])
+    lm, hs, uq, counts = ops.audfprint_landmarks(torch.from_numpy(allm).cuda(), cap=4096)
+    lm, hs, uq, counts = lm.cpu().numpy(), hs.cpu().numpy(), uq.cpu().numpy(), counts.cpu().numpy()
+    for b in range(len(allm)):
+        cols, bins = np.nonzero(allm[b].T)
+        want_lm = np.array(oh.peaks2landmarks(list(zip(cols.tolist(), bins.tolist()))), dtype=np.int32).reshape(-1, 4)
+        want_hs = oh.landmarks2hashes(want_lm)
+        want_uq = oh.unique_sorted_hashes(want_hs)
+        assert counts[b].tolist() == [len(want_lm), len(want_uq)], b
+        np.testing.assert_array_equal(lm[b, :len(want_lm)], want_lm)
+        np.testing.assert_array_equal(hs[b, :len(want_lm)], want_hs)
+        np.testing.assert_array_equal(uq[b, :len(want_uq)], want_uq)
+    for i in range(2):                                   # the reference's own lists
+        np.testing.assert_array_equal(lm[i, :counts[i, 0]], g[f"aud_landmarks{i}"])
+        np.testing.assert_array_equal(uq[i, :counts[i, 1]], g[f"aud_unique{i}"])
+    # capacity overflow is reported, not silently truncated
+    _, _, _, c2 = ops.audfprint_landmarks(torch.from_numpy(allm[2:3]).cuda(), cap=16)
+    assert c2.cpu().numpy().tolist() == [[-1, -1]]
+
+
+def test_dejavu_hashes_golden_and_random(golden):
+    from musicfpaugment_amd import ops
+    from oracle import hashes as oh
+    g = golden("g8_hashes")
+    m0 = unpack(g["dej_mask"], (257, 249))
+    rng = np.random.default_rng(1)
+    m1 = (rng.random((257, 249)) < 0.002).astype(np.uint8)
+    m2 = np.zeros((257, 249), dtype=np.uint8)
+    m2[[0, 256, 9, 10, 100], [0, 0, 5, 248, 248]] = 1   # border peaks, one-digit and three-digit fields
+    allm = np.stack([m0, m1, m2, np.zeros_like(m0)])
+    dig, t1, counts = ops.dejavu_hashes(torch.from_numpy(allm).cuda())
+    dig, t1, counts = dig.cpu().numpy(), t1.cpu().numpy(), counts.cpu().numpy()
+    for b in range(len(allm)):
+        want = oh.dejavu_hashes_from_mask(allm[b])
+        assert counts[b] == len(want)
+        got_hex = [bytes(dig[b, i]).hex() for i in range(counts[b])]
+        assert got_hex == [h for h, _ in want]
+        assert t1[b, :counts[b]].tolist() == [t for _, t in want]
+    assert [bytes(dig[0, i]).hex() for i in range(counts[0])] == [str(x) for x in g["dej_hex"]]
+
+
+def test_reference_call_surface_and_batch_paths(golden):
+    """peaks2landmarks / landmarks2hashes / generate_hashes with the reference's list arguments, and the batched
+    wav -> hashes paths against the oracle chain."""
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks, landmarks2hashes
+    from musicfpaugment_amd.afp.dejavu.fingerprint import fingerprint_batch, generate_hashes
+    from oracle import audfprint as oa
+    from oracle import dejavu as od
+    from oracle import hashes as oh
+    g = golden("g8_hashes")
+    ext = Audfprint_peaks()
+    mask0 = unpack(g["aud_mask0"], (256, 251))
+    cols, bins = np.nonzero(mask0.T)
+    lms = ext.peaks2landmarks(list(zip(cols.tolist(), bins.tolist())))
+    assert np.array_equal(np.array(lms, dtype=np.int32), g["aud_landmarks0"])
+    assert np.array_equal(landmarks2hashes(lms), g["aud_hashes0"])
+    assert ext.peaks2landmarks([]) == [] and landmarks2hashes([]).shape == (0, 2)
+    dmask = unpack(g["dej_mask"], (257, 249))
+    f_idx, t_idx = np.nonzero(dmask)
+    dh = generate_hashes(list(zip(f_idx.tolist(), t_idx.tolist())), fan_value=3)
+    assert [h for h, _ in dh] == [str(x) for x in g["dej_hex"]] and [t for _, t in dh] == g["dej_t1"].tolist()
+    wav = synth.batch(3, seed=59)
+    uniq, counts = ext.hashes_batch(torch.from_numpy(wav).cuda())
+    for b in range(3):
+        want = oh.audfprint_hashes_from_mask(oa.find_peaks(wav[b])[1])
+        assert int(counts[b]) == len(want)
+        np.testing.assert_array_equal(uniq[b, :len(want)].cpu().numpy(), want)
+    np.testing.assert_array_equal(uniq[0, :int(counts[0])].cpu().numpy(), g["aud_unique0"])    # clip seed 59 = golden clip 0
+    dig, t1, cnt, dmask_b, _ = fingerprint_batch(torch.from_numpy(wav).cuda())
+    for b in range(3):
+        _, m, _ = od.fingerprint_peaks(wav[b].astype(np.float64) * 32767.0)
+        want = oh.dejavu_hashes_from_mask(m)
+        assert int(cnt[b]) == len(want)
+        assert [bytes(dig[b, i].cpu().numpy()).hex() for i in range(len(want))] == [h for h, _ in want]

@@ -121,3 +121,22 @@ def test_g6_unet_forward(golden):
     sub = torch.from_numpy(g["y8_sub"])
     assert ou.relative_l1(y8[0, 0, ::4, ::4], sub) < 1e-5
     assert abs(float(y8.double().abs().sum()) - float(g["y8_abs_sum"])) < 1e-5 * float(g["y8_abs_sum"])
+
+
+def test_g8_landmarks_and_hashes(golden):
+    from oracle import hashes as oh
+    g = golden("g8_hashes")
+    for i in range(2):
+        mask = unpack(g[f"aud_mask{i}"], (256, 251))
+        cols, bins = np.nonzero(mask.T)
+        lms = oh.peaks2landmarks(list(zip(cols.tolist(), bins.tolist())))
+        assert np.array_equal(np.array(lms, dtype=np.int32).reshape(-1, 4), g[f"aud_landmarks{i}"])
+        hs = oh.landmarks2hashes(lms)
+        assert hs.dtype == np.int32 and np.array_equal(hs, g[f"aud_hashes{i}"])
+        assert np.array_equal(oh.unique_sorted_hashes(hs), g[f"aud_unique{i}"])
+        assert np.array_equal(oh.audfprint_hashes_from_mask(mask), g[f"aud_unique{i}"])
+    dmask = unpack(g["dej_mask"], (257, 249))
+    dh = oh.dejavu_hashes_from_mask(dmask)
+    assert [h for h, _ in dh] == [str(x) for x in g["dej_hex"]]
+    assert [t for _, t in dh] == g["dej_t1"].tolist()
+    assert oh.peaks2landmarks([]) == [] and oh.landmarks2hashes([]).shape == (0, 2)

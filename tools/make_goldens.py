@@ -254,6 +254,30 @@ def main():
          loss_dtype=str(loss.dtype), names=np.array(names), grad_norm=gnorm, grad_head=ghead, weight_head=whead,
          running_mean_head=rm, running_var_head=rv, pred_sub=pred.detach().numpy()[:, ::4, ::4].copy(),
          versions=versions)
+    # ---- G8: landmarks / hashes ---------------------------------------------------
+    g8 = {}
+    for i, (s_, t_) in enumerate([(59, True), (2059, False)]):
+        d = synth.clip(s_, tonal=t_)
+        pklist, mask, _ = analyzer.find_peaks(d)
+        lms = analyzer.peaks2landmarks(pklist)
+        hashes = pe.landmarks2hashes(lms)
+        merged = (hashes[:, 0].astype(np.uint64) << np.uint64(32)) + hashes[:, 1].astype(np.uint64)   # peak_extractor.py:447-459
+        u = np.sort(np.unique(merged))
+        uniq = np.hstack([(u >> np.uint64(32))[:, np.newaxis], (u & np.uint64((1 << 32) - 1))[:, np.newaxis]]).astype(np.int32)
+        g8[f"aud_mask{i}"] = np.packbits(mask.astype(bool))
+        g8[f"aud_landmarks{i}"] = np.array(lms, dtype=np.int32).reshape(-1, 4)
+        g8[f"aud_hashes{i}"] = hashes
+        g8[f"aud_unique{i}"] = uniq
+        print(f"  audfprint clip {s_}: {len(pklist)} peaks -> {len(lms)} landmarks -> {len(uniq)} unique hashes")
+    rng = np.random.default_rng(8)
+    dmask = (rng.random((257, 249)) < 0.004)
+    f_idx, t_idx = np.nonzero(dmask)
+    dh = fp.generate_hashes(list(zip(f_idx.tolist(), t_idx.tolist())), fan_value=3)
+    g8["dej_mask"] = np.packbits(dmask)
+    g8["dej_hex"] = np.array([h for h, _ in dh])
+    g8["dej_t1"] = np.array([int(t) for _, t in dh], dtype=np.int32)
+    print(f"  dejavu: {int(dmask.sum())} peaks -> {len(dh)} hashes")
+    save("g8_hashes", versions=versions, **g8)
     print("done")
 
 
