@@ -142,6 +142,12 @@ int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double a
 int mfpa_peak_metrics(const uint8_t* predicted, const uint8_t* gt, int B, int N1, int N2,
                       int64_t* counts, void* stream);
 
+/* Per-clip PSNR statistics (testing/metrics.py:7, torchmetrics PeakSignalNoiseRatio; used by
+ * testing/audfprint_exps.py:136-137): pred (B,n) float32|float64, target (B,n) float64,
+ * out (B,3) float64 = [sum (pred-target)^2, min(target), max(target)]. */
+int mfpa_psnr_stats(const void* pred, int pred_dtype, const double* target, int B, long long n, double* out,
+                    void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Landmark pairing + hashing, the step after the pickers (next-tier row SURVEY.md §8f-1).  Integer only.
  *

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "mfpa_dejavu_prepare": ([c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p], c_int),
     "mfpa_localmax2d": ([c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_peak_metrics": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_psnr_stats": ([c_void_p, c_int, c_void_p, c_int, c_longlong, c_void_p, c_void_p], c_int),
     "mfpa_audfprint_landmarks": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_dejavu_hashes": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

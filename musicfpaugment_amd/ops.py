@@ -280,3 +280,17 @@ def dejavu_hashes(mask: torch.Tensor, cap: int = 4096, peak_cap: int = 4096, fan
     check(lib().mfpa_dejavu_hashes(ptr(mask), B, F, T, cap, peak_cap, fan_value, min_dt, max_dt, ptr(dig), ptr(t1),
                                    ptr(counts), stream()), "mfpa_dejavu_hashes")
     return dig, t1, counts
+
+
+def psnr_stats(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """(B, ...) pred (float32|float64) vs float64 target -> (B, 3) float64 [sse, min(target), max(target)]."""
+    require_gpu(pred, "pred")
+    require_gpu(target, "target")
+    if pred.shape != target.shape or target.dtype != torch.float64:
+        raise ValueError("pred/target must have the same shape, target float64")
+    pred, target = pred.contiguous(), target.contiguous()
+    B = pred.shape[0]
+    n = pred[0].numel() if B else 0
+    out = torch.empty((B, 3), dtype=torch.float64, device=pred.device)
+    check(lib().mfpa_psnr_stats(ptr(pred), _dtype_code(pred), ptr(target), B, n, ptr(out), stream()), "mfpa_psnr_stats")
+    return out

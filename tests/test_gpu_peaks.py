@@ -163,3 +163,35 @@ def test_peak_metrics(ops, golden):
     a[:, :, 0] |= rng.random((5, 251)) < 0.1
     c = ops.peak_metrics_counts(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
     np.testing.assert_array_equal(c, om.counts(a, b))
+
+
+def test_peaks_metrics_harness_vs_oracle():
+    """compute_peaks_metrics (testing/audfprint_exps.py:86-157) on synthetic queries: per-query P/R/F1 means and PSNR."""
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+    from musicfpaugment_amd.testing.audfprint_exps import compute_peaks_metrics
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict
+    from oracle import audfprint as oa
+    from oracle import metrics as om
+    n = 5
+    clean = synth.batch(n, seed=800)
+    aug = (0.8 * clean + 0.2 * synth.batch(n, seed=900, tonal=False)).astype(np.float32)
+    net = UNet(1, 1, rate=0.05)
+    net.load_state_dict(formula_state_dict(0))
+    a0 = Audfprint_peaks()
+    a1 = Audfprint_peaks(None, denoising=True, denoising_model="unet", unet=net)
+    res = compute_peaks_metrics(torch.from_numpy(clean), torch.from_numpy(aug), a0, a1, batch=2)
+    # oracle for the un-denoised half (exact), sanity for the denoised half
+    P = R = F = 0.0
+    for k in range(n):
+        mc = oa.find_peaks(clean[k])[1].T[None]
+        ma = oa.find_peaks(aug[k])[1].T[None]
+        P += om.precision(ma, mc); R += om.recall(ma, mc); F += om.f1score(ma, mc)
+    assert abs(res["precision_no_den"] - P / n) < 1e-12 and abs(res["recall_no_den"] - R / n) < 1e-12
+    assert abs(res["f1_score_no_den"] - F / n) < 1e-12
+    assert 0.0 <= res["prec_den"] <= 1.0 and 0.0 <= res["rec_den"] <= 1.0 and np.isfinite(res["psnr_den_spec"])
+    from oracle import stft as ostft
+    sc = np.stack([(lambda m: m / m.max())(ostft.magnitude(c)) for c in clean])
+    sa = np.stack([(lambda m: m / m.max())(ostft.magnitude(c)) for c in aug])
+    want_psnr = np.mean([10 * np.log10((sc[k].max() - sc[k].min()) ** 2 / np.mean((sa[k] - sc[k]) ** 2)) for k in range(n)])
+    assert abs(res["psnr_no_den_spec"] - want_psnr) < 1e-9
