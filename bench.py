@@ -95,7 +95,7 @@ def bench_train(args, rank, world, dev, dist):
     net = UNet(1, 1, rate=0.05)
     net.load_state_dict(formula_state_dict(0))
     net = net.to(dev).train()
-    eng = UNetTrainEngine(net, lr=1e-3)
+    eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0)
     base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank)
     noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False)
     reps = (B + len(base) - 1) // len(base)
@@ -141,8 +141,9 @@ def bench_train(args, rank, world, dev, dist):
             "metric": "8s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, fp32 MFMA",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 fwd/dgrad convolutions, f32 wgrad" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA",
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -161,7 +162,7 @@ def main():
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
@@ -169,6 +170,8 @@ def main():
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce)")
     args = ap.parse_args()
+    if args.precision is None:      # inference: the fastest arithmetic inside the 1e-4 gate; training: exact fp32 products
+        args.precision = "bf16x3" if args.mode == "infer" else "fp32"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -209,6 +209,7 @@ typedef struct mfpa_conv_desc {
   int yH, yW, mode;
   unsigned drop_seed, drop_thresh; /* training Dropout on source 0 after the affine+ReLU: keep element idx iff */
   float drop_scale;                /* hash(seed, idx) >= thresh (= rate * 2^32), scaled by 1/(1-rate); 0 = off  */
+  int precision;                   /* 0 = fp32 MFMA; 1 = bf16x3 (w must then be in the pre-split row format)     */
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 

@@ -520,10 +520,11 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (a.yH > d->H || a.yW > d->W) return MFPA_EINVAL;
   if (d->drop_thresh && (!d->in_scale0 || d->mode == 2)) return MFPA_EINVAL;
   a.drop_seed = d->drop_seed; a.drop_thresh = d->drop_thresh; a.drop_scale = d->drop_scale;
+  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
-  if (d->mode == 0) return dispatch_conv<0>(a, s);
-  if (d->mode == 1) return dispatch_conv<1>(a, s);
-  return dispatch_conv<2>(a, s);
+  if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);
+  if (d->mode == 1) return dispatch_conv<1>(a, s, d->precision);
+  return dispatch_conv<2>(a, s, d->precision);
 }
 
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,

@@ -51,8 +51,11 @@ def _drop(st):
 
 
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
-              relu=False, out_hw: Optional[Tuple[int, int]] = None):
-    """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output."""
+              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0):
+    """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
+    `w` (fp32, kernel layout) is split into the bf16 hi|lo row format here."""
+    if precision == 1:
+        w = K.split_bf16x3(w)
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -71,7 +74,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2])
+                 drop_scale=_drop(in_affine)[2], precision=precision)
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -133,8 +136,11 @@ def flat_layout():
 class UNetTrainEngine:
     """Owns kernel-layout master parameters, gradients and Adam moments of a UNet(1, 1) and runs train steps."""
 
-    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision: int = 0):
         self.module = module
+        # arithmetic of the forward / input-gradient convolutions: 0 = fp32 MFMA, 1 = bf16x3 (the weight-gradient
+        # kernel and every reduction stay fp32 / fp64)
+        self.precision = precision
         self.device = next(module.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("the training engine runs on the MI355X only")
@@ -262,9 +268,9 @@ class UNetTrainEngine:
             z0 = K.conv3x3_c1_bn_relu(self.P[prefix + ".0.w"], None, None, x32=x32, spec64=spec64, denom=denom,
                                       per_clip=True, relu=False)
         else:
-            z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1)
+            z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1, precision=self.precision)
         st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b")
-        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0)
+        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0, precision=self.precision)
         st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b")
         if drop_id is not None and self.rate > 0:
             st3.drop = dropout_spec(self.drop_seed + 16 * self.step_count + drop_id, self.rate)
@@ -289,7 +295,7 @@ class UNetTrainEngine:
         skips = [recs[ENC[3]], recs[ENC[2]], recs[ENC[1]], recs["inc"]]
         for name, skip in zip(DEC, skips):
             u = conv_mfma(prev["z3"], self.P[name + ".up.w"], self.P[name + ".up.w"].shape[1], mode=1,
-                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"])
+                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"], precision=self.precision)
             if skip["z3"].shape[1] - u.shape[1] > 1 or skip["z3"].shape[2] - u.shape[2] > 1:
                 raise NotImplementedError("skip/upsample size difference > 1 (needs top/left padding offsets)")
             r = self._dconv_fwd(name + ".conv.double_conv", skip["z3"], skip["st3"], src1=u,
@@ -313,7 +319,7 @@ class UNetTrainEngine:
         dz3 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b")
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"])
         wt3 = self.P[prefix + ".3.w"].flip(0).transpose(1, 2).contiguous()          # [tap'][ci][co]
-        dmid = conv_mfma(dz3, wt3, cout)
+        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision)
         del dz3
         dz0 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b")
         if r["first_input"] is not None:
@@ -328,11 +334,12 @@ class UNetTrainEngine:
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
         wt0 = w0.flip(0).transpose(1, 2)                                            # (9, cin, cout) view
         c0 = r["src0"].shape[-1]
-        d0 = conv_mfma(dz0, wt0[:, :c0].contiguous(), c0)
+        d0 = conv_mfma(dz0, wt0[:, :c0].contiguous(), c0, precision=self.precision)
         d1 = None
         if r["src1"] is not None:
             c1 = r["src1"].shape[-1]
-            d1 = conv_mfma(dz0, wt0[:, c0:].contiguous(), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]))
+            d1 = conv_mfma(dz0, wt0[:, c0:].contiguous(), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
+                           precision=self.precision)
         return d0, d1
 
     def backward(self, dpred):
@@ -358,7 +365,7 @@ class UNetTrainEngine:
             prev = r["up_in"]
             wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"])
             wt = self.P[name + ".up.w"].transpose(1, 2).contiguous()                # (4, cin, cout)
-            dy = conv_mfma(d_u, wt, wt.shape[1], mode=2)
+            dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision)
             handles.append(self._reduce_bucket(name))
         for i in range(len(ENC) - 1, -1, -1):                                       # down4 ... inc
             name = ENC[i]

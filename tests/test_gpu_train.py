@@ -225,3 +225,26 @@ def test_train_step_with_dropout_matches_autograd_given_the_same_masks():
     net0.load_state_dict(sd)
     eng0 = UNetTrainEngine(net0.cuda().train())
     assert rel(eng0.forward(spec64=am, denom=aug_den), pred) > 1e-3
+
+
+def test_train_step_bf16x3_forward_and_dgrad():
+    """Engine precision=1 (opt-in): forward / input-gradient convolutions as bf16x3.  Prediction and loss agree to 1e-4;
+    the BatchNorm backward amplifies the 2e-5 operand error, so per-parameter gradients deviate by ~1.5 % (median)
+    from the fp32 path -- which is why fp32 stays the default arithmetic of the training engine."""
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    sd = formula_state_dict(2)
+    am, aug_den, clean_spec = _g7_inputs()
+    out = []
+    for prec in (0, 1):
+        net = UNet(1, 1, rate=0.0)
+        net.load_state_dict(sd)
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec)
+        pred = eng.forward(spec64=am, denom=aug_den)
+        loss, dpred = eng.l1_loss(pred, clean_spec)
+        eng.backward(dpred)
+        out.append((pred.clone(), float(loss), {k: v.clone() for k, v in eng.named_grads().items()}))
+    assert rel(out[1][0], out[0][0]) < 1e-4
+    assert abs(out[1][1] - out[0][1]) < 1e-4 * out[0][1]
+    errs = sorted(rel(out[1][2][k], out[0][2][k]) for k in out[0][2])
+    assert errs[len(errs) // 2] < 3e-2 and errs[-1] < 6e-2, (errs[len(errs) // 2], errs[-1])
