@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MfpaError(RuntimeError):
@@ -86,7 +86,8 @@ class ConvDesc(ctypes.Structure):
                 ("C0", c_int), ("C1", c_int), ("H1", c_int), ("W1", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("relu", c_int),
                 ("yH", c_int), ("yW", c_int), ("mode", c_int),
-                ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int)]
+                ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int),
+                ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):

@@ -48,6 +48,10 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   unsigned drop_seed, drop_thresh;   // dropout on source 0 after the affine+ReLU (thresh 0 = off)
   float drop_scale;
+  float* y_pool;                     // optional fused MaxPool2d(2) of the (affine+ReLU) output: (B,H/2,W/2,Cout)
+  const float* w1x1;                 // optional fused OutConv 1x1 to one class (needs the whole Cout in one workgroup):
+  float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
+  float* y1x1;
   int dbg;                           // timing experiments only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA
 };
 
@@ -298,30 +302,95 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     if (it + 1 < nit) step(it + 1, Set1{});
   }
 
-  // epilogue: y = relu(acc * scale[n] + shift[n]); D[row = pixel][col = channel]
+  // epilogue: out = relu(acc * scale[n] + shift[n]); D[row = pixel][col = channel]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + wn * (NT * 32) + nt * 32 + li;
     const float sc = a.scale ? a.scale[n] : 1.f;
     const float sh = a.shift ? a.shift[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int gy = y0 + m / PW, gx = x0p + m % PW;
-        if (gy < a.yH && gx < a.yW && !((a.dbg & 4) && v_never(acc[mt][nt][r]))) {
-          float v = acc[mt][nt][r] * sc + sh;
-          if (a.relu) v = v > 0.f ? v : 0.f;
-          if (MODE != 1) {
-            a.y[(((size_t)b * a.yH + gy) * a.yW + gx) * a.Cout + n] = v;
-          } else {
-            const int oy = 2 * gy + (ct_tap >> 1), ox = 2 * gx + (ct_tap & 1);
-            a.y[(((size_t)b * (2 * a.H) + oy) * (2 * a.W) + ox) * a.Cout + n] = v;
+        float v = acc[mt][nt][r] * sc + sh;
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        acc[mt][nt][r] = v;
+      }
+  }
+  if (a.y != nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * (NT * 32) + nt * 32 + li;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int gy = y0 + m / PW, gx = x0p + m % PW;
+          if (gy < a.yH && gx < a.yW && !((a.dbg & 4) && v_never(acc[mt][nt][r]))) {
+            const float v = acc[mt][nt][r];
+            if (MODE != 1) {
+              a.y[(((size_t)b * a.yH + gy) * a.yW + gx) * a.Cout + n] = v;
+            } else {
+              const int oy = 2 * gy + (ct_tap >> 1), ox = 2 * gx + (ct_tap & 1);
+              a.y[(((size_t)b * (2 * a.H) + oy) * (2 * a.W) + ox) * a.Cout + n] = v;
+            }
           }
         }
       }
     }
+  }
+  if (MODE == 0 && a.y_pool != nullptr) {
+    // MaxPool2d(2) (floor): every 2x2 window lives in ONE lane's accumulators (the two rows of a window are the
+    // wave's two 32-pixel MFMA tiles for 32-wide patches, registers r / r+8 for 16-wide ones; the two columns are
+    // registers r / r+1), so pooling needs no cross-lane traffic.
+    const int Ho = a.H / 2, Wo = a.W / 2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * (NT * 32) + nt * 32 + li;
+      if (PW == 32) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int py = (y0 + (wm * 2)) / 2, px = (x0p + col) / 2;
+          if (py < Ho && px < Wo) {
+            const float v = fmaxf(fmaxf(acc[0][nt][r], acc[0][nt][r + 1]), fmaxf(acc[1][nt][r], acc[1][nt][r + 1]));
+            a.y_pool[(((size_t)b * Ho + py) * Wo + px) * a.Cout + n] = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 8; r += 2) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;       // pixel in the 2x16 tile, row 0
+            const int py = (y0 + 2 * (wm * 2 + mt)) / 2, px = (x0p + (q % 16)) / 2;
+            if (py < Ho && px < Wo) {
+              const float v = fmaxf(fmaxf(acc[mt][nt][r], acc[mt][nt][r + 1]), fmaxf(acc[mt][nt][r + 8], acc[mt][nt][r + 9]));
+              a.y_pool[(((size_t)b * Ho + py) * Wo + px) * a.Cout + n] = v;
+            }
+          }
+      }
+    }
+  }
+  if (MODE == 0 && WN == 1 && a.w1x1 != nullptr) {
+    // OutConv 1x1 to one class: the wave holds all channels of its 64 pixels; reduce over the 32 channel lanes
+    float wv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wv[nt] = a.w1x1[n0 + nt * 32 + li];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) p += acc[mt][nt][r] * wv[nt];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = y0 + m / PW, gx = x0p + m % PW;
+        if (li == 0 && gy < a.H && gx < a.W) a.y1x1[((size_t)b * a.H + gy) * a.W + gx] = p + a.b1x1;
+      }
   }
 }
 
@@ -345,25 +414,50 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
     gden = 0.0;
     for (int i = 0; i < B; ++i) gden = fmax(gden, denom[i]);
   }
-  const long long npix = (long long)B * H * W;
-  for (long long p = (long long)blockIdx.x * pix_per_block + pl; p < npix; p += (long long)gridDim.x * pix_per_block) {
-    const int gx = (int)(p % W);
-    const int gy = (int)((p / W) % H);
-    const int b = (int)(p / ((long long)W * H));
-    const double den = (spec64 && denom) ? (per_clip ? denom[b] : gden) : 1.0;
+  // one workgroup per (clip, bin row): no 64-bit index divisions in the pixel loop
+  const int b = blockIdx.x / H, gy = blockIdx.x % H;
+  const double den = (spec64 && denom) ? (per_clip ? denom[b] : gden) : 1.0;
+  const int iters = (W + pix_per_block - 1) / pix_per_block;
+  for (int itr = 0; itr < iters; ++itr) {              // uniform trip count: every lane takes part in the shuffles
+    const int gx_raw = itr * pix_per_block + pl;
+    const bool live = gx_raw < W;
+    const int gx = live ? gx_raw : W - 1;
+    const size_t p = ((size_t)b * H + gy) * W + gx;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
-      float v = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const size_t o = ((size_t)b * H + yy) * W + xx;
-        v = spec64 ? (float)(spec64[o] / den) : x32[o];
+    if (lanes_per_pix >= 9) {
+      // the lanes of a pixel share its 3x3 input window: lane `sub` < 9 loads (and normalises) tap `sub`, the others
+      // receive it by shuffle -- one float64 division per lane instead of nine
+      float mine = 0.f;
+      if (sub < 9) {
+        const int yy = gy + sub / 3 - 1, xx = gx + sub % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const size_t o = ((size_t)b * H + yy) * W + xx;
+          mine = spec64 ? (float)(spec64[o] / den) : x32[o];
+        }
       }
-      acc.x += v * wt[t].x;
-      acc.y += v * wt[t].y;
-      acc.z += v * wt[t].z;
-      acc.w += v * wt[t].w;
+      const int base = (threadIdx.x & 63) - sub;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float v = __shfl(mine, base + t);
+        acc.x += v * wt[t].x;
+        acc.y += v * wt[t].y;
+        acc.z += v * wt[t].z;
+        acc.w += v * wt[t].w;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const size_t o = ((size_t)b * H + yy) * W + xx;
+          v = spec64 ? (float)(spec64[o] / den) : x32[o];
+        }
+        acc.x += v * wt[t].x;
+        acc.y += v * wt[t].y;
+        acc.z += v * wt[t].z;
+        acc.w += v * wt[t].w;
+      }
     }
     float4 o4;
     o4.x = acc.x * sc.x + sh.x;
@@ -376,7 +470,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
       o4.z = fmaxf(o4.z, 0.f);
       o4.w = fmaxf(o4.w, 0.f);
     }
-    *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
+    if (live) *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
   }
 }
 
@@ -503,7 +597,7 @@ int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, 
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (!d) return MFPA_EINVAL;
   if (d->B == 0) return MFPA_OK;
-  if (!d->x0 || !d->w || !d->y || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
+  if (!d->x0 || !d->w || (!d->y && !d->w1x1) || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
   if (d->C0 < KC || d->C0 % KC || d->C1 < 0 || d->C1 % KC || d->Cout < 64 || d->Cout % 64) return MFPA_EINVAL;
   if (d->mode < 0 || d->mode > 2) return MFPA_EINVAL;
   if (d->C1 > 0 && (d->mode != 0 || !d->x1 || d->H1 < 1 || d->W1 < 1 || d->H1 > d->H || d->W1 > d->W)) return MFPA_EINVAL;
@@ -520,6 +614,10 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (a.yH > d->H || a.yW > d->W) return MFPA_EINVAL;
   if (d->drop_thresh && (!d->in_scale0 || d->mode == 2)) return MFPA_EINVAL;
   a.drop_seed = d->drop_seed; a.drop_thresh = d->drop_thresh; a.drop_scale = d->drop_scale;
+  if ((d->y_pool || d->w1x1) && d->mode != 0) return MFPA_EINVAL;
+  if (d->y_pool && (d->H < 2 || d->W < 2 || a.yH != d->H || a.yW != d->W)) return MFPA_EINVAL;
+  if (d->w1x1 && (!d->y1x1 || d->Cout != 64)) return MFPA_EINVAL;      // the 64-channel tile holds every channel
+  a.y_pool = d->y_pool; a.w1x1 = d->w1x1; a.b1x1 = d->b1x1; a.y1x1 = d->y1x1;
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);
@@ -533,10 +631,8 @@ int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double
   if (B == 0) return MFPA_OK;
   if ((!x32 && !spec64) || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
   if (Cout % 4 || Cout < 4 || Cout > 1024 || (256 % (Cout / 4)) != 0) return MFPA_EINVAL;
-  const long long npix = (long long)B * H * W;
-  const int ppb = 256 / (Cout / 4);
-  long long blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 256 * 64) blocks = 256 * 64;
+  if ((long long)B * H > 0x7fffffffLL) return MFPA_EINVAL;
+  const long long blocks = (long long)B * H;
   hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x32, spec64, denom,
                      per_clip, B, H, W, w, Cout, scale, shift, relu, y);
   MFPA_CHECK_LAUNCH();

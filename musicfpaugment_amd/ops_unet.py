@@ -8,7 +8,9 @@ from typing import Dict, Optional
 
 import torch
 
-from ._lib import check, lib, ptr, stream
+import ctypes
+
+from ._lib import ConvDesc, check, lib, ptr, stream
 
 BN_EPS = 1e-5  # nn.BatchNorm2d default (training/unet.py:17,20)
 
@@ -126,6 +128,30 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
     return y
 
 
+def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True):
+    """3x3 conv + folded BN + ReLU through mfpa_conv_mfma with optional fused epilogues: `pool` also writes
+    MaxPool2d(2) of the output, `out1x1 = (w (64,), bias)` also writes the OutConv result (B,H,W); `store=False`
+    skips the full-resolution output.  `w` must already be in the layout of `precision` (pre-split for bf16x3).
+    Returns (y | None, y_pool | None, y1x1 | None)."""
+    B, H, W, C0 = x0.shape
+    Cout = w.shape[1]
+    C1 = 0 if x1 is None else x1.shape[3]
+    dev = x0.device
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev) if store else None
+    yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=dev) if pool else None
+    y1 = torch.empty((B, H, W), dtype=torch.float32, device=dev) if out1x1 is not None else None
+    d = ConvDesc(x0=ptr(x0), in_scale0=0, in_shift0=0, x1=ptr(x1), w=ptr(w), out_scale=ptr(scale), out_shift=ptr(shift),
+                 y=ptr(y), C0=C0, C1=C1, H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
+                 B=B, H=H, W=W, Cout=Cout, relu=1, yH=H, yW=W, mode=0, drop_seed=0, drop_thresh=0, drop_scale=1.0,
+                 precision=precision, y_pool=ptr(yp), w1x1=ptr(out1x1[0]) if out1x1 is not None else 0,
+                 b1x1=float(out1x1[1]) if out1x1 is not None else 0.0, y1x1=ptr(y1))
+    t0 = _TIMER.start() if _TIMER is not None else None
+    check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
+    if t0 is not None:
+        _TIMER.stop(t0)
+    return y, yp, y1
+
+
 def conv3x3_c1_bn_relu(w, scale, shift, x32=None, spec64=None, denom=None, per_clip=True, relu=True):
     src = x32 if x32 is not None else spec64
     B, H, W = src.shape
@@ -166,34 +192,38 @@ def conv1x1_out(x, w, bias: float):
 
 def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] = None,
                       spec64: Optional[torch.Tensor] = None, denom: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """UNet.forward in eval mode (training/unet.py:97-108) on (B, F, T) -> (B, F, T) float32."""
+    """UNet.forward in eval mode (training/unet.py:97-108) on (B, F, T) -> (B, F, T) float32.
+    The max-pools (unet.py:34) and the final OutConv (unet.py:71) run inside the epilogues of the convolutions that
+    produce their inputs, so neither the pooled tensors' sources are re-read nor is up4's 64-channel output stored."""
     prec = int(pw.get("precision", 0))
     sfx = "3" if prec == 1 else ""
 
-    def dconv(x, prefix, skip=None):
-        if skip is None:
-            m = conv3x3_bn_relu(x, pw[prefix + ".0.w" + sfx], pw[prefix + ".0.scale"], pw[prefix + ".0.shift"],
-                                precision=prec)
-        else:  # decoder: channels = [skip | upsampled], upsampled zero-padded bottom/right to the skip extent
-            m = conv3x3_bn_relu(skip, pw[prefix + ".0.w" + sfx], pw[prefix + ".0.scale"], pw[prefix + ".0.shift"], x1=x,
-                                precision=prec)
-        return conv3x3_bn_relu(m, pw[prefix + ".3.w" + sfx], pw[prefix + ".3.scale"], pw[prefix + ".3.shift"],
-                               precision=prec)
+    def c(x, prefix, idx, **kw):
+        return conv3x3_fused(x, pw[f"{prefix}.{idx}.w{sfx}"], pw[f"{prefix}.{idx}.scale"], pw[f"{prefix}.{idx}.shift"],
+                             precision=prec, **kw)
 
     p = ENC[0]
     m = conv3x3_c1_bn_relu(pw[p + ".0.w"], pw[p + ".0.scale"], pw[p + ".0.shift"], x32=x32, spec64=spec64, denom=denom)
-    x1 = conv3x3_bn_relu(m, pw[p + ".3.w" + sfx], pw[p + ".3.scale"], pw[p + ".3.shift"], precision=prec)
+    skips = []
+    x, xp, _ = c(m, p, 3, pool=True)
     del m
-    x2 = dconv(maxpool2(x1), ENC[1])
-    x3 = dconv(maxpool2(x2), ENC[2])
-    x4 = dconv(maxpool2(x3), ENC[3])
-    x5 = dconv(maxpool2(x4), ENC[4])
-    y = dconv(convT2x2(x5, pw["up1.up.w" + sfx], pw["up1.up.b"], precision=prec), "up1.conv.double_conv", skip=x4)
-    del x5, x4
-    y = dconv(convT2x2(y, pw["up2.up.w" + sfx], pw["up2.up.b"], precision=prec), "up2.conv.double_conv", skip=x3)
-    del x3
-    y = dconv(convT2x2(y, pw["up3.up.w" + sfx], pw["up3.up.b"], precision=prec), "up3.conv.double_conv", skip=x2)
-    del x2
-    y = dconv(convT2x2(y, pw["up4.up.w" + sfx], pw["up4.up.b"], precision=prec), "up4.conv.double_conv", skip=x1)
-    del x1
-    return conv1x1_out(y, pw["outc.w"], pw["outc.b_host"])
+    skips.append(x)
+    for name in ENC[1:]:
+        m, _, _ = c(xp, name, 0)
+        last = name == ENC[-1]
+        x, xp, _ = c(m, name, 3, pool=not last)
+        del m
+        if not last:
+            skips.append(x)
+    y = x                                                   # x5
+    for name in DEC:
+        skip = skips.pop()
+        u = convT2x2(y, pw[name + ".up.w" + sfx], pw[name + ".up.b"], precision=prec)
+        m, _, _ = c(skip, name + ".conv.double_conv", 0, x1=u)
+        del u, skip
+        if name != DEC[-1]:
+            y, _, _ = c(m, name + ".conv.double_conv", 3)
+        else:                                               # up4: OutConv fused, the 64-channel tensor is never written
+            _, _, y = c(m, name + ".conv.double_conv", 3, out1x1=(pw["outc.w"], pw["outc.b_host"]), store=False)
+        del m
+    return y
