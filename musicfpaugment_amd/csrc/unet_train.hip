@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, unsigned drop_seed,
                                                            unsigned drop_thresh, float drop_scale) {
-  const int C4 = C / 4;
+  const int C4 = C / 4;                      // a power of two (checked on the host): no 64-bit division per element
   const long long total = npix * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int cq = (int)(e % C4);
+    const int cq = (int)(e & (C4 - 1));
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * cq);
@@ -211,13 +211,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
                                                            const float* __restrict__ shift, float* __restrict__ p,
                                                            unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
-  const long long total = (long long)B * Ho * Wo * C4;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int cq = (int)(e % C4);
-    long long q = e / C4;
-    const int xo = (int)(q % Wo); q /= Wo;
-    const int yo = (int)(q % Ho);
-    const int b = (int)(q / Ho);
+  const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
+  for (int e32 = threadIdx.x; e32 < Wo * C4; e32 += 256) {
+    const int cq = e32 % C4, xo = e32 / C4;
+    const size_t e = ((size_t)blockIdx.x * Wo + xo) * C4 + cq;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
     const float* base = z + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * cq;
@@ -245,13 +242,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
                                                               const float* __restrict__ dp, float* __restrict__ dy,
                                                               unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
-  const long long total = (long long)B * Ho * Wo * C4;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int cq = (int)(e % C4);
-    long long q = e / C4;
-    const int xo = (int)(q % Wo); q /= Wo;
-    const int yo = (int)(q % Ho);
-    const int b = (int)(q / Ho);
+  const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
+  for (int e32 = threadIdx.x; e32 < Wo * C4; e32 += 256) {
+    const int cq = e32 % C4, xo = e32 / C4;
+    const size_t e = ((size_t)blockIdx.x * Wo + xo) * C4 + cq;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
     const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * cq;
@@ -616,6 +610,7 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
                      void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!dy || !z || !gamma || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace) return MFPA_EINVAL;
+  if (C & (C - 1)) return MFPA_EINVAL;   // channel counts of this UNet are powers of two (64 ... 1024)
   if (npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
@@ -650,8 +645,8 @@ int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* s
                       unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !p || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
-  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3(grid_for(total)), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C, scale,
+  if ((long long)B * (H / 2) > 0x7fffffffLL) return MFPA_EINVAL;
+  hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C, scale,
                      shift, p, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
@@ -662,8 +657,8 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
                           void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !dp || !dy || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
-  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3(grid_for(total)), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
+  if ((long long)B * (H / 2) > 0x7fffffffLL) return MFPA_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
                      scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
