@@ -308,6 +308,43 @@ int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dp
 int mfpa_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Demucs causal waveform denoiser, forward (next-tier row SURVEY.md §8f-2), training/model.py:22-110,163-326.
+ * Activations are time-major (B, L, C) float32.  Every Conv1d / ConvTranspose1d / LSTM projection is one batched
+ * GEMM over (possibly overlapping) row windows on the fp32 matrix cores:
+ *     C[b][m][n] = epi( sum_k A[b*strideA + m*lda + k] * W[n*K + k] + bias[n] ),  m < M
+ *   W (npad, K) with npad a multiple of 64 (rows beyond N zero), K a multiple of 16
+ *   mode 0: + bias, optional ReLU (relu = 1);  mode 2: additionally + addend[b*strideAdd + m*ldadd + n]
+ *           (relu = 1: after the addition, relu = 2: before it -- `relu(convT(x)) + skip`, model.py:316)
+ *   mode 1: GLU -- each 64-row tile of W holds 32 value rows then their 32 gate rows; N = output columns
+ */
+typedef struct mfpa_gemm_desc {
+  const float* A; long long lda, strideA;
+  const float* W; const float* bias;
+  const float* addend; long long ldadd, strideAdd;
+  float* C; long long ldc, strideC;
+  int batch, M, N, K, npad, mode, relu;
+} mfpa_gemm_desc;
+int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream);
+
+/* mix / (floor + std) zero-padded to VL samples, std = unbiased std over time (model.py:293-301). */
+int mfpa_demucs_prep(const float* wav, int B, int T, int VL, float floor_, float* out, float* stdv, void* stream);
+/* sinc x2 resamplers (model.py:41-88), kernel112 = sinc(t)*hann at the half-sample offsets (model.py:28-38).
+ * upsample2: (B,T) -> (B,2T).  downsample2: (B,T) -> first Tkeep (or all ceil(T/2)) samples of the result, row pitch To,
+ * each multiplied by scale[b] when scale != NULL (the final `std * x` of model.py:326). */
+int mfpa_upsample2(const float* x, int B, int T, const float* kernel112, float* y, void* stream);
+int mfpa_downsample2(const float* x, int B, int T, const float* kernel112, float* y, int To, const float* scale,
+                     int Tkeep, void* stream);
+/* First encoder layer Conv1d(1->C, k8, s4)+ReLU: x (B,Lin) -> y (B,Lout,C), w (8,C) tap-major. */
+int mfpa_conv1d_c1_relu(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, float* y,
+                        void* stream);
+/* Last decoder layer ConvTranspose1d(C->1, k8, s4): P (B,L+2,C) with zero first/last rows -> y (B, 4(L+1)), w (8,C). */
+int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float bias, float* y, void* stream);
+/* LSTM cell (gate order i,f,g,o; model.py:91-110 via nn.LSTM): gates (B,4H) rows ldg apart, c (B,H) in/out,
+ * hout rows ldh apart; optional hsum = h + addend (the first decoder skip). */
+int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
+                   const float* addend, long long ldadd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

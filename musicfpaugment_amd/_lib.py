@@ -57,6 +57,14 @@ _SIGNATURES = {
                        c_void_p], c_int),
     "mfpa_conv1x1_out": ([c_void_p, c_longlong, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "mfpa_conv_mfma": ([c_void_p, c_void_p], c_int),
+    "mfpa_gemm_mfma": ([c_void_p, c_void_p], c_int),
+    "mfpa_demucs_prep": ([c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_upsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_downsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
+    "mfpa_conv1d_c1_relu": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_convT1d_c1": ([c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
+    "mfpa_lstm_cell": ([c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,
+                        c_longlong, c_void_p], c_int),
     "mfpa_red_blocks": ([], c_int),
     "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
@@ -88,6 +96,15 @@ class ConvDesc(ctypes.Structure):
                 ("yH", c_int), ("yW", c_int), ("mode", c_int),
                 ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int),
                 ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p)]
+
+
+class GemmDesc(ctypes.Structure):
+    """mfpa_gemm_desc of include/mfpa.h."""
+    _fields_ = [("A", c_void_p), ("lda", c_longlong), ("strideA", c_longlong), ("W", c_void_p), ("bias", c_void_p),
+                ("addend", c_void_p), ("ldadd", c_longlong), ("strideAdd", c_longlong),
+                ("C", c_void_p), ("ldc", c_longlong), ("strideC", c_longlong),
+                ("batch", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("npad", c_int), ("mode", c_int),
+                ("relu", c_int)]
 
 
 class WgradDesc(ctypes.Structure):

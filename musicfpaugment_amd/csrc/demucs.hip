@@ -1,0 +1,339 @@
+// Demucs causal waveform denoiser, forward, for MI355X (gfx950) -- next-tier row SURVEY.md §8f-2.
+// Reference: training/model.py:22-110 (sinc resampling, LSTM) and :163-326 (Demucs) of deezer/musicFPaugment.
+//
+// Activations are time-major "NLC": (B, L, C) float32, channels contiguous.  In that layout every layer is a
+// plain GEMM over overlapping row windows, all served by ONE batched strided fp32-MFMA kernel:
+//   Conv1d(k=8, s=4)        : row t = x[4t : 4t+8] flattened (8C contiguous floats), row stride 4C, K = 8C
+//   Conv1d(k=1) + GLU       : K = C, weights packed so a wave's 64-column tile is [32 values | their 32 gates]
+//   ConvTranspose1d(k8, s4) : row t = [g[t-1] | g[t]] (2C contiguous floats of a buffer with one zero row at each
+//                             end), N = 4*Cout: output row t is positions 4t..4t+3 -- the overlap-add of the
+//                             transposed convolution becomes part of K; the skip connection of the next decoder
+//                             layer is added in the epilogue
+//   LSTM                    : input projection of all steps as one GEMM; per step gates = h[t-1] W_hh^T + X[t]
+//                             (the same kernel, rows = clips) followed by the cell kernel
+// The 1-channel ends (first Conv1d, last ConvTranspose1d), the sinc x2 resamplers and the std normalisation are
+// small VALU kernels.
+#include "mfpa_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GKC = 16;            // K chunk
+constexpr int GLD = GKC + 4;       // padded LDS row (floats): 80 B, conflict-free ds_read_b128 fragments
+constexpr int GBM = 128, GBN = 64; // workgroup tile; 4 waves stacked along M, each 32 x 64
+
+struct GemmArgs {
+  const float* A; long long lda, strideA;      // A[b][m][k] = A[b*strideA + m*lda + k]
+  const float* W;                              // [Npad][K], K contiguous, Npad multiple of 64 (zero rows beyond N)
+  const float* bias;                           // [Npad] or null
+  const float* addend; long long ldadd, strideAdd;   // mode 2: y += addend[b*strideAdd + m*ldadd + n]
+  float* C; long long ldc, strideC;
+  int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][GBM * GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GBN * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN, b = blockIdx.z;
+  const float* Ab = a.A + (size_t)b * a.strideA;
+  const int nk = a.K / GKC;
+
+  // staging: A tile 128 rows x 4 float4, B tile 64 rows x 4 float4
+  f32x4 ar[2], br;
+  const int arow0 = tid >> 2, aq = tid & 3;             // rows arow0 and arow0 + 64
+  const int brow = tid >> 2, bq = tid & 3;              // 64 rows
+  auto load = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + arow0 + 64 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + kc * GKC + 4 * aq);
+      ar[i] = v;
+    }
+    br = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + brow) * a.K + kc * GKC + 4 * bq);
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&As[buf][(arow0 + 64 * i) * GLD + 4 * aq]) = ar[i];
+    *reinterpret_cast<f32x4*>(&Bs[buf][brow * GLD + 4 * bq]) = br;
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  load(0);
+  store(0);
+  if (nk > 1) load(1);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) store(buf ^ 1);          // B/A(kc+1) registers -> the other LDS buffer (free since the last barrier)
+    if (kc + 2 < nk) load(kc + 2);
+    const float* Ap = &As[buf][(wave * 32 + li) * GLD + 4 * lh];
+    const float* Bp = &Bs[buf][li * GLD + 4 * lh];
+#pragma unroll
+    for (int s = 0; s < GKC / 8; ++s) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(Ap + 8 * s);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bp + 8 * s);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bp + 32 * GLD + 8 * s);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], b0[k], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], b1[k], acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D[row = m][col = n]; lane holds column li of both 32-wide n tiles
+  const float bias0 = a.bias ? a.bias[n0 + li] : 0.f;
+  const float bias1 = a.bias ? a.bias[n0 + 32 + li] : 0.f;
+  float* Cb = a.C + (size_t)b * a.strideC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m >= a.M) continue;
+    float v0 = acc[0][r] + bias0, v1 = acc[1][r] + bias1;
+    if (a.mode == 1) {                         // GLU: value * sigmoid(gate); output column = (tile index) * 32 + li
+      const int n = blockIdx.y * 32 + li;
+      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0 * (1.f / (1.f + __expf(-v1)));
+    } else {
+      const int n = n0 + li;
+      if (a.relu == 2) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }   // ReLU before the skip addition
+      if (a.mode == 2) {
+        const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
+        if (n < a.N) v0 += ad[n];
+        if (n + 32 < a.N) v1 += ad[n + 32];
+      }
+      if (a.relu == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0;
+      if (n + 32 < a.N) Cb[(size_t)m * a.ldc + n + 32] = v1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- small kernels
+// mix / (floor + std), zero-padded to VL samples; std = unbiased std over time (model.py:293-301).
+__global__ __launch_bounds__(256) void demucs_prep_kernel(const float* __restrict__ wav, int T, int VL, float floor_,
+                                                          float* __restrict__ out, float* __restrict__ stdv) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* x = wav + (size_t)b * T;
+  double s = 0, ss = 0;
+  for (int i = tid; i < T; i += 256) { const double v = x[i]; s += v; ss += v * v; }
+  __shared__ double sh[2][256];
+  sh[0][tid] = s; sh[1][tid] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+    __syncthreads();
+  }
+  const double mean = sh[0][0] / T;
+  double var = (sh[1][0] - T * mean * mean) / (T - 1);
+  if (var < 0) var = 0;
+  const float sd = (float)sqrt(var);
+  if (tid == 0) stdv[b] = sd;
+  const float inv = sd + floor_;
+  float* o = out + (size_t)b * VL;
+  for (int i = tid; i < VL; i += 256) o[i] = i < T ? x[i] / inv : 0.f;
+}
+
+// upsample2 (model.py:41-53): y[2i] = x[i], y[2i+1] = sum_k x[i + k - 55] ker[k], k < 112.
+__global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, int T, const float* __restrict__ ker,
+                                                        float* __restrict__ y) {
+  __shared__ float kk[112];
+  if (threadIdx.x < 112) kk[threadIdx.x] = ker[threadIdx.x];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const float* xb = x + (size_t)b * T;
+  float* yb = y + (size_t)b * 2 * T;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < T; i += gridDim.x * 256) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 112; ++k) {
+      const int j = i + k - 55;
+      if (j >= 0 && j < T) acc += xb[j] * kk[k];
+    }
+    yb[2 * i] = xb[i];
+    yb[2 * i + 1] = acc;
+  }
+}
+
+// downsample2 (model.py:69-88): out[i] = 0.5 * (x[2i] + sum_k xodd[i + k - 56] ker[k]), xodd[j] = x[2j+1] (0 beyond the end).
+__global__ __launch_bounds__(256) void downsample2_kernel(const float* __restrict__ x, int T, const float* __restrict__ ker,
+                                                          float* __restrict__ y, int To, const float* __restrict__ scale,
+                                                          int Tkeep) {
+  __shared__ float kk[112];
+  if (threadIdx.x < 112) kk[threadIdx.x] = ker[threadIdx.x];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const float* xb = x + (size_t)b * T;
+  const int Th = (T + 1) / 2;                       // length of xeven / xodd after the odd-length zero pad
+  const float sc = scale ? scale[b] : 1.f;
+  const int nout = Tkeep > 0 ? Tkeep : Th;
+  float* yb = y + (size_t)b * To;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nout; i += gridDim.x * 256) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 112; ++k) {
+      const int j = i + k - 56;
+      if (j >= 0 && j < Th && 2 * j + 1 < T) acc += xb[2 * j + 1] * kk[k];
+    }
+    yb[i] = sc * (0.5f * (xb[2 * i] + acc));
+  }
+}
+
+// First encoder conv: Conv1d(1 -> C, k=8, s=4) + ReLU on (B, Lin) -> (B, Lout, C).  w [8][C] (tap-major), bias [C].
+__global__ __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict__ x, int Lin, int Lout, int C,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y) {
+  const int b = blockIdx.y, C4 = C / 4;
+  const float* xb = x + (size_t)b * Lin;
+  float* yb = y + (size_t)b * Lout * C;
+  const long long total = (long long)Lout * C4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int cq = (int)(e % C4);
+    const int t = (int)(e / C4);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = xb[4 * t + j];
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + j * C + 4 * cq);
+      acc += v * ww;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : 0.f;
+    *reinterpret_cast<f32x4*>(yb + (size_t)t * C + 4 * cq) = acc;
+  }
+}
+
+// Last decoder layer: ConvTranspose1d(C -> 1, k=8, s=4) on the zero-padded GLU output P (B, L+2, C):
+// out[4t + j] = bias + sum_c P[t+1][c] w[c][j] + P[t][c] w[c][j+4],  t = 0..L, j = 0..3.   w [8][C] (tap-major).
+__global__ __launch_bounds__(256) void convT1d_c1_kernel(const float* __restrict__ P, int L, int C,
+                                                         const float* __restrict__ w, float bias, float* __restrict__ y) {
+  const int b = blockIdx.y;
+  const float* Pb = P + (size_t)b * (L + 2) * C;
+  float* yb = y + (size_t)b * 4 * (L + 1);
+  const int total = 4 * (L + 1);
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+    const int t = p >> 2, j = p & 3;
+    const float* cur = Pb + (size_t)(t + 1) * C;
+    const float* prev = Pb + (size_t)t * C;
+    float acc = bias;
+    for (int c = 0; c < C; c += 4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(cur + c), a1 = *reinterpret_cast<const f32x4*>(prev + c);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + j * C + c), w1 = *reinterpret_cast<const f32x4*>(w + (j + 4) * C + c);
+      acc += a0[0] * w0[0] + a0[1] * w0[1] + a0[2] * w0[2] + a0[3] * w0[3];
+      acc += a1[0] * w1[0] + a1[1] * w1[1] + a1[2] * w1[2] + a1[3] * w1[3];
+    }
+    yb[p] = acc;
+  }
+}
+
+// LSTM cell (gate order i, f, g, o): c = sig(f) c + sig(i) tanh(g); h = sig(o) tanh(c).
+// gates (B, 4H); c (B, H) in/out; h written to hseq[b*ldh + n] (+ optional addend for the decoder's first skip).
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gates, long long ldg, float* __restrict__ c, int B, int H,
+                                                        float* __restrict__ hout, long long ldh,
+                                                        float* __restrict__ hsum, const float* __restrict__ addend, long long ldadd) {
+  const int total = B * H;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int b = e / H, n = e % H;
+    const float* g = gates + (size_t)b * ldg;
+    const float gi = g[n], gf = g[H + n], gg = g[2 * H + n], go = g[3 * H + n];
+    const float si = 1.f / (1.f + expf(-gi)), sf = 1.f / (1.f + expf(-gf)), so = 1.f / (1.f + expf(-go));
+    const float cn = sf * c[e] + si * tanhf(gg);
+    c[e] = cn;
+    const float h = so * tanhf(cn);
+    hout[(size_t)b * ldh + n] = h;
+    if (hsum) hsum[(size_t)b * ldh + n] = h + addend[(size_t)b * ldadd + n];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
+  if (!d) return MFPA_EINVAL;
+  if (d->batch == 0 || d->M == 0) return MFPA_OK;
+  if (!d->A || !d->W || !d->C || d->batch < 0 || d->M < 0 || d->N < 1 || d->K < GKC || d->K % GKC) return MFPA_EINVAL;
+  if (d->npad < 64 || d->npad % 64 || d->mode < 0 || d->mode > 2 || (d->mode == 2 && !d->addend)) return MFPA_EINVAL;
+  if (d->lda % 4 || d->strideA % 4) return MFPA_EINVAL;   // float4 row loads
+  if (d->mode == 1 ? (d->N > d->npad / 2) : (d->N > d->npad)) return MFPA_EINVAL;
+  GemmArgs a{};
+  a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.W = d->W; a.bias = d->bias;
+  a.addend = d->addend; a.ldadd = d->ldadd; a.strideAdd = d->strideAdd;
+  a.C = d->C; a.ldc = d->ldc; a.strideC = d->strideC;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.mode = d->mode; a.relu = d->relu;
+  dim3 grid((d->M + GBM - 1) / GBM, d->npad / GBN, d->batch);
+  if (grid.y > 65535 || grid.z > 65535) return MFPA_EINVAL;
+  hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_demucs_prep(const float* wav, int B, int T, int VL, float floor_, float* out, float* stdv, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!wav || !out || !stdv || B < 0 || T < 2 || VL < T) return MFPA_EINVAL;
+  hipLaunchKernelGGL(demucs_prep_kernel, dim3(B), dim3(256), 0, mfpa_stream(stream), wav, T, VL, floor_, out, stdv);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_upsample2(const float* x, int B, int T, const float* kernel112, float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !kernel112 || !y || B < 0 || B > 65535 || T < 1) return MFPA_EINVAL;
+  int gx = (T + 255) / 256; if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(upsample2_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), x, T, kernel112, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_downsample2(const float* x, int B, int T, const float* kernel112, float* y, int To, const float* scale, int Tkeep,
+                     void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !kernel112 || !y || B < 0 || B > 65535 || T < 2) return MFPA_EINVAL;
+  const int nout = Tkeep > 0 ? Tkeep : (T + 1) / 2;
+  if (nout > (T + 1) / 2 || To < nout) return MFPA_EINVAL;
+  int gx = (nout + 255) / 256; if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(downsample2_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), x, T, kernel112, y, To, scale, Tkeep);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_conv1d_c1_relu(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, float* y,
+                        void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !w || !bias || !y || B < 0 || B > 65535 || C < 4 || C % 4 || Lout < 1 || Lin < 4 * (Lout - 1) + 8) return MFPA_EINVAL;
+  long long blocks = ((long long)Lout * (C / 4) + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(conv1d_c1_kernel, dim3((unsigned)blocks, B), dim3(256), 0, mfpa_stream(stream), x, Lin, Lout, C, w, bias, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float bias, float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!P || !w || !y || B < 0 || B > 65535 || L < 1 || C < 4 || C % 4) return MFPA_EINVAL;
+  int gx = (4 * (L + 1) + 255) / 256; if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(convT1d_c1_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), P, L, C, w, bias, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
+                   const float* addend, long long ldadd, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!gates || !c || !hout || B < 0 || H < 1 || (hsum && !addend)) return MFPA_EINVAL;
+  int gx = (B * H + 255) / 256; if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(gx), dim3(256), 0, mfpa_stream(stream), gates, ldg, c, B, H, hout, ldh, hsum, addend, ldadd);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+"""Demucs forward over the C ABI (csrc/demucs.hip): weight packing and the layer schedule.
+
+Reference: Demucs.forward, training/model.py:290-326.  Activations are (B, L, C) float32 tensors."""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict
+
+import torch
+
+from ._lib import GemmDesc, check, lib, ptr, stream
+
+DEPTH, KERNEL, STRIDE, RESAMPLE, FLOOR, ZEROS = 5, 8, 4, 4, 1e-3, 56
+
+
+def sinc_kernel(device) -> torch.Tensor:
+    """kernel_upsample2 / kernel_downsample2 (model.py:28-38,56-66), computed with torch exactly as the reference."""
+    win = torch.hann_window(4 * ZEROS + 1, periodic=False)
+    winodd = win[1::2]
+    t = torch.linspace(-ZEROS + 0.5, ZEROS - 0.5, 2 * ZEROS) * math.pi
+    return (torch.sin(t) / t * winodd).contiguous().to(device)
+
+
+def valid_length(length: int) -> int:
+    """Demucs.valid_length, model.py:269-285."""
+    length = math.ceil(length * RESAMPLE)
+    for _ in range(DEPTH):
+        length = max(math.ceil((length - KERNEL) / STRIDE) + 1, 1)
+    for _ in range(DEPTH):
+        length = (length - 1) * STRIDE + KERNEL
+    return int(math.ceil(length / RESAMPLE))
+
+
+def _pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    n = w.shape[0]
+    npad = (n + mult - 1) // mult * mult
+    if npad == n:
+        return w.contiguous()
+    out = torch.zeros((npad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[:n] = w
+    return out
+
+
+def _pack_glu(w: torch.Tensor, b: torch.Tensor):
+    """(2h, h) value|gate rows -> tiles of 64 rows: [32 value rows | their 32 gate rows] (zero padded), same for the bias."""
+    h = w.shape[0] // 2
+    nt = (h + 31) // 32
+    wp = torch.zeros((nt * 64, w.shape[1]), dtype=torch.float32, device=w.device)
+    bp = torch.zeros((nt * 64,), dtype=torch.float32, device=w.device)
+    for t in range(nt):
+        n = min(32, h - 32 * t)
+        wp[64 * t:64 * t + n] = w[32 * t:32 * t + n]
+        wp[64 * t + 32:64 * t + 32 + n] = w[h + 32 * t:h + 32 * t + n]
+        bp[64 * t:64 * t + n] = b[32 * t:32 * t + n]
+        bp[64 * t + 32:64 * t + 32 + n] = b[h + 32 * t:h + 32 * t + n]
+    return wp, bp
+
+
+def pack_demucs_weights(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+    f = lambda k: sd[k].detach().to(device, torch.float32)
+    pw: Dict[str, torch.Tensor] = {"sinc": sinc_kernel(device)}
+    for i in range(DEPTH):
+        w = f(f"encoder.{i}.0.weight")                         # (h, cin, 8)
+        if i == 0:
+            pw["enc0.w"] = w[:, 0, :].t().contiguous()         # (8, h) tap-major
+            pw["enc0.b"] = f("encoder.0.0.bias").contiguous()
+        else:
+            pw[f"enc{i}.w"] = _pad_rows(w.permute(0, 2, 1).reshape(w.shape[0], -1))    # [co][j][c]: K = j*cin + c
+            pw[f"enc{i}.b"] = _pad_rows(f(f"encoder.{i}.0.bias"))
+        pw[f"enc{i}.gw"], pw[f"enc{i}.gb"] = _pack_glu(f(f"encoder.{i}.2.weight")[:, :, 0], f(f"encoder.{i}.2.bias"))
+    for d in range(DEPTH):
+        pw[f"dec{d}.gw"], pw[f"dec{d}.gb"] = _pack_glu(f(f"decoder.{d}.0.weight")[:, :, 0], f(f"decoder.{d}.0.bias"))
+        w = f(f"decoder.{d}.2.weight")                         # (h, cout, 8)
+        h, cout = w.shape[0], w.shape[1]
+        if d == DEPTH - 1:
+            pw["decL.w"] = w[:, 0, :].t().contiguous()         # (8, h): rows j (current row taps 0..3) and j+4 (previous row)
+            pw["decL.b"] = float(f(f"decoder.{d}.2.bias")[0])
+        else:
+            # row n = j*cout + co, K = [previous row g[t-1] -> tap j+4 | current row g[t] -> tap j]
+            wt = torch.cat([w[:, :, 4:8].permute(2, 1, 0), w[:, :, 0:4].permute(2, 1, 0)], dim=2)   # (4, cout, 2h)
+            pw[f"dec{d}.w"] = _pad_rows(wt.reshape(4 * cout, 2 * h))
+            pw[f"dec{d}.b"] = _pad_rows(f(f"decoder.{d}.2.bias").repeat(4))
+    for layer in range(2):
+        pw[f"lstm{layer}.wih"] = f(f"lstm.lstm.weight_ih_l{layer}").contiguous()
+        pw[f"lstm{layer}.whh"] = f(f"lstm.lstm.weight_hh_l{layer}").contiguous()
+        pw[f"lstm{layer}.b"] = (f(f"lstm.lstm.bias_ih_l{layer}") + f(f"lstm.lstm.bias_hh_l{layer}")).contiguous()
+    return pw
+
+
+def _p(t: torch.Tensor, off_floats: int = 0) -> int:
+    """Device address of element `off_floats` of a contiguous float32 tensor."""
+    return ptr(t) + 4 * off_floats
+
+
+def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mode=0, relu=0, addend: int = 0, ldadd=0,
+         strideAdd=0):
+    """C[b][m][:N] = epi(A-window[b][m] @ W^T + bias); A, C, addend are device addresses, strides in floats."""
+    d = GemmDesc(A=A, lda=lda, strideA=strideA, W=ptr(W), bias=ptr(bias), addend=addend, ldadd=ldadd,
+                 strideAdd=strideAdd, C=C, ldc=ldc, strideC=strideC, batch=batch, M=M, N=N, K=W.shape[1], npad=W.shape[0],
+                 mode=mode, relu=int(relu))
+    check(lib().mfpa_gemm_mfma(ctypes.byref(d), stream()), "mfpa_gemm_mfma")
+
+
+def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
+    """(B, T) float32 on the GPU -> (B, T) denoised waveform.  model.py:290-326."""
+    B, T = wav.shape
+    dev = wav.device
+    L = lib()
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    VL = valid_length(T)
+    x, std = new(B, VL), new(B)
+    check(L.mfpa_demucs_prep(ptr(wav), B, T, VL, FLOOR, ptr(x), ptr(std), stream()), "mfpa_demucs_prep")
+    for _ in range(2):                                           # resample 4 = two sinc x2 stages (model.py:303-307)
+        y = new(B, 2 * x.shape[1])
+        check(L.mfpa_upsample2(ptr(x), B, x.shape[1], ptr(pw["sinc"]), ptr(y), stream()), "mfpa_upsample2")
+        x = y
+    # ---- encoder: [Conv1d(k8,s4) + ReLU, Conv1d(1x1) + GLU] x 5
+    chans = [pw[f"enc{i}.gw"].shape[1] for i in range(DEPTH)]    # 48 ... 768
+    skips, h, Lin = [], None, x.shape[1]
+    for i in range(DEPTH):
+        C = chans[i]
+        Lout = (Lin - KERNEL) // STRIDE + 1
+        a = new(B, Lout, C)
+        if i == 0:
+            check(L.mfpa_conv1d_c1_relu(ptr(x), B, Lin, Lout, C, ptr(pw["enc0.w"]), ptr(pw["enc0.b"]), ptr(a), stream()),
+                  "mfpa_conv1d_c1_relu")
+        else:
+            Cin = chans[i - 1]                                   # row t = h[4t : 4t+8] flattened: stride 4*Cin, K = 8*Cin
+            gemm(_p(h), STRIDE * Cin, Lin * Cin, B, Lout, pw[f"enc{i}.w"], pw[f"enc{i}.b"], C, _p(a), C, Lout * C, relu=1)
+        h = new(B, Lout, C)
+        gemm(_p(a), C, Lout * C, B, Lout, pw[f"enc{i}.gw"], pw[f"enc{i}.gb"], C, _p(h), C, Lout * C, mode=1)
+        skips.append(h)
+        Lin = Lout
+    # ---- LSTM: 2 layers, unidirectional, zero initial state (model.py:91-110); the last layer also emits h + skip
+    Tn, H = Lin, chans[-1]
+    seq, xsum = h, None
+    for layer in range(2):
+        xp = new(B, Tn, 4 * H)                                   # input projection of every step at once
+        gemm(_p(seq), H, 0, 1, B * Tn, pw[f"lstm{layer}.wih"], pw[f"lstm{layer}.b"], 4 * H, _p(xp), 4 * H, 0)
+        hseq, gates = new(B, Tn, H), new(B, 4 * H)
+        c = torch.zeros((B, H), dtype=torch.float32, device=dev)
+        last = layer == 1
+        if last:
+            xsum = new(B, Tn, H)
+        for t in range(Tn):
+            if t == 0:                                           # h[-1] = 0: the gates are the input projection itself
+                g_addr, ldg = _p(xp), Tn * 4 * H
+            else:                                                # gates = h[t-1] @ W_hh^T + xp[:, t]   (rows = clips)
+                gemm(_p(hseq, (t - 1) * H), Tn * H, 0, 1, B, pw[f"lstm{layer}.whh"], None, 4 * H, _p(gates), 4 * H, 0,
+                     mode=2, addend=_p(xp, t * 4 * H), ldadd=Tn * 4 * H)
+                g_addr, ldg = _p(gates), 4 * H
+            check(L.mfpa_lstm_cell(g_addr, ldg, ptr(c), B, H, _p(hseq, t * H), Tn * H,
+                                   _p(xsum, t * H) if last else 0, _p(skips[-1], t * H) if last else 0, Tn * H, stream()),
+                  "mfpa_lstm_cell")
+        seq = hseq
+    # ---- decoder: (x + skip) -> Conv1d(1x1) + GLU -> ConvTranspose1d(k8,s4) [+ ReLU], next skip added in the epilogue
+    x = xsum
+    skips.pop()
+    Lcur = Tn
+    for d in range(DEPTH):
+        C = chans[DEPTH - 1 - d]
+        P = torch.zeros((B, Lcur + 2, C), dtype=torch.float32, device=dev)      # rows 0 and L+1 stay zero
+        gemm(_p(x), C, Lcur * C, B, Lcur, pw[f"dec{d}.gw"], pw[f"dec{d}.gb"], C, _p(P, C), C, (Lcur + 2) * C, mode=1)
+        Lnext = 4 * (Lcur + 1)                                   # (L - 1) * 4 + 8
+        if d < DEPTH - 1:
+            cout = chans[DEPTH - 2 - d]
+            skip = skips.pop()                                   # (B, Lnext, cout)
+            y = new(B, Lnext, cout)                              # row t = [g[t-1] | g[t]] -> positions 4t .. 4t+3
+            gemm(_p(P), C, (Lcur + 2) * C, B, Lcur + 1, pw[f"dec{d}.w"], pw[f"dec{d}.b"], 4 * cout, _p(y), 4 * cout,
+                 Lnext * cout, mode=2, relu=2, addend=_p(skip), ldadd=4 * cout, strideAdd=Lnext * cout)
+        else:
+            y = new(B, Lnext)
+            check(L.mfpa_convT1d_c1(ptr(P), B, Lcur, C, ptr(pw["decL.w"]), pw["decL.b"], ptr(y), stream()), "mfpa_convT1d_c1")
+        x, Lcur = y, Lnext
+    # ---- sinc x4 down, trim to T, times std (model.py:319-326)
+    half = new(B, (Lcur + 1) // 2)
+    check(L.mfpa_downsample2(ptr(x), B, Lcur, ptr(pw["sinc"]), ptr(half), half.shape[1], 0, 0, stream()), "mfpa_downsample2")
+    out = new(B, T)
+    check(L.mfpa_downsample2(ptr(half), B, half.shape[1], ptr(pw["sinc"]), ptr(out), T, ptr(std), T, stream()),
+          "mfpa_downsample2")
+    return out

@@ -140,3 +140,18 @@ def test_g8_landmarks_and_hashes(golden):
     assert [h for h, _ in dh] == [str(x) for x in g["dej_hex"]]
     assert [t for _, t in dh] == g["dej_t1"].tolist()
     assert oh.peaks2landmarks([]) == [] and oh.landmarks2hashes([]).shape == (0, 2)
+
+
+def test_g9_demucs_forward(golden):
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    from oracle import demucs as odm
+    g = golden("g9_demucs_forward")
+    sd = demucs_formula(int(g["weight_seed"]))
+    w1 = synth.batch(2, seed=int(g["seed1"]), n=int(g["n1"]))
+    assert synth.digest(w1) == str(g["wav1_digest"])
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        y1 = odm.forward(torch.from_numpy(w1), sd)
+    assert ou.relative_l1(y1, torch.from_numpy(g["y1"])) < 1e-5
+    assert odm.valid_length(64000) == int(g["valid_length_64000"]) == 64085
+    assert odm.valid_length(8000) == int(g["valid_length_8000"])

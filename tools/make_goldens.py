@@ -278,6 +278,21 @@ def main():
     g8["dej_t1"] = np.array([int(t) for _, t in dh], dtype=np.int32)
     print(f"  dejavu: {int(dmask.sum())} peaks -> {len(dh)} hashes")
     save("g8_hashes", versions=versions, **g8)
+
+    # ---- G9: Demucs forward (training/model.py:290-326) with formula weights ----------------------
+    from training.model import Demucs
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    dm = Demucs()
+    dm.load_state_dict(demucs_formula(0))
+    dm.eval()
+    w1 = synth.batch(2, seed=70, n=8000)
+    w8 = synth.batch(1, seed=71)
+    with torch.no_grad():
+        y1 = dm(torch.from_numpy(w1)).numpy()
+        y8 = dm(torch.from_numpy(w8)).numpy()
+    save("g9_demucs_forward", weight_seed=0, seed1=70, n1=8000, wav1_digest=synth.digest(w1), y1=y1, seed8=71,
+         wav8_digest=synth.digest(w8), y8_sub=y8[0, 0, ::16].copy(), y8_abs_sum=float(np.abs(y8.astype(np.float64)).sum()),
+         valid_length_64000=dm.valid_length(64000), valid_length_8000=dm.valid_length(8000), versions=versions)
     print("done")
 
 
