@@ -83,6 +83,64 @@ def cpu_baseline(budget_s: float, seed: int):
                       f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
 
 
+def bench_demucs(args, rank, world, dev, dist):
+    """BASELINE config 5 (next tier): Demucs forward on the waveform, then STFT + Audfprint peak-pick of the denoised clip
+    (wavfile2peaks with denoising_model="demucs", afp/audfprint/peak_extractor.py:369-376,406)."""
+    from musicfpaugment_amd import ops_unet, synth
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    from musicfpaugment_amd.training.model import Demucs
+
+    B = args.clips
+    net = Demucs()
+    net.load_state_dict(demucs_formula(0))
+    net = net.to(dev).eval()
+    ext = Audfprint_peaks(None, device=dev)
+    base = synth.batch(min(B, 32), seed=synth.BASE_SEED + 1000 * rank)
+    wav = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B].copy()).to(dev)
+
+    def step():
+        den = net(wav)[:, 0].contiguous()
+        return ext.find_peaks_batch(den)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = ops_unet.KernelTimer()
+    ops_unet.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mask, npeaks, _ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops_unet.set_timer(None)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    if rank == 0:
+        gemm_ms = timer.total_ms()
+        achieved = 20.13e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "8s/8kHz clips/sec (Demucs forward + STFT + peak-pick)", "value": round(world * B * args.steps / dt_max, 3),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Demucs() causal denoiser forward (fp32 MFMA GEMMs, formula weights) -> STFT -> Audfprint "
+                                   "peak-pick, 8 s clips", "clips_per_gpu_per_step": B, "peaks_last_step_rank0": int(npeaks.sum()),
+                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": "gemm_mfma_kernel",
+                         "launches": timer.launches(), "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_train(args, rank, world, dev, dist):
     """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips, Dropout(0.05) as the reference
     trains (training/train.py:646), fp32 MFMA."""
@@ -166,9 +224,10 @@ def main():
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "demucs"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
-                         "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce)")
+                         "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
+                         "config 5's Demucs waveform denoiser forward + STFT + peak-pick")
     args = ap.parse_args()
     if args.precision is None:      # inference: the fastest arithmetic inside the 1e-4 gate; training: exact fp32 products
         args.precision = "bf16x3" if args.mode == "infer" else "fp32"
@@ -192,6 +251,8 @@ def main():
 
     if args.mode == "train":
         return bench_train(args, rank, world, dev, dist)
+    if args.mode == "demucs":
+        return bench_demucs(args, rank, world, dev, dist)
 
     from musicfpaugment_amd import ops_unet, synth
     from musicfpaugment_amd.pipeline import UNET_MFMA_GFLOP_PER_CLIP, HotPath

@@ -9,6 +9,7 @@ from typing import Dict
 
 import torch
 
+from . import ops_unet as _K
 from ._lib import GemmDesc, check, lib, ptr, stream
 
 DEPTH, KERNEL, STRIDE, RESAMPLE, FLOOR, ZEROS = 5, 8, 4, 4, 1e-3, 56
@@ -99,7 +100,10 @@ def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mo
     d = GemmDesc(A=A, lda=lda, strideA=strideA, W=ptr(W), bias=ptr(bias), addend=addend, ldadd=ldadd,
                  strideAdd=strideAdd, C=C, ldc=ldc, strideC=strideC, batch=batch, M=M, N=N, K=W.shape[1], npad=W.shape[0],
                  mode=mode, relu=int(relu))
+    t0 = _K._TIMER.start() if _K._TIMER is not None else None
     check(lib().mfpa_gemm_mfma(ctypes.byref(d), stream()), "mfpa_gemm_mfma")
+    if t0 is not None:
+        _K._TIMER.stop(t0)
 
 
 def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
