@@ -345,6 +345,32 @@ int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float b
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
                    const float* addend, long long ldadd, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * AugmentFP signal chain (next-tier row SURVEY.md §8f-3), augmentation/__init__.py:46-93 and
+ * augmentation/transformations/ (every transform).  Waveforms are (B, T) float32; `apply` (B) uint8 is the transform's Bernoulli
+ * gate (0 = copy the example through).  The random draws are made by the host like the reference does.
+ */
+/* Windowed-sinc low-pass taps, julius 0.2.7 design (zeros 8; pass_filters.py:100 -- julius is NOT in the reference
+ * tree: parity unpinned): taps (B, max_taps), example b uses 2*half[b]+1 of them, cutoff = f_c / sample_rate. */
+int mfpa_lowpass_taps(const float* cutoff, const int* half, int B, int max_taps, float* taps, void* stream);
+/* y[t] = sum_{k < ntaps[b]} taps[b][k] * xpad[t + k - off[b]],  pad_mode 0 replicate / 1 zero;
+ * out_mode 0: y (LowPassFilter);  1: x - y (HighPassFilter, pass_filters.py:158-171);
+ * out_mode 2: impulse response (impulse_response.py:73-117): taps = time-reversed IR, off = n-1, stores t < T and
+ *             writes peak[b] = max |y[t]| over ALL t < Tout = T + n_max - 1 (the reference normalises by the peak of the
+ *             full convolution before truncating). */
+int mfpa_fir(const float* x, int B, int T, int Tout, const float* taps, int max_taps, const int* ntaps, const int* off,
+             const uint8_t* apply, int pad_mode, int out_mode, float* y, float* peak, void* stream);
+/* y[b] = x[b] * factor[b] (invert 0: Gain, gain.py:62-70) or x[b] / factor[b] (invert 1) where apply[b] (NULL = all). */
+int mfpa_scale_rows(const float* x, int B, int T, const float* factor, const uint8_t* apply, int invert, float* y,
+                    void* stream);
+/* AddBackgroundNoise (background_noise.py:183-215): y = x + rms(x)/10^(snr/20) * noise, then y /= max|y|.
+ * With noise == NULL: PeakNormalization (peak_normalization.py:38-67): y = x / max|x| when the peak is > 0. */
+int mfpa_mix_background(const float* x, int B, int T, const float* noise, const float* snr_db, const uint8_t* apply,
+                        float* y, void* stream);
+/* Clipping (clipping.py:67-100) one example at a time, as AugmentFP.__call__ applies it: clamp to torch.quantile(x, p/2)
+ * and torch.quantile(x, 1 - p/2) (linear interpolation), found by an in-LDS radix select. */
+int mfpa_clip_quantile(const float* x, int B, int T, const float* pct, const uint8_t* apply, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,239 @@
+"""AugmentFP on MI355X -- mirror of the reference's augmentation/__init__.py:16-101 (next-tier row SURVEY.md §8f-3).
+
+Same fixed chain and defaults (HighPass -> impulse response -> background noise @SNR -> Gain -> Clipping -> LowPass ->
+HighPass -> PeakNormalization, each Bernoulli-gated per example), same `__call__((1,T)) -> (1,T)` and
+`batch_augment((B,1,T)) -> (B,1,T)`, `.augmentation_pipeline.transforms[i].transform_parameters` with the reference's keys.
+
+Differences, on purpose:
+  * impulse responses and background noises come from IN-MEMORY banks (`ir_bank`, `noise_bank`): the reference needs
+    .wav files + torchaudio (file I/O is out of scope); `synthetic_banks()` builds deterministic ones;
+  * the random draws use the same distributions (torch.distributions / random.choice) but are made for the whole batch
+    on the host; the per-sample arithmetic runs in csrc/augment.hip;
+  * `batch_augment` treats every example like `__call__` does (the reference's Clipping takes its quantile over the
+    flattened selected sub-batch when B > 1, clipping.py:72-86 -- a quirk only its streamlit UI can trigger);
+  * the windowed-sinc filters restate julius 0.2.7 (not in the reference tree): parity unpinned, property-tested.
+"""
+from __future__ import annotations
+
+import ctypes
+import random
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .._lib import MfpaError, check, lib, ptr, stream
+from .constants import DEFAULT_PARAMETERS, IMPULSE_RESPONSE_DIR  # noqa: F401
+
+ZEROS = 8
+
+
+def _mels(f: torch.Tensor) -> torch.Tensor:          # augmentation/utils.py:36-42
+    return 2595.0 * torch.log10(1.0 + f / 700.0)
+
+
+def _hz(m: torch.Tensor) -> torch.Tensor:            # augmentation/utils.py:45-51
+    return 700.0 * (10 ** (m / 2595.0) - 1.0)
+
+
+def rms_normalize(x: torch.Tensor) -> torch.Tensor:  # augmentation/utils.py:190-205
+    return x / (x.square().mean(dim=-1, keepdim=True).sqrt() + 1e-8)
+
+
+def synthetic_banks(seed: int = 0, sample_rate: int = 8000, n_ir: int = 8, n_noise: int = 8, noise_seconds: float = 10.0):
+    """Deterministic stand-ins for the MIT IR survey / DCASE scenes: decaying-noise impulse responses and coloured noises."""
+    from .. import synth
+    rng = np.random.default_rng(seed)
+    irs = []
+    for i in range(n_ir):
+        L = int(sample_rate * (0.05 + 0.1 * i))
+        e = np.exp(-np.arange(L) / (0.2 * L)) * synth.noise(seed * 100 + i, L)
+        e[int(rng.integers(0, 20))] += 4.0
+        irs.append(torch.from_numpy(e.astype(np.float32)))
+    noises = {}
+    for s in range(2):
+        noises[f"scene{s}"] = []
+        for i in range(n_noise // 2):
+            n = synth.noise(seed * 100 + 50 + 10 * s + i, int(sample_rate * noise_seconds))
+            n = np.convolve(n, np.ones(1 + 4 * s + i) / (1 + 4 * s + i), mode="same")
+            noises[f"scene{s}"].append(torch.from_numpy(n.astype(np.float32)))
+    return irs, noises
+
+
+class _Transform:
+    """One Bernoulli-gated stage: holds `p` and the `transform_parameters` of the last call (reference key names)."""
+
+    def __init__(self, name: str, p: float):
+        self.name, self.p = name, p
+        self.transform_parameters: Dict[str, Any] = {}
+
+    def gate(self, B: int) -> torch.Tensor:
+        should = torch.distributions.Bernoulli(self.p).sample((B,)).to(torch.bool)     # transform.py:101-105
+        self.transform_parameters = {"should_apply": should}
+        return should
+
+
+class _Pipeline:
+    def __init__(self, transforms):
+        self.transforms = transforms
+        self.are_parameters_frozen = False
+
+    def freeze_parameters(self, seed: int = 0) -> None:       # transform.py:158-165: reseeds, nothing else
+        self.are_parameters_frozen = True
+        random.seed(seed)
+        torch.manual_seed(seed)
+
+    def unfreeze_parameters(self) -> None:
+        self.are_parameters_frozen = False
+
+    def to(self, device):
+        return self
+
+
+class AugmentFP(object):
+    def __init__(self, background_paths: Optional[Dict[str, List[str]]] = None, sample_rate: int = 8000,
+                 parameters: Dict[str, float] = DEFAULT_PARAMETERS, impulse_response_dir: Optional[str] = None, *,
+                 ir_bank: Optional[List[torch.Tensor]] = None, noise_bank: Optional[Dict[str, List[torch.Tensor]]] = None,
+                 device="cuda") -> None:
+        if ir_bank is None or noise_bank is None:
+            raise NotImplementedError("reading .wav impulse responses / DCASE noises is outside the hot path: pass in-memory "
+                                      "`ir_bank` (list of 1-D tensors) and `noise_bank` ({scene: [1-D tensors]}), e.g. "
+                                      "synthetic_banks()")
+        if len(ir_bank) == 0 or len(noise_bank) == 0:
+            raise ValueError("There are no supported audio files found.")     # EmptyPathException in the reference
+        self.sample_rate = int(sample_rate)
+        self.parameters = dict(parameters)
+        self.device = torch.device(device)
+        self.ir_bank = [torch.as_tensor(i, dtype=torch.float32).reshape(-1) for i in ir_bank]
+        self.noise_bank = {k: [torch.as_tensor(n, dtype=torch.float32).reshape(-1) for n in v] for k, v in noise_bank.items()}
+        p = self.parameters
+        self.t_hp1 = _Transform("HighPassFilter", p["proba_cutoff_freq1"])
+        self.t_ir = _Transform("ApplyImpulseResponse", p["proba_ir_response"])
+        self.t_bg = _Transform("AddBackgroundNoise", p["proba_snr_in_db"])
+        self.t_gain = _Transform("Gain", p["proba_gain_in_db"])
+        self.t_clip = _Transform("Clipping", p["proba_percentile_threshold"])
+        self.t_lp = _Transform("LowPassFilter", p["proba_cutoff_freq2"])
+        self.t_hp3 = _Transform("HighPassFilter", p["proba_cutoff_freq3"])
+        self.t_peak = _Transform("PeakNormalization", 1.0)
+        self.augmentation_pipeline = _Pipeline([self.t_hp1, self.t_ir, self.t_bg, self.t_gain, self.t_clip, self.t_lp,
+                                                self.t_hp3, self.t_peak])
+
+    # ------------------------------------------------------------------ host-side draws
+    def _cutoffs(self, t: _Transform, lo: float, hi: float, B: int) -> torch.Tensor:
+        """pass_filters.py:59-82: uniform in mel space between ceil(mel(lo)) and floor(mel(hi))."""
+        dist = torch.distributions.Uniform(low=torch.ceil(_mels(torch.tensor(lo, dtype=torch.float32))),
+                                           high=torch.floor(_mels(torch.tensor(hi, dtype=torch.float32))), validate_args=True)
+        cut = _hz(dist.sample((B,)))
+        t.transform_parameters["cutoff_freq"] = cut[t.transform_parameters["should_apply"]]
+        return cut
+
+    def _random_background(self, T: int) -> torch.Tensor:
+        """background_noise.py:64-141 (non-mixup branch): random scene, random file, random offset; pieces are
+        RMS-normalised, concatenated until T samples, and RMS-normalised again."""
+        pieces, missing = [], T
+        while missing > 0:
+            scene = random.choice(list(self.noise_bank.keys()))
+            n = random.choice(self.noise_bank[scene])
+            if len(n) >= missing:
+                off = random.randint(0, len(n) - missing)
+                pieces.append(n[off:off + missing])
+                missing = 0
+            else:
+                pieces.append(n)
+                missing -= len(n)
+        return rms_normalize(torch.cat([rms_normalize(pc) for pc in pieces]))
+
+    # ------------------------------------------------------------------ device chain
+    def _filter(self, x, t: _Transform, cut_hz: torch.Tensor, highpass: bool):
+        B, T = x.shape
+        should = t.transform_parameters["should_apply"]
+        frac = (cut_hz / self.sample_rate).tolist()
+        half = []
+        for b in range(B):
+            if should[b]:
+                c = frac[b]
+                if not (0.0 < c <= 0.5):
+                    raise ValueError(f"Buggy cutoff freq. {c}")            # pass_filters.py:103-110
+                half.append(int(ZEROS / c / 2))
+            else:
+                half.append(1)
+        max_taps = 2 * max(half) + 1
+        if max_taps > 131073:
+            raise ValueError("cut-off too low for the FIR kernel (more than 131073 taps)")
+        dev = x.device
+        cutoff_d = torch.tensor([f if s else 0.25 for f, s in zip(frac, should.tolist())], dtype=torch.float32, device=dev)
+        half_d = torch.tensor(half, dtype=torch.int32, device=dev)
+        ntaps_d = 2 * half_d + 1
+        taps = torch.empty((B, max_taps), dtype=torch.float32, device=dev)
+        check(lib().mfpa_lowpass_taps(ptr(cutoff_d), ptr(half_d), B, max_taps, ptr(taps), stream()), "mfpa_lowpass_taps")
+        y = torch.empty_like(x)
+        apply_d = should.to(dev, torch.uint8)
+        check(lib().mfpa_fir(ptr(x), B, T, T, ptr(taps), max_taps, ptr(ntaps_d.to(torch.int32)), ptr(half_d), ptr(apply_d), 0,
+                             1 if highpass else 0, ptr(y), 0, stream()), "mfpa_fir")
+        return y
+
+    @torch.no_grad()
+    def batch_augment(self, waveforms: torch.Tensor) -> Any:
+        if waveforms.dim() != 3 or waveforms.shape[1] != 1:
+            raise RuntimeError("expects three-dimensional input tensors [batch_size, 1, num_samples]")    # transform.py:67-73
+        x = waveforms[:, 0].to(self.device, torch.float32).contiguous()
+        B, T = x.shape
+        if B * T == 0:
+            return waveforms
+        dev, L, p = x.device, lib(), self.parameters
+        u8 = lambda m: m.to(dev, torch.uint8)
+        # 1 HighPass(0-150 Hz)
+        self.t_hp1.gate(B)
+        x = self._filter(x, self.t_hp1, self._cutoffs(self.t_hp1, p["min_cutoff_freq1"], p["max_cutoff_freq1"], B), True)
+        # 2 impulse response: full convolution, / peak of the full result, first T samples (impulse_response.py:73-117)
+        should = self.t_ir.gate(B)
+        irs = [random.choice(self.ir_bank) for _ in range(B)]
+        nmax = max(len(i) for i in irs)
+        taps = torch.zeros((B, nmax), dtype=torch.float32)
+        for b, ir in enumerate(irs):
+            taps[b, nmax - len(ir):] = ir.flip(0)                    # time-reversed, right-aligned: off = nmax - 1 for all
+        self.t_ir.transform_parameters["ir"] = irs
+        n_d = torch.full((B,), nmax, dtype=torch.int32, device=dev)
+        off_d = torch.full((B,), nmax - 1, dtype=torch.int32, device=dev)
+        y, peak = torch.empty_like(x), torch.empty((B,), dtype=torch.float32, device=dev)
+        check(L.mfpa_fir(ptr(x), B, T, T + nmax - 1, ptr(taps.to(dev)), nmax, ptr(n_d), ptr(off_d), ptr(u8(should)), 1, 2, ptr(y),
+                         ptr(peak), stream()), "mfpa_fir")
+        check(L.mfpa_scale_rows(ptr(y), B, T, ptr(peak), ptr(u8(should)), 1, ptr(y), stream()), "mfpa_scale_rows")
+        x = y
+        # 3 background noise at a random SNR (background_noise.py:143-215)
+        should = self.t_bg.gate(B)
+        noise = torch.stack([self._random_background(T) for _ in range(B)])
+        snr = torch.distributions.Uniform(torch.tensor(float(p["min_snr_in_db"])), torch.tensor(float(p["max_snr_in_db"]))).sample((B,))
+        self.t_bg.transform_parameters.update(background=noise[should], snr_in_db=snr[should])
+        y = torch.empty_like(x)
+        check(L.mfpa_mix_background(ptr(x), B, T, ptr(noise.to(dev)), ptr(snr.to(dev)), ptr(u8(should)), ptr(y), stream()),
+              "mfpa_mix_background")
+        x = y
+        # 4 gain (gain.py:44-70)
+        should = self.t_gain.gate(B)
+        gdb = torch.distributions.Uniform(torch.tensor(float(p["min_gain_in_db"])), torch.tensor(float(p["max_gain_in_db"]))).sample((B,))
+        fac = 10 ** (gdb / 20)
+        self.t_gain.transform_parameters["gain_factors"] = fac[should].unsqueeze(1).unsqueeze(1)
+        y = torch.empty_like(x)
+        check(L.mfpa_scale_rows(ptr(x), B, T, ptr(fac.to(dev)), ptr(u8(should)), 0, ptr(y), stream()), "mfpa_scale_rows")
+        x = y
+        # 5 clipping at per-example quantiles (clipping.py:40-100)
+        should = self.t_clip.gate(B)
+        pct = torch.distributions.Uniform(torch.tensor(0.0), torch.tensor(float(p["max_percentile_threshold"]))).sample((B,))
+        self.t_clip.transform_parameters["percentile_threshold"] = pct[should].unsqueeze(1)
+        y = torch.empty_like(x)
+        check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct.to(dev)), ptr(u8(should)), ptr(y), stream()), "mfpa_clip_quantile")
+        x = y
+        # 6 LowPass(3000-3999 Hz), 7 HighPass(30-150 Hz)
+        self.t_lp.gate(B)
+        x = self._filter(x, self.t_lp, self._cutoffs(self.t_lp, p["min_cutoff_freq2"], p["max_cutoff_freq2"], B), False)
+        self.t_hp3.gate(B)
+        x = self._filter(x, self.t_hp3, self._cutoffs(self.t_hp3, p["min_cutoff_freq3"], p["max_cutoff_freq3"], B), True)
+        # 8 peak normalisation, p = 1 (peak_normalization.py:38-67)
+        self.t_peak.gate(B)
+        y = torch.empty_like(x)
+        check(L.mfpa_mix_background(ptr(x), B, T, 0, 0, 0, ptr(y), stream()), "mfpa_mix_background")
+        return y.unsqueeze(1)
+
+    def __call__(self, waveform: torch.Tensor) -> Any:
+        return self.batch_augment(waveform.unsqueeze(0)).squeeze(0)

@@ -1,5 +1,7 @@
 """Pin the CPU oracle against golden vectors produced by the real reference
 (tools/make_goldens.py, run in the build container against /root/reference)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -155,3 +157,34 @@ def test_g9_demucs_forward(golden):
     assert ou.relative_l1(y1, torch.from_numpy(g["y1"])) < 1e-5
     assert odm.valid_length(64000) == int(g["valid_length_64000"]) == 64085
     assert odm.valid_length(8000) == int(g["valid_length_8000"])
+
+
+def test_g10_augment_transforms(golden):
+    from oracle import augment as oau
+    g = golden("g10_augment")
+    x = torch.from_numpy(synth.batch(3, seed=int(g["seed_x"]), n=int(g["n"])))[:, None, :]
+    ir = torch.from_numpy(g["ir"])
+    np.testing.assert_allclose(oau.convolve_full(x[:1], ir[:1]).numpy(), g["conv_full"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(oau.apply_ir(x, ir).numpy(), g["y_ir"], rtol=0, atol=2e-6)
+    noise = oau.rms_normalize(torch.from_numpy(synth.batch(3, seed=int(g["seed_noise"]), n=int(g["n"]), tonal=False)))
+    np.testing.assert_allclose(oau.add_background(x, noise, torch.from_numpy(g["snr"])).numpy(), g["y_bg"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(oau.gain(x, torch.from_numpy(g["gain_db"])).numpy(), g["y_gain"])
+    np.testing.assert_array_equal(oau.clipping(x, torch.from_numpy(g["percentile"])).numpy(), g["y_clip"])
+    xs = x * torch.from_numpy(g["peak_scale"]).view(3, 1, 1)
+    np.testing.assert_array_equal(oau.peak_normalize(xs).numpy(), g["y_peak"])
+
+
+def test_julius_lowpass_restatement_properties():
+    """julius is not in the reference tree (parity unpinned): check the documented design instead."""
+    from oracle import augment as oau
+    taps = oau.lowpass_taps(0.25)
+    assert len(taps) == 2 * int(8 / 0.25 / 2) + 1 == 33 and abs(float(taps.sum()) - 1.0) < 1e-6
+    assert torch.allclose(taps, taps.flip(0))
+    t = torch.arange(8000, dtype=torch.float32) / 8000
+    lo_tone, hi_tone = torch.sin(2 * math.pi * 100 * t)[None], torch.sin(2 * math.pi * 3000 * t)[None]
+    y = oau.lowpass(lo_tone + hi_tone, 1000 / 8000)
+    assert float((y - lo_tone)[0, 500:-500].abs().max()) < 2e-2          # passes 100 Hz, removes 3 kHz
+    z = oau.highpass(lo_tone + hi_tone, 1000 / 8000)
+    assert float((z - hi_tone)[0, 500:-500].abs().max()) < 2e-2
+    with pytest.raises(ValueError):
+        oau.lowpass_taps(0.0)

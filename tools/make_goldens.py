@@ -293,6 +293,55 @@ def main():
     save("g9_demucs_forward", weight_seed=0, seed1=70, n1=8000, wav1_digest=synth.digest(w1), y1=y1, seed8=71,
          wav8_digest=synth.digest(w8), y8_sub=y8[0, 0, ::16].copy(), y8_abs_sum=float(np.abs(y8.astype(np.float64)).sum()),
          valid_length_64000=dm.valid_length(64000), valid_length_8000=dm.valid_length(8000), versions=versions)
+
+    # ---- G10: AugmentFP transforms with explicit parameters (augmentation/transformations/*.py) --------------
+    # The transform classes are created without __init__ (which needs audio files) and fed their parameters directly.
+    from augmentation.transformations.background_noise import AddBackgroundNoise
+    from augmentation.transformations.clipping import Clipping
+    from augmentation.transformations.gain import Gain
+    from augmentation.transformations.impulse_response import ApplyImpulseResponse, convolve
+    from augmentation.transformations.peak_normalization import PeakNormalization
+    from augmentation.utils import Audio
+
+    def bare(cls, **attrs):
+        obj = object.__new__(cls)
+        torch.nn.Module.__init__(obj)
+        obj.__dict__.update(attrs)
+        return obj
+
+    x = torch.from_numpy(synth.batch(3, seed=1200, n=8000))[:, None, :]                       # (3,1,8000)
+    rng = np.random.default_rng(10)
+    ir = torch.zeros(3, 1, 700)
+    for b, L_ in enumerate((700, 431, 96)):
+        e = np.exp(-np.arange(L_) / (0.15 * L_)) * rng.normal(size=L_)
+        e[3 * b] += 2.0
+        ir[b, 0, :L_] = torch.from_numpy(e.astype(np.float32))
+    t_ir = bare(ApplyImpulseResponse, convolve_mode="full", compensate_for_propagation_delay=False,
+                transform_parameters={"ir": ir})
+    y_ir = t_ir.apply_transform(x.clone(), 8000).samples
+    noise = Audio.rms_normalize(torch.from_numpy(synth.batch(3, seed=1300, n=8000, tonal=False)))
+    snr = torch.tensor([-10.0, 0.0, 7.5])
+    t_bg = bare(AddBackgroundNoise, transform_parameters={"background": noise, "snr_in_db": snr})
+    y_bg = t_bg.apply_transform(x.clone(), 8000).samples
+    gdb = torch.tensor([-5.0, 0.3, 5.0])
+    t_g = bare(Gain, transform_parameters={"gain_factors": (10 ** (gdb / 20)).unsqueeze(1).unsqueeze(1)})
+    y_g = t_g.apply_transform(x.clone(), 8000).samples
+    pct = torch.tensor([0.0, 0.004, 0.01])
+    # one example at a time, as AugmentFP.__call__ is used by the data pipeline (training/dataset.py:143-154,
+    # testing/generate_queries.py:72-92).  (With B > 1 the reference's torch.quantile call flattens the whole batch:
+    # clipping.py:72-86 -- a batch_augment-only quirk, see y_clip_batchquirk.)
+    y_c = torch.cat([bare(Clipping, transform_parameters={"percentile_threshold": pct[b:b + 1].unsqueeze(1)})
+                     .apply_transform(x[b:b + 1].clone(), 8000).samples for b in range(3)])
+    y_cq = bare(Clipping, transform_parameters={"percentile_threshold": pct.unsqueeze(1)}).apply_transform(x.clone(), 8000).samples
+    t_p = bare(PeakNormalization)
+    xs = x.clone() * torch.tensor([0.3, 0.0, 2.0]).view(3, 1, 1)
+    t_p.transform_parameters = {}
+    t_p.randomize_parameters(xs)
+    y_p = t_p.apply_transform(xs.clone(), 8000).samples
+    save("g10_augment", seed_x=1200, seed_noise=1300, n=8000, ir=ir.numpy(), y_ir=y_ir.numpy(), snr=snr.numpy(),
+         y_bg=y_bg.numpy(), gain_db=gdb.numpy(), y_gain=y_g.numpy(), percentile=pct.numpy(), y_clip=y_c.numpy(), y_clip_batchquirk=y_cq.numpy(),
+         peak_scale=np.array([0.3, 0.0, 2.0], dtype=np.float32), y_peak=y_p.numpy(),
+         conv_full=convolve(x[:1], ir[:1]).numpy(), versions=versions)
     print("done")
 
 
