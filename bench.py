@@ -160,10 +160,19 @@ def bench_train(args, rank, world, dev, dist):
     clean = np.concatenate([base] * reps)[:B]
     aug = np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * reps)[:B]
     clean, aug = torch.from_numpy(clean).to(dev), torch.from_numpy(aug).to(dev)
+    af = None
+    if args.augment:                                   # config 4's "AugmentFP synthetic noise": the chain runs inside the step
+        import random
+        from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
+        random.seed(100 + rank)
+        torch.manual_seed(100 + rank)
+        irs, noises = synthetic_banks(rank)
+        af = AugmentFP(None, 8000, ir_bank=irs, noise_bank=noises, device=dev)
 
     def step():
         cm, cmax = ops.stft_mag(clean, torch.float64)
-        am, amax = ops.stft_mag(aug, torch.float64)
+        a = af.batch_augment(clean[:, None, :])[:, 0] if af is not None else aug
+        am, amax = ops.stft_mag(a, torch.float64)
         gmax_c, gmax_a = cmax.max(), amax.max()           # spectrogram(): one max over the (global) batch
         if dist is not None:
             dist.all_reduce(gmax_c, op=dist.ReduceOp.MAX)
@@ -201,7 +210,8 @@ def bench_train(args, rank, world, dev, dist):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 fwd/dgrad convolutions, f32 wgrad" if args.precision == "bf16x3" else "f32", "data": "synthetic",
-            "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA",
+            "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA, "
+                                   + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -224,6 +234,7 @@ def main():
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
+    ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
     ap.add_argument("--mode", choices=["infer", "train", "demucs"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "

@@ -351,18 +351,25 @@ int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, fl
  * gate (0 = copy the example through).  The random draws are made by the host like the reference does.
  */
 /* Windowed-sinc low-pass taps, julius 0.2.7 design (zeros 8; pass_filters.py:100 -- julius is NOT in the reference
- * tree: parity unpinned): taps (B, max_taps), example b uses 2*half[b]+1 of them, cutoff = f_c / sample_rate. */
-int mfpa_lowpass_taps(const float* cutoff, const int* half, int B, int max_taps, float* taps, void* stream);
-/* y[t] = sum_{k < ntaps[b]} taps[b][k] * xpad[t + k - off[b]],  pad_mode 0 replicate / 1 zero;
+ * tree: parity unpinned): example b owns the 2*half[b]+1 taps at taps + tap_off[b] (ragged: a 0.5 Hz cut-off at 8 kHz
+ * has 128 001 taps, a 3.5 kHz one 19), cutoff = f_c / sample_rate. */
+int mfpa_lowpass_taps(const float* cutoff, const int* half, const long long* tap_off, int B, float* taps, void* stream);
+/* y[t] = sum_{k < ntaps[b]} taps[tap_off[b] + k] * xpad[t + k - off[b]],  pad_mode 0 replicate / 1 zero;
  * out_mode 0: y (LowPassFilter);  1: x - y (HighPassFilter, pass_filters.py:158-171);
  * out_mode 2: impulse response (impulse_response.py:73-117): taps = time-reversed IR, off = n-1, stores t < T and
  *             writes peak[b] = max |y[t]| over ALL t < Tout = T + n_max - 1 (the reference normalises by the peak of the
  *             full convolution before truncating). */
-int mfpa_fir(const float* x, int B, int T, int Tout, const float* taps, int max_taps, const int* ntaps, const int* off,
-             const uint8_t* apply, int pad_mode, int out_mode, float* y, float* peak, void* stream);
+int mfpa_fir(const float* x, int B, int T, int Tout, const float* taps, const long long* tap_off, const int* ntaps,
+             const int* off, const uint8_t* apply, int pad_mode, int out_mode, float* y, float* peak, void* stream);
 /* y[b] = x[b] * factor[b] (invert 0: Gain, gain.py:62-70) or x[b] / factor[b] (invert 1) where apply[b] (NULL = all). */
 int mfpa_scale_rows(const float* x, int B, int T, const float* factor, const uint8_t* apply, int invert, float* y,
                     void* stream);
+/* AddBackgroundNoise.random_background (background_noise.py:64-141, non-mixup branch): out[b] (T samples) = the
+ * concatenation of up to P slices bank[src[b*P+p] .. + len[b*P+p]) (len 0 ends the list; the lengths of one example sum
+ * to T) of a device-resident noise bank, every slice RMS-normalised (x / (rms + 1e-8), utils.py:190-205) and the whole
+ * RMS-normalised again.  The host draws scene / file / offset like the reference (python `random`). */
+int mfpa_gather_background(const float* bank, const long long* src, const int* len, int B, int P, int T, float* out,
+                           void* stream);
 /* AddBackgroundNoise (background_noise.py:183-215): y = x + rms(x)/10^(snr/20) * noise, then y /= max|y|.
  * With noise == NULL: PeakNormalization (peak_normalization.py:38-67): y = x / max|x| when the peak is > 0. */
 int mfpa_mix_background(const float* x, int B, int T, const float* noise, const float* snr_db, const uint8_t* apply,

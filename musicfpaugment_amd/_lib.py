@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MfpaError(RuntimeError):
@@ -58,10 +58,11 @@ _SIGNATURES = {
     "mfpa_conv1x1_out": ([c_void_p, c_longlong, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "mfpa_conv_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_gemm_mfma": ([c_void_p, c_void_p], c_int),
-    "mfpa_lowpass_taps": ([c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
-    "mfpa_fir": ([c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+    "mfpa_lowpass_taps": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_fir": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                   c_void_p, c_void_p], c_int),
     "mfpa_scale_rows": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_gather_background": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_mix_background": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_clip_quantile": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_demucs_prep": ([c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p], c_int),

@@ -66,6 +66,7 @@ class _Transform:
     def __init__(self, name: str, p: float):
         self.name, self.p = name, p
         self.transform_parameters: Dict[str, Any] = {}
+        self.draws: Dict[str, Any] = {}          # the un-gated per-example draws of the last call (for replaying a batch)
 
     def gate(self, B: int) -> torch.Tensor:
         should = torch.distributions.Bernoulli(self.p).sample((B,)).to(torch.bool)     # transform.py:101-105
@@ -106,6 +107,13 @@ class AugmentFP(object):
         self.device = torch.device(device)
         self.ir_bank = [torch.as_tensor(i, dtype=torch.float32).reshape(-1) for i in ir_bank]
         self.noise_bank = {k: [torch.as_tensor(n, dtype=torch.float32).reshape(-1) for n in v] for k, v in noise_bank.items()}
+        # both banks live in HBM: impulse responses time-reversed (FIR taps), noises back to back
+        self._ir_off = np.concatenate([[0], np.cumsum([len(i) for i in self.ir_bank])]).astype(np.int64)
+        self._ir_dev = torch.cat([i.flip(0) for i in self.ir_bank]).to(self.device)
+        self._noise_files = [(scene, k) for scene, v in self.noise_bank.items() for k in range(len(v))]
+        flat = [self.noise_bank[sc][k] for sc, k in self._noise_files]
+        self._noise_off = dict(zip(self._noise_files, np.concatenate([[0], np.cumsum([len(n) for n in flat])]).tolist()))
+        self._noise_dev = torch.cat(flat).to(self.device)
         p = self.parameters
         self.t_hp1 = _Transform("HighPassFilter", p["proba_cutoff_freq1"])
         self.t_ir = _Transform("ApplyImpulseResponse", p["proba_ir_response"])
@@ -125,23 +133,25 @@ class AugmentFP(object):
                                            high=torch.floor(_mels(torch.tensor(hi, dtype=torch.float32))), validate_args=True)
         cut = _hz(dist.sample((B,)))
         t.transform_parameters["cutoff_freq"] = cut[t.transform_parameters["should_apply"]]
+        t.draws = {"cutoff_freq": cut}
         return cut
 
-    def _random_background(self, T: int) -> torch.Tensor:
-        """background_noise.py:64-141 (non-mixup branch): random scene, random file, random offset; pieces are
-        RMS-normalised, concatenated until T samples, and RMS-normalised again."""
+    def _random_background(self, T: int):
+        """background_noise.py:64-141 (non-mixup branch): random scene, random file, random offset; the slices are
+        RMS-normalised, concatenated until T samples, and RMS-normalised again (on the device: mfpa_gather_background).
+        Returns [(scene, file index, offset, length)]."""
         pieces, missing = [], T
         while missing > 0:
             scene = random.choice(list(self.noise_bank.keys()))
-            n = random.choice(self.noise_bank[scene])
-            if len(n) >= missing:
-                off = random.randint(0, len(n) - missing)
-                pieces.append(n[off:off + missing])
+            k = random.randrange(len(self.noise_bank[scene]))       # random.choice(list) draws the same index
+            n = len(self.noise_bank[scene][k])
+            if n >= missing:
+                pieces.append((scene, k, random.randint(0, n - missing), missing))
                 missing = 0
             else:
-                pieces.append(n)
-                missing -= len(n)
-        return rms_normalize(torch.cat([rms_normalize(pc) for pc in pieces]))
+                pieces.append((scene, k, 0, n))
+                missing -= n
+        return pieces
 
     # ------------------------------------------------------------------ device chain
     def _filter(self, x, t: _Transform, cut_hz: torch.Tensor, highpass: bool):
@@ -154,21 +164,23 @@ class AugmentFP(object):
                 c = frac[b]
                 if not (0.0 < c <= 0.5):
                     raise ValueError(f"Buggy cutoff freq. {c}")            # pass_filters.py:103-110
+                if ZEROS / c / 2 >= 2 ** 30:
+                    raise ValueError(f"Buggy cutoff freq. {c}: more than 2^31 taps")
                 half.append(int(ZEROS / c / 2))
             else:
                 half.append(1)
-        max_taps = 2 * max(half) + 1
-        if max_taps > 131073:
-            raise ValueError("cut-off too low for the FIR kernel (more than 131073 taps)")
         dev = x.device
+        ntaps = [2 * h + 1 for h in half]
+        tap_off = np.concatenate([[0], np.cumsum(ntaps)]).astype(np.int64)          # ragged: a 0.5 Hz cut-off has 128 001 taps
         cutoff_d = torch.tensor([f if s else 0.25 for f, s in zip(frac, should.tolist())], dtype=torch.float32, device=dev)
         half_d = torch.tensor(half, dtype=torch.int32, device=dev)
-        ntaps_d = 2 * half_d + 1
-        taps = torch.empty((B, max_taps), dtype=torch.float32, device=dev)
-        check(lib().mfpa_lowpass_taps(ptr(cutoff_d), ptr(half_d), B, max_taps, ptr(taps), stream()), "mfpa_lowpass_taps")
+        ntaps_d = torch.tensor(ntaps, dtype=torch.int32, device=dev)
+        off_d = torch.from_numpy(tap_off[:-1].copy()).to(dev)
+        taps = torch.empty((int(tap_off[-1]),), dtype=torch.float32, device=dev)
+        check(lib().mfpa_lowpass_taps(ptr(cutoff_d), ptr(half_d), ptr(off_d), B, ptr(taps), stream()), "mfpa_lowpass_taps")
         y = torch.empty_like(x)
         apply_d = should.to(dev, torch.uint8)
-        check(lib().mfpa_fir(ptr(x), B, T, T, ptr(taps), max_taps, ptr(ntaps_d.to(torch.int32)), ptr(half_d), ptr(apply_d), 0,
+        check(lib().mfpa_fir(ptr(x), B, T, T, ptr(taps), ptr(off_d), ptr(ntaps_d), ptr(half_d), ptr(apply_d), 0,
                              1 if highpass else 0, ptr(y), 0, stream()), "mfpa_fir")
         return y
 
@@ -187,42 +199,56 @@ class AugmentFP(object):
         x = self._filter(x, self.t_hp1, self._cutoffs(self.t_hp1, p["min_cutoff_freq1"], p["max_cutoff_freq1"], B), True)
         # 2 impulse response: full convolution, / peak of the full result, first T samples (impulse_response.py:73-117)
         should = self.t_ir.gate(B)
-        irs = [random.choice(self.ir_bank) for _ in range(B)]
-        nmax = max(len(i) for i in irs)
-        taps = torch.zeros((B, nmax), dtype=torch.float32)
-        for b, ir in enumerate(irs):
-            taps[b, nmax - len(ir):] = ir.flip(0)                    # time-reversed, right-aligned: off = nmax - 1 for all
+        pick = [random.randrange(len(self.ir_bank)) for _ in range(B)]
+        irs = [self.ir_bank[i] for i in pick]
+        nlen = [len(i) for i in irs]
+        nmax = max(nlen)
         self.t_ir.transform_parameters["ir"] = irs
-        n_d = torch.full((B,), nmax, dtype=torch.int32, device=dev)
-        off_d = torch.full((B,), nmax - 1, dtype=torch.int32, device=dev)
-        y, peak = torch.empty_like(x), torch.empty((B,), dtype=torch.float32, device=dev)
-        check(L.mfpa_fir(ptr(x), B, T, T + nmax - 1, ptr(taps.to(dev)), nmax, ptr(n_d), ptr(off_d), ptr(u8(should)), 1, 2, ptr(y),
+        self.t_ir.draws = {"ir": irs}
+        n_d = torch.tensor(nlen, dtype=torch.int32, device=dev)
+        off_d = n_d - 1                                              # y[t] = sum_k ir[n-1-k] x[t + k - (n-1)]
+        toff_d = torch.from_numpy(self._ir_off[pick]).to(dev)
+        y, peak, on_d = torch.empty_like(x), torch.empty((B,), dtype=torch.float32, device=dev), u8(should)
+        check(L.mfpa_fir(ptr(x), B, T, T + nmax - 1, ptr(self._ir_dev), ptr(toff_d), ptr(n_d), ptr(off_d), ptr(on_d), 1, 2, ptr(y),
                          ptr(peak), stream()), "mfpa_fir")
-        check(L.mfpa_scale_rows(ptr(y), B, T, ptr(peak), ptr(u8(should)), 1, ptr(y), stream()), "mfpa_scale_rows")
+        check(L.mfpa_scale_rows(ptr(y), B, T, ptr(peak), ptr(on_d), 1, ptr(y), stream()), "mfpa_scale_rows")
         x = y
         # 3 background noise at a random SNR (background_noise.py:143-215)
         should = self.t_bg.gate(B)
-        noise = torch.stack([self._random_background(T) for _ in range(B)])
+        pieces = [self._random_background(T) for _ in range(B)]
+        P = max(len(pc) for pc in pieces)
+        src, ln = np.zeros((B, P), dtype=np.int64), np.zeros((B, P), dtype=np.int32)
+        for b, pc in enumerate(pieces):
+            for j, (scene, k, off, n) in enumerate(pc):
+                src[b, j], ln[b, j] = self._noise_off[(scene, k)] + off, n
+        src_d, ln_d = torch.from_numpy(src).to(dev), torch.from_numpy(ln).to(dev)
+        noise = torch.empty((B, T), dtype=torch.float32, device=dev)
+        check(L.mfpa_gather_background(ptr(self._noise_dev), ptr(src_d), ptr(ln_d), B, P, T, ptr(noise), stream()),
+              "mfpa_gather_background")
         snr = torch.distributions.Uniform(torch.tensor(float(p["min_snr_in_db"])), torch.tensor(float(p["max_snr_in_db"]))).sample((B,))
-        self.t_bg.transform_parameters.update(background=noise[should], snr_in_db=snr[should])
-        y = torch.empty_like(x)
-        check(L.mfpa_mix_background(ptr(x), B, T, ptr(noise.to(dev)), ptr(snr.to(dev)), ptr(u8(should)), ptr(y), stream()),
-              "mfpa_mix_background")
+        self.t_bg.transform_parameters.update(background=noise[should.to(dev)], snr_in_db=snr[should])
+        self.t_bg.draws = {"background": noise, "snr_in_db": snr, "pieces": pieces}
+        y, snr_d, on_d = torch.empty_like(x), snr.to(dev), u8(should)
+        check(L.mfpa_mix_background(ptr(x), B, T, ptr(noise), ptr(snr_d), ptr(on_d), ptr(y), stream()), "mfpa_mix_background")
         x = y
         # 4 gain (gain.py:44-70)
         should = self.t_gain.gate(B)
         gdb = torch.distributions.Uniform(torch.tensor(float(p["min_gain_in_db"])), torch.tensor(float(p["max_gain_in_db"]))).sample((B,))
         fac = 10 ** (gdb / 20)
         self.t_gain.transform_parameters["gain_factors"] = fac[should].unsqueeze(1).unsqueeze(1)
+        self.t_gain.draws = {"gain_in_db": gdb}
         y = torch.empty_like(x)
-        check(L.mfpa_scale_rows(ptr(x), B, T, ptr(fac.to(dev)), ptr(u8(should)), 0, ptr(y), stream()), "mfpa_scale_rows")
+        fac_d, on_d = fac.to(dev), u8(should)
+        check(L.mfpa_scale_rows(ptr(x), B, T, ptr(fac_d), ptr(on_d), 0, ptr(y), stream()), "mfpa_scale_rows")
         x = y
         # 5 clipping at per-example quantiles (clipping.py:40-100)
         should = self.t_clip.gate(B)
         pct = torch.distributions.Uniform(torch.tensor(0.0), torch.tensor(float(p["max_percentile_threshold"]))).sample((B,))
         self.t_clip.transform_parameters["percentile_threshold"] = pct[should].unsqueeze(1)
+        self.t_clip.draws = {"percentile_threshold": pct}
         y = torch.empty_like(x)
-        check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct.to(dev)), ptr(u8(should)), ptr(y), stream()), "mfpa_clip_quantile")
+        pct_d, on_d = pct.to(dev), u8(should)
+        check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct_d), ptr(on_d), ptr(y), stream()), "mfpa_clip_quantile")
         x = y
         # 6 LowPass(3000-3999 Hz), 7 HighPass(30-150 Hz)
         self.t_lp.gate(B)

@@ -21,13 +21,13 @@ constexpr int FIR_OUT = 1024;   // outputs per workgroup (256 threads x 4)
 constexpr int FIR_KCH = 512;    // taps per LDS chunk
 
 // Windowed-sinc low-pass taps (julius.LowPassFilters 0.2.7, zeros = 8): taps[k] = 2c hann(k) sinc(2c pi (k - half)),
-// k = 0..2*half, normalised to unit sum.  One workgroup per example.
+// k = 0..2*half, normalised to unit sum.  One workgroup per example; example b owns taps[tap_off[b] .. + 2*half[b]+1).
 __global__ __launch_bounds__(256) void lowpass_taps_kernel(const float* __restrict__ cutoff, const int* __restrict__ half,
-                                                           int max_taps, float* __restrict__ taps) {
+                                                           const long long* __restrict__ tap_off, float* __restrict__ taps) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int h = half[b], n = 2 * h + 1;
   const float c = cutoff[b];
-  float* T = taps + (size_t)b * max_taps;
+  float* T = taps + tap_off[b];
   double s = 0.0;
   for (int k = tid; k < n; k += 256) {
     const float win = 0.5f - 0.5f * cosf(6.283185307179586f * (float)k / (float)(n - 1));   // hann_window(n, periodic=False)
@@ -46,17 +46,21 @@ __global__ __launch_bounds__(256) void lowpass_taps_kernel(const float* __restri
     __syncthreads();
   }
   const float inv = (float)(1.0 / sh[0]);
-  for (int k = tid; k < max_taps; k += 256) T[k] = k < n ? T[k] * inv : 0.f;
+  for (int k = tid; k < n; k += 256) T[k] *= inv;
 }
 
 // y[t] = sum_k taps[k] * xpad[t + k - off[b]],  k < ntaps[b];  xpad = x with replicate (pad_mode 0) or zero (1) padding.
 // out_mode 0: y;  1: x - y (high-pass);  2: store t < T only and track max |y| over all t < Tout (impulse response).
+// A filter may be far longer than the clip (a 0.5 Hz high-pass at 8 kHz has 128 001 taps): a workgroup only multiplies the
+// taps that meet a real sample for at least one of its outputs, [klo, khi); the taps before / after that range see only
+// the replicated first / last sample (or zeros), so they enter as two tap sums.  Work per clip <= T * (T + 1023) MACs.
 __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, int T, int Tout, const float* __restrict__ taps,
-                                                  int max_taps, const int* __restrict__ ntaps, const int* __restrict__ off,
-                                                  const uint8_t* __restrict__ apply, int pad_mode, int out_mode,
-                                                  float* __restrict__ y, float* __restrict__ peak) {
+                                                  const long long* __restrict__ tap_off, const int* __restrict__ ntaps,
+                                                  const int* __restrict__ off, const uint8_t* __restrict__ apply, int pad_mode,
+                                                  int out_mode, float* __restrict__ y, float* __restrict__ peak) {
   __shared__ __attribute__((aligned(16))) float win[FIR_OUT + FIR_KCH + 8];
   __shared__ __attribute__((aligned(16))) float tp[FIR_KCH];
+  __shared__ double esum[2][4];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int t0 = blockIdx.x * FIR_OUT;
   const float* xb = x + (size_t)b * T;
@@ -67,12 +71,32 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, i
     return;
   }
   const int n = ntaps[b], of = off[b];
-  const float* tb = taps + (size_t)b * max_taps;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < n; k0 += FIR_KCH) {
+  const float* tb = taps + tap_off[b];
+  // taps k in [klo, khi) read a sample index in [0, T) for some output of this workgroup
+  const long long klo_l = (long long)of - (t0 + FIR_OUT - 1), khi_l = (long long)of - t0 + T;
+  const int klo = klo_l < 0 ? 0 : (klo_l > n ? n : (int)klo_l);
+  const int khi = khi_l > n ? n : (khi_l < klo ? klo : (int)khi_l);
+  float edge = 0.f;
+  if (pad_mode == 0 && (klo > 0 || khi < n)) {            // uniform per workgroup
+    double lo = 0.0, hi = 0.0;
+    for (int k = tid; k < klo; k += 256) lo += (double)tb[k];
+    for (int k = khi + tid; k < n; k += 256) hi += (double)tb[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo += __shfl_xor(lo, o);
+      hi += __shfl_xor(hi, o);
+    }
+    if ((tid & 63) == 0) { esum[0][tid >> 6] = lo; esum[1][tid >> 6] = hi; }
+    __syncthreads();
+    lo = esum[0][0] + esum[0][1] + esum[0][2] + esum[0][3];
+    hi = esum[1][0] + esum[1][1] + esum[1][2] + esum[1][3];
+    edge = (float)(lo * (double)xb[0] + hi * (double)xb[T - 1]);
+  }
+  f32x4 acc = {edge, edge, edge, edge};
+  for (int k0 = klo; k0 < khi; k0 += FIR_KCH) {
     __syncthreads();
     for (int i = tid; i < FIR_OUT + FIR_KCH + 4; i += 256) {       // window: xpad[t0 + k0 - of + i]
-      int s = t0 + k0 - of + i;
+      long long s = (long long)t0 + k0 - of + i;
       float v;
       if (pad_mode == 0) {
         s = s < 0 ? 0 : (s >= T ? T - 1 : s);
@@ -82,7 +106,7 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, i
       }
       win[i] = v;
     }
-    for (int i = tid; i < FIR_KCH; i += 256) tp[i] = (k0 + i < n) ? tb[k0 + i] : 0.f;
+    for (int i = tid; i < FIR_KCH; i += 256) tp[i] = (k0 + i < khi) ? tb[k0 + i] : 0.f;
     __syncthreads();
     const float* w = win + 4 * tid;
     f32x4 lo = *reinterpret_cast<const f32x4*>(w);
@@ -141,6 +165,35 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
   float r = sh[0];
   for (int w = 1; w < 16; ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
   return r;
+}
+
+// AddBackgroundNoise.random_background (background_noise.py:64-141, non-mixup branch): example b is the concatenation of
+// up to P slices bank[src .. src+len) of the resident noise bank, each RMS-normalised on its own, the whole RMS-normalised
+// again (x / (rms + 1e-8), utils.py:190-205).  One workgroup per example.
+__global__ __launch_bounds__(1024) void gather_background_kernel(const float* __restrict__ bank, const long long* __restrict__ src,
+                                                                 const int* __restrict__ len, int P, int T,
+                                                                 float* __restrict__ out) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* ob = out + (size_t)b * T;
+  int pos = 0;
+  for (int p = 0; p < P && pos < T; ++p) {
+    const int L = len[b * P + p];
+    if (L <= 0) break;
+    const float* sp = bank + src[b * P + p];
+    float s = 0.f;
+    for (int i = tid; i < L; i += 1024) s += sp[i] * sp[i];
+    s = block_reduce(s, sh, false);
+    const float r = sqrtf(s / (float)L) + 1e-8f;
+    for (int i = tid; i < L; i += 1024) ob[pos + i] = sp[i] / r;
+    pos += L;
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < T; i += 1024) s += ob[i] * ob[i];
+  s = block_reduce(s, sh, false);
+  const float r = sqrtf(s / (float)T) + 1e-8f;
+  for (int i = tid; i < T; i += 1024) ob[i] = ob[i] / r;
 }
 
 // AddBackgroundNoise.apply_transform (background_noise.py:183-215): y = x + rms(x) / 10^(snr/20) * noise; y /= max|y|.
@@ -243,23 +296,24 @@ __global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x,
 
 extern "C" {
 
-int mfpa_lowpass_taps(const float* cutoff, const int* half, int B, int max_taps, float* taps, void* stream) {
+int mfpa_lowpass_taps(const float* cutoff, const int* half, const long long* tap_off, int B, float* taps, void* stream) {
   if (B == 0) return MFPA_OK;
-  if (!cutoff || !half || !taps || B < 0 || max_taps < 3) return MFPA_EINVAL;
-  hipLaunchKernelGGL(lowpass_taps_kernel, dim3(B), dim3(256), 0, mfpa_stream(stream), cutoff, half, max_taps, taps);
+  if (!cutoff || !half || !tap_off || !taps || B < 0) return MFPA_EINVAL;
+  hipLaunchKernelGGL(lowpass_taps_kernel, dim3(B), dim3(256), 0, mfpa_stream(stream), cutoff, half, tap_off, taps);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
-int mfpa_fir(const float* x, int B, int T, int Tout, const float* taps, int max_taps, const int* ntaps, const int* off,
+int mfpa_fir(const float* x, int B, int T, int Tout, const float* taps, const long long* tap_off, const int* ntaps, const int* off,
              const uint8_t* apply, int pad_mode, int out_mode, float* y, float* peak, void* stream) {
   if (B == 0) return MFPA_OK;
-  if (!x || !taps || !ntaps || !off || !apply || !y || B < 0 || B > 65535 || T < 1 || Tout < T || max_taps < 1) return MFPA_EINVAL;
+  if (!x || !taps || !tap_off || !ntaps || !off || !apply || !y || B < 0 || B > 65535 || T < 1 || Tout < T) return MFPA_EINVAL;
   if (pad_mode < 0 || pad_mode > 1 || out_mode < 0 || out_mode > 2 || (out_mode == 2 && !peak)) return MFPA_EINVAL;
+  if ((long long)Tout + FIR_OUT > 0x7fffffffLL) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   if (out_mode == 2) MFPA_HIP(hipMemsetAsync(peak, 0, sizeof(float) * B, s));
   dim3 grid((Tout + FIR_OUT - 1) / FIR_OUT, B);
-  hipLaunchKernelGGL(fir_kernel, grid, dim3(256), 0, s, x, T, Tout, taps, max_taps, ntaps, off, apply, pad_mode, out_mode, y, peak);
+  hipLaunchKernelGGL(fir_kernel, grid, dim3(256), 0, s, x, T, Tout, taps, tap_off, ntaps, off, apply, pad_mode, out_mode, y, peak);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -269,6 +323,15 @@ int mfpa_scale_rows(const float* x, int B, int T, const float* factor, const uin
   if (!x || !factor || !y || B < 0 || B > 65535 || T < 1) return MFPA_EINVAL;
   int gx = (T + 255) / 256; if (gx > 256) gx = 256;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), x, T, factor, apply, invert, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_gather_background(const float* bank, const long long* src, const int* len, int B, int P, int T, float* out,
+                           void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!bank || !src || !len || !out || B < 0 || P < 1 || T < 1) return MFPA_EINVAL;
+  hipLaunchKernelGGL(gather_background_kernel, dim3(B), dim3(1024), 0, mfpa_stream(stream), bank, src, len, P, T, out);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -37,10 +37,11 @@ def test_building_blocks():
     x = torch.randn(3, 1001, generator=g)
     ker = D.sinc_kernel("cuda")
     y = torch.empty(3, 2002, device="cuda")
-    check(lib().mfpa_upsample2(ptr(x.cuda()), 3, 1001, ptr(ker), ptr(y), stream()), "up")
+    xd = x.cuda()
+    check(lib().mfpa_upsample2(ptr(xd), 3, 1001, ptr(ker), ptr(y), stream()), "up")
     assert relative_l1(y.cpu(), od.upsample2(x)) < 1e-6
     z = torch.empty(3, 501, device="cuda")
-    check(lib().mfpa_downsample2(ptr(x.cuda()), 3, 1001, ptr(ker), ptr(z), 501, 0, 0, stream()), "down")
+    check(lib().mfpa_downsample2(ptr(xd), 3, 1001, ptr(ker), ptr(z), 501, 0, 0, stream()), "down")
     assert relative_l1(z.cpu(), od.downsample2(x)) < 1e-6
     # strided-window GEMM = Conv1d(k8, s4) + ReLU on (B, L, C)
     B, Lin, Cin, Cout = 2, 404, 48, 96
