@@ -143,7 +143,9 @@ def bench_demucs(args, rank, world, dev, dist):
 
 def bench_train(args, rank, world, dev, dist):
     """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips, Dropout(0.05) as the reference
-    trains (training/train.py:646), fp32 MFMA."""
+    trains (training/train.py:646).  Default arithmetic: bf16x3 products on the bf16 matrix cores (BASELINE config 4 says
+    "bf16 MFMA"; bf16x3 is its fp32-accurate form) for forward, input-gradient and weight-gradient convolutions;
+    --precision fp32 runs the exact-fp32 MFMA path."""
     from musicfpaugment_amd import ops, ops_unet, synth
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
@@ -209,15 +211,22 @@ def bench_train(args, rank, world, dev, dist):
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 fwd/dgrad convolutions, f32 wgrad" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "dtype": ("bf16x3 convolutions (forward, input and weight gradients; fp32 operands split into bf16 hi+lo, fp32 "
+                      "accumulate), fp32/fp64 reductions and Adam") if args.precision == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_mfma_kernel + wgrad_mfma_kernel", "launches": timer.launches(),
-                         "kernel_ms_per_step": round(conv_ms / args.steps, 3)}}), flush=True)
+            "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                          "mfma_flops_issued_per_algorithmic_flop": 3,
+                          "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                          "kernel": "conv_mfma_kernel<PREC 1> + wgrad_bf16x3_kernel", "launches": timer.launches(),
+                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)} if args.precision == "bf16x3" else
+                         {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                          "kernel": "conv_mfma_kernel<PREC 0> + wgrad_mfma_kernel", "launches": timer.launches(),
+                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)})}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -240,8 +249,8 @@ def main():
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick")
     args = ap.parse_args()
-    if args.precision is None:      # inference: the fastest arithmetic inside the 1e-4 gate; training: exact fp32 products
-        args.precision = "bf16x3" if args.mode == "infer" else "fp32"
+    if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
+        args.precision = "fp32" if args.mode == "demucs" else "bf16x3"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -275,7 +275,8 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
  *   mode 0: dw[tap][co][ci] += sum_p dz[p][co] * xin[p + tap][ci]          (3x3 conv; dw (9,Cout,C0+C1))
  *   mode 1: dw[tap][co][ci] += sum_p dz[2y+dy,2x+dx][co] * xin[y,x][ci]    (transposed conv; dw (4,Cout,C0))
  * xin = [x0 (affine+ReLU on load if in_scale0) | x1 zero-padded] exactly as the forward saw it.
- * C0, C1, Cout multiples of 64. */
+ * C0, C1, Cout multiples of 64.  precision 0: fp32 MFMA; 1: bf16x3 (both operands split hi + lo, 3 bf16 MFMAs per
+ * product, fp32 accumulate) -- like mfpa_conv_desc.precision. */
 typedef struct mfpa_wgrad_desc {
   const float* dz; const float* x0; const float* in_scale0; const float* in_shift0; const float* x1;
   float* dw;
@@ -283,6 +284,7 @@ typedef struct mfpa_wgrad_desc {
   int B, H, W, Cout, mode;
   unsigned drop_seed, drop_thresh;
   float drop_scale;
+  int precision;
 } mfpa_wgrad_desc;
 int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream);
 

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MfpaError(RuntimeError):
@@ -120,7 +120,7 @@ class WgradDesc(ctypes.Structure):
                 ("x1", c_void_p), ("dw", c_void_p),
                 ("C0", c_int), ("C1", c_int), ("H1", c_int), ("W1", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("mode", c_int),
-                ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float)]
+                ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int)]
 
 _lib = None
 

@@ -113,6 +113,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   f32x4 areg[A_F4];
   f32x4 breg[2][B_F4];   // two register sets for the weight tile, always indexed with compile-time constants
 
+  // load_a only ISSUES the global loads of a halo tile (nothing in it reads a loaded value, so no wait lands between
+  // the loads); the on-load affine + ReLU + dropout and the bf16 split happen in store_a, a whole chunk later.
+  static_assert(THREADS % (KC / 4) == 0, "a thread keeps one channel quad for all of its halo pixels");
   auto load_a = [&](int chunk, int tap) __attribute__((always_inline)) {
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
@@ -131,20 +134,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
             } else {
               v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
             }
-            if (a.in_scale0) {
-              const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * q);
-              const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * q);
-              v = v * sc + sh;
-              v.x = v.x > 0.f ? v.x : 0.f;
-              v.y = v.y > 0.f ? v.y : 0.f;
-              v.z = v.z > 0.f ? v.z : 0.f;
-              v.w = v.w > 0.f ? v.w : 0.f;
-              if (a.drop_thresh) {
-                const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
-              }
-            }
           } else {
             const int y1 = gy - a.oy1, x1 = gx - a.ox1;
             if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
@@ -155,20 +144,41 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
       areg[it] = v;
     }
   };
-  auto store_a = [&]() __attribute__((always_inline)) {
+  auto store_a = [&](int chunk) __attribute__((always_inline)) {
+    const int c0 = chunk * KC;
+    const bool affine = a.in_scale0 != nullptr && c0 < a.C0;
+    f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+      a_sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * (tid % (KC / 4)));
+      a_sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * (tid % (KC / 4)));
+    }
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
       const int idx = tid + it * THREADS;
       if (idx < HP * (KC / 4)) {
         const int pix = idx / (KC / 4), q = idx % (KC / 4);
+        f32x4 v = areg[it];
+        const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+        if (affine && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {      // padding stays exactly zero
+          v = v * a_sc + a_sh;
+          v.x = v.x > 0.f ? v.x : 0.f;
+          v.y = v.y > 0.f ? v.y : 0.f;
+          v.z = v.z > 0.f ? v.z : 0.f;
+          v.w = v.w > 0.f ? v.w : 0.f;
+          if (a.drop_thresh) {
+            const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+          }
+        }
         if (PREC == 0) {
-          *reinterpret_cast<f32x4*>(As + pix * LDK + 4 * q) = areg[it];
+          *reinterpret_cast<f32x4*>(As + pix * LDK + 4 * q) = v;
         } else {
           bf16x4 hi, lo;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            hi[k] = (__bf16)areg[it][k];
-            lo[k] = (__bf16)(areg[it][k] - (float)hi[k]);
+            hi[k] = (__bf16)v[k];
+            lo[k] = (__bf16)(v[k] - (float)hi[k]);
           }
           char* row = reinterpret_cast<char*>(As + pix * LDK);
           *reinterpret_cast<bf16x4*>(row + 8 * q) = hi;
@@ -285,14 +295,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     if (!(a.dbg & 8)) compute(tap, Bs0 + (it & 1) * (BN * LDK));
     if ((chunk_end || A_PER_TAP) && it + 1 < nit) {
       if (!(a.dbg & 2)) __syncthreads();            // every wave is done reading As
-      store_a();
+      store_a((it + 1) / TAPS);
     }
     if (!(a.dbg & 2)) __syncthreads();
   };
 
   load_a(0, 0);
   load_b(0, Set0{});
-  store_a();
+  store_a(0);
   store_b(Set0{}, Bs0);
   if (nit > 1) load_b(1, Set0{});
   __syncthreads();

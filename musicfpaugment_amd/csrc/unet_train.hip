@@ -409,6 +409,226 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     }
 }
 
+// The same weight gradient with bf16x3 products (precision 1): both operands are split x = hi + lo (bf16) while they are
+// staged and each tap's product is dz_lo*x_hi + dz_hi*x_lo + dz_hi*x_hi on v_mfma_f32_32x32x16_bf16 -- 3 matrix
+// instructions at 16x the fp32-MFMA rate.  K is the PIXEL index, but NHWC tiles are pixel-major: the fragments (8
+// consecutive pixels of one channel per lane) come from gfx950's transposing LDS read ds_read_b64_tr_b16, which hands
+// lane i of a 16-lane group column i of a 4-row block -- so the tiles stay in their natural order, and a tap shift is a
+// whole-row offset folded into the instruction's immediate.  LDS pixel row = [64 ch hi | 64 ch lo | 64 B pad] = 320 B:
+// the four rows of a block land on bank offsets 0 / 64 / 128 / 192 (conflict-free).
+typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int WGB_ROW = 320;   // bytes per staged pixel
+
+__device__ __forceinline__ wg_bf16x8 wg_tr_frag(const char* p0, const char* p1) {
+  typedef wg_s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const wg_s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
+  const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p1));
+  union { short s[8]; wg_bf16x8 b; } r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r.s[j] = u[j]; r.s[4 + j] = v[j]; }
+  return r.b;
+}
+
+__device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
+  wg_bf16x4 hi, lo;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hi[k] = (__bf16)v[k];
+    lo[k] = (__bf16)(v[k] - (float)hi[k]);
+  }
+  *reinterpret_cast<wg_bf16x4*>(row + 8 * c4) = hi;
+  *reinterpret_cast<wg_bf16x4*>(row + 128 + 8 * c4) = lo;
+}
+
+// 8 waves: (co half) x (ci half) x (pixel half of a 128-pixel patch, 4x32 or 8x16 for narrow images); one workgroup
+// per CU, two waves per SIMD.
+constexpr int WGB_PIX = 128, WGB_THREADS = 512;
+
+template <int MODE, int PW>
+__global__ __launch_bounds__(WGB_THREADS, 1) void wgrad_bf16x3_kernel(WgradArgs a) {
+  constexpr int WGB_PH = WGB_PIX / PW;
+  constexpr int HALO = (MODE == 0) ? 1 : 0;
+  constexpr int TAPS = (MODE == 0) ? 9 : 4;
+  constexpr int HPW = PW + 2 * HALO, HPH = WGB_PH + 2 * HALO, HP = HPW * HPH;
+  constexpr int X_F4 = (HP * (WG_T / 4) + WGB_THREADS - 1) / WGB_THREADS;        // float4 loads per thread for the xin tile
+  constexpr int D_F4 = WGB_PIX * (WG_T / 4) / WGB_THREADS;            // ... and for the dz tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ds = smem;                          // [128 px][320 B]  dz tile
+  char* Xs = smem + WGB_PIX * WGB_ROW;       // [HP px][320 B]   xin tile with halo
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cot = wave & 1, cit = (wave >> 1) & 1, ph = wave >> 2;   // ph: the patch's upper / lower 64 pixels
+  const int co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T;
+  const int Cin = a.C0 + a.C1;
+  const bool from0 = ci0 < a.C0;
+  const bool affine = from0 && a.in_scale0 != nullptr;
+  const long long npatch = (long long)a.B * a.tiles_x * a.tiles_y;
+  const int c4 = tid % (WG_T / 4);          // this thread's channel quad (the same for every staged pixel: 512 % 16 == 0)
+  // transposing read: lane 4q+p of a 16-lane group addresses row q (pixel), columns 4p..4p+3 (channels) of its block
+  const int gl = lane & 15, tq = gl >> 2, tp = gl & 3, gsel = (lane >> 4) & 1;
+  const char* a_lane = Ds + (64 * ph + 8 * lh + tq) * WGB_ROW + (32 * cot + 16 * gsel + 4 * tp) * 2;
+  const char* b_lane = Xs + ((WGB_PH / 2) * ph * HPW + 8 * lh + tq) * WGB_ROW + (32 * cit + 16 * gsel + 4 * tp) * 2;
+
+  f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};
+  if (affine) {
+    a_sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + ci0 + 4 * c4);
+    a_sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + ci0 + 4 * c4);
+  }
+
+  floatx16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // Software pipeline over patches: the global loads of patch n+1 are issued (into registers, no dependent use) before
+  // the MFMA block of patch n and are split / written to LDS after it.
+  f32x4 xr[X_F4], dr[D_F4];
+  auto decode = [&](long long patch, int& b, int& y0, int& x0p) __attribute__((always_inline)) {
+    long long q = patch;
+    const int tx = (int)(q % a.tiles_x); q /= a.tiles_x;
+    const int ty = (int)(q % a.tiles_y);
+    b = (int)(q / a.tiles_y);
+    y0 = ty * WGB_PH; x0p = tx * PW;
+  };
+  auto load_x = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < X_F4; ++it) {
+      const int pix = (tid + it * WGB_THREADS) / (WG_T / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < HP) {
+        const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+          if (from0) {
+            v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4);
+          } else {
+            const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+            if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
+              v = *reinterpret_cast<const f32x4*>(a.x1 + (((size_t)b * a.H1 + y1) * a.W1 + x1) * a.C1 + (ci0 - a.C0) + 4 * c4);
+          }
+        }
+      }
+      xr[it] = v;
+    }
+  };
+  auto store_x = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < X_F4; ++it) {
+      const int pix = (tid + it * WGB_THREADS) / (WG_T / 4);
+      if (pix < HP) {
+        f32x4 v = xr[it];
+        if (affine) {
+          const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {       // padding stays exactly zero
+            v = v * a_sc + a_sh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            if (a.drop_thresh) {
+              const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+            }
+          }
+        }
+        wg_store_split(Xs + pix * WGB_ROW, c4, v);
+      }
+    }
+  };
+  auto load_d = [&](int b, int y0, int x0p, int tap) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < D_F4; ++it) {
+      const int pix = (tid + it * WGB_THREADS) / (WG_T / 4);
+      const int gy = y0 + pix / PW, gx = x0p + pix % PW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < a.H && gx < a.W) {
+        if (MODE == 0)
+          v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
+        else
+          v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)b * (2 * a.H) + 2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout + co0 + 4 * c4);
+      }
+      dr[it] = v;
+    }
+  };
+  auto store_d = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < D_F4; ++it) wg_store_split(Ds + ((tid + it * WGB_THREADS) / (WG_T / 4)) * WGB_ROW, c4, dr[it]);
+  };
+  auto mfma3 = [&](floatx16& c, wg_bf16x8 ah, wg_bf16x8 al, wg_bf16x8 bh, wg_bf16x8 bl) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  };
+
+  int b = 0, y0 = 0, x0p = 0;
+  long long patch = blockIdx.z;
+  if (patch < npatch) {
+    decode(patch, b, y0, x0p);
+    load_x(b, y0, x0p);
+    load_d(b, y0, x0p, 0);
+  }
+  for (; patch < npatch; patch += gridDim.z) {
+    __syncthreads();                       // the previous patch's fragment reads are done
+    store_x(b, y0, x0p);
+    store_d();
+    __syncthreads();
+    const long long next = patch + gridDim.z;
+    int nb = 0, ny0 = 0, nx0 = 0;
+    if (MODE == 0 && next < npatch) {      // prefetch the next patch; the loads land during the MFMA block below
+      decode(next, nb, ny0, nx0);
+      load_x(nb, ny0, nx0);
+      load_d(nb, ny0, nx0, 0);
+    }
+    for (int tap = 0; tap < (MODE == 0 ? 1 : TAPS); ++tap) {
+      if (MODE == 1 && tap > 0) {          // transposed conv: the tap's strided view of dz replaces the dz tile
+        __syncthreads();
+        load_d(b, y0, x0p, tap);
+        store_d();
+        __syncthreads();
+      }
+#pragma unroll 1   // one k-step's 9 taps in flight at a time: bounds the live fragment registers next to 144 accumulators
+      for (int ks = 0; ks < WG_PIX / 16; ++ks) {
+        // this lane's 8 pixels: k = 16 ks + 8 lh + (0..7) of the wave's 64: patch row 16 ks / PW, columns 16 ks % PW + 8 lh + (0..7)
+        const char* ap = a_lane + (16 * ks) * WGB_ROW;
+        const wg_bf16x8 ah = wg_tr_frag(ap, ap + 4 * WGB_ROW);
+        const wg_bf16x8 al = wg_tr_frag(ap + 128, ap + 4 * WGB_ROW + 128);
+        if (MODE == 0) {
+          const char* bk = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * WGB_ROW;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const char* bp = bk + ((t / 3) * HPW + (t % 3)) * WGB_ROW;
+            mfma3(acc[t], ah, al, wg_tr_frag(bp, bp + 4 * WGB_ROW), wg_tr_frag(bp + 128, bp + 4 * WGB_ROW + 128));
+          }
+        } else {
+          const char* bp = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * WGB_ROW;
+          const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * WGB_ROW);
+          const wg_bf16x8 bl = wg_tr_frag(bp + 128, bp + 4 * WGB_ROW + 128);
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t)
+            if (t == tap) mfma3(acc[t], ah, al, bh, bl);
+        }
+      }
+    }
+    if (MODE == 1 && next < npatch) {
+      decode(next, nb, ny0, nx0);
+      load_x(nb, ny0, nx0);
+      load_d(nb, ny0, nx0, 0);
+    }
+    b = nb; y0 = ny0; x0p = nx0;
+  }
+  // D[row = co][col = ci]
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int ci = ci0 + cit * 32 + li;
+      atomicAdd(a.dw + ((size_t)t * a.Cout + co) * Cin + ci, acc[t][r]);
+    }
+}
+
 // First layer weight gradient (1 input channel): dW[tap][co] += sum_p dz[p][co] * x[p + tap].
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const float* __restrict__ dz, const float* __restrict__ x32,
                                                        const double* __restrict__ spec64,
@@ -691,7 +911,24 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
   if (split > 65535) split = 65535;
   dim3 grid(d->Cout / WG_T, (d->C0 + d->C1) / WG_T, (unsigned)split);
   hipStream_t s = mfpa_stream(stream);
-  if (d->mode == 0) {
+  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
+  if (d->precision == 1) {
+    // transposing LDS reads need every lane live (512-thread workgroups, no early exits) -- guaranteed by the kernel shape
+    const int pw = d->W <= 16 ? 16 : 32, phh = WGB_PIX / pw;
+    a.tiles_x = (d->W + pw - 1) / pw;
+    a.tiles_y = (d->H + phh - 1) / phh;
+    const long long npatch_b = (long long)a.B * a.tiles_x * a.tiles_y;
+    long long split_b = (1024 + tiles - 1) / tiles;   // ~4 workgroups per CU over the launch
+    if (split_b > npatch_b) split_b = npatch_b;
+    if (split_b < 1) split_b = 1;
+    if (split_b > 65535) split_b = 65535;
+    grid.z = (unsigned)split_b;
+    const size_t lds = (size_t)WGB_ROW * (WGB_PIX + (d->mode == 0 ? (phh + 2) * (pw + 2) : WGB_PIX));
+    if (d->mode == 0 && pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 32>), grid, dim3(WGB_THREADS), lds, s, a);
+    else if (d->mode == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 16>), grid, dim3(WGB_THREADS), lds, s, a);
+    else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32>), grid, dim3(WGB_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 16>), grid, dim3(WGB_THREADS), lds, s, a);
+  } else if (d->mode == 0) {
     const size_t lds = sizeof(float) * ((size_t)WG_PIX * WG_T + (size_t)(WG_PH + 2) * (WG_PW + 2) * WG_T);
     hipLaunchKernelGGL(wgrad_mfma_kernel<0>, grid, dim3(256), lds, s, a);
   } else {

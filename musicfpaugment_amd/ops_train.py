@@ -82,13 +82,14 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
-def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None):
+def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0):
     B, H, W, C0 = x0.shape
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
                   in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), dw=ptr(dw), C0=C0,
                   C1=0 if x1 is None else x1.shape[3], H1=0 if x1 is None else x1.shape[1],
                   W1=0 if x1 is None else x1.shape[2], B=B, H=H, W=W, Cout=Cout, mode=mode,
-                  drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1], drop_scale=_drop(in_affine)[2])
+                  drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1], drop_scale=_drop(in_affine)[2],
+                  precision=precision)
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_wgrad_mfma(ctypes.byref(d), stream()), "mfpa_wgrad_mfma")
     if t0 is not None:
@@ -136,11 +137,13 @@ def flat_layout():
 class UNetTrainEngine:
     """Owns kernel-layout master parameters, gradients and Adam moments of a UNet(1, 1) and runs train steps."""
 
-    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision: int = 0):
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision: int = 0,
+                 wgrad_precision: Optional[int] = None):
         self.module = module
-        # arithmetic of the forward / input-gradient convolutions: 0 = fp32 MFMA, 1 = bf16x3 (the weight-gradient
-        # kernel and every reduction stay fp32 / fp64)
+        # arithmetic of the convolutions: 0 = fp32 MFMA, 1 = bf16x3 (3 bf16 MFMAs per fp32 product); `wgrad_precision`
+        # overrides it for the weight-gradient kernel.  Reductions, BatchNorm statistics, the loss and Adam are fp32/fp64.
         self.precision = precision
+        self.wgrad_precision = precision if wgrad_precision is None else wgrad_precision
         self.device = next(module.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("the training engine runs on the MI355X only")
@@ -317,7 +320,7 @@ class UNetTrainEngine:
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
         dz3 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b")
-        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"])
+        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision)
         wt3 = self.P[prefix + ".3.w"].flip(0).transpose(1, 2).contiguous()          # [tap'][ci][co]
         dmid = conv_mfma(dz3, wt3, cout, precision=self.precision)
         del dz3
@@ -328,7 +331,8 @@ class UNetTrainEngine:
             check(lib().mfpa_wgrad_c1(ptr(dz0), ptr(x32), ptr(spec64), ptr(denom), B, H, W, C, ptr(self.G[prefix + ".0.w"]),
                                       stream()), "mfpa_wgrad_c1")
             return None, None
-        wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"])
+        wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"],
+                   precision=self.wgrad_precision)
         if not need_input_grad:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
@@ -363,7 +367,8 @@ class UNetTrainEngine:
             check(lib().mfpa_colsum(ptr(d_u), _npix(d_u), cout, ptr(self.G[name + ".up.b"]), ptr(self.workspace),
                                     stream()), "mfpa_colsum")
             prev = r["up_in"]
-            wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"])
+            wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"],
+                       precision=self.wgrad_precision)
             wt = self.P[name + ".up.w"].transpose(1, 2).contiguous()                # (4, cin, cout)
             dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision)
             handles.append(self._reduce_bucket(name))

@@ -39,6 +39,9 @@ def test_wgrad_and_dgrad_blocks_vs_autograd():
         dw = torch.zeros_like(wp)
         T.wgrad_mfma(nhwc(dz), nhwc(x0), dw, Cout, in_affine=st, x1=None if x1 is None else nhwc(x1))
         assert rel(dw, K.pack_conv3x3(w.grad)) < 1e-4, (B, H, W, C0, C1, Cout)
+        dw3 = torch.zeros_like(wp)           # bf16x3 products through the transposing LDS reads: ~2^-17 per product
+        T.wgrad_mfma(nhwc(dz), nhwc(x0), dw3, Cout, in_affine=st, x1=None if x1 is None else nhwc(x1), precision=1)
+        assert rel(dw3, K.pack_conv3x3(w.grad)) < 1e-4, (B, H, W, C0, C1, Cout, rel(dw3, K.pack_conv3x3(w.grad)))
         # input gradient w.r.t. the lazy activation a0 (and x1): conv of dz with flipped, transposed weights
         wt = wp.flip(0).transpose(1, 2)
         d0 = T.conv_mfma(nhwc(dz), wt[:, :C0].contiguous(), C0)
@@ -50,22 +53,25 @@ def test_wgrad_and_dgrad_blocks_vs_autograd():
             d1 = T.conv_mfma(nhwc(dz), wt[:, C0:].contiguous(), C1, out_hw=(H - 1, W - 1))
             assert rel(d1.permute(0, 3, 1, 2), x1.grad) < 1e-5
     # transposed conv: forward (lazy input), weight / input gradients
-    B, H, W, Cin = 2, 7, 33, 128
-    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
-    w = (torch.randn(Cin, Cin // 2, 2, 2, generator=g) / np.sqrt(Cin)).requires_grad_()
-    bias = torch.randn(Cin // 2, generator=g)
-    u = F.conv_transpose2d(x, w, bias, stride=2)
-    du = torch.randn(u.shape, generator=g)
-    u.backward(du)
-    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
-    wp = K.pack_convT2x2(w).cuda()
-    got = T.conv_mfma(nhwc(x), wp, Cin // 2, mode=1, out_shift=bias.cuda())
-    assert rel(got.permute(0, 3, 1, 2), u.detach()) < 1e-5
-    dw = torch.zeros_like(wp)
-    T.wgrad_mfma(nhwc(du), nhwc(x), dw, Cin // 2, mode=1)
-    assert rel(dw, K.pack_convT2x2(w.grad)) < 1e-4
-    dx = T.conv_mfma(nhwc(du), wp.transpose(1, 2).contiguous(), Cin, mode=2)
-    assert rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-5
+    for (B, H, W, Cin) in [(2, 7, 33, 128), (3, 9, 15, 128)]:
+        x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+        w = (torch.randn(Cin, Cin // 2, 2, 2, generator=g) / np.sqrt(Cin)).requires_grad_()
+        bias = torch.randn(Cin // 2, generator=g)
+        u = F.conv_transpose2d(x, w, bias, stride=2)
+        du = torch.randn(u.shape, generator=g)
+        u.backward(du)
+        nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+        wp = K.pack_convT2x2(w).cuda()
+        got = T.conv_mfma(nhwc(x), wp, Cin // 2, mode=1, out_shift=bias.cuda())
+        assert rel(got.permute(0, 3, 1, 2), u.detach()) < 1e-5
+        dw = torch.zeros_like(wp)
+        T.wgrad_mfma(nhwc(du), nhwc(x), dw, Cin // 2, mode=1)
+        assert rel(dw, K.pack_convT2x2(w.grad)) < 1e-4
+        dw3 = torch.zeros_like(wp)
+        T.wgrad_mfma(nhwc(du), nhwc(x), dw3, Cin // 2, mode=1, precision=1)
+        assert rel(dw3, K.pack_convT2x2(w.grad)) < 1e-4, rel(dw3, K.pack_convT2x2(w.grad))
+        dx = T.conv_mfma(nhwc(du), wp.transpose(1, 2).contiguous(), Cin, mode=2)
+        assert rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-5
 
 
 def _g7_inputs():
