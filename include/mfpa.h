@@ -326,6 +326,7 @@ typedef struct mfpa_gemm_desc {
   const float* addend; long long ldadd, strideAdd;
   float* C; long long ldc, strideC;
   int batch, M, N, K, npad, mode, relu;
+  int precision;   /* 0: fp32 MFMA (K multiple of 16); 1: bf16x3 where K >= 256 is a multiple of 32 (fp32 MFMA otherwise) */
 } mfpa_gemm_desc;
 int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream);
 
@@ -346,6 +347,13 @@ int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float b
  * hout rows ldh apart; optional hsum = h + addend (the first decoder skip). */
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
                    const float* addend, long long ldadd, void* stream);
+
+/* One LSTM time step in ONE launch: gates = hprev W_hh^T + xp (hprev NULL at t = 0: gates = xp), then the cell update of
+ * mfpa_lstm_cell.  whh_grouped = W_hh (4H,H) with rows regrouped to [H/16][i16|f16|g16|o16][H] so a workgroup owns all
+ * four gates of its 16 hidden units; xp (B,4H) in the standard gate order, rows ldxp apart, includes both biases.
+ * bf16x3 products, fp32 accumulate.  H multiple of 128. */
+int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp, float* c,
+                   int B, int H, float* hout, long long ldh, float* hsum, const float* addend, long long ldadd, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * AugmentFP signal chain (next-tier row SURVEY.md §8f-3), augmentation/__init__.py:46-93 and

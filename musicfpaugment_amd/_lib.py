@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MfpaError(RuntimeError):
@@ -70,6 +70,8 @@ _SIGNATURES = {
     "mfpa_downsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
     "mfpa_conv1d_c1_relu": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_convT1d_c1": ([c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
+    "mfpa_lstm_step": ([c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong,
+                        c_void_p, c_void_p, c_longlong, c_void_p], c_int),
     "mfpa_lstm_cell": ([c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,
                         c_longlong, c_void_p], c_int),
     "mfpa_red_blocks": ([], c_int),
@@ -111,7 +113,7 @@ class GemmDesc(ctypes.Structure):
                 ("addend", c_void_p), ("ldadd", c_longlong), ("strideAdd", c_longlong),
                 ("C", c_void_p), ("ldc", c_longlong), ("strideC", c_longlong),
                 ("batch", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("npad", c_int), ("mode", c_int),
-                ("relu", c_int)]
+                ("relu", c_int), ("precision", c_int)]
 
 
 class WgradDesc(ctypes.Structure):

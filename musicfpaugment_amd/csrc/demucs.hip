@@ -33,12 +33,40 @@ struct GemmArgs {
   int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend
 };
 
+// epilogue shared by both precisions: D[row = m][col = n]; a lane holds column li of both 32-wide n tiles
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, floatx16 (&acc)[2], int m0, int n0, int b, int wave, int li, int lh) {
+  const float bias0 = a.bias ? a.bias[n0 + li] : 0.f;
+  const float bias1 = a.bias ? a.bias[n0 + 32 + li] : 0.f;
+  float* Cb = a.C + (size_t)b * a.strideC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m >= a.M) continue;
+    float v0 = acc[0][r] + bias0, v1 = acc[1][r] + bias1;
+    if (a.mode == 1) {                         // GLU: value * sigmoid(gate); output column = (tile index) * 32 + li
+      const int n = (n0 / 64) * 32 + li;
+      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0 * (1.f / (1.f + __expf(-v1)));
+    } else {
+      const int n = n0 + li;
+      if (a.relu == 2) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }   // ReLU before the skip addition
+      if (a.mode == 2) {
+        const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
+        if (n < a.N) v0 += ad[n];
+        if (n + 32 < a.N) v1 += ad[n + 32];
+      }
+      if (a.relu == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0;
+      if (n + 32 < a.N) Cb[(size_t)m * a.ldc + n + 32] = v1;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][GBM * GLD];
   __shared__ __attribute__((aligned(16))) float Bs[2][GBN * GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN, b = blockIdx.z;
+  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;   // n tiles fastest: the workgroups that share an A tile run together
   const float* Ab = a.A + (size_t)b * a.strideA;
   const int nk = a.K / GKC;
 
@@ -92,31 +120,88 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
     __syncthreads();
   }
 
-  // epilogue: D[row = m][col = n]; lane holds column li of both 32-wide n tiles
-  const float bias0 = a.bias ? a.bias[n0 + li] : 0.f;
-  const float bias1 = a.bias ? a.bias[n0 + 32 + li] : 0.f;
-  float* Cb = a.C + (size_t)b * a.strideC;
+  gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
+}
+
+// The same GEMM with bf16x3 products (precision 1): K chunks of 32, LDS rows [32 hi | 32 lo | pad] = 144 B (the layout of
+// conv_mfma_kernel<PREC 1>), operands split while they are staged, 3 x v_mfma_f32_32x32x16_bf16 per fp32 product.
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int HKC = 32, HROW = 144;
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) char As[2][GBM * HROW];
+  __shared__ __attribute__((aligned(16))) char Bs[2][GBN * HROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;   // n tiles fastest: the workgroups that share an A tile run together
+  const float* Ab = a.A + (size_t)b * a.strideA;
+  const int nk = a.K / HKC;
+
+  // staging: A tile 128 rows x 8 float4 (4 per thread), B tile 64 rows x 8 float4 (2 per thread)
+  f32x4 ar[4], br[2];
+  const int q = tid & 7, r0 = tid >> 3;                  // rows r0 + 32 i
+  auto load = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (m >= a.M) continue;
-    float v0 = acc[0][r] + bias0, v1 = acc[1][r] + bias1;
-    if (a.mode == 1) {                         // GLU: value * sigmoid(gate); output column = (tile index) * 32 + li
-      const int n = blockIdx.y * 32 + li;
-      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0 * (1.f / (1.f + __expf(-v1)));
-    } else {
-      const int n = n0 + li;
-      if (a.relu == 2) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }   // ReLU before the skip addition
-      if (a.mode == 2) {
-        const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
-        if (n < a.N) v0 += ad[n];
-        if (n + 32 < a.N) v1 += ad[n + 32];
-      }
-      if (a.relu == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0;
-      if (n + 32 < a.N) Cb[(size_t)m * a.ldc + n + 32] = v1;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + kc * HKC + 4 * q);
+      ar[i] = v;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      br[i] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + r0 + 32 * i) * a.K + kc * HKC + 4 * q);
+  };
+  auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
+    g_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
+    *reinterpret_cast<g_bf16x4*>(row + 64 + 8 * q) = lo;
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store(&As[buf][(r0 + 32 * i) * HROW], ar[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split_store(&Bs[buf][(r0 + 32 * i) * HROW], br[i]);
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  load(0);
+  store(0);
+  if (nk > 1) load(1);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) store(buf ^ 1);
+    if (kc + 2 < nk) load(kc + 2);
+    const char* Ap = &As[buf][(wave * 32 + li) * HROW + 16 * lh];
+    const char* Bp = &Bs[buf][li * HROW + 16 * lh];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(Ap + 32 * s);
+      const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(Ap + 64 + 32 * s);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * HROW + 32 * s);
+        const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * HROW + 64 + 32 * s);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
   }
+  gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
 }
 
 // ---------------------------------------------------------------------------------- small kernels
@@ -255,6 +340,140 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------- fused LSTM time step
+// One launch per time step: gates = h[t-1] W_hh^T (+ xp[t], the input projection incl. both biases) AND the cell update,
+// so the recurrence costs one short kernel per step instead of a GEMM + a cell kernel.
+//   * a workgroup owns 64 clips x 16 hidden units = 64 x 64 gate columns [i16 | f16 | g16 | o16] (W_hh rows regrouped
+//     on the host), K = H walked in chunks of 128 with the operands double-buffered in LDS and the next chunk's global
+//     loads in flight during the MFMA block;
+//   * bf16x3 products (operands split hi + lo while they are staged), fp32 accumulate, like conv_mfma_kernel<PREC 1>;
+//   * workgroup id -> (XCD, slot): the 6 unit groups an XCD owns keep their W_hh slices (1.2 MB) in that XCD's L2 for
+//     all 248 steps.
+typedef __bf16 l_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 l_bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LKC = 128;                 // K chunk
+constexpr int LROW = 4 * LKC + 16;       // LDS row bytes: [128 hi | 128 lo | pad]
+constexpr int LBM = 64, LU = 16;         // clips x hidden units per workgroup
+
+__global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restrict__ hprev, long long ldhp,
+                                                           const float* __restrict__ whh, const float* __restrict__ xp,
+                                                           long long ldxp, float* __restrict__ c, int B, int H,
+                                                           float* __restrict__ hout, long long ldh, float* __restrict__ hsum,
+                                                           const float* __restrict__ addend, long long ldadd, int mtiles) {
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  char* As = lsm;                            // [2][64][LROW]
+  char* Bs = lsm + 2 * LBM * LROW;           // [2][64][LROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs
+  const int ngroups = H / LU;
+  int grp, mt;
+  {
+    const int id = blockIdx.x, total = ngroups * mtiles;
+    const int per_xcd = (total + 7) / 8;
+    const int lin = (id % 8) * per_xcd + id / 8;        // position in (group-major, m-tile-minor) order
+    if (lin >= total) return;                           // uniform per workgroup (before any barrier)
+    grp = lin / mtiles; mt = lin % mtiles;
+  }
+  const int m0 = mt * LBM;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  if (hprev != nullptr) {
+    const float* Wg = whh + (size_t)grp * 64 * H;
+    const int nk = H / LKC;
+    constexpr int F4 = LBM * (LKC / 4) / 256;            // float4 per thread per operand per chunk (8)
+    f32x4 ar[F4], br[F4];
+    const int q = tid % (LKC / 4), r0 = tid / (LKC / 4); // column quad, first row; rows r0 + 8 i
+    auto load = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < F4; ++i) {
+        const int row = r0 + (256 / (LKC / 4)) * i;
+        const int m = m0 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < B) v = *reinterpret_cast<const f32x4*>(hprev + (size_t)m * ldhp + kc * LKC + 4 * q);
+        ar[i] = v;
+        br[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)row * H + kc * LKC + 4 * q);
+      }
+    };
+    auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
+      l_bf16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (__bf16)v[k];
+        lo[k] = (__bf16)(v[k] - (float)hi[k]);
+      }
+      *reinterpret_cast<l_bf16x4*>(row + 8 * q) = hi;
+      *reinterpret_cast<l_bf16x4*>(row + 2 * LKC + 8 * q) = lo;
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < F4; ++i) {
+        const int row = r0 + (256 / (LKC / 4)) * i;
+        split_store(As + (buf * LBM + row) * LROW, ar[i]);
+        split_store(Bs + (buf * LBM + row) * LROW, br[i]);
+      }
+    };
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < nk) store(buf ^ 1);
+      if (kc + 2 < nk) load(kc + 2);
+      const char* Ap = As + (buf * LBM + wm * 32 + li) * LROW + 16 * lh;
+      const char* Bp = Bs + (buf * LBM + wn * 32 + li) * LROW + 16 * lh;
+#pragma unroll
+      for (int s = 0; s < LKC / 16; ++s) {
+        const l_bf16x8 ah = *reinterpret_cast<const l_bf16x8*>(Ap + 32 * s);
+        const l_bf16x8 al = *reinterpret_cast<const l_bf16x8*>(Ap + 2 * LKC + 32 * s);
+        const l_bf16x8 bh = *reinterpret_cast<const l_bf16x8*>(Bp + 32 * s);
+        const l_bf16x8 bl = *reinterpret_cast<const l_bf16x8*>(Bp + 2 * LKC + 32 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  // gates of the tile -> LDS [64 clips][64 + 4], then one thread per (clip, 4 units) runs the cell
+  float* G = reinterpret_cast<float*>(lsm);
+  constexpr int GLDW = 68;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    G[m * GLDW + wn * 32 + li] = acc[r];
+  }
+  __syncthreads();
+  const int clip = tid >> 2, uq = tid & 3;
+  const int m = m0 + clip;
+  if (m < B) {
+    const int u0 = grp * LU + 4 * uq;
+    const float* xr = xp + (size_t)m * ldxp;
+    const f32x4 xi = *reinterpret_cast<const f32x4*>(xr + u0), xf = *reinterpret_cast<const f32x4*>(xr + H + u0);
+    const f32x4 xg = *reinterpret_cast<const f32x4*>(xr + 2 * H + u0), xo = *reinterpret_cast<const f32x4*>(xr + 3 * H + u0);
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(c + (size_t)m * H + u0);
+    const float* g = G + clip * GLDW + 4 * uq;
+    f32x4 cn, hn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gi = g[k] + xi[k], gf = g[16 + k] + xf[k], gg = g[32 + k] + xg[k], go = g[48 + k] + xo[k];
+      const float si = 1.f / (1.f + expf(-gi)), sf = 1.f / (1.f + expf(-gf)), so = 1.f / (1.f + expf(-go));
+      cn[k] = sf * cp[k] + si * tanhf(gg);
+      hn[k] = so * tanhf(cn[k]);
+    }
+    *reinterpret_cast<f32x4*>(c + (size_t)m * H + u0) = cn;
+    *reinterpret_cast<f32x4*>(hout + (size_t)m * ldh + u0) = hn;
+    if (hsum) {
+      const f32x4 ad = *reinterpret_cast<const f32x4*>(addend + (size_t)m * ldadd + u0);
+      *reinterpret_cast<f32x4*>(hsum + (size_t)m * ldh + u0) = hn + ad;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -271,9 +490,16 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   a.addend = d->addend; a.ldadd = d->ldadd; a.strideAdd = d->strideAdd;
   a.C = d->C; a.ldc = d->ldc; a.strideC = d->strideC;
   a.M = d->M; a.N = d->N; a.K = d->K; a.mode = d->mode; a.relu = d->relu;
-  dim3 grid((d->M + GBM - 1) / GBM, d->npad / GBN, d->batch);
+  dim3 grid(d->npad / GBN, (d->M + GBM - 1) / GBM, d->batch);
   if (grid.y > 65535 || grid.z > 65535) return MFPA_EINVAL;
-  hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
+  // Short-K layers (K < 256: the outer, full-rate encoder / decoder levels) are HBM-bound; the fp32 kernel's smaller
+  // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_*).
+  if (d->precision == 1 && d->K % HKC == 0 && d->K >= 256) {
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  }
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -322,6 +548,22 @@ int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float b
   if (!P || !w || !y || B < 0 || B > 65535 || L < 1 || C < 4 || C % 4) return MFPA_EINVAL;
   int gx = (4 * (L + 1) + 255) / 256; if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(convT1d_c1_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), P, L, C, w, bias, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp, float* c,
+                   int B, int H, float* hout, long long ldh, float* hsum, const float* addend, long long ldadd, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!whh_grouped || !xp || !c || !hout || B < 0 || H < LKC || H % LKC) return MFPA_EINVAL;
+  if (ldhp % 4 || ldxp % 4 || ldh % 4 || ldadd % 4 || (hsum && !addend)) return MFPA_EINVAL;   // float4 rows
+  const int mtiles = (B + LBM - 1) / LBM;
+  const long long total = (long long)(H / LU) * mtiles;
+  if (total > 0x7fffff) return MFPA_EINVAL;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  const size_t lds = (size_t)4 * LBM * LROW;
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(256), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, c, B,
+                     H, hout, ldh, hsum, addend, ldadd, mtiles);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

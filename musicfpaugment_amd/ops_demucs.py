@@ -84,7 +84,10 @@ def pack_demucs_weights(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.
             pw[f"dec{d}.b"] = _pad_rows(f(f"decoder.{d}.2.bias").repeat(4))
     for layer in range(2):
         pw[f"lstm{layer}.wih"] = f(f"lstm.lstm.weight_ih_l{layer}").contiguous()
-        pw[f"lstm{layer}.whh"] = f(f"lstm.lstm.weight_hh_l{layer}").contiguous()
+        whh = f(f"lstm.lstm.weight_hh_l{layer}")                # (4H, H), gate blocks i | f | g | o
+        pw[f"lstm{layer}.whh"] = whh.contiguous()
+        H = whh.shape[1]                                         # rows regrouped [H/16][i16|f16|g16|o16] for mfpa_lstm_step
+        pw[f"lstm{layer}.whh_grouped"] = whh.reshape(4, H // 16, 16, H).permute(1, 0, 2, 3).reshape(4 * H, H).contiguous()
         pw[f"lstm{layer}.b"] = (f(f"lstm.lstm.bias_ih_l{layer}") + f(f"lstm.lstm.bias_hh_l{layer}")).contiguous()
     return pw
 
@@ -94,20 +97,26 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
     return ptr(t) + 4 * off_floats
 
 
+PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (3 bf16 MFMAs per product, fp32 accumulate)
+
+
 def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mode=0, relu=0, addend: int = 0, ldadd=0,
-         strideAdd=0):
+         strideAdd=0, precision=None):
     """C[b][m][:N] = epi(A-window[b][m] @ W^T + bias); A, C, addend are device addresses, strides in floats."""
     d = GemmDesc(A=A, lda=lda, strideA=strideA, W=ptr(W), bias=ptr(bias), addend=addend, ldadd=ldadd,
                  strideAdd=strideAdd, C=C, ldc=ldc, strideC=strideC, batch=batch, M=M, N=N, K=W.shape[1], npad=W.shape[0],
-                 mode=mode, relu=int(relu))
+                 mode=mode, relu=int(relu), precision=PRECISION if precision is None else precision)
     t0 = _K._TIMER.start() if _K._TIMER is not None else None
     check(lib().mfpa_gemm_mfma(ctypes.byref(d), stream()), "mfpa_gemm_mfma")
     if t0 is not None:
         _K._TIMER.stop(t0)
 
 
-def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
-    """(B, T) float32 on the GPU -> (B, T) denoised waveform.  model.py:290-326."""
+def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: int = PRECISION) -> torch.Tensor:
+    """(B, T) float32 on the GPU -> (B, T) denoised waveform.  model.py:290-326.  `precision` selects the GEMM arithmetic
+    (the fused LSTM step is always bf16x3)."""
+    import functools
+    gemm_p = functools.partial(gemm, precision=precision)
     B, T = wav.shape
     dev = wav.device
     L = lib()
@@ -131,9 +140,9 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tens
                   "mfpa_conv1d_c1_relu")
         else:
             Cin = chans[i - 1]                                   # row t = h[4t : 4t+8] flattened: stride 4*Cin, K = 8*Cin
-            gemm(_p(h), STRIDE * Cin, Lin * Cin, B, Lout, pw[f"enc{i}.w"], pw[f"enc{i}.b"], C, _p(a), C, Lout * C, relu=1)
+            gemm_p(_p(h), STRIDE * Cin, Lin * Cin, B, Lout, pw[f"enc{i}.w"], pw[f"enc{i}.b"], C, _p(a), C, Lout * C, relu=1)
         h = new(B, Lout, C)
-        gemm(_p(a), C, Lout * C, B, Lout, pw[f"enc{i}.gw"], pw[f"enc{i}.gb"], C, _p(h), C, Lout * C, mode=1)
+        gemm_p(_p(a), C, Lout * C, B, Lout, pw[f"enc{i}.gw"], pw[f"enc{i}.gb"], C, _p(h), C, Lout * C, mode=1)
         skips.append(h)
         Lin = Lout
     # ---- LSTM: 2 layers, unidirectional, zero initial state (model.py:91-110); the last layer also emits h + skip
@@ -141,22 +150,20 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tens
     seq, xsum = h, None
     for layer in range(2):
         xp = new(B, Tn, 4 * H)                                   # input projection of every step at once
-        gemm(_p(seq), H, 0, 1, B * Tn, pw[f"lstm{layer}.wih"], pw[f"lstm{layer}.b"], 4 * H, _p(xp), 4 * H, 0)
-        hseq, gates = new(B, Tn, H), new(B, 4 * H)
+        gemm_p(_p(seq), H, 0, 1, B * Tn, pw[f"lstm{layer}.wih"], pw[f"lstm{layer}.b"], 4 * H, _p(xp), 4 * H, 0)
+        hseq = new(B, Tn, H)
         c = torch.zeros((B, H), dtype=torch.float32, device=dev)
         last = layer == 1
         if last:
             xsum = new(B, Tn, H)
-        for t in range(Tn):
-            if t == 0:                                           # h[-1] = 0: the gates are the input projection itself
-                g_addr, ldg = _p(xp), Tn * 4 * H
-            else:                                                # gates = h[t-1] @ W_hh^T + xp[:, t]   (rows = clips)
-                gemm(_p(hseq, (t - 1) * H), Tn * H, 0, 1, B, pw[f"lstm{layer}.whh"], None, 4 * H, _p(gates), 4 * H, 0,
-                     mode=2, addend=_p(xp, t * 4 * H), ldadd=Tn * 4 * H)
-                g_addr, ldg = _p(gates), 4 * H
-            check(L.mfpa_lstm_cell(g_addr, ldg, ptr(c), B, H, _p(hseq, t * H), Tn * H,
+        t0 = _K._TIMER.start() if _K._TIMER is not None else None     # the whole recurrence as one timed group
+        for t in range(Tn):                                      # gates = h[t-1] @ W_hh^T + xp[:, t], cell, in one launch
+            check(L.mfpa_lstm_step(_p(hseq, (t - 1) * H) if t else 0, Tn * H, ptr(pw[f"lstm{layer}.whh_grouped"]),
+                                   _p(xp, t * 4 * H), Tn * 4 * H, ptr(c), B, H, _p(hseq, t * H), Tn * H,
                                    _p(xsum, t * H) if last else 0, _p(skips[-1], t * H) if last else 0, Tn * H, stream()),
-                  "mfpa_lstm_cell")
+                  "mfpa_lstm_step")
+        if t0 is not None:
+            _K._TIMER.stop(t0)
         seq = hseq
     # ---- decoder: (x + skip) -> Conv1d(1x1) + GLU -> ConvTranspose1d(k8,s4) [+ ReLU], next skip added in the epilogue
     x = xsum
@@ -165,13 +172,13 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tens
     for d in range(DEPTH):
         C = chans[DEPTH - 1 - d]
         P = torch.zeros((B, Lcur + 2, C), dtype=torch.float32, device=dev)      # rows 0 and L+1 stay zero
-        gemm(_p(x), C, Lcur * C, B, Lcur, pw[f"dec{d}.gw"], pw[f"dec{d}.gb"], C, _p(P, C), C, (Lcur + 2) * C, mode=1)
+        gemm_p(_p(x), C, Lcur * C, B, Lcur, pw[f"dec{d}.gw"], pw[f"dec{d}.gb"], C, _p(P, C), C, (Lcur + 2) * C, mode=1)
         Lnext = 4 * (Lcur + 1)                                   # (L - 1) * 4 + 8
         if d < DEPTH - 1:
             cout = chans[DEPTH - 2 - d]
             skip = skips.pop()                                   # (B, Lnext, cout)
             y = new(B, Lnext, cout)                              # row t = [g[t-1] | g[t]] -> positions 4t .. 4t+3
-            gemm(_p(P), C, (Lcur + 2) * C, B, Lcur + 1, pw[f"dec{d}.w"], pw[f"dec{d}.b"], 4 * cout, _p(y), 4 * cout,
+            gemm_p(_p(P), C, (Lcur + 2) * C, B, Lcur + 1, pw[f"dec{d}.w"], pw[f"dec{d}.b"], 4 * cout, _p(y), 4 * cout,
                  Lnext * cout, mode=2, relu=2, addend=_p(skip), ldadd=4 * cout, strideAdd=Lnext * cout)
         else:
             y = new(B, Lnext)
