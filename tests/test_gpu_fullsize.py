@@ -1,0 +1,103 @@
+"""GPU parity at BASELINE.json's FULL sizes (configs[1]: 256 clips STFT + peak-pick, configs[2]: 512 clips UNet forward,
+configs[3]: the 64-clip train step), where the oracle cannot run the whole batch in seconds: a sampled subset goes through
+the oracle, the rest is covered by size-independent properties -- determinism, invariance to batch composition / order /
+sub-batching, the per-frame peak bound, and a digest over the whole batch."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from musicfpaugment_amd import synth
+from musicfpaugment_amd.training.weights import formula_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(t: torch.Tensor) -> str:
+    return hashlib.sha1(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def net():
+    from musicfpaugment_amd.training.unet import UNet
+    m = UNet(1, 1, rate=0.05)
+    m.load_state_dict(formula_state_dict(0))
+    return m.cuda().eval()
+
+
+def test_config1_stft_peakpick_256_clips_bit_exact_and_batch_invariant():
+    from musicfpaugment_amd.pipeline import HotPath
+    from oracle import audfprint as oa
+    B = 256
+    wav = np.stack([synth.clip(3000 + i, tonal=(i % 3 != 0)) for i in range(B)])
+    wav[17] = 0.0                                                      # a silent clip inside the batch
+    wav[200, :32000] = 0.0                                             # half-silent
+    x = torch.from_numpy(wav).cuda()
+    hp = HotPath(None)
+    mask, npk = hp(x)
+    assert mask.shape == (B, 256, 251) and mask.dtype == torch.uint8
+    # sampled clips through the oracle: bit-exact index sets
+    for i in (0, 17, 100, 200, 255):
+        want = oa.find_peaks(wav[i])[1]
+        np.testing.assert_array_equal(mask[i].cpu().numpy(), np.asarray(want).reshape(256, 251).astype(np.uint8) if np.size(want) else 0)
+    assert int(npk[17]) == 0 and not mask[17].any()                    # find_peaks of silence: no peaks (peak_extractor.py:262)
+    np.testing.assert_array_equal(npk.cpu().numpy(), mask.reshape(B, -1).sum(dim=1).cpu().numpy())
+    assert int(mask.sum(dim=1).max()) <= 2 * 5                         # <= maxpksperframe per column and pruning direction
+    # determinism and invariance to order / sub-batching (clips are independent units)
+    mask2, _ = hp(x)
+    assert _digest(mask2) == _digest(mask)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).cuda()
+    maskp, _ = hp(x[perm].contiguous())
+    assert torch.equal(maskp, mask[perm])
+    parts = torch.cat([hp(x[s:s + 37].contiguous())[0] for s in range(0, B, 37)])      # ragged shards
+    assert torch.equal(parts, mask)
+
+
+def test_config2_unet_forward_512_clips_within_tolerance_and_batch_invariant(net):
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    B = 512
+    wav = np.stack([synth.clip(4000 + i, tonal=(i % 2 == 0)) for i in range(B)])
+    from musicfpaugment_amd import ops
+    mag, cmax = ops.stft_mag(torch.from_numpy(wav).cuda(), torch.float64)
+    sd = formula_state_dict(0)
+    picks = [0, 255, 511]
+    x = torch.from_numpy(np.stack([ostft.spectrogram(wav[i:i + 1])[0] for i in picks])).float().unsqueeze(1)
+    with torch.no_grad():
+        want = ou.forward(x, sd)
+    for prec, tol in ((0, 1e-5), (1, 1e-4)):                            # fp32 MFMA, bf16x3 (the bench default)
+        net.precision = prec
+        out = net.denoise_spectrogram(mag, cmax, per_clip=True)        # (512, 257, 251) float32
+        assert out.shape == (B, 257, 251) and torch.isfinite(out).all()
+        got = out[picks].cpu().unsqueeze(1)
+        assert ou.relative_l1(got, want) <= tol, (prec, ou.relative_l1(got, want))
+        # the same clips in a different batch composition: bit-identical (no cross-clip arithmetic, no atomics)
+        sub = net.denoise_spectrogram(mag[picks].contiguous(), cmax[picks].contiguous(), per_clip=True)
+        assert torch.equal(sub, out[picks])
+        assert _digest(net.denoise_spectrogram(mag, cmax, per_clip=True)) == _digest(out)
+    net.precision = 0
+
+
+def test_config3_train_step_64_clips_precisions_agree_and_loss_falls():
+    from musicfpaugment_amd import ops
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    B = 64
+    clean = synth.batch(B, seed=5000, n=24000)                         # the reference's 3 s training windows
+    aug = (0.7 * clean + 0.3 * synth.batch(B, seed=6000, n=24000, tonal=False)).astype(np.float32)
+    cm, cmax = ops.stft_mag(torch.from_numpy(clean).cuda(), torch.float64)
+    am, amax = ops.stft_mag(torch.from_numpy(aug).cuda(), torch.float64)
+    target = ops.normalize_(cm, cmax.max().expand(B).contiguous(), per_clip=True)
+    den = amax.max().expand(B).contiguous()
+    losses = {}
+    for prec in (0, 1):
+        torch.manual_seed(0)
+        net = UNet(1, 1, rate=0.05)
+        net.load_state_dict(formula_state_dict(0))
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec)
+        losses[prec] = [float(eng.train_step(am, den, target)) for _ in range(4)]
+        assert all(np.isfinite(losses[prec])) and losses[prec][-1] < losses[prec][0]
+    # the first step sees identical weights and dropout masks: the two arithmetic paths give the same loss to 1e-4
+    assert abs(losses[0][0] - losses[1][0]) <= 1e-4 * abs(losses[0][0]), losses
+    assert abs(losses[0][-1] - losses[1][-1]) <= 2e-2 * abs(losses[0][-1]), losses
