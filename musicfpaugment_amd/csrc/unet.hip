@@ -404,6 +404,180 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   }
 }
 
+// ConvTranspose2d(k = 2, s = 2) forward: out[2y+dy, 2x+dx][co] = sum_ci x[y,x][ci] * w[dy,dx][co][ci] + bias[co].
+// K = C_in only, so the generic kernel's one-tap-per-workgroup form re-staged the same input tile four times around a
+// 4..32-iteration loop.  Here a workgroup keeps FOUR accumulator sets (one per tap) for 128 input pixels x 64 output
+// channels: the input chunk is staged once per 32 channels and its fragments are reused by all four taps; a wave owns
+// 32 pixels x 64 channels x 4 taps (128 accumulator VGPRs).  Two workgroups per CU overlap each other's staging.
+template <int PH, int PW, int PREC>
+__global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
+  constexpr int BM = PH * PW, BN = 64, NT = 2;
+  static_assert(BM == 128, "four waves of 32 pixels");
+  constexpr int A_F4 = BM * (KC / 4) / 256;            // 4
+  constexpr int B_F4 = 4 * BN * (KC / 4) / 256;        // 8
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);          // [128][LDK]
+  float* Bs = As + BM * LDK;                           // [4 taps][64][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+  const int b = bx;
+  const int n0 = blockIdx.y * BN;
+  const int y0 = ty * PH, x0p = tx * PW;
+  const int nchunks = a.C0 / KC;
+  const int q = tid % (KC / 4);
+  const bool affine = a.in_scale0 != nullptr;
+
+  f32x4 areg[A_F4], breg[B_F4];
+  auto load = [&](int chunk) __attribute__((always_inline)) {
+    const int c0 = chunk * KC;
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) {
+      const int pix = (tid + it * 256) / (KC / 4);
+      const int gy = y0 + pix / PW, gx = x0p + pix % PW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < a.H && gx < a.W) v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
+      areg[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_F4; ++it) {
+      const int row = (tid + it * 256) / (KC / 4);     // tap * 64 + n
+      const int tap = row / BN, n = row % BN;
+      breg[it] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.Cout + n0 + n) * a.C0 + c0 + 4 * q);
+    }
+  };
+  auto store = [&](int chunk) __attribute__((always_inline)) {
+    const int c0 = chunk * KC;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+      sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * q);
+      sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * q);
+    }
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) {
+      const int pix = (tid + it * 256) / (KC / 4);
+      f32x4 v = areg[it];
+      if (affine) {
+        v = v * sc + sh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        if (a.drop_thresh) {
+          const int gy = y0 + pix / PW, gx = x0p + pix % PW;
+          const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+        }
+      }
+      if (PREC == 0) {
+        *reinterpret_cast<f32x4*>(As + pix * LDK + 4 * q) = v;
+      } else {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hi[k] = (__bf16)v[k];
+          lo[k] = (__bf16)(v[k] - (float)hi[k]);
+        }
+        char* row = reinterpret_cast<char*>(As + pix * LDK);
+        *reinterpret_cast<bf16x4*>(row + 8 * q) = hi;
+        *reinterpret_cast<bf16x4*>(row + 64 + 8 * q) = lo;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_F4; ++it) {
+      const int row = (tid + it * 256) / (KC / 4);
+      *reinterpret_cast<f32x4*>(Bs + row * LDK + 4 * q) = breg[it];      // PREC 1: rows are pre-split [32 hi | 32 lo]
+    }
+  };
+
+  floatx16 acc[4][NT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
+
+  const int a_off = (wave * 32 + li) * LDK + 4 * lh;
+  const int b_off = li * LDK + 4 * lh;
+
+  load(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();                                   // the previous chunk's fragment reads are done
+    store(chunk);
+    __syncthreads();
+    if (chunk + 1 < nchunks) load(chunk + 1);          // lands during the MFMA block
+    if (PREC == 1) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const char* ar = reinterpret_cast<const char*>(As + a_off) + 32 * s;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ar);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ar + 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const char* br = reinterpret_cast<const char*>(Bs + (t * BN + nt * 32) * LDK + b_off) + 32 * s;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(br);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(br + 64);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t][nt], 0, 0, 0);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t][nt], 0, 0, 0);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t][nt], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KC / 8; ++s) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(As + a_off + 8 * s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(Bs + (t * BN + nt * 32) * LDK + b_off + 8 * s);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[t][nt], 0, 0, 0);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[t][nt], 0, 0, 0);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[t][nt], 0, 0, 0);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[t][nt], 0, 0, 0);
+          }
+      }
+    }
+  }
+  // epilogue: D[row = pixel][col = channel]; tap t writes output pixel (2 gy + (t >> 1), 2 gx + (t & 1))
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 32 + li;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int gy = y0 + m / PW, gx = x0p + m % PW;
+      if (gy < a.H && gx < a.W) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float v = acc[t][nt][r] * sc + sh;
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          a.y[(((size_t)b * (2 * a.H) + 2 * gy + (t >> 1)) * (2 * a.W) + 2 * gx + (t & 1)) * a.Cout + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int PH, int PW, int PREC>
+int launch_convT(ConvArgs& a, hipStream_t s) {
+  a.tiles_x = (a.W + PW - 1) / PW;
+  a.tiles_y = (a.H + PH - 1) / PH;
+  if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
+  const size_t lds = sizeof(float) * ((size_t)PH * PW * LDK + 4 * (size_t)64 * LDK);
+  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / 64));
+  hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC>), grid, dim3(256), lds, s, a);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
 // First layer: 1 input channel -> Cout (multiple of 4), fused spectrogram normalisation.
 // 16 lanes per pixel x 4 channels per lane... generalised: Cout/4 lanes per pixel.
 __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x32, const double* __restrict__ spec64,
@@ -551,6 +725,8 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
 //   W <= 16 (the 16x15 bottleneck): 8x16 patches.
 template <int MODE, int PREC>
 int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
+  static const int ct_old = getenv("MFPA_CONVT_OLD") ? atoi(getenv("MFPA_CONVT_OLD")) : 0;   // experiments: generic kernel
+  if (MODE == 1 && !ct_old) return a.W > 16 ? launch_convT<4, 32, PREC>(a, s) : launch_convT<8, 16, PREC>(a, s);
   const int taps_y = (MODE == 1) ? 4 : 1;
   const bool bn128 = (a.Cout % 128 == 0);
   static const int wm_env = getenv("MFPA_CONV_WM") ? atoi(getenv("MFPA_CONV_WM")) : 0;   // experiments
