@@ -151,6 +151,75 @@ def bench_demucs(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def bench_metrics(args, rank, world, dev, dist):
+    """BASELINE config 5, second half: the end-to-end peak-metrics experiment (testing/audfprint_exps.py:86-157) over
+    --queries synthetic queries: clean clip -> AugmentFP query (device) -> peaks of clean / query / denoised query
+    (Demucs on the waveform, or the UNet on the spectrogram) -> per-query precision / recall / F1 / PSNR -> means.
+    The queries are a FIXED total split over the ranks (strong scaling); the only collective is the all-gather of the
+    per-query result rows."""
+    import random
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+    from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
+    from musicfpaugment_amd.testing.audfprint_exps import compute_peaks_metrics
+    N, T = args.queries, 64000
+    if args.denoiser == "demucs":
+        from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+        from musicfpaugment_amd.training.model import Demucs
+        net = Demucs()
+        net.load_state_dict(demucs_formula(0))
+        an_den = Audfprint_peaks(None, denoising=True, denoising_model="demucs", demucs=net.to(dev).eval(), device=dev)
+    else:
+        from musicfpaugment_amd.training.unet import UNet
+        from musicfpaugment_amd.training.weights import formula_state_dict
+        net = UNet(1, 1)
+        net.load_state_dict(formula_state_dict(0))
+        net = net.to(dev).eval()
+        net.precision = 1 if args.precision == "bf16x3" else 0
+        an_den = Audfprint_peaks(None, denoising=True, denoising_model="unet", unet=net, device=dev)
+    an_no = Audfprint_peaks(None, device=dev)
+    # every rank builds the same N queries (identical seeds), resident in HBM: 64 base clips, rolled and re-augmented
+    base = torch.from_numpy(synth.batch(64, seed=synth.BASE_SEED)).to(dev)
+    idx = torch.arange(N, device=dev)
+    shift = (idx // 64 * 977) % T
+    cols = (torch.arange(T, device=dev)[None, :] + shift[:, None]) % T
+    clean = torch.gather(base[idx % 64], 1, cols)
+    random.seed(7); torch.manual_seed(7)
+    irs, noises = synthetic_banks(0)
+    af = AugmentFP(None, 8000, ir_bank=irs, noise_bank=noises, device=dev)
+    aug = torch.cat([af.batch_augment(clean[s:s + 256][:, None, :])[:, 0] for s in range(0, N, 256)])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        compute_peaks_metrics(clean[:512 * world], aug[:512 * world], an_no, an_den, batch=args.clips)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = compute_peaks_metrics(clean, aug, an_no, an_den, batch=args.clips)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "queries/sec (peak-metrics experiment: 3 peak extractions + denoiser + P/R/F1/PSNR per query)",
+            "value": round(N * args.steps / dt_max, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{N} synthetic 8 s queries (AugmentFP on the device), denoiser {args.denoiser}, Audfprint "
+                                   "peaks, per-query precision/recall/F1/PSNR means", "queries": N,
+                       "parallelism": f"queries sharded x{world}, one all-gather of the per-query rows"},
+            "result": {k: round(v, 6) for k, v in res.items()}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_train(args, rank, world, dev, dist):
     """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips, Dropout(0.05) as the reference
     trains (training/train.py:646).  Default arithmetic: bf16x3 products on the bf16 matrix cores (BASELINE config 4 says
@@ -254,7 +323,9 @@ def main():
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
-    ap.add_argument("--mode", choices=["infer", "train", "demucs"], default="infer",
+    ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
+    ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
+    ap.add_argument("--mode", choices=["infer", "train", "demucs", "metrics"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick")
@@ -283,6 +354,8 @@ def main():
         return bench_train(args, rank, world, dev, dist)
     if args.mode == "demucs":
         return bench_demucs(args, rank, world, dev, dist)
+    if args.mode == "metrics":
+        return bench_metrics(args, rank, world, dev, dist)
 
     from musicfpaugment_amd import ops_unet, synth
     from musicfpaugment_amd.pipeline import UNET_MFMA_GFLOP_PER_CLIP, HotPath

@@ -32,7 +32,7 @@ def landmarks2hashes(landmarks_list) -> np.ndarray:
 
 class Audfprint_peaks(object):
     def __init__(self, params: Optional[Dict[str, Any]] = None, denoising: bool = False, denoising_model=None,
-                 unet=None, device="cuda") -> None:
+                 unet=None, device="cuda", demucs=None) -> None:
         params = afp_settings["audfprint"] if params is None else params
         self.density = params["density"]
         self.target_sr = params["samplerate"]
@@ -53,12 +53,15 @@ class Audfprint_peaks(object):
         if self.denoising:
             assert self.denoising_model in ["demucs", "unet"]
             if self.denoising_model == "demucs":
-                raise NotImplementedError("Demucs waveform denoising is a next-tier row (SURVEY.md §8f-2)")
-            if unet is None:
-                raise ValueError("denoising=True needs the UNet instance (unet=...): this module loads no checkpoint")
-            self.unet = unet.to(self.device).eval()
+                if demucs is None:
+                    raise ValueError("denoising_model='demucs' needs the Demucs instance (demucs=...): this module loads no checkpoint")
+                self.unet, self.demucs = None, demucs.to(self.device).eval()
+            else:
+                if unet is None:
+                    raise ValueError("denoising=True needs the UNet instance (unet=...): this module loads no checkpoint")
+                self.unet, self.demucs = unet.to(self.device).eval(), None
         else:
-            self.unet = None
+            self.unet, self.demucs = None, None
 
     # ------------------------------------------------------------------ batched device path
     def find_peaks_batch(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -77,6 +80,13 @@ class Audfprint_peaks(object):
             filtered = ops.audfprint_prepare(spec, None, mean_order=1)            # |stft| is a transposed view there
         mask, npeaks = ops.audfprint_prune(filtered, a_dec, self.maxpksperframe, float(self.f_sd))
         return mask, npeaks, spec
+
+    def wav2peaks_batch(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """wavfile2peaks (peak_extractor.py:347-430) for waveforms already in memory: with denoising_model == "demucs" the
+        WAVEFORM goes through the Demucs denoiser first (:369-376), then find_peaks; the UNet acts inside find_peaks."""
+        if self.demucs is not None:
+            wav = self.demucs(wav)[:, 0].contiguous()
+        return self.find_peaks_batch(wav)
 
     # ------------------------------------------------------------------ reference call surface
     def find_peaks(self, d) -> Tuple[List[Tuple[int, int]], np.ndarray, np.ndarray]:

@@ -53,9 +53,9 @@ def compute_peaks_metrics(clean_wav: torch.Tensor, augmented_wav: torch.Tensor, 
         e = min(hi, s + batch)
         clean = clean_wav[s:e].to(dev, torch.float32).contiguous()
         aug = augmented_wav[s:e].to(dev, torch.float32).contiguous()
-        m_clean, _, sg_clean = analyzer_no_den.find_peaks_batch(clean)
-        m_aug, _, sg_aug = analyzer_no_den.find_peaks_batch(aug)
-        m_den, _, sg_den = analyzer_den.find_peaks_batch(aug)
+        m_clean, _, sg_clean = analyzer_no_den.wav2peaks_batch(clean)
+        m_aug, _, sg_aug = analyzer_no_den.wav2peaks_batch(aug)
+        m_den, _, sg_den = analyzer_den.wav2peaks_batch(aug)          # UNet inside find_peaks, Demucs on the waveform
         tr = lambda m: m.transpose(1, 2).contiguous()               # (B, 251, 256): audfprint_exps.py:119-121
         c_aug = ops.peak_metrics_counts(tr(m_aug), tr(m_clean))
         c_den = ops.peak_metrics_counts(tr(m_den), tr(m_clean))
