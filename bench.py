@@ -230,7 +230,7 @@ def bench_train(args, rank, world, dev, dist):
     from musicfpaugment_amd.training.unet import UNet
     from musicfpaugment_amd.training.weights import formula_state_dict
 
-    B = args.clips
+    B = args.clips if args.scaling == "weak" else max(1, args.clips // world)
     net = UNet(1, 1, rate=0.05)
     net.load_state_dict(formula_state_dict(0))
     net = net.to(dev).train()
@@ -289,13 +289,14 @@ def bench_train(args, rank, world, dev, dist):
             "metric": "8s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": ("bf16x3 convolutions (forward, input and weight gradients; fp32 operands split into bf16 hi+lo, fp32 "
                       "accumulate), fp32/fp64 reductions and Adam") if args.precision == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
-                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients"},
+                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, per-GPU "
+                                      "BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
             "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           "mfma_flops_issued_per_algorithmic_flop": 3,
@@ -323,6 +324,8 @@ def main():
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
     ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
     ap.add_argument("--mode", choices=["infer", "train", "demucs", "metrics"], default="infer",
@@ -440,7 +443,7 @@ def main():
             if precision == "fp32":
                 return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "kernel": "conv_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                        "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
                         "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
             traffic, tsrc = None, None
             pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_bf16x3.json")
@@ -452,7 +455,7 @@ def main():
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "mfma_flops_issued_per_algorithmic_flop": 3,
                     "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "kernel": "conv_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 "
+                    "kernel": "conv_mfma_kernel<PREC 1> + convT_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 "
                               "per fp32 product)",
                     "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
 
