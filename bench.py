@@ -77,7 +77,24 @@ def cpu_baseline(budget_s: float, seed: int):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 2000:
             break
+    # one-thread figure on two clips, and the host it ran on
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    for k in range(2):
+        one(wav[k])
+    one_thread = 2.0 / (time.perf_counter() - t1)
+    torch.set_num_threads(best_thr)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(n / dt, 4), "unit": "clips/s", "cores": best_thr, "kind": "port",
+            "one_thread_value": round(one_thread, 4), "host_cpu_count": ncpu, "host_cpu_model": model,
             "sample": f"{n} synthetic 8 s clips in {dt:.1f} s, one at a time like the reference "
                       f"(peak_extractor.py:236-311): numpy float64 STFT -> torch-CPU fp32 UNet forward (batch 1, "
                       f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}

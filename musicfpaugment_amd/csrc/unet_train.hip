@@ -444,10 +444,12 @@ __device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
 
 // 8 waves: (co half) x (ci half) x (pixel half of a 128-pixel patch, 4x32 or 8x16 for narrow images); one workgroup
 // per CU, two waves per SIMD.
-constexpr int WGB_PIX = 128, WGB_THREADS = 512;
 
-template <int MODE, int PW>
-__global__ __launch_bounds__(WGB_THREADS, 1) void wgrad_bf16x3_kernel(WgradArgs a) {
+// NW = 8: one workgroup per CU on 128-pixel patches; NW = 4: 64-pixel patches, two workgroups per CU whose staging and
+// MFMA phases overlap each other.
+template <int MODE, int PW, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(WgradArgs a) {
+  constexpr int WGB_THREADS = 64 * NW, WGB_PIX = 16 * NW;
   constexpr int WGB_PH = WGB_PIX / PW;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int TAPS = (MODE == 0) ? 9 : 4;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(WGB_THREADS, 1) void wgrad_bf16x3_kernel(WgradArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int cot = wave & 1, cit = (wave >> 1) & 1, ph = wave >> 2;   // ph: the patch's upper / lower 64 pixels
+  const int cot = wave & 1, cit = (wave >> 1) & 1, ph = wave >> 2;   // ph: the patch's upper / lower 64 pixels (NW = 8)
   const int co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T;
   const int Cin = a.C0 + a.C1;
   const bool from0 = ci0 < a.C0;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(WGB_THREADS, 1) void wgrad_bf16x3_kernel(WgradArgs 
   // transposing read: lane 4q+p of a 16-lane group addresses row q (pixel), columns 4p..4p+3 (channels) of its block
   const int gl = lane & 15, tq = gl >> 2, tp = gl & 3, gsel = (lane >> 4) & 1;
   const char* a_lane = Ds + (64 * ph + 8 * lh + tq) * WGB_ROW + (32 * cot + 16 * gsel + 4 * tp) * 2;
-  const char* b_lane = Xs + ((WGB_PH / 2) * ph * HPW + 8 * lh + tq) * WGB_ROW + (32 * cit + 16 * gsel + 4 * tp) * 2;
+  const char* b_lane = Xs + ((64 / PW) * ph * HPW + 8 * lh + tq) * WGB_ROW + (32 * cit + 16 * gsel + 4 * tp) * 2;
 
   f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};
   if (affine) {
@@ -914,20 +916,33 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   if (d->precision == 1) {
     // transposing LDS reads need every lane live (512-thread workgroups, no early exits) -- guaranteed by the kernel shape
-    const int pw = d->W <= 16 ? 16 : 32, phh = WGB_PIX / pw;
+    static const int nw_env = getenv("MFPA_WGRAD_NW") ? atoi(getenv("MFPA_WGRAD_NW")) : 0;   // experiments: 4 or 8 waves
+    const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : 8;
+    const int pix = 16 * nw;
+    const int pw = d->W <= 16 ? 16 : 32, phh = pix / pw;
     a.tiles_x = (d->W + pw - 1) / pw;
     a.tiles_y = (d->H + phh - 1) / phh;
     const long long npatch_b = (long long)a.B * a.tiles_x * a.tiles_y;
-    long long split_b = (1024 + tiles - 1) / tiles;   // ~4 workgroups per CU over the launch
+    long long split_b = ((nw == 8 ? 1024 : 2048) + tiles - 1) / tiles;   // ~4 workgroup rounds over the launch
     if (split_b > npatch_b) split_b = npatch_b;
     if (split_b < 1) split_b = 1;
     if (split_b > 65535) split_b = 65535;
     grid.z = (unsigned)split_b;
-    const size_t lds = (size_t)WGB_ROW * (WGB_PIX + (d->mode == 0 ? (phh + 2) * (pw + 2) : WGB_PIX));
-    if (d->mode == 0 && pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 32>), grid, dim3(WGB_THREADS), lds, s, a);
-    else if (d->mode == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 16>), grid, dim3(WGB_THREADS), lds, s, a);
-    else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32>), grid, dim3(WGB_THREADS), lds, s, a);
-    else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 16>), grid, dim3(WGB_THREADS), lds, s, a);
+    const size_t lds = (size_t)WGB_ROW * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
+    const dim3 blk(64 * nw);
+#define MFPA_WG_LAUNCH(M, P, N) hipLaunchKernelGGL((wgrad_bf16x3_kernel<M, P, N>), grid, blk, lds, s, a)
+    if (nw == 8) {
+      if (d->mode == 0 && pw == 32) MFPA_WG_LAUNCH(0, 32, 8);
+      else if (d->mode == 0) MFPA_WG_LAUNCH(0, 16, 8);
+      else if (pw == 32) MFPA_WG_LAUNCH(1, 32, 8);
+      else MFPA_WG_LAUNCH(1, 16, 8);
+    } else {
+      if (d->mode == 0 && pw == 32) MFPA_WG_LAUNCH(0, 32, 4);
+      else if (d->mode == 0) MFPA_WG_LAUNCH(0, 16, 4);
+      else if (pw == 32) MFPA_WG_LAUNCH(1, 32, 4);
+      else MFPA_WG_LAUNCH(1, 16, 4);
+    }
+#undef MFPA_WG_LAUNCH
   } else if (d->mode == 0) {
     const size_t lds = sizeof(float) * ((size_t)WG_PIX * WG_T + (size_t)(WG_PH + 2) * (WG_PW + 2) * WG_T);
     hipLaunchKernelGGL(wgrad_mfma_kernel<0>, grid, dim3(256), lds, s, a);
