@@ -448,8 +448,10 @@ def main():
             "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "f32")
                      if net is not None else "f64",
             "data": "synthetic",
-            "config": {"workload": f"STFT(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights) -> "
-                                   "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms",
+            "config": {"workload": (f"STFT(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights) -> "
+                                    "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms") if net is not None else
+                                   "STFT(512/256,f64) -> per-clip normalise -> log/mean/high-pass -> Audfprint forward+backward "
+                                   "prune (BASELINE configs[1]); 8 s / 8 kHz clips",
                        "clips_per_gpu_per_step": B, "peaks_last_step_rank0": total_peaks,
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
         }
@@ -478,6 +480,14 @@ def main():
 
         if net is not None and timer.launches():
             out["roofline"] = roofline(timer, args.precision)
+        if net is None:
+            # fused STFT -> magnitude -> mask moves 578 284 algorithmic bytes per clip (256 000 B of samples in,
+            # the float32 spectrogram out and back in, 64 256 B of mask out).  The chain is three short launches whose
+            # pruner walks 251 frames sequentially per clip: at 256 clips it is latency-bound, not bandwidth-bound.
+            gbs = 578284.0 * B * args.steps / dt_max / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(gbs / 8000.0, 5), "traffic": None,
+                               "kernel": "stft_kernel + prepare_kernel + prune_kernel (whole chain, wall clock)"}
         if other is not None:
             oname = "fp32" if args.precision == "bf16x3" else "bf16x3"
             out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),
