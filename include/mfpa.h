@@ -126,7 +126,7 @@ int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const doub
  * mlab.specgram hands back a frame-major array, so the reference sums with mean_order = 1).  mfpa_localmax2d: get_2D_peaks,
  * afp/dejavu/fingerprint.py:94-171: (2r+1)^2 maximum filter with scipy 'reflect' borders,
  * equality test, XOR with the eroded exact-zero background (border_value 1), amp > amp_min.
- *   arr  (B, F, T) float64;  mask (B, F, T) uint8;  npeaks (B) int32
+ *   arr  (B, F, T) float64;  mask (B, F, T) uint8;  npeaks (B) int32;  2 <= radius <= 16 (the reference uses 10)
  */
 int mfpa_dejavu_prepare(const double* psd, int B, int F, int T, const double* denom, double scale,
                         int mean_order, double* arr, void* stream);

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const doub
 constexpr int TH = 32, TW = 64, LM_THREADS = 256;
 
 __device__ __forceinline__ int reflect_index(int i, int n) {  // scipy.ndimage mode='reflect'
+  if (i >= 0 && i < n) return i;                  // the common case without an integer division
+  if (i < 0 && i >= -n) return -1 - i;
+  if (i >= n && i < 2 * n) return 2 * n - 1 - i;
   const int period = 2 * n;
   i %= period;
   if (i < 0) i += period;
@@ -91,38 +94,78 @@ __global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __
     Bg[e] = inside ? (uint8_t)(v == 0.0) : (uint8_t)1;
   }
   __syncthreads();
-  for (int e = tid; e < HH * TW; e += LM_THREADS) {
-    const int hi = e / TW, j = e % TW;
+  // Both passes give every thread FOUR adjacent outputs: the 2r + 4 inputs they share are read from LDS once (6 reads
+  // per output instead of 2r + 1) and the window maxima are formed in registers: the 2r - 2 interior values are common
+  // to all four windows.
+  for (int e = tid; e < HH * (TW / 4); e += LM_THREADS) {
+    const int hi = e / (TW / 4), j = 4 * (e % (TW / 4));
     const double* row = A + hi * HW + j;
     const uint8_t* brow = Bg + hi * HW + j;
-    double m = row[0];
-    uint8_t bg = brow[0];
-    for (int d = 1; d <= 2 * r; ++d) {
+    double m = row[3];                         // common part: offsets 3 .. 2r
+    uint8_t bg = brow[3];
+    for (int d = 4; d <= 2 * r; ++d) {
       m = row[d] > m ? row[d] : m;
       bg &= brow[d];
     }
-    Hm[e] = m;
-    Hb[e] = bg;
+    double lo[3], hi3[3];
+    uint8_t blo[3], bhi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = row[k]; hi3[k] = row[2 * r + 1 + k]; blo[k] = brow[k]; bhi[k] = brow[2 * r + 1 + k]; }
+    // output o covers offsets o .. o + 2r: the common part plus lo[o..2] and hi3[0..o-1]
+    double mo[4];
+    uint8_t bo[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      double v = m;
+      uint8_t g = bg;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= o) { v = lo[k] > v ? lo[k] : v; g &= blo[k]; }
+        if (k < o) { v = hi3[k] > v ? hi3[k] : v; g &= bhi[k]; }
+      }
+      mo[o] = v; bo[o] = g;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { Hm[hi * TW + j + o] = mo[o]; Hb[hi * TW + j + o] = bo[o]; }
   }
   __syncthreads();
   int count = 0;
-  for (int e = tid; e < TH * TW; e += LM_THREADS) {
-    const int i = e / TW, j = e % TW;
-    const int gi = i0 + i, gj = j0 + j;
-    if (gi < F && gj < T) {
-      double m = Hm[i * TW + j];
-      uint8_t bg = Hb[i * TW + j];
-      for (int d = 1; d <= 2 * r; ++d) {
-        const double v = Hm[(i + d) * TW + j];
-        m = v > m ? v : m;
-        bg &= Hb[(i + d) * TW + j];
+  for (int e = tid; e < (TH / 4) * TW; e += LM_THREADS) {
+    const int i = 4 * (e / TW), j = e % TW;
+    const double* col = Hm + i * TW + j;
+    const uint8_t* bcol = Hb + i * TW + j;
+    double m = col[3 * TW];
+    uint8_t bg = bcol[3 * TW];
+    for (int d = 4; d <= 2 * r; ++d) {
+      const double v = col[d * TW];
+      m = v > m ? v : m;
+      bg &= bcol[d * TW];
+    }
+    double lo[3], hi3[3];
+    uint8_t blo[3], bhi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = col[k * TW]; hi3[k] = col[(2 * r + 1 + k) * TW];
+      blo[k] = bcol[k * TW]; bhi[k] = bcol[(2 * r + 1 + k) * TW];
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      double mm = m;
+      uint8_t g = bg;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= o) { mm = lo[k] > mm ? lo[k] : mm; g &= blo[k]; }
+        if (k < o) { mm = hi3[k] > mm ? hi3[k] : mm; g &= bhi[k]; }
       }
-      const double val = A[(i + r) * HW + j + r];
-      const bool local_max = (m == val);
-      const bool detected = local_max != (bg != 0);
-      const bool keep = detected && (val > amp_min);
-      mask[((size_t)b * F + gi) * T + gj] = keep ? 1 : 0;
-      count += keep ? 1 : 0;
+      const int gi = i0 + i + o, gj = j0 + j;
+      if (gi < F && gj < T) {
+        const double val = A[(i + o + r) * HW + j + r];
+        const bool local_max = (mm == val);
+        const bool detected = local_max != (g != 0);
+        const bool keep = detected && (val > amp_min);
+        mask[((size_t)b * F + gi) * T + gj] = keep ? 1 : 0;
+        count += keep ? 1 : 0;
+      }
     }
   }
 #pragma unroll
@@ -150,7 +193,7 @@ int mfpa_dejavu_prepare(const double* psd, int B, int F, int T, const double* de
 int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double amp_min, uint8_t* mask,
                     int32_t* npeaks, void* stream) {
   if (B == 0) return MFPA_OK;
-  if (!arr || !mask || !npeaks || B < 0 || F < 1 || T < 1 || radius < 0 || radius > 16) return MFPA_EINVAL;
+  if (!arr || !mask || !npeaks || B < 0 || F < 1 || T < 1 || radius < 2 || radius > 16) return MFPA_EINVAL;   // the 4-outputs-per-thread passes need 2r >= 3
   if (B > 65535) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   MFPA_HIP(hipMemsetAsync(npeaks, 0, sizeof(int32_t) * B, s));
