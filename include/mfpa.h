@@ -356,6 +356,21 @@ int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped,
                    int B, int H, float* hout, long long ldh, float* hsum, const float* addend, long long ldadd, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Waveform-domain spectral losses of the Demucs branch, training/loss.py:10-186 (MultiResolutionSTFTLoss; forward).
+ * The STFT of a resolution is mfpa_reflect_pad + mfpa_gemm_mfma (precision 0) with a windowed DFT matrix
+ * (rows [re bins | zero rows up to im_off | im bins], K = window length padded to a multiple of 16); then:
+ *   mfpa_dft_mag        mag[row][k] = sqrt(clamp(re^2 + im^2, 1e-7))                          (loss.py:10-41, `stft`)
+ *   mfpa_stft_loss_sums out3 = [sum (|Y|-|X|)^2, sum |Y|^2, sum |log|Y| - log|X||] (float64)   (loss.py:44-83)
+ * workspace: 3 * mfpa_loss_blocks() doubles.  mfpa_reflect_pad: out (B, Lout), out[i] = x[reflect(i + shift - pad)]
+ * for i + shift < T + 2 pad, else 0 (torch.stft center=True / pad_mode "reflect"; `shift` makes the 16-byte-aligned copy
+ * the odd frames of a hop that is not a multiple of 4 need). */
+int mfpa_loss_blocks(void);
+int mfpa_reflect_pad(const float* x, int B, int T, int pad, int shift, int Lout, float* out, void* stream);
+int mfpa_dft_mag(const float* c, long long rows, int bins, long long ldc, int im_off, float* mag, void* stream);
+int mfpa_stft_loss_sums(const float* cx, const float* cy, long long rows, int bins, long long ldc, int im_off, double* out3,
+                        double* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * AugmentFP signal chain (next-tier row SURVEY.md §8f-3), augmentation/__init__.py:46-93 and
  * augmentation/transformations/ (every transform).  Waveforms are (B, T) float32; `apply` (B) uint8 is the transform's Bernoulli
  * gate (0 = copy the example through).  The random draws are made by the host like the reference does.

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MfpaError(RuntimeError):
@@ -70,6 +70,10 @@ _SIGNATURES = {
     "mfpa_downsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
     "mfpa_conv1d_c1_relu": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_convT1d_c1": ([c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
+    "mfpa_loss_blocks": ([], c_int),
+    "mfpa_reflect_pad": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_dft_mag": ([c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_stft_loss_sums": ([c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_lstm_step": ([c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong,
                         c_void_p, c_void_p, c_longlong, c_void_p], c_int),
     "mfpa_lstm_cell": ([c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,

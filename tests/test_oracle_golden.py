@@ -188,3 +188,22 @@ def test_julius_lowpass_restatement_properties():
     assert float((z - hi_tone)[0, 500:-500].abs().max()) < 2e-2
     with pytest.raises(ValueError):
         oau.lowpass_taps(0.0)
+
+
+def test_g11_multi_resolution_stft_loss(golden):
+    import torch
+    from oracle import loss as ol
+    g = golden("g11_mrstft_loss")
+    n = int(g["n"])
+    x = torch.from_numpy(synth.batch(3, seed=int(g["seed_x"]), n=n))
+    y = torch.from_numpy((0.8 * synth.batch(3, seed=int(g["seed_x"]), n=n)
+                          + 0.2 * synth.batch(3, seed=int(g["seed_noise"]), n=n, tonal=False)).astype(np.float32))
+    sc, mag, per = ol.multi_resolution_stft_loss(x, y, factor_sc=float(g["factor_sc"]), factor_mag=float(g["factor_mag"]))
+    # float32 reductions over ~1e5 elements: torch's summation order depends on the thread count -> 1e-6, not bit equality
+    np.testing.assert_allclose([float(sc), float(mag)], [float(g["sc"]), float(g["mag"])], rtol=1e-6)
+    np.testing.assert_allclose(np.array([[float(a), float(b)] for a, b in per]), g["per_resolution"], rtol=1e-6)
+    m0 = ol.stft_mag(x[:1], 1024, 120, 600).numpy()
+    assert list(m0.shape) == list(g["mag0_shape"])
+    np.testing.assert_array_equal(m0[0, ::7, ::9], g["mag0_sub"])
+    zs, zm, _ = ol.multi_resolution_stft_loss(torch.zeros(2, 8000), y[:2, :8000])
+    np.testing.assert_allclose([float(zs), float(zm)], [float(g["sc_silent"]), float(g["mag_silent"])], rtol=1e-6)

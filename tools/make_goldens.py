@@ -342,6 +342,28 @@ def main():
          y_bg=y_bg.numpy(), gain_db=gdb.numpy(), y_gain=y_g.numpy(), percentile=pct.numpy(), y_clip=y_c.numpy(), y_clip_batchquirk=y_cq.numpy(),
          peak_scale=np.array([0.3, 0.0, 2.0], dtype=np.float32), y_peak=y_p.numpy(),
          conv_full=convolve(x[:1], ir[:1]).numpy(), versions=versions)
+    # ---- G11: MultiResolutionSTFTLoss (training/loss.py:10-186) --------------------------------------------
+    # loss.py calls torch.stft without return_complex (torch 1.11 API); the shim only adds that keyword and the
+    # view_as_real the old API implied -- the reference's arithmetic runs unmodified.
+    import training.loss as rloss
+    real_stft = torch.stft
+
+    def stft_shim(x, n_fft, hop_length=None, win_length=None, window=None, **kw):
+        return torch.view_as_real(real_stft(x, n_fft, hop_length, win_length, window, return_complex=True, **kw))
+
+    torch.stft = stft_shim
+    try:
+        crit = rloss.MultiResolutionSTFTLoss(factor_sc=0.1, factor_mag=0.1)       # training/train.py:116-119
+        xs = torch.from_numpy(synth.batch(3, seed=1400, n=24000))
+        ys = torch.from_numpy((0.8 * synth.batch(3, seed=1400, n=24000) + 0.2 * synth.batch(3, seed=1401, n=24000, tonal=False)).astype(np.float32))
+        sc, mag = crit(xs, ys)
+        per = [[float(v) for v in f(xs, ys)] for f in crit.stft_losses]
+        m0 = rloss.stft(xs[:1], 1024, 120, 600, torch.hann_window(600)).numpy()
+        zs, zm = crit(torch.zeros(2, 8000), ys[:2, :8000])                          # a silent prediction (clamp 1e-7 path)
+    finally:
+        torch.stft = real_stft
+    save("g11_mrstft_loss", seed_x=1400, seed_noise=1401, n=24000, factor_sc=0.1, factor_mag=0.1, sc=float(sc), mag=float(mag), per_resolution=np.array(per),
+         mag0_sub=m0[0, ::7, ::9].copy(), mag0_shape=np.array(m0.shape), sc_silent=float(zs), mag_silent=float(zm), versions=versions)
     print("done")
 
 
