@@ -55,6 +55,37 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert h.mfpa_peak_metrics(1, 1, 1, 1, 5, 1, None) == lib.EINVAL                      # N1 < 2
     assert h.mfpa_conv3x3_bn_relu(1, 48, None, 0, 0, 0, 1, 8, 8, 1, 64, None, None, 1, 0, 1, None) == lib.EINVAL
     assert h.mfpa_stft_mag(None, 0, 8000, None, None, 0, None, None) == 0      # empty batch is a no-op
+    # descriptor entry points: null descriptors, bad modes / precisions / channel counts
+    assert h.mfpa_conv_mfma(None, None) == lib.EINVAL and h.mfpa_wgrad_mfma(None, None) == lib.EINVAL
+    assert h.mfpa_gemm_mfma(None, None) == lib.EINVAL
+    d = lib.ConvDesc(x0=1, w=1, y=1, C0=64, C1=0, B=1, H=8, W=8, Cout=64, mode=3)
+    assert h.mfpa_conv_mfma(ctypes.byref(d), None) == lib.EINVAL                          # mode
+    d = lib.ConvDesc(x0=1, w=1, y=1, C0=64, C1=0, B=1, H=8, W=8, Cout=64, mode=0, precision=2)
+    assert h.mfpa_conv_mfma(ctypes.byref(d), None) == lib.EINVAL                          # precision
+    d = lib.ConvDesc(x0=1, w=1, y=1, C0=48, C1=0, B=1, H=8, W=8, Cout=64)
+    assert h.mfpa_conv_mfma(ctypes.byref(d), None) == lib.EINVAL                          # C0 % 32
+    d = lib.ConvDesc(x0=1, w=1, y=1, C0=64, C1=0, B=0, H=8, W=8, Cout=64)
+    assert h.mfpa_conv_mfma(ctypes.byref(d), None) == 0                                   # empty batch
+    g = lib.WgradDesc(dz=1, x0=1, dw=1, C0=96, C1=0, B=1, H=8, W=8, Cout=64)
+    assert h.mfpa_wgrad_mfma(ctypes.byref(g), None) == lib.EINVAL                         # C0 % 64
+    g = lib.WgradDesc(dz=1, x0=1, dw=1, C0=64, C1=0, B=1, H=8, W=8, Cout=64, precision=7)
+    assert h.mfpa_wgrad_mfma(ctypes.byref(g), None) == lib.EINVAL
+    m = lib.GemmDesc(A=1, lda=6, strideA=0, W=1, C=1, ldc=64, strideC=0, batch=1, M=8, N=64, K=16, npad=64)
+    assert h.mfpa_gemm_mfma(ctypes.byref(m), None) == lib.EINVAL                          # lda % 4: float4 rows
+    m = lib.GemmDesc(A=1, lda=8, strideA=0, W=1, C=1, ldc=64, strideC=0, batch=1, M=8, N=64, K=24, npad=64)
+    assert h.mfpa_gemm_mfma(ctypes.byref(m), None) == lib.EINVAL                          # K % 16
+    # AugmentFP, Demucs and loss entry points
+    assert h.mfpa_fir(1, 1, 100, 99, 1, 1, 1, 1, 1, 0, 0, 1, None, None) == lib.EINVAL    # Tout < T
+    assert h.mfpa_fir(1, 1, 100, 100, 1, 1, 1, 1, 1, 2, 0, 1, None, None) == lib.EINVAL   # pad_mode
+    assert h.mfpa_fir(1, 1, 100, 100, 1, 1, 1, 1, 1, 0, 2, 1, None, None) == lib.EINVAL   # impulse-response mode needs `peak`
+    assert h.mfpa_clip_quantile(None, 1, 100, 1, 1, 1, None) == lib.EINVAL
+    assert h.mfpa_gather_background(1, 1, 1, 1, 0, 100, 1, None) == lib.EINVAL            # P < 1
+    assert h.mfpa_lstm_step(None, 0, 1, 1, 3072, 1, 4, 760, 1, 768, None, None, 0, None) == lib.EINVAL   # H % 128
+    assert h.mfpa_lstm_step(None, 0, 1, 1, 3072, 1, 0, 768, 1, 768, None, None, 0, None) == 0           # empty batch
+    assert h.mfpa_localmax2d(1, 1, 257, 249, 1, 50.0, 1, 1, None) == lib.EINVAL           # radius < 2
+    assert h.mfpa_reflect_pad(1, 1, 100, 100, 0, 400, 1, None) == lib.EINVAL              # pad >= T
+    assert h.mfpa_stft_loss_sums(1, 1, 10, 513, 1000, 576, 1, 1, None) == lib.EINVAL      # ldc < im_off + bins
+    assert h.mfpa_loss_blocks() > 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -68,6 +99,12 @@ def test_no_cpu_fallback():
         UNet(1, 1).eval()(torch.zeros(1, 1, 257, 32))
     with pytest.raises(MfpaError):
         ops.peak_metrics_counts(torch.zeros(1, 4, 4, dtype=torch.uint8), torch.zeros(1, 4, 4, dtype=torch.uint8))
+    from musicfpaugment_amd.training.loss import MultiResolutionSTFTLoss
+    from musicfpaugment_amd.training.model import Demucs
+    with pytest.raises(MfpaError):
+        MultiResolutionSTFTLoss()(torch.zeros(1, 8000), torch.zeros(1, 8000))
+    with pytest.raises(MfpaError):
+        Demucs().eval()(torch.zeros(1, 8000))
 
 
 def test_product_package_never_imports_the_oracle():
