@@ -213,6 +213,12 @@ typedef struct mfpa_conv_desc {
   float* y_pool;                   /* mode 0, optional: MaxPool2d(2) of the output fused in the epilogue, (B,H/2,W/2,Cout) */
   const float* w1x1; float b1x1;   /* mode 0, Cout == 64, optional: OutConv 1x1 to one class fused in the epilogue:        */
   float* y1x1;                     /*   y1x1 (B,H,W) = sum_c out[..][c]*w1x1[c] + b1x1; y may then be NULL (not stored)    */
+  /* mode 0, C0 == Cout == 64, C1 == 0, optional: source 0 is COMPUTED while it is staged (x0 may be NULL) as the UNet's
+   * first layer of mfpa_conv3x3_c1_bn_relu -- relu((conv3x3 of the 1-channel input) * c1_scale + c1_shift), input =
+   * c1_x32 (B,H,W) or (float)(c1_spec64 / c1_denom[b]) -- so inc.double_conv's 64-channel intermediate never exists
+   * in HBM (unet.py:8-24, 86). */
+  const float* c1_x32; const double* c1_spec64; const double* c1_denom;
+  const float* c1_w; const float* c1_scale; const float* c1_shift;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 

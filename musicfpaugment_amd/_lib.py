@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MfpaError(RuntimeError):
@@ -108,7 +108,9 @@ class ConvDesc(ctypes.Structure):
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cout", c_int), ("relu", c_int),
                 ("yH", c_int), ("yW", c_int), ("mode", c_int),
                 ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int),
-                ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p)]
+                ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p),
+                ("c1_x32", c_void_p), ("c1_spec64", c_void_p), ("c1_denom", c_void_p),
+                ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p)]
 
 
 class GemmDesc(ctypes.Structure):

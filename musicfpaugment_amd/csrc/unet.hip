@@ -53,6 +53,14 @@ struct ConvArgs {
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
   int dbg;                           // timing experiments only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA
+  // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
+  // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
+  const float* c1_x32;               // (B,H,W) float32, or
+  const double* c1_spec64;           // (B,H,W) float64 divided by c1_denom[b] (the fused spectrogram normalisation)
+  const double* c1_denom;
+  const float* c1_w;                 // (9, 64)
+  const float* c1_scale;             // (64) folded BatchNorm of the first layer
+  const float* c1_shift;
 };
 
 // MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).
@@ -73,7 +81,7 @@ struct ConvArgs {
 //     MFMA block of iteration it from As / Bs[it&1]
 //     one barrier                                 (+ barrier, halo store, at a chunk's last tap)
 // so weight loads have two MFMA blocks to land, and the only exposed cost per iteration is the wave skew.
-template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC>
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
@@ -92,6 +100,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);         // [HP][LDK]
   float* Bs0 = As + HP * LDK;                         // [2][BN][LDK]
+  constexpr int SW = PW + 4, SH = PH + 4;             // C1SRC: spectrogram patch with a 2-pixel halo, then the (9, 64) weights
+  float* Sp = Bs0 + 2 * BN * LDK;                     // [SH][SW]
+  float* W1s = Sp + SH * SW;                          // [9][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -117,6 +128,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   // the loads); the on-load affine + ReLU + dropout and the bf16 split happen in store_a, a whole chunk later.
   static_assert(THREADS % (KC / 4) == 0, "a thread keeps one channel quad for all of its halo pixels");
   auto load_a = [&](int chunk, int tap) __attribute__((always_inline)) {
+    if (C1SRC) return;                                 // the tile is computed from the LDS-resident spectrogram patch in store_a
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
 #pragma unroll
@@ -159,7 +171,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
         const int pix = idx / (KC / 4), q = idx % (KC / 4);
         f32x4 v = areg[it];
         const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
-        if (affine && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {      // padding stays exactly zero
+        if (C1SRC) {
+          v = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {               // conv2's zero padding stays exactly zero
+            const float* sp = Sp + (pix / HPW) * SW + (pix % HPW);        // 3x3 window of the first layer around (gy, gx)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+              const float sv = sp[(t / 3) * SW + (t % 3)];
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(W1s + t * 64 + c0 + 4 * q);
+              v.x += sv * wv.x; v.y += sv * wv.y; v.z += sv * wv.z; v.w += sv * wv.w;
+            }
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.c1_scale + c0 + 4 * q);
+            const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.c1_shift + c0 + 4 * q);
+            v = v * s1 + h1;
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+        }
+        if (!C1SRC && affine && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {      // padding stays exactly zero
           v = v * a_sc + a_sh;
           v.x = v.x > 0.f ? v.x : 0.f;
           v.y = v.y > 0.f ? v.y : 0.f;
@@ -300,6 +328,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     if (!(a.dbg & 2)) __syncthreads();
   };
 
+  if (C1SRC) {
+    const double den = a.c1_denom ? a.c1_denom[b] : 1.0;
+    for (int i = tid; i < SH * SW; i += THREADS) {
+      const int gy = y0 - 2 + i / SW, gx = x0p - 2 + i % SW;
+      float v = 0.f;                                   // the first layer's own zero padding
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t o = ((size_t)b * a.H + gy) * a.W + gx;
+        v = a.c1_spec64 ? (float)(a.c1_spec64[o] / den) : a.c1_x32[o];
+      }
+      Sp[i] = v;
+    }
+    for (int i = tid; i < 9 * 64; i += THREADS) W1s[i] = a.c1_w[i];
+    __syncthreads();
+  }
   load_a(0, 0);
   load_b(0, Set0{});
   store_a(0);
@@ -701,7 +743,7 @@ __global__ __launch_bounds__(256) void conv1x1_out_kernel(const float* __restric
   }
 }
 
-template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC>
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false>
 int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
@@ -710,9 +752,9 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   static const int dbg_env = getenv("MFPA_CONV_DBG") ? atoi(getenv("MFPA_CONV_DBG")) : 0;
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  const size_t lds = sizeof(float) * ((size_t)HP * LDK + 2 * (size_t)BN * LDK);
+  const size_t lds = sizeof(float) * ((size_t)HP * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(taps_y * (a.Cout / BN)));
-  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC>), grid, dim3(64 * WM * WN), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -732,6 +774,9 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   static const int wm_env = getenv("MFPA_CONV_WM") ? atoi(getenv("MFPA_CONV_WM")) : 0;   // experiments
   const int cin = a.C0 + a.C1;
   const bool big = (wm_env == 4) || (wm_env == 0 && cin >= 256);
+  if (MODE == 0 && (a.c1_x32 || a.c1_spec64)) {        // checked by the caller: C0 == 64, C1 == 0, Cout == 64, W > 16, H >= 8
+    return launch_conv<64, 8, 32, 4, 1, 0, PREC, true>(a, 1, s);
+  }
   if (a.W > 16 && a.H >= 8) {
     if (!bn128) return launch_conv<64, 8, 32, 4, 1, MODE, PREC>(a, taps_y, s);
     if (big) return launch_conv<128, 8, 32, 4, 2, MODE, PREC>(a, taps_y, s);
@@ -783,7 +828,7 @@ int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, 
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (!d) return MFPA_EINVAL;
   if (d->B == 0) return MFPA_OK;
-  if (!d->x0 || !d->w || (!d->y && !d->w1x1) || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
+  if ((!d->x0 && !d->c1_x32 && !d->c1_spec64) || !d->w || (!d->y && !d->w1x1) || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
   if (d->C0 < KC || d->C0 % KC || d->C1 < 0 || d->C1 % KC || d->Cout < 64 || d->Cout % 64) return MFPA_EINVAL;
   if (d->mode < 0 || d->mode > 2) return MFPA_EINVAL;
   if (d->C1 > 0 && (d->mode != 0 || !d->x1 || d->H1 < 1 || d->W1 < 1 || d->H1 > d->H || d->W1 > d->W)) return MFPA_EINVAL;
@@ -804,6 +849,12 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->y_pool && (d->H < 2 || d->W < 2 || a.yH != d->H || a.yW != d->W)) return MFPA_EINVAL;
   if (d->w1x1 && (!d->y1x1 || d->Cout != 64)) return MFPA_EINVAL;      // the 64-channel tile holds every channel
   a.y_pool = d->y_pool; a.w1x1 = d->w1x1; a.b1x1 = d->b1x1; a.y1x1 = d->y1x1;
+  if (d->c1_x32 || d->c1_spec64) {
+    if (d->mode != 0 || d->C0 != 64 || d->C1 != 0 || d->Cout != 64 || d->W <= 16 || d->H < 8) return MFPA_EINVAL;
+    if (!d->c1_w || !d->c1_scale || !d->c1_shift || d->in_scale0 || (d->c1_x32 && d->c1_spec64)) return MFPA_EINVAL;
+    a.c1_x32 = d->c1_x32; a.c1_spec64 = d->c1_spec64; a.c1_denom = d->c1_spec64 ? d->c1_denom : nullptr;
+    a.c1_w = d->c1_w; a.c1_scale = d->c1_scale; a.c1_shift = d->c1_shift;
+  }
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);

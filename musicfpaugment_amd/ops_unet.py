@@ -128,15 +128,21 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
     return y
 
 
-def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True):
+def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None):
     """3x3 conv + folded BN + ReLU through mfpa_conv_mfma with optional fused epilogues: `pool` also writes
     MaxPool2d(2) of the output, `out1x1 = (w (64,), bias)` also writes the OutConv result (B,H,W); `store=False`
     skips the full-resolution output.  `w` must already be in the layout of `precision` (pre-split for bf16x3).
+    `c1 = dict(x32= | spec64=, denom=, w, scale, shift)` (x0 None): the 64 input channels are the UNet's first layer, computed
+    from the 1-channel input while the tile is staged (mfpa_conv_desc.c1_*).
     Returns (y | None, y_pool | None, y1x1 | None)."""
-    B, H, W, C0 = x0.shape
+    if c1 is not None:
+        src = c1.get("x32") if c1.get("x32") is not None else c1["spec64"]
+        (B, H, W), C0 = src.shape, 64
+    else:
+        B, H, W, C0 = x0.shape
     Cout = w.shape[1]
     C1 = 0 if x1 is None else x1.shape[3]
-    dev = x0.device
+    dev = w.device
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev) if store else None
     yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=dev) if pool else None
     y1 = torch.empty((B, H, W), dtype=torch.float32, device=dev) if out1x1 is not None else None
@@ -145,6 +151,9 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
                  B=B, H=H, W=W, Cout=Cout, relu=1, yH=H, yW=W, mode=0, drop_seed=0, drop_thresh=0, drop_scale=1.0,
                  precision=precision, y_pool=ptr(yp), w1x1=ptr(out1x1[0]) if out1x1 is not None else 0,
                  b1x1=float(out1x1[1]) if out1x1 is not None else 0.0, y1x1=ptr(y1))
+    if c1 is not None:
+        d.c1_x32, d.c1_spec64, d.c1_denom = ptr(c1.get("x32")), ptr(c1.get("spec64")), ptr(c1.get("denom"))
+        d.c1_w, d.c1_scale, d.c1_shift = ptr(c1["w"]), ptr(c1["scale"]), ptr(c1["shift"])
     t0 = _TIMER.start() if _TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -190,6 +199,9 @@ def conv1x1_out(x, w, bias: float):
     return y
 
 
+FUSE_FIRST_LAYER = True    # False: run mfpa_conv3x3_c1_bn_relu as its own launch (timing experiments, tiny images)
+
+
 def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] = None,
                       spec64: Optional[torch.Tensor] = None, denom: Optional[torch.Tensor] = None) -> torch.Tensor:
     """UNet.forward in eval mode (training/unet.py:97-108) on (B, F, T) -> (B, F, T) float32.
@@ -203,10 +215,16 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
                              precision=prec, **kw)
 
     p = ENC[0]
-    m = conv3x3_c1_bn_relu(pw[p + ".0.w"], pw[p + ".0.scale"], pw[p + ".0.shift"], x32=x32, spec64=spec64, denom=denom)
     skips = []
-    x, xp, _ = c(m, p, 3, pool=True)
-    del m
+    src = x32 if x32 is not None else spec64
+    if FUSE_FIRST_LAYER and src.shape[2] > 16 and src.shape[1] >= 8:
+        # inc.double_conv: the 1 -> 64 layer is evaluated inside the loader of the 64 -> 64 layer (no 64-channel intermediate)
+        x, xp, _ = c(None, p, 3, pool=True, c1=dict(x32=x32, spec64=spec64, denom=denom, w=pw[p + ".0.w"],
+                                                    scale=pw[p + ".0.scale"], shift=pw[p + ".0.shift"]))
+    else:
+        m = conv3x3_c1_bn_relu(pw[p + ".0.w"], pw[p + ".0.scale"], pw[p + ".0.shift"], x32=x32, spec64=spec64, denom=denom)
+        x, xp, _ = c(m, p, 3, pool=True)
+        del m
     skips.append(x)
     for name in ENC[1:]:
         m, _, _ = c(xp, name, 0)
