@@ -355,7 +355,9 @@ constexpr int LKC = 128;                 // K chunk
 constexpr int LROW = 4 * LKC + 16;       // LDS row bytes: [128 hi | 128 lo | pad]
 constexpr int LBM = 64, LU = 16;         // clips x hidden units per workgroup
 
-__global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restrict__ hprev, long long ldhp,
+constexpr int LTHREADS = 512;   // 8 waves: (clip half) x (gate-column half) x (k-step half of every chunk)
+
+__global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __restrict__ hprev, long long ldhp,
                                                            const float* __restrict__ whh, const float* __restrict__ xp,
                                                            long long ldxp, float* __restrict__ c, int B, int H,
                                                            float* __restrict__ hout, long long ldh, float* __restrict__ hsum,
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restri
   char* Bs = lsm + 2 * LBM * LROW;           // [2][64][LROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave & 1, wn = (wave >> 1) & 1, wk = wave >> 2;   // wk: k-steps 4 wk .. 4 wk + 3 of each 128-wide chunk
   // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs
   const int ngroups = H / LU;
   int grp, mt;
@@ -384,13 +386,13 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restri
   if (hprev != nullptr) {
     const float* Wg = whh + (size_t)grp * 64 * H;
     const int nk = H / LKC;
-    constexpr int F4 = LBM * (LKC / 4) / 256;            // float4 per thread per operand per chunk (8)
+    constexpr int F4 = LBM * (LKC / 4) / LTHREADS;       // float4 per thread per operand per chunk (4)
     f32x4 ar[F4], br[F4];
     const int q = tid % (LKC / 4), r0 = tid / (LKC / 4); // column quad, first row; rows r0 + 8 i
     auto load = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
-        const int row = r0 + (256 / (LKC / 4)) * i;
+        const int row = r0 + (LTHREADS / (LKC / 4)) * i;
         const int m = m0 + row;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < B) v = *reinterpret_cast<const f32x4*>(hprev + (size_t)m * ldhp + kc * LKC + 4 * q);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restri
     auto store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
-        const int row = r0 + (256 / (LKC / 4)) * i;
+        const int row = r0 + (LTHREADS / (LKC / 4)) * i;
         split_store(As + (buf * LBM + row) * LROW, ar[i]);
         split_store(Bs + (buf * LBM + row) * LROW, br[i]);
       }
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restri
       const char* Ap = As + (buf * LBM + wm * 32 + li) * LROW + 16 * lh;
       const char* Bp = Bs + (buf * LBM + wn * 32 + li) * LROW + 16 * lh;
 #pragma unroll
-      for (int s = 0; s < LKC / 16; ++s) {
+      for (int s = 4 * wk; s < 4 * wk + 4; ++s) {
         const l_bf16x8 ah = *reinterpret_cast<const l_bf16x8*>(Ap + 32 * s);
         const l_bf16x8 al = *reinterpret_cast<const l_bf16x8*>(Ap + 2 * LKC + 32 * s);
         const l_bf16x8 bh = *reinterpret_cast<const l_bf16x8*>(Bp + 32 * s);
@@ -442,15 +444,25 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const float* __restri
   // gates of the tile -> LDS [64 clips][64 + 4], then one thread per (clip, 4 units) runs the cell
   float* G = reinterpret_cast<float*>(lsm);
   constexpr int GLDW = 68;
+  if (wk == 0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    G[m * GLDW + wn * 32 + li] = acc[r];
+    for (int r = 0; r < 16; ++r) {
+      const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      G[m * GLDW + wn * 32 + li] = acc[r];
+    }
+  }
+  __syncthreads();
+  if (wk == 1) {                                       // the other half of K
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      G[m * GLDW + wn * 32 + li] += acc[r];
+    }
   }
   __syncthreads();
   const int clip = tid >> 2, uq = tid & 3;
   const int m = m0 + clip;
-  if (m < B) {
+  if (tid < 256 && m < B) {
     const int u0 = grp * LU + 4 * uq;
     const float* xr = xp + (size_t)m * ldxp;
     const f32x4 xi = *reinterpret_cast<const f32x4*>(xr + u0), xf = *reinterpret_cast<const f32x4*>(xr + H + u0);
@@ -562,7 +574,7 @@ int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped,
   if (total > 0x7fffff) return MFPA_EINVAL;
   const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
   const size_t lds = (size_t)4 * LBM * LROW;
-  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(256), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, c, B,
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, c, B,
                      H, hout, ldh, hsum, addend, ldadd, mtiles);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
