@@ -100,13 +100,39 @@ class Audfprint_peaks(object):
         return pklist, m.to(torch.float32).cpu().numpy(), spec[0].cpu().numpy()
 
     # ------------------------------------------------------------------ landmarks / hashes (next-tier row §8f-1)
-    def hashes_batch(self, wav: torch.Tensor, cap: int = 4096):
-        """(B, T) float32 on the GPU -> (unique sorted (time, hash) rows (B, cap, 2) int32, counts (B,) int32):
-        wavfile2hashes with shifts = 1 (peak_extractor.py:426-460) for a whole batch, peaks never leaving the device."""
-        mask, _, _ = self.find_peaks_batch(wav)
-        _, _, uniq, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf,
-                                                     self.maxpairsperpeak)
-        return uniq, counts[:, 1].contiguous()
+    def hashes_batch(self, wav: torch.Tensor, cap: int = 4096, shifts: Optional[int] = None):
+        """(B, T) float32 on the GPU -> (unique sorted (time, hash) rows (B, cap', 2) int32, counts (B,) int32):
+        wavfile2hashes (peak_extractor.py:426-460) for a whole batch, peaks never leaving the device.  `shifts` (default:
+        the instance's, 1 in testing/parameters.py): hashes of the waveform advanced by s / shifts frames, s = 0..shifts-1,
+        are merged before the duplicate removal (:406-424, :437-444); cap' = cap * shifts."""
+        shifts = self.shifts if shifts is None else shifts
+        if shifts is None or shifts < 2:
+            mask, _, _ = self.find_peaks_batch(wav)
+            _, _, uniq, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf,
+                                                         self.maxpairsperpeak)
+            return uniq, counts[:, 1].contiguous()
+        B = wav.shape[0]
+        keys = []
+        for s in range(shifts):
+            shiftsamps = int(s / self.shifts * self.n_hop) if self.shifts and self.shifts > 1 else int(s / shifts * self.n_hop)
+            mask, _, _ = self.find_peaks_batch(wav[:, shiftsamps:].contiguous())
+            _, hs, _, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf, self.maxpairsperpeak)
+            if bool((counts[:, 0] < 0).any()):
+                raise ValueError("landmark capacity exceeded: raise `cap`")
+            k = (hs[:, :, 0].to(torch.int64) << 32) + (hs[:, :, 1].to(torch.int64) & 0xFFFFFFFF)     # :447-449
+            valid = torch.arange(cap, device=wav.device)[None, :] < counts[:, :1]
+            keys.append(torch.where(valid, k, torch.full_like(k, torch.iinfo(torch.int64).max)))
+        k = torch.sort(torch.cat(keys, dim=1), dim=1).values                                           # np.sort(np.unique(.))
+        first = torch.ones_like(k, dtype=torch.bool)
+        first[:, 1:] = k[:, 1:] != k[:, :-1]
+        first &= k != torch.iinfo(torch.int64).max
+        n = first.sum(dim=1).to(torch.int32)
+        pos = torch.cumsum(first.to(torch.int64), dim=1) - 1
+        out = torch.zeros((B, cap * shifts, 2), dtype=torch.int32, device=wav.device)
+        b_idx = torch.arange(B, device=wav.device)[:, None].expand_as(k)
+        out[b_idx[first], pos[first], 0] = (k[first] >> 32).to(torch.int32)
+        out[b_idx[first], pos[first], 1] = (k[first] & 0xFFFFFFFF).to(torch.int32)
+        return out, n
 
     def peaks2landmarks(self, pklist: List[Tuple[int, int]]) -> List[Tuple[int, int, int, int]]:
         """[(col, bin)] -> [(col, bin1, bin2, dcol)], peak_extractor.py:313-346, through the device kernel."""
