@@ -465,11 +465,11 @@ def main():
                         "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
                         "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_bf16x3.json")
+            pmc = os.path.join(ROOT, "profiles", "r01d_pmc_traffic_bf16x3.json")
             if os.path.exists(pmc):      # HBM bytes per step from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
                 with open(pmc) as fh:    # (FETCH_SIZE x2 per MI355X_MICROARCH.md), scaled to this batch size
                     traffic = json.load(fh)["per_256_clip_step_bytes"] * B / 256.0
-                tsrc = "profiles/r01c_pmc_traffic_bf16x3.json (offline PMC passes, bytes per step of all MFMA conv launches)"
+                tsrc = "profiles/r01d_pmc_traffic_bf16x3.json (offline PMC passes, bytes per step of all MFMA conv launches)"
             return {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "mfma_flops_issued_per_algorithmic_flop": 3,

@@ -506,7 +506,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if (grid.y > 65535 || grid.z > 65535) return MFPA_EINVAL;
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   // Short-K layers (K < 256: the outer, full-rate encoder / decoder levels) are HBM-bound; the fp32 kernel's smaller
-  // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_*).
+  // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_gemm_calls.md).
   if (d->precision == 1 && d->K % HKC == 0 && d->K >= 256) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
   } else {

@@ -16,9 +16,11 @@ def load(d, counter):
             continue
         disp[r["Dispatch_Id"]] += float(r["Counter_Value"]); name[r["Dispatch_Id"]] = r["Kernel_Name"]
     for k, v in disp.items():
-        if "conv_mfma_kernel" in name[k]:
-            n = name[k].split("conv_mfma_kernel")[1].split("(")[0]
-            per["conv_mfma_kernel" + n][0] += 1; per["conv_mfma_kernel" + n][1] += v
+        for fam in ("conv_mfma_kernel", "convT_mfma_kernel"):
+            if fam in name[k]:
+                n = name[k].split(fam)[1].split("(")[0]
+                per[fam + n][0] += 1; per[fam + n][1] += v
+                break
     return per
 
 fd, wd, out = sys.argv[1:4]
