@@ -48,10 +48,24 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
   TIn floor_v = 0;
   if (!log_input) {
     // pass A: max of the (normalised) spectrogram
+    // One workgroup streams its clip: keep 8 independent loads in flight per thread (a single dependent load per
+    // iteration leaves the CU waiting on memory latency: 8 waves x 1 load = 4 KB in flight).
     TIn m = -INFINITY;
-    for (int i = tid; i < N; i += PREP_THREADS) {
-      TIn s = has_den ? (TIn)((double)x[i] / den) : x[i];
-      m = s > m ? s : m;
+    constexpr int UN = 8;
+    for (int i0 = tid; i0 < N; i0 += UN * PREP_THREADS) {
+      TIn v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + u * PREP_THREADS;
+        v[u] = i < N ? x[i] : (TIn)0;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (i0 + u * PREP_THREADS < N) {
+          const TIn s = has_den ? (TIn)((double)v[u] / den) : v[u];
+          m = s > m ? s : m;
+        }
+      }
     }
     double md = mfpa_wave_max((double)m);
     if ((tid & 63) == 0) red[tid >> 6] = md;
@@ -67,20 +81,32 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
     floor_v = smax / (TIn)1e6;               // np.max(sgram) / 1e6 in the array's dtype
   }
   // pass B: log values (kept in the spectrogram's dtype, stored widened) in the input's bin-major layout
-  for (int i = tid; i < N; i += PREP_THREADS) {
-    TIn s = has_den ? (TIn)((double)x[i] / den) : x[i];
-    if (do_log) {
-      s = s > floor_v ? s : floor_v;
-      s = (TIn)log((double)s);
+  for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
+    TIn v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * PREP_THREADS;
+      v[u] = i < N ? x[i] : (TIn)1;
     }
-    L[i] = (double)s;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * PREP_THREADS;
+      if (i < N) {
+        TIn s = has_den ? (TIn)((double)v[u] / den) : v[u];
+        if (do_log) {
+          s = s > floor_v ? s : floor_v;
+          s = (TIn)log((double)s);
+        }
+        L[i] = (double)s;
+      }
+    }
   }
   __syncthreads();
 
   TIn mean = 0;
   if (do_log || log_input) {
     // numpy mean: chunked pairwise sum in the array's memory order, one divide in the array's dtype
-    const TIn total = block_numpy_sum<TIn>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
+        const TIn total = block_numpy_sum<TIn>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
     mean = (TIn)(total / (TIn)N);
   }
 
@@ -88,13 +114,37 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
   double z = 0.0;
   const double npole = -pole;
   double* outp = filtered + (size_t)b * T * R;
+  // Tiles of TT frames; the next tile's global loads are issued (into registers) before the sequential filter of the
+  // current one runs, so the 16 dependent steps per bin hide the memory latency.
+  constexpr int TL = 8;                                    // tile elements per thread: R * TT / PREP_THREADS for R = 256
+  double pre[TL];
+  auto load_tile = [&](int t0) __attribute__((always_inline)) {
+    const int nt = min(TT, T - t0);
+#pragma unroll
+    for (int u = 0; u < TL; ++u) {
+      const int e = tid + u * PREP_THREADS;
+      const int r = e / TT, tt = e % TT;
+      pre[u] = (e < R * TT && tt < nt) ? L[(size_t)r * T + t0 + tt] : 0.0;
+    }
+  };
+  const bool fits = R * TT <= TL * PREP_THREADS;           // otherwise fall back to direct loads below
+  if (fits) load_tile(0);
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = min(TT, T - t0);
-    for (int e = tid; e < R * TT; e += PREP_THREADS) {
-      const int r = e / TT, tt = e % TT;
-      if (tt < nt) tile_in[r * (TT + 1) + tt] = L[(size_t)r * T + t0 + tt];
+    if (fits) {
+#pragma unroll
+      for (int u = 0; u < TL; ++u) {
+        const int e = tid + u * PREP_THREADS;
+        if (e < R * TT) tile_in[(e / TT) * (TT + 1) + e % TT] = pre[u];
+      }
+    } else {
+      for (int e = tid; e < R * TT; e += PREP_THREADS) {
+        const int r = e / TT, tt = e % TT;
+        if (tt < nt) tile_in[r * (TT + 1) + tt] = L[(size_t)r * T + t0 + tt];
+      }
     }
     __syncthreads();
+    if (fits && t0 + TT < T) load_tile(t0 + TT);
     if (tid < R) {
       for (int tt = 0; tt < nt; ++tt) {
         const TIn lv = (TIn)tile_in[tid * (TT + 1) + tt];
@@ -124,13 +174,34 @@ __device__ __forceinline__ Best best_of(Best a, Best b) {
   return take_b ? b : a;
 }
 
+// v of lane `src` (wave-uniform index) through v_readlane: a scalar-path broadcast, ~10x the speed of the LDS-crossbar
+// shuffle the generic __shfl lowers to
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// One-lane wavefront shifts as DPP moves (GFX9 wave_shr:1 / wave_shl:1): no LDS crossbar round trip.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false),
+                          __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+
+// Wavefront arg-max on (value, bin).  A frame has only a handful of candidate lanes (0 or 1 in most frames), so the
+// candidates are visited one by one from the ballot mask with scalar broadcasts instead of a 6-level butterfly of
+// 3 cross-lane shuffles each.  The result is wave-uniform.
 __device__ __forceinline__ Best wave_best(Best x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Best y{__shfl_xor(x.v, o), __shfl_xor(x.p, o)};
-    x = best_of(x, y);
+  unsigned long long m = __ballot(x.p >= 0);
+  Best best{0.0, -1};
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    best = best_of(best, Best{readlane_f64(x.v, src), __builtin_amdgcn_readlane(x.p, src)});
   }
-  return x;
+  return best;
 }
 
 __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ filtered, int R, int T,
@@ -162,8 +233,8 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   };
   // locmax flags of a column held 4 bins per lane (peak_extractor.py:61-73)
   auto locmax4 = [&](const double (&v)[4], bool (&pk)[4]) {
-    const double left = __shfl_up(v[3], 1);     // bin k0-1
-    const double right = __shfl_down(v[0], 1);  // bin k0+4
+    const double left = dpp_f64<0x138>(v[3]);   // wave_shr:1 -> lane - 1's value: bin k0-1 (lane 0 keeps its own, unused)
+    const double right = dpp_f64<0x130>(v[0]);  // wave_shl:1 -> lane + 1's value: bin k0+4 (lane 63: unused)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = k0 + s;
@@ -197,7 +268,7 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
       while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const double val = __shfl(v[s], src);
+        const double val = readlane_f64(v[s], src);
         raise(val, 4 * src + s);
       }
     }
@@ -272,7 +343,7 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
       const int p = lb[(size_t)c * MAXP + i];
       const int s_sel = p & 3;
       const double mine = s_sel == 0 ? th[0] : (s_sel == 1 ? th[1] : (s_sel == 2 ? th[2] : th[3]));
-      const double thp = __shfl(mine, p >> 2);
+      const double thp = readlane_f64(mine, p >> 2);
       if (val >= thp) {
         raise(val, p);
         if (c + 1 < T) {  // delete any following peak in the same bin

@@ -33,10 +33,18 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const doub
   const bool has_den = denom != nullptr;
   const double den = has_den ? denom[b] : 1.0;
 
+  // 8 independent loads in flight per thread in every streaming pass (one workgroup per clip: memory-latency-bound otherwise)
   double m = -INFINITY;
-  for (int i = tid; i < N; i += PREP_THREADS) {
-    const double s = has_den ? x[i] / den : x[i];
-    m = s > m ? s : m;
+  for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * PREP_THREADS < N) {
+        const double s = has_den ? v[u] / den : v[u];
+        m = s > m ? s : m;
+      }
   }
   m = mfpa_wave_max(m);
   if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -48,15 +56,29 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const doub
   }
   __syncthreads();
   const double floor_v = bcast[0] / 1e6;
-  for (int i = tid; i < N; i += PREP_THREADS) {
-    double s = has_den ? x[i] / den : x[i];
-    s = s > floor_v ? s : floor_v;
-    L[i] = scale * log(s);
+  for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : 1.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * PREP_THREADS < N) {
+        double s = has_den ? v[u] / den : v[u];
+        s = s > floor_v ? s : floor_v;
+        L[i0 + u * PREP_THREADS] = scale * log(s);
+      }
   }
   __syncthreads();
   const double total = block_numpy_sum<double>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
   const double mean = total / (double)N;
-  for (int i = tid; i < N; i += PREP_THREADS) L[i] = L[i] - mean;
+  for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? L[i0 + u * PREP_THREADS] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * PREP_THREADS < N) L[i0 + u * PREP_THREADS] = v[u] - mean;
+  }
 }
 
 constexpr int TH = 32, TW = 64, LM_THREADS = 256;

@@ -74,11 +74,17 @@ __device__ __forceinline__ S block_numpy_sum(const double* __restrict__ L, int N
       res = 0;
       for (int i = 0; i < nd.n; ++i) res = res + at(i);
     } else {
-      S acc = at(lane8);
-      int i = 8;
-      for (; i < nd.n - (nd.n % 8); i += 8) acc = acc + at(i + lane8);
+      // all of a lane's <= 16 strided elements are loaded before the (ordered) additions: independent loads in flight
+      const int n8 = nd.n - (nd.n % 8);
+      S vals[PW_BLOCK / 8];
+#pragma unroll
+      for (int j = 0; j < PW_BLOCK / 8; ++j) vals[j] = (8 * j < n8) ? at(8 * j + lane8) : (S)0;
+      S acc = vals[0];
+#pragma unroll
+      for (int j = 1; j < PW_BLOCK / 8; ++j)
+        if (8 * j < n8) acc = acc + vals[j];
       res = group8_sum(acc);
-      for (; i < nd.n; ++i) res = res + at(i);
+      for (int i = n8; i < nd.n; ++i) res = res + at(i);
     }
     if (lane8 == 0) heap[c * HEAP + id] = res;
   }
