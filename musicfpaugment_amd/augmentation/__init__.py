@@ -226,7 +226,8 @@ class AugmentFP(object):
         check(L.mfpa_gather_background(ptr(self._noise_dev), ptr(src_d), ptr(ln_d), B, P, T, ptr(noise), stream()),
               "mfpa_gather_background")
         snr = torch.distributions.Uniform(torch.tensor(float(p["min_snr_in_db"])), torch.tensor(float(p["max_snr_in_db"]))).sample((B,))
-        self.t_bg.transform_parameters.update(background=noise[should.to(dev)], snr_in_db=snr[should])
+        sel = torch.nonzero(should).flatten().to(dev)          # host-known indices: no device-side nonzero, no sync
+        self.t_bg.transform_parameters.update(background=noise.index_select(0, sel), snr_in_db=snr[should])
         self.t_bg.draws = {"background": noise, "snr_in_db": snr, "pieces": pieces}
         y, snr_d, on_d = torch.empty_like(x), snr.to(dev), u8(should)
         check(L.mfpa_mix_background(ptr(x), B, T, ptr(noise), ptr(snr_d), ptr(on_d), ptr(y), stream()), "mfpa_mix_background")
