@@ -648,16 +648,36 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const float* __restrict__
     const int gx = (int)(p % W), gy = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
     const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (size_t)p * Cout + 4 * cq);
     const double den = (spec64 && denom) ? denom[b] : 1.0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
-      float v = 0.f;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const size_t o = ((size_t)b * H + yy) * W + xx;
-        v = spec64 ? (float)(spec64[o] / den) : x32[o];
+    if (lanes >= 9) {
+      // the lanes of a pixel share its 3x3 input window: lane cq < 9 loads (and normalises: one float64 division) tap cq,
+      // the others receive it by shuffle -- like conv3x3_c1_kernel
+      float mine = 0.f;
+      if (cq < 9) {
+        const int yy = gy + cq / 3 - 1, xx = gx + cq % 3 - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const size_t o = ((size_t)b * H + yy) * W + xx;
+          mine = spec64 ? (float)(spec64[o] / den) : x32[o];
+        }
       }
+      const int base = (threadIdx.x & 63) - cq;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[t][k] += g[k] * v;
+      for (int t = 0; t < 9; ++t) {
+        const float v = __shfl(mine, base + t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t][k] += g[k] * v;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const size_t o = ((size_t)b * H + yy) * W + xx;
+          v = spec64 ? (float)(spec64[o] / den) : x32[o];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[t][k] += g[k] * v;
+      }
     }
   }
   __shared__ float sh[256 * 36];
