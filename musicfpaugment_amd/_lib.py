@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class MfpaError(RuntimeError):
@@ -119,7 +119,8 @@ class GemmDesc(ctypes.Structure):
                 ("addend", c_void_p), ("ldadd", c_longlong), ("strideAdd", c_longlong),
                 ("C", c_void_p), ("ldc", c_longlong), ("strideC", c_longlong),
                 ("batch", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("npad", c_int), ("mode", c_int),
-                ("relu", c_int), ("precision", c_int)]
+                ("relu", c_int), ("precision", c_int),
+                ("c1_x", c_void_p), ("c1_lin", c_longlong), ("c1_w", c_void_p), ("c1_b", c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):

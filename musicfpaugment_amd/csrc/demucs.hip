@@ -31,6 +31,10 @@ struct GemmArgs {
   const float* addend; long long ldadd, strideAdd;   // mode 2: y += addend[b*strideAdd + m*ldadd + n]
   float* C; long long ldc, strideC;
   int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend
+  // fp32 kernel only: A is not read but COMPUTED while it is staged -- the first encoder layer Conv1d(1 -> K, k8, s4) + ReLU
+  // (conv1d_c1_kernel) of the waveform: A[b][m][c] = relu(c1_b[c] + sum_j c1_w[j][c] * c1_x[b][4 m + j])
+  const float* c1_x; long long c1_lin;         // (batch, c1_lin) samples
+  const float* c1_w; const float* c1_b;        // (8, K), (K)
 };
 
 // epilogue shared by both precisions: D[row = m][col = n]; a lane holds column li of both 32-wide n tiles
@@ -61,9 +65,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, floatx16 (&acc)
   }
 }
 
+template <bool C1SRC>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][GBM * GLD];
   __shared__ __attribute__((aligned(16))) float Bs[2][GBN * GLD];
+  __shared__ __attribute__((aligned(16))) float W1s[C1SRC ? 9 * 256 : 4];      // C1SRC: [8][K] taps then [K] bias, K <= 256
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;   // n tiles fastest: the workgroups that share an A tile run together
@@ -74,13 +80,42 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
   f32x4 ar[2], br;
   const int arow0 = tid >> 2, aq = tid & 3;             // rows arow0 and arow0 + 64
   const int brow = tid >> 2, bq = tid & 3;              // 64 rows
-  auto load = [&](int kc) __attribute__((always_inline)) {
+  f32x4 xr[2][2];                              // C1SRC: the 8 samples under each of this thread's two rows, loaded once
+  if (C1SRC) {
+    const float* xb = a.c1_x + (size_t)b * a.c1_lin;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = m0 + arow0 + 64 * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + kc * GKC + 4 * aq);
-      ar[i] = v;
+      xr[i][0] = xr[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < a.M) {
+        xr[i][0] = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)m);
+        xr[i][1] = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)m + 4);
+      }
+    }
+    for (int i = tid; i < 8 * a.K; i += 256) W1s[i] = a.c1_w[i];
+    for (int i = tid; i < a.K; i += 256) W1s[8 * a.K + i] = a.c1_b[i];
+    __syncthreads();
+  }
+  auto load = [&](int kc) __attribute__((always_inline)) {
+    if (C1SRC) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {             // conv1d_c1_kernel's arithmetic, same order: bias, then taps 0..7
+        const int c = kc * GKC + 4 * aq;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&W1s[8 * a.K + c]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += xr[i][j >> 2][j & 3] * *reinterpret_cast<const f32x4*>(&W1s[j * a.K + c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        ar[i] = (m0 + arow0 + 64 * i < a.M) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + arow0 + 64 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + kc * GKC + 4 * aq);
+        ar[i] = v;
+      }
     }
     br = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + brow) * a.K + kc * GKC + 4 * bq);
   };
@@ -493,7 +528,9 @@ extern "C" {
 int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if (!d) return MFPA_EINVAL;
   if (d->batch == 0 || d->M == 0) return MFPA_OK;
-  if (!d->A || !d->W || !d->C || d->batch < 0 || d->M < 0 || d->N < 1 || d->K < GKC || d->K % GKC) return MFPA_EINVAL;
+  if ((!d->A && !d->c1_x) || !d->W || !d->C || d->batch < 0 || d->M < 0 || d->N < 1 || d->K < GKC || d->K % GKC) return MFPA_EINVAL;
+  if (d->c1_x && (!d->c1_w || !d->c1_b || d->K > 256 || (d->precision == 1 && d->K >= 256) || d->c1_lin < 4 * ((long long)d->M - 1) + 8 ||
+                  d->c1_lin % 4)) return MFPA_EINVAL;
   if (d->npad < 64 || d->npad % 64 || d->mode < 0 || d->mode > 2 || (d->mode == 2 && !d->addend)) return MFPA_EINVAL;
   if (d->lda % 4 || d->strideA % 4) return MFPA_EINVAL;   // float4 row loads
   if (d->mode == 1 ? (d->N > d->npad / 2) : (d->N > d->npad)) return MFPA_EINVAL;
@@ -502,6 +539,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   a.addend = d->addend; a.ldadd = d->ldadd; a.strideAdd = d->strideAdd;
   a.C = d->C; a.ldc = d->ldc; a.strideC = d->strideC;
   a.M = d->M; a.N = d->N; a.K = d->K; a.mode = d->mode; a.relu = d->relu;
+  a.c1_x = d->c1_x; a.c1_lin = d->c1_lin; a.c1_w = d->c1_w; a.c1_b = d->c1_b;
   dim3 grid(d->npad / GBN, (d->M + GBM - 1) / GBM, d->batch);
   if (grid.y > 65535 || grid.z > 65535) return MFPA_EINVAL;
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
@@ -509,8 +547,10 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_gemm_calls.md).
   if (d->precision == 1 && d->K % HKC == 0 && d->K >= 256) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  } else if (d->c1_x) {
+    hipLaunchKernelGGL(gemm_mfma_kernel<true>, grid, dim3(256), 0, mfpa_stream(stream), a);
   } else {
-    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+    hipLaunchKernelGGL(gemm_mfma_kernel<false>, grid, dim3(256), 0, mfpa_stream(stream), a);
   }
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;

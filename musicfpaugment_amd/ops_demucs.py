@@ -97,15 +97,18 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
     return ptr(t) + 4 * off_floats
 
 
+FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
 PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (3 bf16 MFMAs per product, fp32 accumulate)
 
 
 def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mode=0, relu=0, addend: int = 0, ldadd=0,
-         strideAdd=0, precision=None):
+         strideAdd=0, precision=None, c1=None):
     """C[b][m][:N] = epi(A-window[b][m] @ W^T + bias); A, C, addend are device addresses, strides in floats."""
     d = GemmDesc(A=A, lda=lda, strideA=strideA, W=ptr(W), bias=ptr(bias), addend=addend, ldadd=ldadd,
                  strideAdd=strideAdd, C=C, ldc=ldc, strideC=strideC, batch=batch, M=M, N=N, K=W.shape[1], npad=W.shape[0],
                  mode=mode, relu=int(relu), precision=PRECISION if precision is None else precision)
+    if c1 is not None:                 # (x (B, Lin), w (8, K), b (K)): A is the first encoder layer, computed in the loader
+        d.c1_x, d.c1_lin, d.c1_w, d.c1_b = ptr(c1[0]), c1[0].shape[1], ptr(c1[1]), ptr(c1[2])
     t0 = _K._TIMER.start() if _K._TIMER is not None else None
     check(lib().mfpa_gemm_mfma(ctypes.byref(d), stream()), "mfpa_gemm_mfma")
     if t0 is not None:
@@ -134,15 +137,22 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
     for i in range(DEPTH):
         C = chans[i]
         Lout = (Lin - KERNEL) // STRIDE + 1
-        a = new(B, Lout, C)
-        if i == 0:
-            check(L.mfpa_conv1d_c1_relu(ptr(x), B, Lin, Lout, C, ptr(pw["enc0.w"]), ptr(pw["enc0.b"]), ptr(a), stream()),
-                  "mfpa_conv1d_c1_relu")
+        if i == 0 and FUSE_FIRST_LAYER:
+            # Conv1d(1 -> 48, k8, s4) + ReLU is evaluated inside the loader of the 1x1 + GLU GEMM: its (B, L, 48) output
+            # (12 MB per clip) is never written
+            h = new(B, Lout, C)
+            gemm_p(0, C, Lout * C, B, Lout, pw["enc0.gw"], pw["enc0.gb"], C, _p(h), C, Lout * C, mode=1,
+                   c1=(x, pw["enc0.w"], pw["enc0.b"]))
         else:
-            Cin = chans[i - 1]                                   # row t = h[4t : 4t+8] flattened: stride 4*Cin, K = 8*Cin
-            gemm_p(_p(h), STRIDE * Cin, Lin * Cin, B, Lout, pw[f"enc{i}.w"], pw[f"enc{i}.b"], C, _p(a), C, Lout * C, relu=1)
-        h = new(B, Lout, C)
-        gemm_p(_p(a), C, Lout * C, B, Lout, pw[f"enc{i}.gw"], pw[f"enc{i}.gb"], C, _p(h), C, Lout * C, mode=1)
+            a = new(B, Lout, C)
+            if i == 0:
+                check(L.mfpa_conv1d_c1_relu(ptr(x), B, Lin, Lout, C, ptr(pw["enc0.w"]), ptr(pw["enc0.b"]), ptr(a), stream()),
+                      "mfpa_conv1d_c1_relu")
+            else:
+                Cin = chans[i - 1]                               # row t = h[4t : 4t+8] flattened: stride 4*Cin, K = 8*Cin
+                gemm_p(_p(h), STRIDE * Cin, Lin * Cin, B, Lout, pw[f"enc{i}.w"], pw[f"enc{i}.b"], C, _p(a), C, Lout * C, relu=1)
+            h = new(B, Lout, C)
+            gemm_p(_p(a), C, Lout * C, B, Lout, pw[f"enc{i}.gw"], pw[f"enc{i}.gb"], C, _p(h), C, Lout * C, mode=1)
         skips.append(h)
         Lin = Lout
     # ---- LSTM: 2 layers, unidirectional, zero initial state (model.py:91-110); the last layer also emits h + skip
