@@ -362,13 +362,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    backend = os.environ.get("MFPA_DIST_BACKEND", "nccl")          # "gloo": several ranks may share one GPU (tests only)
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     if args.mode == "train":
         return bench_train(args, rank, world, dev, dist)
