@@ -251,7 +251,7 @@ def bench_train(args, rank, world, dev, dist):
     net = UNet(1, 1, rate=0.05)
     net.load_state_dict(formula_state_dict(0))
     net = net.to(dev).train()
-    eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0)
+    eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0, sync_bn=args.sync_bn)
     base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank)
     noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False)
     reps = (B + len(base) - 1) // len(base)
@@ -312,8 +312,9 @@ def bench_train(args, rank, world, dev, dist):
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
-                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, per-GPU "
-                                      "BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
+                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
+                                      + ("synchronised (global-batch)" if eng.sync_bn else "per-GPU")
+                                      + " BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
             "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           "mfma_flops_issued_per_algorithmic_flop": 3,
@@ -341,6 +342,7 @@ def main():
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
+    ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: BatchNorm statistics over the global batch")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")

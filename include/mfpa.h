@@ -264,6 +264,23 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
                      float* dgamma, float* dbeta, float* coef, double* workspace,
                      unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
 
+/* The same two operations split for synchronised BatchNorm under data parallelism (statistics over the GLOBAL batch, as the
+ * single-GPU reference computes them): *_sums reduces this rank's per-channel pairs into sums[2C] float64 -- (sum z, sum z^2)
+ * forward, (sum g, sum g*xhat) backward, g = the ReLU/dropout-masked incoming gradient -- the caller all-reduces (SUM) them
+ * and the pixel count over the ranks, *_finish completes from the global sums.  Backward: dgamma / dbeta come from the LOCAL
+ * sums (the gradient all-reduce adds the ranks), the mean terms of the input gradient from the GLOBAL ones. */
+int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, void* stream);
+int mfpa_bn_stats_finish(const double* sums, double count, int C, const float* gamma, const float* beta, float eps,
+                         float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                         float* running_var, void* stream);
+int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, double* sums, double* workspace, unsigned drop_seed,
+                          unsigned drop_thresh, float drop_scale, void* stream);
+int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, const double* local_sums,
+                            const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
+
 /* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
 int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);
 

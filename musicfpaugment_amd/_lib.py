@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class MfpaError(RuntimeError):
@@ -83,6 +83,14 @@ _SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
+    "mfpa_bn_stats_sums": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_stats_finish": ([c_void_p, c_double, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_relu_bwd_sums": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
+    "mfpa_bn_relu_bwd_finish": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
+                                 c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
                            c_void_p], c_int),

@@ -162,6 +162,37 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __rest
   coef[2 * C + c] = (float)(ka * sgx / count);
 }
 
+// SyncBN building blocks: per-channel partial pairs -> one [C][2] float64 row (the caller all-reduces it across ranks) ...
+__global__ __launch_bounds__(256) void pair_sums_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                        double* __restrict__ sums) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int b = lane; b < nblk; b += 64) {
+    s += partial[((size_t)b * C + c) * 2];
+    ss += partial[((size_t)b * C + c) * 2 + 1];
+  }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if (lane == 0) { sums[2 * c] = s; sums[2 * c + 1] = ss; }
+}
+
+// ... and the backward finish from LOCAL sums (this rank's dgamma / dbeta: the gradient all-reduce adds the ranks) and GLOBAL
+// sums over `count` pixels of all ranks (the mean terms of the input gradient).
+__global__ __launch_bounds__(256) void bn_bwd_finish_sync_kernel(const double* __restrict__ local, const double* __restrict__ global,
+                                                                 int C, double count, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] = (float)local[2 * c + 1];
+  dbeta[c] = (float)local[2 * c];
+  const double ka = (double)gamma[c] * (double)invstd[c];
+  coef[c] = (float)ka;
+  coef[C + c] = (float)(ka * global[2 * c] / count);
+  coef[2 * C + c] = (float)(ka * global[2 * c + 1] / count);
+}
+
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ partial, int nblk, int C,
                                                             float* __restrict__ out) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -863,6 +894,68 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+static bool bn_shape_ok(long long npix, int C) {
+  return npix >= 0 && C >= 4 && C % 4 == 0 && !(C / 4 < 256 && 256 % (C / 4) != 0) && !(C / 4 > 256 && (C / 4) % 256 != 0);
+}
+
+int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, void* stream) {
+  if (!sums || !workspace || !bn_shape_ok(npix, C) || (npix > 0 && !z)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  if (npix == 0) { MFPA_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s)); return MFPA_OK; }
+  const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
+  const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
+                     nullptr, nullptr, workspace, 0u, 0u, 1.f);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, sums);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_bn_stats_finish(const double* sums, double count, int C, const float* gamma, const float* beta, float eps,
+                         float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                         float* running_var, void* stream) {
+  if (!sums || !gamma || !beta || !mean || !invstd || !scale || !shift || C < 1 || !(count >= 1.0)) return MFPA_EINVAL;
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, mfpa_stream(stream), sums, 1, C, count, eps,
+                     momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, double* sums, double* workspace, unsigned drop_seed,
+                          unsigned drop_thresh, float drop_scale, void* stream) {
+  if (!sums || !workspace || !scale || !shift || !mean || !invstd || !bn_shape_ok(npix, C) || (C & (C - 1))) return MFPA_EINVAL;
+  if (npix > 0 && (!dy || !z)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  if (npix == 0) { MFPA_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s)); return MFPA_OK; }
+  const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
+  const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, z, npix, C, scale, shift, mean, invstd,
+                     workspace, drop_seed, drop_thresh, drop_scale);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, sums);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, const double* local_sums,
+                            const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream) {
+  if (!gamma || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !dgamma || !dbeta || !coef) return MFPA_EINVAL;
+  if (!bn_shape_ok(npix, C) || (C & (C - 1)) || !(global_count >= 1.0) || (npix > 0 && (!dy || !z))) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_finish_sync_kernel, dim3((C + 255) / 256), dim3(256), 0, s, local_sums, global_sums, C, global_count,
+                     gamma, invstd, dgamma, dbeta, coef);
+  MFPA_CHECK_LAUNCH();
+  if (npix == 0) return MFPA_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
                      mean, invstd, coef, drop_seed, drop_thresh, drop_scale);
   MFPA_CHECK_LAUNCH();

@@ -138,12 +138,17 @@ class UNetTrainEngine:
     """Owns kernel-layout master parameters, gradients and Adam moments of a UNet(1, 1) and runs train steps."""
 
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision: int = 0,
-                 wgrad_precision: Optional[int] = None):
+                 wgrad_precision: Optional[int] = None, sync_bn: bool = False):
         self.module = module
         # arithmetic of the convolutions: 0 = fp32 MFMA, 1 = bf16x3 (3 bf16 MFMAs per fp32 product); `wgrad_precision`
         # overrides it for the weight-gradient kernel.  Reductions, BatchNorm statistics, the loss and Adam are fp32/fp64.
         self.precision = precision
         self.wgrad_precision = precision if wgrad_precision is None else wgrad_precision
+        # sync_bn: BatchNorm statistics over the global batch of all ranks (what the single-GPU reference computes) instead of
+        # per-GPU statistics (the DDP default): two small float64 all-reduces per BatchNorm layer and step
+        import torch.distributed as _dist
+        self._global_over_local_batch = 1.0
+        self.sync_bn = bool(sync_bn) and _dist.is_available() and _dist.is_initialized() and _dist.get_world_size(process_group) > 1
         self.device = next(module.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("the training engine runs on the MI355X only")
@@ -246,9 +251,27 @@ class UNetTrainEngine:
         return out
 
     # ------------------------------------------------------------------ kernels with engine state
+    def _all_reduce_sums(self, sums_and_count: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        dist.all_reduce(sums_and_count, op=dist.ReduceOp.SUM, group=self.group)
+        return sums_and_count
+
     def _bn_stats(self, z, bn, g, b) -> Stats:
         C = z.shape[-1]
         st = Stats(C, z.device)
+        if self.sync_bn:
+            # statistics over the GLOBAL batch (the single-GPU reference's semantics): local (sum, sum^2) + pixel count,
+            # one small SUM all-reduce, finish from the global sums
+            sc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
+            check(lib().mfpa_bn_stats_sums(ptr(z), _npix(z), C, ptr(sc), ptr(self.workspace), stream()), "mfpa_bn_stats_sums")
+            self._all_reduce_sums(sc)
+            count = float(_npix(z)) * self._global_over_local_batch      # every rank holds clips of the same H x W
+            check(lib().mfpa_bn_stats_finish(ptr(sc), count, C, ptr(self.P[g]), ptr(self.P[b]), BN_EPS, BN_MOMENTUM,
+                                             ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
+                                             ptr(self.running[bn + ".running_mean"]), ptr(self.running[bn + ".running_var"]),
+                                             stream()), "mfpa_bn_stats_finish")
+            st.count_host = count
+            return st
         check(lib().mfpa_bn_stats(ptr(z), _npix(z), C, ptr(self.P[g]), ptr(self.P[b]), BN_EPS, BN_MOMENTUM, ptr(st.mean),
                                   ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(self.running[bn + ".running_mean"]),
                                   ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
@@ -257,6 +280,17 @@ class UNetTrainEngine:
     def _bn_relu_bwd(self, dy, z, st: Stats, g, b):
         C = z.shape[-1]
         coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
+        if self.sync_bn:
+            loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
+            check(lib().mfpa_bn_relu_bwd_sums(ptr(dy), ptr(z), _npix(z), C, ptr(st.scale), ptr(st.shift), ptr(st.mean),
+                                              ptr(st.invstd), ptr(loc), ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2],
+                                              stream()), "mfpa_bn_relu_bwd_sums")
+            glob = self._all_reduce_sums(loc.clone())
+            check(lib().mfpa_bn_relu_bwd_finish(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
+                                                ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
+                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], stream()),
+                  "mfpa_bn_relu_bwd_finish")
+            return dy
         check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                      ptr(st.mean), ptr(st.invstd), ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
                                      ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], stream()),
@@ -417,6 +451,11 @@ class UNetTrainEngine:
     def train_step(self, aug_spec64, aug_denom, clean_spec64):
         """One optimisation step on spectrograms: aug_spec64 raw float64 |STFT| (B,F,T) with its normaliser
         aug_denom (B,), clean_spec64 the normalised float64 target.  Returns the loss (device float64 scalar)."""
+        if self.sync_bn:                      # one host round trip per step: global batch size / local batch size
+            import torch.distributed as dist
+            nb = torch.tensor([float(aug_spec64.shape[0])], dtype=torch.float64, device=aug_spec64.device)
+            dist.all_reduce(nb, op=dist.ReduceOp.SUM, group=self.group)
+            self._global_over_local_batch = float(nb.item()) / float(aug_spec64.shape[0])
         pred = self.forward(spec64=aug_spec64, denom=aug_denom)
         loss, dpred = self.l1_loss(pred, clean_spec64)
         self.backward(dpred)

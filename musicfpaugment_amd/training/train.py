@@ -81,14 +81,16 @@ class Trainer:
                  learning_rate: float = LEARNING_RATE, train_steps: int = TRAIN_STEPS, val_steps: int = VAL_STEPS,
                  device="cuda", ckpt_path: Optional[str] = None, input_type: str = "spec",
                  scheduler_factor: float = 0.1, scheduler_patience: int = 10, early_stop_patience: int = 20,
-                 precision: int = 0):
+                 precision: int = 0, sync_bn: bool = False):
         """`precision` (not in the reference): 0 = exact fp32 products on the fp32 matrix cores, 1 = bf16x3 (2.4x the
-        step rate; gradients deviate ~1e-2 relative from fp32 autograd, see tests/test_gpu_train.py)."""
+        step rate; gradients deviate ~1e-2 relative from fp32 autograd, see tests/test_gpu_train.py).  `sync_bn` (multi-GPU):
+        BatchNorm statistics over the global batch, so that N GPUs x B/N clips reproduce the reference's single-GPU step on
+        B clips (tests/test_gpu_dist.py); default per-GPU statistics."""
         if input_type != "spec":
             raise NotImplementedError("input_type='audio' is the Demucs branch (next tier, SURVEY.md §8f-2)")
         self.device = torch.device(device)
         self.model = model.to(self.device)
-        self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, precision=precision)
+        self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, precision=precision, sync_bn=sync_bn)
         self.scheduler = ReduceLROnPlateau(self.engine, scheduler_factor, scheduler_patience)
         self.early_stopping = EarlyStopping(early_stop_patience)
         self.train_loader_iter, self.val_loader_iter = train_loader, val_loader

@@ -97,3 +97,28 @@ def test_bench_runs_under_torchrun_with_two_ranks(mode):
     assert out["scaling"] == "weak" and out["unit"] == "clips/s" and "roofline" in out
     assert "cpu_baseline" not in out                                             # N = 1 only
     assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 0.01 * out["value"]   # whole-job aggregate
+
+
+def test_two_rank_sync_batchnorm_step_equals_the_single_gpu_step():
+    """sync_bn=True: BatchNorm statistics over the global batch -- a 2 x 2-clip data-parallel step reproduces the 4-clip
+    single-GPU step of the reference semantics (parameters, running statistics, mean loss)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dist_syncbn_worker", os.path.join(ROOT, "tests", "_dist_syncbn_worker.py"))
+    worker = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(worker)
+    eng, loss = worker.step(0, 4, False)                                         # one process, the whole batch, plain BatchNorm
+    want = eng.flat_p.cpu().numpy()
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29536", os.path.join(ROOT, "tests", "_dist_syncbn_worker.py"), tmp]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]
+    np.testing.assert_array_equal(got[0]["params"], got[1]["params"])
+    np.testing.assert_allclose(0.5 * (got[0]["loss"] + got[1]["loss"]), loss, rtol=1e-6)     # mean of the shard means
+    np.testing.assert_allclose(got[0]["rm"], eng.running["inc.double_conv.1.running_mean"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got[0]["rv"], eng.running["down4.maxpool_conv.1.double_conv.4.running_var"].cpu().numpy(), rtol=1e-4)
+    diff = np.abs(got[0]["params"] - want)                                       # Adam's first step is lr * sign-like: see above
+    assert np.quantile(diff, 0.999) <= 1e-6, np.quantile(diff, 0.999)
+    assert float(np.mean(diff > 1e-5)) < 1e-4 and diff.max() <= 2.1e-3
