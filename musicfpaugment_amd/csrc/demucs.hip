@@ -14,6 +14,7 @@
 // The 1-channel ends (first Conv1d, last ConvTranspose1d), the sinc x2 resamplers and the std normalisation are
 // small VALU kernels.
 #include "mfpa_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -155,6 +156,97 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
     __syncthreads();
   }
 
+  gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
+}
+
+// Short-K form (the 48-channel 1x1 + GLU layers at the full-rate ends of the network: 16.4 M rows x 48 x 96, as much HBM time
+// as MFMA time).  The whole K extent of both tiles is staged at once -- every global load of the workgroup is in flight
+// together, one barrier, no chunk loop -- which is what a three-chunk pipeline cannot do: it exposed one memory latency
+// per chunk.
+template <bool C1SRC, int K>
+__global__ __launch_bounds__(256, 3) void gemm_smallk_kernel(GemmArgs a) {
+  constexpr int LD = K + 4, QPR = K / 4;                // LDS row (floats): 208 B for K = 48, conflict-free ds_read_b128
+  constexpr int A_F4 = (GBM * QPR + 255) / 256, B_F4 = (GBN * QPR + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[GBM * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[GBN * LD];
+  __shared__ __attribute__((aligned(16))) float W1s[C1SRC ? 9 * K : 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;
+  f32x4 ar[A_F4], br[B_F4], x0[C1SRC ? A_F4 : 1], x1[C1SRC ? A_F4 : 1];
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    const int idx = tid + 256 * i;
+    br[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < GBN * QPR) br[i] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + idx / QPR) * K + 4 * (idx % QPR));
+  }
+  if (C1SRC) {
+    const float* xb = a.c1_x + (size_t)b * a.c1_lin;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + 256 * i, m = m0 + idx / QPR;
+      x0[i] = x1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < GBM * QPR && m < a.M) {
+        x0[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)m);
+        x1[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)m + 4);
+      }
+    }
+    for (int i = tid; i < 8 * K; i += 256) W1s[i] = a.c1_w[i];
+    for (int i = tid; i < K; i += 256) W1s[8 * K + i] = a.c1_b[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {              // conv1d_c1_kernel's arithmetic, same order: bias, then taps 0..7
+      const int idx = tid + 256 * i, c = 4 * (idx % QPR);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < GBM * QPR && m0 + idx / QPR < a.M) {
+        v = *reinterpret_cast<const f32x4*>(&W1s[8 * K + c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += x0[i][j] * *reinterpret_cast<const f32x4*>(&W1s[j * K + c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += x1[i][j] * *reinterpret_cast<const f32x4*>(&W1s[(4 + j) * K + c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      }
+      ar[i] = v;
+    }
+  } else {
+    const float* Ab = a.A + (size_t)b * a.strideA;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + 256 * i, m = m0 + idx / QPR;
+      ar[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < GBM * QPR && m < a.M) ar[i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + 4 * (idx % QPR));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < GBM * QPR) *reinterpret_cast<f32x4*>(&As[(idx / QPR) * LD + 4 * (idx % QPR)]) = ar[i];
+  }
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < GBN * QPR) *reinterpret_cast<f32x4*>(&Bs[(idx / QPR) * LD + 4 * (idx % QPR)]) = br[i];
+  }
+  __syncthreads();
+  floatx16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  const float* Ap = &As[(wave * 32 + li) * LD + 4 * lh];
+  const float* Bp = &Bs[li * LD + 4 * lh];
+#pragma unroll
+  for (int s = 0; s < K / 8; ++s) {
+    const f32x4 af = *reinterpret_cast<const f32x4*>(Ap + 8 * s);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bp + 8 * s);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bp + 32 * LD + 8 * s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], b0[k], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], b1[k], acc[1], 0, 0, 0);
+    }
+  }
   gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
 }
 
@@ -576,6 +668,11 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_gemm_calls.md).
   if (d->precision == 1 && d->K % HKC == 0 && d->K >= 256) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  } else if (d->K == 48 && d->c1_x) {
+    hipLaunchKernelGGL((gemm_smallk_kernel<true, 48>), grid, dim3(256), 0, mfpa_stream(stream), a);
+  } else if (d->K == 48) {
+    hipLaunchKernelGGL((gemm_smallk_kernel<false, 48>), grid, dim3(256), 0, mfpa_stream(stream), a);
+
   } else if (d->c1_x) {
     hipLaunchKernelGGL(gemm_mfma_kernel<true>, grid, dim3(256), 0, mfpa_stream(stream), a);
   } else {
