@@ -251,7 +251,9 @@ def bench_train(args, rank, world, dev, dist):
     net = UNet(1, 1, rate=0.05)
     net.load_state_dict(formula_state_dict(0))
     net = net.to(dev).train()
-    eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0, sync_bn=args.sync_bn)
+    wprec = {"fp32": 0, "bf16x3": 1, "bf16": 2}[args.wgrad]
+    eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0, wgrad_precision=wprec,
+                          sync_bn=args.sync_bn)
     base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank)
     noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False)
     reps = (B + len(base) - 1) // len(base)
@@ -302,13 +304,15 @@ def bench_train(args, rank, world, dev, dist):
         mfma_gflop = 280.1 - 3 * 0.082               # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU)
         conv_ms = timer.total_ms()
         achieved = mfma_gflop * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12
+        issue_x = 2.0 + {"bf16x3": 3, "bf16": 1, "fp32": 0}[args.wgrad] / 3.0      # fp32 weight gradients run on the fp32 cores
         print(json.dumps({
             "metric": "8s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": ("bf16x3 convolutions (forward, input and weight gradients; fp32 operands split into bf16 hi+lo, fp32 "
-                      "accumulate), fp32/fp64 reductions and Adam") if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "dtype": (f"bf16x3 forward and input-gradient convolutions (fp32 operands split into bf16 hi+lo, fp32 accumulate), "
+                      f"{args.wgrad} weight gradients, fp32/fp64 reductions and Adam") if args.precision == "bf16x3"
+                     else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
@@ -317,9 +321,10 @@ def bench_train(args, rank, world, dev, dist):
                                       + " BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
             "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                          "mfma_flops_issued_per_algorithmic_flop": 3,
-                          "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                          "kernel": "conv_mfma_kernel<PREC 1> + wgrad_bf16x3_kernel", "launches": timer.launches(),
+                          # forward + input gradients (2/3 of the FLOPs) issue 3 bf16 MFMAs per product, the weight gradients 3 or 1
+                          "mfma_flops_issued_per_algorithmic_flop": round(issue_x, 3),
+                          "mfma_issue_frac": round(issue_x * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                          "kernel": f"conv_mfma_kernel<PREC 1> + wgrad_bf16x3_kernel ({args.wgrad} products)", "launches": timer.launches(),
                           "kernel_ms_per_step": round(conv_ms / args.steps, 3)} if args.precision == "bf16x3" else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -342,6 +347,9 @@ def main():
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
+    ap.add_argument("--wgrad", choices=["fp32", "bf16x3", "bf16"], default=None,
+                    help="train mode: arithmetic of the weight-gradient kernel (default: bf16 with --precision bf16x3 -- one bf16 MFMA "
+                         "per product, the sum over all pixels averages the rounding: relative L1 2e-3 per layer -- else fp32)")
     ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: BatchNorm statistics over the global batch")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
@@ -354,6 +362,8 @@ def main():
     args = ap.parse_args()
     if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
         args.precision = "bf16x3"
+    if args.wgrad is None:
+        args.wgrad = "bf16" if args.precision == "bf16x3" else "fp32"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

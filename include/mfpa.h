@@ -299,7 +299,8 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
  *   mode 1: dw[tap][co][ci] += sum_p dz[2y+dy,2x+dx][co] * xin[y,x][ci]    (transposed conv; dw (4,Cout,C0))
  * xin = [x0 (affine+ReLU on load if in_scale0) | x1 zero-padded] exactly as the forward saw it.
  * C0, C1, Cout multiples of 64.  precision 0: fp32 MFMA; 1: bf16x3 (both operands split hi + lo, 3 bf16 MFMAs per
- * product, fp32 accumulate) -- like mfpa_conv_desc.precision. */
+ * product, fp32 accumulate) -- like mfpa_conv_desc.precision; 2: plain bf16 products (one MFMA; the sum over every pixel of
+ * the batch averages the 2^-9 product rounding: relative L1 ~2e-3 per layer, and only the optimiser consumes the result). */
 typedef struct mfpa_wgrad_desc {
   const float* dz; const float* x0; const float* in_scale0; const float* in_shift0; const float* x1;
   float* dw;

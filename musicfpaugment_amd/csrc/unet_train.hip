@@ -462,6 +462,7 @@ __device__ __forceinline__ wg_bf16x8 wg_tr_frag(const char* p0, const char* p1) 
   return r.b;
 }
 
+template <bool PLAIN>
 __device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
   wg_bf16x4 hi, lo;
 #pragma unroll
@@ -470,7 +471,7 @@ __device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
     lo[k] = (__bf16)(v[k] - (float)hi[k]);
   }
   *reinterpret_cast<wg_bf16x4*>(row + 8 * c4) = hi;
-  *reinterpret_cast<wg_bf16x4*>(row + 128 + 8 * c4) = lo;
+  if (!PLAIN) *reinterpret_cast<wg_bf16x4*>(row + 128 + 8 * c4) = lo;
 }
 
 // 8 waves: (co half) x (ci half) x (pixel half of a 128-pixel patch, 4x32 or 8x16 for narrow images); one workgroup
@@ -478,8 +479,13 @@ __device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
 
 // NW = 8: one workgroup per CU on 128-pixel patches; NW = 4: 64-pixel patches, two workgroups per CU whose staging and
 // MFMA phases overlap each other.
-template <int MODE, int PW, int NW>
+// PLAIN: one bf16 MFMA per product (precision 2) -- only the hi halves are staged (192-byte pixel rows: 128 B + 64 B pad keep
+// the four rows of a transposing block on bank offsets 0 / 192 / 128 / 64).  A weight gradient sums over every pixel of the
+// batch, so the 2^-9 rounding of the products averages out (relative L1 2e-3 vs fp32 on one layer, the level of fp32
+// autograd's own noise through the BatchNorm backward) and nothing downstream consumes it except the optimiser.
+template <int MODE, int PW, int NW, bool PLAIN>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(WgradArgs a) {
+  constexpr int ROW = PLAIN ? 192 : WGB_ROW;
   constexpr int WGB_THREADS = 64 * NW, WGB_PIX = 16 * NW;
   constexpr int WGB_PH = WGB_PIX / PW;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   constexpr int D_F4 = WGB_PIX * (WG_T / 4) / WGB_THREADS;            // ... and for the dz tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ds = smem;                          // [128 px][320 B]  dz tile
-  char* Xs = smem + WGB_PIX * WGB_ROW;       // [HP px][320 B]   xin tile with halo
+  char* Xs = smem + WGB_PIX * ROW;       // [HP px][320 B]   xin tile with halo
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -502,8 +508,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   const int c4 = tid % (WG_T / 4);          // this thread's channel quad (the same for every staged pixel: 512 % 16 == 0)
   // transposing read: lane 4q+p of a 16-lane group addresses row q (pixel), columns 4p..4p+3 (channels) of its block
   const int gl = lane & 15, tq = gl >> 2, tp = gl & 3, gsel = (lane >> 4) & 1;
-  const char* a_lane = Ds + (64 * ph + 8 * lh + tq) * WGB_ROW + (32 * cot + 16 * gsel + 4 * tp) * 2;
-  const char* b_lane = Xs + ((64 / PW) * ph * HPW + 8 * lh + tq) * WGB_ROW + (32 * cit + 16 * gsel + 4 * tp) * 2;
+  const char* a_lane = Ds + (64 * ph + 8 * lh + tq) * ROW + (32 * cot + 16 * gsel + 4 * tp) * 2;
+  const char* b_lane = Xs + ((64 / PW) * ph * HPW + 8 * lh + tq) * ROW + (32 * cit + 16 * gsel + 4 * tp) * 2;
 
   f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};
   if (affine) {
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
             }
           }
         }
-        wg_store_split(Xs + pix * WGB_ROW, c4, v);
+        wg_store_split<PLAIN>(Xs + pix * ROW, c4, v);
       }
     }
   };
@@ -587,11 +593,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   };
   auto store_d = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < D_F4; ++it) wg_store_split(Ds + ((tid + it * WGB_THREADS) / (WG_T / 4)) * WGB_ROW, c4, dr[it]);
+    for (int it = 0; it < D_F4; ++it) wg_store_split<PLAIN>(Ds + ((tid + it * WGB_THREADS) / (WG_T / 4)) * ROW, c4, dr[it]);
   };
   auto mfma3 = [&](floatx16& c, wg_bf16x8 ah, wg_bf16x8 al, wg_bf16x8 bh, wg_bf16x8 bl) __attribute__((always_inline)) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    if (!PLAIN) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    }
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
   };
 
@@ -624,20 +632,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
 #pragma unroll 1   // one k-step's 9 taps in flight at a time: bounds the live fragment registers next to 144 accumulators
       for (int ks = 0; ks < WG_PIX / 16; ++ks) {
         // this lane's 8 pixels: k = 16 ks + 8 lh + (0..7) of the wave's 64: patch row 16 ks / PW, columns 16 ks % PW + 8 lh + (0..7)
-        const char* ap = a_lane + (16 * ks) * WGB_ROW;
-        const wg_bf16x8 ah = wg_tr_frag(ap, ap + 4 * WGB_ROW);
-        const wg_bf16x8 al = wg_tr_frag(ap + 128, ap + 4 * WGB_ROW + 128);
+        const char* ap = a_lane + (16 * ks) * ROW;
+        const wg_bf16x8 ah = wg_tr_frag(ap, ap + 4 * ROW);
+        const wg_bf16x8 al = PLAIN ? ah : wg_tr_frag(ap + 128, ap + 4 * ROW + 128);
         if (MODE == 0) {
-          const char* bk = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * WGB_ROW;
+          const char* bk = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * ROW;
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
-            const char* bp = bk + ((t / 3) * HPW + (t % 3)) * WGB_ROW;
-            mfma3(acc[t], ah, al, wg_tr_frag(bp, bp + 4 * WGB_ROW), wg_tr_frag(bp + 128, bp + 4 * WGB_ROW + 128));
+            const char* bp = bk + ((t / 3) * HPW + (t % 3)) * ROW;
+            const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * ROW);
+            mfma3(acc[t], ah, al, bh, PLAIN ? bh : wg_tr_frag(bp + 128, bp + 4 * ROW + 128));
           }
         } else {
-          const char* bp = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * WGB_ROW;
-          const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * WGB_ROW);
-          const wg_bf16x8 bl = wg_tr_frag(bp + 128, bp + 4 * WGB_ROW + 128);
+          const char* bp = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * ROW;
+          const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * ROW);
+          const wg_bf16x8 bl = PLAIN ? bh : wg_tr_frag(bp + 128, bp + 4 * ROW + 128);
 #pragma unroll
           for (int t = 0; t < TAPS; ++t)
             if (t == tap) mfma3(acc[t], ah, al, bh, bl);
@@ -1026,8 +1035,8 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
   if (split > 65535) split = 65535;
   dim3 grid(d->Cout / WG_T, (d->C0 + d->C1) / WG_T, (unsigned)split);
   hipStream_t s = mfpa_stream(stream);
-  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
-  if (d->precision == 1) {
+  if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
+  if (d->precision >= 1) {
     // transposing LDS reads need every lane live (512-thread workgroups, no early exits) -- guaranteed by the kernel shape
     static const int nw_env = getenv("MFPA_WGRAD_NW") ? atoi(getenv("MFPA_WGRAD_NW")) : 0;   // experiments: 4 or 8 waves
     const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : 8;
@@ -1041,20 +1050,22 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
     if (split_b < 1) split_b = 1;
     if (split_b > 65535) split_b = 65535;
     grid.z = (unsigned)split_b;
-    const size_t lds = (size_t)WGB_ROW * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
+    const bool plain = d->precision == 2;
+    const size_t lds = (size_t)(plain ? 192 : WGB_ROW) * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
     const dim3 blk(64 * nw);
-#define MFPA_WG_LAUNCH(M, P, N) hipLaunchKernelGGL((wgrad_bf16x3_kernel<M, P, N>), grid, blk, lds, s, a)
-    if (nw == 8) {
-      if (d->mode == 0 && pw == 32) MFPA_WG_LAUNCH(0, 32, 8);
-      else if (d->mode == 0) MFPA_WG_LAUNCH(0, 16, 8);
-      else if (pw == 32) MFPA_WG_LAUNCH(1, 32, 8);
-      else MFPA_WG_LAUNCH(1, 16, 8);
-    } else {
-      if (d->mode == 0 && pw == 32) MFPA_WG_LAUNCH(0, 32, 4);
-      else if (d->mode == 0) MFPA_WG_LAUNCH(0, 16, 4);
-      else if (pw == 32) MFPA_WG_LAUNCH(1, 32, 4);
-      else MFPA_WG_LAUNCH(1, 16, 4);
-    }
+#define MFPA_WG_LAUNCH(M, P, N, Q) hipLaunchKernelGGL((wgrad_bf16x3_kernel<M, P, N, Q>), grid, blk, lds, s, a)
+#define MFPA_WG_PICK(N, Q)                                  \
+    do {                                                    \
+      if (d->mode == 0 && pw == 32) MFPA_WG_LAUNCH(0, 32, N, Q); \
+      else if (d->mode == 0) MFPA_WG_LAUNCH(0, 16, N, Q);   \
+      else if (pw == 32) MFPA_WG_LAUNCH(1, 32, N, Q);       \
+      else MFPA_WG_LAUNCH(1, 16, N, Q);                     \
+    } while (0)
+    if (nw == 8 && plain) MFPA_WG_PICK(8, true);
+    else if (nw == 8) MFPA_WG_PICK(8, false);
+    else if (plain) MFPA_WG_PICK(4, true);
+    else MFPA_WG_PICK(4, false);
+#undef MFPA_WG_PICK
 #undef MFPA_WG_LAUNCH
   } else if (d->mode == 0) {
     const size_t lds = sizeof(float) * ((size_t)WG_PIX * WG_T + (size_t)(WG_PH + 2) * (WG_PW + 2) * WG_T);

@@ -141,7 +141,8 @@ class UNetTrainEngine:
                  wgrad_precision: Optional[int] = None, sync_bn: bool = False):
         self.module = module
         # arithmetic of the convolutions: 0 = fp32 MFMA, 1 = bf16x3 (3 bf16 MFMAs per fp32 product); `wgrad_precision`
-        # overrides it for the weight-gradient kernel.  Reductions, BatchNorm statistics, the loss and Adam are fp32/fp64.
+        # overrides it for the weight-gradient kernel, which also offers 2 = plain bf16 products (a weight gradient sums over
+        # every pixel of the batch: relative L1 ~2e-3).  Reductions, BatchNorm statistics, the loss and Adam are fp32/fp64.
         self.precision = precision
         self.wgrad_precision = precision if wgrad_precision is None else wgrad_precision
         # sync_bn: BatchNorm statistics over the global batch of all ranks (what the single-GPU reference computes) instead of

@@ -242,15 +242,19 @@ def test_train_step_bf16x3_forward_and_dgrad():
     sd = formula_state_dict(2)
     am, aug_den, clean_spec = _g7_inputs()
     out = []
-    for prec in (0, 1):
+    for prec, wprec in ((0, 0), (1, 1), (1, 2)):          # fp32 | bf16x3 everywhere | bf16x3 + plain-bf16 weight gradients
         net = UNet(1, 1, rate=0.0)
         net.load_state_dict(sd)
-        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec)
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec, wgrad_precision=wprec)
         pred = eng.forward(spec64=am, denom=aug_den)
         loss, dpred = eng.l1_loss(pred, clean_spec)
         eng.backward(dpred)
         out.append((pred.clone(), float(loss), {k: v.clone() for k, v in eng.named_grads().items()}))
-    assert rel(out[1][0], out[0][0]) < 1e-4
-    assert abs(out[1][1] - out[0][1]) < 1e-4 * out[0][1]
-    errs = sorted(rel(out[1][2][k], out[0][2][k]) for k in out[0][2])
-    assert errs[len(errs) // 2] < 3e-2 and errs[-1] < 6e-2, (errs[len(errs) // 2], errs[-1])
+    for o in out[1:]:
+        assert rel(o[0], out[0][0]) < 1e-4
+        assert abs(o[1] - out[0][1]) < 1e-4 * out[0][1]
+        errs = sorted(rel(o[2][k], out[0][2][k]) for k in out[0][2])
+        assert errs[len(errs) // 2] < 3e-2 and errs[-1] < 6e-2, (errs[len(errs) // 2], errs[-1])
+    # the plain-bf16 weight gradient adds little on top of what the bf16x3 input-gradient chain already carries
+    extra = sorted(rel(out[2][2][k], out[1][2][k]) for k in out[0][2])
+    assert extra[len(extra) // 2] < 1e-2, extra[len(extra) // 2]

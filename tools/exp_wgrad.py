@@ -12,11 +12,11 @@ for name, B, H, W, Ci, Co in layers:
     dz = torch.randn(B, H, W, Co, device="cuda")
     dw = torch.zeros(9, Co, Ci, device="cuda")
     out = []
-    for prec in (0, 1):
+    for prec in (0, 1, 2):
         T.wgrad_mfma(dz, x, dw, Co, precision=prec); torch.cuda.synchronize()
         t = time.time()
         for _ in range(3): T.wgrad_mfma(dz, x, dw, Co, precision=prec)
         torch.cuda.synchronize(); dt = (time.time() - t) / 3
         fl = 2.0 * B * H * W * Ci * Co * 9
         out.append(f"{dt*1e6:9.1f} us {fl/dt/1e12:6.1f} TF/s-eq")
-    print(f"{name:26s} fp32 {out[0]}   bf16x3 {out[1]}", flush=True)
+    print(f"{name:26s} fp32 {out[0]}   bf16x3 {out[1]}   bf16 {out[2]}", flush=True)
