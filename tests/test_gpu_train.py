@@ -42,6 +42,9 @@ def test_wgrad_and_dgrad_blocks_vs_autograd():
         dw3 = torch.zeros_like(wp)           # bf16x3 products through the transposing LDS reads: ~2^-17 per product
         T.wgrad_mfma(nhwc(dz), nhwc(x0), dw3, Cout, in_affine=st, x1=None if x1 is None else nhwc(x1), precision=1)
         assert rel(dw3, K.pack_conv3x3(w.grad)) < 1e-4, (B, H, W, C0, C1, Cout, rel(dw3, K.pack_conv3x3(w.grad)))
+        dw2 = torch.zeros_like(wp)           # plain bf16 products: 2^-9 per product, averaged over the pixel sum
+        T.wgrad_mfma(nhwc(dz), nhwc(x0), dw2, Cout, in_affine=st, x1=None if x1 is None else nhwc(x1), precision=2)
+        assert rel(dw2, K.pack_conv3x3(w.grad)) < 2e-2, (B, H, W, C0, C1, Cout, rel(dw2, K.pack_conv3x3(w.grad)))
         # input gradient w.r.t. the lazy activation a0 (and x1): conv of dz with flipped, transposed weights
         wt = wp.flip(0).transpose(1, 2)
         d0 = T.conv_mfma(nhwc(dz), wt[:, :C0].contiguous(), C0)
@@ -70,6 +73,9 @@ def test_wgrad_and_dgrad_blocks_vs_autograd():
         dw3 = torch.zeros_like(wp)
         T.wgrad_mfma(nhwc(du), nhwc(x), dw3, Cin // 2, mode=1, precision=1)
         assert rel(dw3, K.pack_convT2x2(w.grad)) < 1e-4, rel(dw3, K.pack_convT2x2(w.grad))
+        dw2 = torch.zeros_like(wp)
+        T.wgrad_mfma(nhwc(du), nhwc(x), dw2, Cin // 2, mode=1, precision=2)
+        assert rel(dw2, K.pack_convT2x2(w.grad)) < 2e-2, rel(dw2, K.pack_convT2x2(w.grad))
         dx = T.conv_mfma(nhwc(du), wp.transpose(1, 2).contiguous(), Cin, mode=2)
         assert rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-5
 
