@@ -397,6 +397,17 @@ int mfpa_reflect_pad(const float* x, int B, int T, int pad, int shift, int Lout,
 int mfpa_dft_mag(const float* c, long long rows, int bins, long long ldc, int im_off, float* mag, void* stream);
 int mfpa_stft_loss_sums(const float* cx, const float* cy, long long rows, int bins, long long ldc, int im_off, double* out3,
                         double* workspace, void* stream);
+/* Gradient of one resolution with respect to the PREDICTED signal (the adjoint chain of the forward above):
+ *   mfpa_stft_loss_grad       in place on cx: (re, im) <- dL/d(re, im), L = w_sc * sc + w_mag * mag (w_* carry the factors and the
+ *                             1/#resolutions); sums = out3 of mfpa_stft_loss_sums (device); zero below the 1e-7 clamp
+ *   (GEMM with the transposed DFT matrix: dframes = d(re, im) x W)
+ *   mfpa_frames_adjoint       dxp[b][i] = sum_t dframes[b][t][i - t*hop - off]   (overlap-add of the frame gradients)
+ *   mfpa_reflect_pad_adjoint  dx (+)= the reflect padding's adjoint of dxp */
+int mfpa_stft_loss_grad(float* cx, const float* cy, long long rows, int bins, long long ldc, int im_off, const double* sums,
+                        double w_sc, double w_mag, void* stream);
+int mfpa_frames_adjoint(const float* dframes, int B, int frames, long long ldf, int win, int hop, int off, int L, float* dxp,
+                        void* stream);
+int mfpa_reflect_pad_adjoint(const float* dxp, int B, int T, int pad, int L, int accumulate, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * AugmentFP signal chain (next-tier row SURVEY.md §8f-3), augmentation/__init__.py:46-93 and

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class MfpaError(RuntimeError):
@@ -74,6 +74,9 @@ _SIGNATURES = {
     "mfpa_reflect_pad": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_dft_mag": ([c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_void_p], c_int),
     "mfpa_stft_loss_sums": ([c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_stft_loss_grad": ([c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_double, c_double, c_void_p], c_int),
+    "mfpa_frames_adjoint": ([c_void_p, c_int, c_int, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_reflect_pad_adjoint": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_lstm_step": ([c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong,
                         c_void_p, c_void_p, c_longlong, c_void_p], c_int),
     "mfpa_lstm_cell": ([c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,

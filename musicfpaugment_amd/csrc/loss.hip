@@ -80,6 +80,69 @@ __global__ __launch_bounds__(64) void stft_loss_finish_kernel(const double* __re
   }
 }
 
+// Backward of one resolution with respect to the PREDICTED signal x.  In place on the GEMM output of x:
+//   c[row][re k], c[row][im k]  <-  dL/d re, dL/d im,   L = w_sc * ||Y|-|X||_F / ||Y||_F + w_mag * mean |log|Y| - log|X||
+// (loss.py:44-83; w_* carry the factors and the 1/#resolutions of MultiResolutionSTFTLoss).  sums = the forward's
+// [sum (|Y|-|X|)^2, sum |Y|^2, .] (device).  The clamp at 1e-7 has zero gradient below it.
+__global__ __launch_bounds__(256) void stft_loss_grad_kernel(float* __restrict__ cx, const float* __restrict__ cy, long long rows,
+                                                             int bins, long long ldc, int im_off, const double* __restrict__ sums,
+                                                             double w_sc, double w_mag) {
+  const long long total = rows * bins;
+  const double n_diff = sqrt(sums[0]), n_y = sqrt(sums[1]);
+  const float k_sc = (n_diff > 0.0 && n_y > 0.0) ? (float)(w_sc / (n_diff * n_y)) : 0.f;      // d sc / d|X| = -(|Y|-|X|) * k_sc
+  const float k_mag = (float)(w_mag / (double)total);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / bins;
+    const int k = (int)(e % bins);
+    float* row = cx + r * ldc;
+    const float re = row[k], im = row[im_off + k];
+    const float p = re * re + im * im;
+    const float xm = sqrtf(fmaxf(p, 1e-7f)), ym = dft_mag(cy + r * ldc, k, im_off);
+    const float dl = logf(ym) - logf(xm);
+    float g = -(ym - xm) * k_sc;                                           // spectral convergence
+    g -= (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f)) * k_mag / xm;          // log-magnitude L1
+    const float s = p > 1e-7f ? g / xm : 0.f;                              // d|X| / d(re, im) = (re, im) / |X| above the clamp
+    row[k] = s * re;
+    row[im_off + k] = s * im;
+  }
+}
+
+// Adjoint of the framing: dxp[b][i] = sum over frames t of dframes[b][t][i - t*hop - off]  (0 <= . < win).
+__global__ __launch_bounds__(256) void frames_adjoint_kernel(const float* __restrict__ df, int frames, long long ldf, int win,
+                                                             int hop, int off, int L, float* __restrict__ dxp) {
+  const int b = blockIdx.y;
+  const float* dfb = df + (size_t)b * frames * ldf;
+  float* ob = dxp + (size_t)b * L;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+    const int u = i - off;                                   // u = t*hop + j, 0 <= j < win
+    float acc = 0.f;
+    if (u >= 0) {
+      int t_hi = u / hop; if (t_hi > frames - 1) t_hi = frames - 1;
+      for (int t = t_hi; t >= 0; --t) {
+        const int j = u - t * hop;
+        if (j >= win) break;
+        acc += dfb[(size_t)t * ldf + j];
+      }
+    }
+    ob[i] = acc;
+  }
+}
+
+// Adjoint of the reflect padding: dx[s] = dxp[s + pad] + dxp[pad - s] (1 <= s <= pad) + dxp[2(T-1) - s + pad] (T-1-pad <= s <= T-2);
+// accumulate != 0 adds to dx (the three resolutions and the L1 term share one gradient buffer).
+__global__ __launch_bounds__(256) void reflect_pad_adjoint_kernel(const float* __restrict__ dxp, int T, int pad, int L, int accumulate,
+                                                                  float* __restrict__ dx) {
+  const int b = blockIdx.y;
+  const float* ib = dxp + (size_t)b * L;
+  float* ob = dx + (size_t)b * T;
+  for (int s = blockIdx.x * 256 + threadIdx.x; s < T; s += gridDim.x * 256) {
+    float v = ib[s + pad];
+    if (s >= 1 && s <= pad) v += ib[pad - s];
+    if (s >= T - 1 - pad && s <= T - 2) v += ib[2 * (T - 1) - s + pad];
+    ob[s] = accumulate ? ob[s] + v : v;
+  }
+}
+
 constexpr int LOSS_BLOCKS = 1024;
 
 }  // namespace
@@ -116,6 +179,36 @@ int mfpa_stft_loss_sums(const float* cx, const float* cy, long long rows, int bi
   hipLaunchKernelGGL(stft_loss_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cx, cy, rows, bins, ldc, im_off, workspace);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(stft_loss_finish_kernel, dim3(1), dim3(64), 0, s, workspace, (int)blocks, out3);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_stft_loss_grad(float* cx, const float* cy, long long rows, int bins, long long ldc, int im_off, const double* sums,
+                        double w_sc, double w_mag, void* stream) {
+  if (rows == 0) return MFPA_OK;
+  if (!cx || !cy || !sums || rows < 0 || bins < 1 || im_off < bins || ldc < im_off + bins) return MFPA_EINVAL;
+  long long blocks = (rows * bins + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(stft_loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), cx, cy, rows, bins, ldc, im_off,
+                     sums, w_sc, w_mag);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_frames_adjoint(const float* dframes, int B, int frames, long long ldf, int win, int hop, int off, int L, float* dxp,
+                        void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!dframes || !dxp || B < 0 || B > 65535 || frames < 1 || win < 1 || hop < 1 || off < 0 || L < 1 || ldf < win) return MFPA_EINVAL;
+  int gx = (L + 255) / 256; if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(frames_adjoint_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), dframes, frames, ldf, win, hop, off, L, dxp);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_reflect_pad_adjoint(const float* dxp, int B, int T, int pad, int L, int accumulate, float* dx, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!dxp || !dx || B < 0 || B > 65535 || T < 2 || pad < 0 || pad >= T || L < T + 2 * pad) return MFPA_EINVAL;
+  int gx = (T + 255) / 256; if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(reflect_pad_adjoint_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), dxp, T, pad, L, accumulate, dx);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -3,8 +3,9 @@
 ``stft(x, fft_size, hop_size, win_length, window)``, ``STFTLoss`` and ``MultiResolutionSTFTLoss`` keep the reference's
 names, arguments and return conventions ((B, frames, bins) magnitudes; ``(sc_loss, mag_loss)`` scalars, the multi-resolution
 mean multiplied by ``factor_sc`` / ``factor_mag``).  The CQT losses of the file (loss.py:189-322, nnAudio) are never
-instantiated by train.py and are not built.  These are the loss VALUES (validation_epoch, monitoring): the Demucs backward
-pass is not built, so no gradient is produced.
+instantiated by train.py and are not built.  `forward` gives the loss VALUES (validation_epoch, monitoring);
+`value_and_grad` also returns the gradient with respect to the predicted waveform (the Demucs backward pass that would consume it is
+not built).
 
 How: a resolution's STFT is one strided-window GEMM on the fp32 matrix cores (csrc/loss.hip, csrc/demucs.hip):
 frames x windowed-DFT matrix, K = the window length (600 / 1200 / 240 of the 1024 / 2048 / 512-point frames).
@@ -22,6 +23,19 @@ from .._lib import check, lib, ptr, require_gpu, stream
 from ..ops_demucs import gemm
 
 _DFT_CACHE: Dict[Tuple[int, int, int, int], Tuple[torch.Tensor, int, int, int]] = {}
+_DFT_T_CACHE: Dict[Tuple[int, int, int], torch.Tensor] = {}
+
+
+def _dft_matrix_t(fft_size: int, win_length: int, device) -> torch.Tensor:
+    """The transposed windowed DFT matrix (rows = window samples, padded to a multiple of 64; K = npad) for the backward GEMM."""
+    key = (fft_size, win_length, device.index or 0)
+    if key not in _DFT_T_CACHE:
+        W, _, _, kpad = _dft_matrix(fft_size, win_length, device)
+        rows = (kpad + 63) // 64 * 64
+        Wt = torch.zeros((rows, W.shape[0]), dtype=torch.float32, device=device)
+        Wt[:kpad] = W.t()
+        _DFT_T_CACHE[key] = Wt.contiguous()
+    return _DFT_T_CACHE[key]
 
 
 def _dft_matrix(fft_size: int, win_length: int, device) -> Tuple[torch.Tensor, int, int, int]:
@@ -124,6 +138,36 @@ class STFTLoss(torch.nn.Module):
         mag = out[2] / float(rows * bins)                                         # F.l1_loss(log y, log x) (loss.py:83)
         return sc.to(torch.float32), mag.to(torch.float32)
 
+    @torch.no_grad()
+    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor, w_sc: float, w_mag: float, dx: torch.Tensor, accumulate: bool):
+        """(sc, mag) and d(w_sc * sc + w_mag * mag) / dx written (or added) to dx (B, T): the adjoint chain of the forward --
+        loss gradient on (re, im), GEMM with the transposed DFT matrix, overlap-add of the frames, reflect-padding adjoint."""
+        if x.shape != y.shape or dx.shape != x.shape or dx.dtype != torch.float32:
+            raise ValueError("x, y and dx must be float32 tensors of one shape")
+        fs, hop, wl = self.fft_size, self.shift_size, self.win_length
+        Cx, bins, im_off, frames = _dft_rows(x, fs, hop, wl)
+        Cy, _, _, _ = _dft_rows(y, fs, hop, wl)
+        B, T = x.shape
+        rows, npad = B * frames, Cx.shape[2]
+        L = lib()
+        out = torch.empty(3, dtype=torch.float64, device=x.device)
+        ws = torch.empty(3 * L.mfpa_loss_blocks(), dtype=torch.float64, device=x.device)
+        check(L.mfpa_stft_loss_sums(ptr(Cx), ptr(Cy), rows, bins, npad, im_off, ptr(out), ptr(ws), stream()), "mfpa_stft_loss_sums")
+        check(L.mfpa_stft_loss_grad(ptr(Cx), ptr(Cy), rows, bins, npad, im_off, ptr(out), float(w_sc), float(w_mag), stream()),
+              "mfpa_stft_loss_grad")
+        Wt = _dft_matrix_t(fs, wl, x.device)
+        kp = Wt.shape[0]
+        dfr = torch.empty((B, frames, kp), dtype=torch.float32, device=x.device)
+        gemm(ptr(Cx), npad, frames * npad, B, frames, Wt, None, kp, ptr(dfr), kp, frames * kp, precision=0)
+        pad, off = fs // 2, (fs - wl) // 2
+        Lp = T + 2 * pad
+        dxp = torch.empty((B, Lp), dtype=torch.float32, device=x.device)
+        check(L.mfpa_frames_adjoint(ptr(dfr), B, frames, kp, wl, hop, off, Lp, ptr(dxp), stream()), "mfpa_frames_adjoint")
+        check(L.mfpa_reflect_pad_adjoint(ptr(dxp), B, T, pad, Lp, int(accumulate), ptr(dx), stream()), "mfpa_reflect_pad_adjoint")
+        sc = torch.sqrt(out[0]) / torch.sqrt(out[1])
+        mag = out[2] / float(rows * bins)
+        return sc.to(torch.float32), mag.to(torch.float32)
+
 
 class MultiResolutionSTFTLoss(torch.nn.Module):
     """loss.py:128-186."""
@@ -146,3 +190,16 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         sc_loss = sc_loss / len(self.stft_losses)
         mag_loss = mag_loss / len(self.stft_losses)
         return self.factor_sc * sc_loss, self.factor_mag * mag_loss
+
+    @torch.no_grad()
+    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor):
+        """(sc_loss, mag_loss, d(sc_loss + mag_loss) / dx): the two terms training/train.py:297 adds to the L1 loss, and their
+        gradient with respect to the predicted waveform x (what the reference's autograd hands to the Demucs backward pass)."""
+        n = len(self.stft_losses)
+        dx = torch.empty_like(x, dtype=torch.float32)
+        sc_loss, mag_loss = 0.0, 0.0
+        for i, f in enumerate(self.stft_losses):
+            sc_l, mag_l = f.value_and_grad(x, y, self.factor_sc / n, self.factor_mag / n, dx, accumulate=i > 0)
+            sc_loss = sc_loss + sc_l
+            mag_loss = mag_loss + mag_l
+        return self.factor_sc * sc_loss / n, self.factor_mag * mag_loss / n, dx

@@ -55,3 +55,28 @@ def test_multi_resolution_loss_vs_reference_golden_and_oracle(golden):
     # identical signals: both terms vanish
     s0, m0 = crit(x.cuda(), x.cuda())
     assert float(s0) == 0.0 and float(m0) == 0.0
+
+
+def test_multi_resolution_loss_gradient_vs_oracle_autograd(golden):
+    """d(sc + mag) / d(predicted waveform): device adjoint chain vs torch autograd through the oracle (CPU, float32)."""
+    from musicfpaugment_amd.training.loss import MultiResolutionSTFTLoss
+    from oracle import loss as ol
+    g = golden("g11_mrstft_loss")
+    x, y = _signals(g)
+    for fsc, fmag in ((0.5, 0.5), (0.1, 0.0), (0.0, 0.1)):                            # training factors; each term alone
+        crit = MultiResolutionSTFTLoss(factor_sc=fsc, factor_mag=fmag).cuda()
+        sc, mag, dx = crit.value_and_grad(x.cuda(), y.cuda())
+        xr = x.clone().requires_grad_()
+        wsc, wmag, _ = ol.multi_resolution_stft_loss(xr, y, factor_sc=fsc, factor_mag=fmag)
+        (wsc + wmag).backward()
+        np.testing.assert_allclose([float(sc), float(mag)], [float(wsc), float(wmag)], rtol=2e-5, atol=1e-9)
+        err = float((dx.cpu() - xr.grad).abs().sum() / xr.grad.abs().sum())
+        assert err < 2e-4, (fsc, fmag, err)
+    # hop 50 / odd frame counts / a short clip
+    xs, ys = x[:2, :9000].contiguous(), y[:2, :9000].contiguous()
+    crit = MultiResolutionSTFTLoss(factor_sc=0.5, factor_mag=0.5).cuda()
+    _, _, dx = crit.value_and_grad(xs.cuda(), ys.cuda())
+    xr = xs.clone().requires_grad_()
+    a, b, _ = ol.multi_resolution_stft_loss(xr, ys, factor_sc=0.5, factor_mag=0.5)
+    (a + b).backward()
+    assert float((dx.cpu() - xr.grad).abs().sum() / xr.grad.abs().sum()) < 2e-4
