@@ -5,8 +5,10 @@ HighPass -> PeakNormalization, each Bernoulli-gated per example), same `__call__
 `batch_augment((B,1,T)) -> (B,1,T)`, `.augmentation_pipeline.transforms[i].transform_parameters` with the reference's keys.
 
 Differences, on purpose:
-  * impulse responses and background noises come from IN-MEMORY banks (`ir_bank`, `noise_bank`): the reference needs
-    .wav files + torchaudio (file I/O is out of scope, SURVEY.md §2); `synthetic_banks()` builds deterministic ones;
+  * impulse responses and background noises live in banks resident in HBM, given in memory (`ir_bank`, `noise_bank`;
+    `synthetic_banks()` builds deterministic ones) or read ONCE at construction from the reference's arguments
+    (`impulse_response_dir`, `background_paths`) when they hold PCM / float .wav files already at `sample_rate` -- the
+    reference decodes and resamples a file per example with torchaudio (file I/O is out of scope, SURVEY.md §2);
   * the random draws use the same distributions (torch.distributions / random.choice) but are made for the whole batch
     on the host; the per-sample arithmetic runs in csrc/augment.hip;
   * `batch_augment` treats every example like `__call__` does (the reference's Clipping takes its quantile over the
@@ -16,6 +18,7 @@ Differences, on purpose:
 from __future__ import annotations
 
 import ctypes
+import os
 import random
 from typing import Any, Dict, List, Optional
 
@@ -38,6 +41,38 @@ def _hz(m: torch.Tensor) -> torch.Tensor:            # augmentation/utils.py:45-
 
 def rms_normalize(x: torch.Tensor) -> torch.Tensor:  # augmentation/utils.py:190-205
     return x / (x.square().mean(dim=-1, keepdim=True).sqrt() + 1e-8)
+
+
+def _find_wavs(paths: List[str]) -> List[str]:
+    """augmentation/utils.py:83-137: .wav files given directly or found (recursively, sorted per directory) under directories."""
+    out: List[str] = []
+    for p in paths:
+        if str(p).lower().endswith(".wav"):
+            out.append(os.path.abspath(p))
+        elif os.path.isdir(p):
+            for root, _, names in os.walk(p, followlinks=True):
+                out += [os.path.join(root, n) for n in sorted(names) if n.lower().endswith(".wav")]
+    return out
+
+
+def _read_wav(path: str, sample_rate: int) -> torch.Tensor:
+    """A PCM / float .wav as a mono float32 tensor in [-1, 1] (the reference decodes with torchaudio and resamples on the fly,
+    augmentation/utils.py:140-330; here the file must already be at `sample_rate`: resampling and other codecs are file I/O,
+    outside the hot path)."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path)
+    if int(sr) != int(sample_rate):
+        raise NotImplementedError(f"{path}: {sr} Hz, expected {sample_rate} Hz -- resample the banks offline")
+    x = np.asarray(data)
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(2 ** (8 * x.dtype.itemsize - 1))
+    elif x.dtype.kind == "u":                                            # 8-bit PCM is unsigned
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = x.astype(np.float32)
+    if x.ndim == 2:
+        x = x.mean(axis=1)                                               # mono=True
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
 
 
 def synthetic_banks(seed: int = 0, sample_rate: int = 8000, n_ir: int = 8, n_noise: int = 8, noise_seconds: float = 10.0):
@@ -96,10 +131,17 @@ class AugmentFP(object):
                  parameters: Dict[str, float] = DEFAULT_PARAMETERS, impulse_response_dir: Optional[str] = None, *,
                  ir_bank: Optional[List[torch.Tensor]] = None, noise_bank: Optional[Dict[str, List[torch.Tensor]]] = None,
                  device="cuda") -> None:
-        if ir_bank is None or noise_bank is None:
-            raise NotImplementedError("reading .wav impulse responses / DCASE noises is outside the hot path: pass in-memory "
-                                      "`ir_bank` (list of 1-D tensors) and `noise_bank` ({scene: [1-D tensors]}), e.g. "
-                                      "synthetic_banks()")
+        if ir_bank is None:
+            if impulse_response_dir is None:
+                raise ValueError("pass `impulse_response_dir` (a directory of .wav files) or an in-memory `ir_bank`")
+            ir_bank = [_read_wav(os.path.join(impulse_response_dir, f), int(sample_rate))
+                       for f in sorted(os.listdir(impulse_response_dir)) if f.endswith(".wav")]      # __init__.py:41-45
+        if noise_bank is None:
+            if background_paths is None:
+                raise ValueError("pass `background_paths` ({scene: [files or directories]}) or an in-memory `noise_bank`")
+            noise_bank = {scene: [_read_wav(f, int(sample_rate)) for f in _find_wavs(paths)]
+                          for scene, paths in background_paths.items()}
+            noise_bank = {k: v for k, v in noise_bank.items() if len(v) > 0}
         if len(ir_bank) == 0 or len(noise_bank) == 0:
             raise ValueError("There are no supported audio files found.")     # EmptyPathException in the reference
         self.sample_rate = int(sample_rate)
