@@ -99,6 +99,50 @@ class Audfprint_peaks(object):
         pklist = list(zip(cols.tolist(), bins.tolist()))
         return pklist, m.to(torch.float32).cpu().numpy(), spec[0].cpu().numpy()
 
+    # ------------------------------------------------------------------ file-level entry points of the reference
+    @staticmethod
+    def _read_waveform(filename: str, target_sr: int) -> torch.Tensor:
+        """.pkl: the pickled 8 kHz waveform of the reference's query sets (peak_extractor.py:361-368); .wav: PCM / float at the
+        target rate.  mp3 decoding and resampling (torchaudio) are file I/O outside the hot path."""
+        ext = filename.rsplit(".", 1)[-1].lower()
+        if ext == "pkl":
+            import pickle
+            with open(filename, "rb") as fh:
+                return torch.as_tensor(np.asarray(pickle.load(fh)), dtype=torch.float32).reshape(-1)
+        if ext == "wav":
+            from scipy.io import wavfile
+            sr, data = wavfile.read(filename)
+            if int(sr) != int(target_sr):
+                raise NotImplementedError(f"{filename}: {sr} Hz, expected {target_sr} Hz -- resample offline")
+            x = np.asarray(data)
+            x = x.astype(np.float32) / float(2 ** (8 * x.dtype.itemsize - 1)) if x.dtype.kind == "i" else x.astype(np.float32)
+            return torch.from_numpy(np.ascontiguousarray(x.mean(axis=1) if x.ndim == 2 else x, dtype=np.float32))
+        raise NotImplementedError(f"{filename}: only .pkl and .wav inputs (decode other formats offline)")
+
+    def wavfile2peaks(self, filename: str, shifts: Optional[int] = None, get_masks_waveforms: bool = False):
+        """peak_extractor.py:347-424: [(time, bin)] of one file, or the list of `shifts` such lists, or
+        (peaks_mask, waveform, sgram) with get_masks_waveforms."""
+        d = self._read_waveform(filename, self.target_sr)
+        if self.demucs is not None:
+            d = self.demucs(d.reshape(1, -1).to(self.device))[0, 0].cpu()           # :369-376
+        self.soundfiledur = len(d) / self.target_sr
+        if shifts is None or shifts < 2:
+            peaks, peaks_mask, sgram = self.find_peaks(d)
+        else:
+            peaks = [self.find_peaks(d[int(s / self.shifts * self.n_hop):])[0] for s in range(shifts)]
+            peaks_mask = sgram = None
+        if get_masks_waveforms:
+            return peaks_mask, d, sgram
+        return peaks
+
+    def wavfile2hashes(self, filename: str) -> np.ndarray:
+        """peak_extractor.py:426-460: unique sorted (time, hash) rows of one file (the instance's `shifts`)."""
+        d = self._read_waveform(filename, self.target_sr).reshape(1, -1).to(self.device)
+        if self.demucs is not None:
+            d = self.demucs(d)[:, 0].contiguous()
+        uq, n = self.hashes_batch(d)
+        return uq[0, : int(n[0])].cpu().numpy().astype(np.int32)
+
     # ------------------------------------------------------------------ landmarks / hashes (next-tier row §8f-1)
     def hashes_batch(self, wav: torch.Tensor, cap: int = 4096, shifts: Optional[int] = None):
         """(B, T) float32 on the GPU -> (unique sorted (time, hash) rows (B, cap', 2) int32, counts (B,) int32):

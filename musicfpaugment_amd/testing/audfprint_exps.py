@@ -74,3 +74,17 @@ def compute_peaks_metrics(clean_wav: torch.Tensor, augmented_wav: torch.Tensor, 
     keys = ["precision_no_den", "recall_no_den", "f1_score_no_den", "psnr_no_den_spec", "prec_den", "rec_den", "f1_den",
             "psnr_den_spec"]
     return dict(zip(keys, mean))
+
+
+def compute_peaks_metrics_files(queries_augmented, clean_dir: str, analyzer_no_den: Audfprint_peaks, analyzer_den: Audfprint_peaks,
+                                batch: int = 256) -> Dict[str, float]:
+    """The reference's signature (audfprint_exps.py:86-157): a list of augmented query files (.pkl / .wav) whose clean
+    counterparts carry the same file name under `clean_dir` (queries_paths["cleans"], :106-107).  Files are read on the host
+    and handed to the batched device path; queries must share one length."""
+    import os
+    aug = [Audfprint_peaks._read_waveform(q, analyzer_no_den.target_sr) for q in queries_augmented]
+    clean = [Audfprint_peaks._read_waveform(os.path.join(clean_dir, os.path.basename(q)), analyzer_no_den.target_sr)
+             for q in queries_augmented]
+    if len({len(a) for a in aug} | {len(c) for c in clean}) > 1:
+        raise ValueError("queries of different lengths: group them by length before calling the batched harness")
+    return compute_peaks_metrics(torch.stack(clean), torch.stack(aug), analyzer_no_den, analyzer_den, batch=batch)

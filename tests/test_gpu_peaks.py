@@ -195,3 +195,38 @@ def test_peaks_metrics_harness_vs_oracle():
     sa = np.stack([(lambda m: m / m.max())(ostft.magnitude(c)) for c in aug])
     want_psnr = np.mean([10 * np.log10((sc[k].max() - sc[k].min()) ** 2 / np.mean((sa[k] - sc[k]) ** 2)) for k in range(n)])
     assert abs(res["psnr_no_den_spec"] - want_psnr) < 1e-9
+
+
+def test_file_level_entry_points(tmp_path):
+    """wavfile2peaks / wavfile2hashes / compute_peaks_metrics on .pkl and .wav files (reference: peak_extractor.py:347-460,
+    audfprint_exps.py:86-157) agree with the tensor paths."""
+    import pickle
+    from scipy.io import wavfile
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+    from musicfpaugment_amd.testing.audfprint_exps import compute_peaks_metrics, compute_peaks_metrics_files
+    clean = synth.batch(3, seed=2300, n=16000)
+    aug = (0.8 * clean + 0.2 * synth.batch(3, seed=2301, n=16000, tonal=False)).astype(np.float32)
+    (tmp_path / "cleans").mkdir(); (tmp_path / "aug").mkdir()
+    files = []
+    for i in range(3):
+        with open(tmp_path / "cleans" / f"q{i}.pkl", "wb") as fh:
+            pickle.dump(clean[i], fh)
+        with open(tmp_path / "aug" / f"q{i}.pkl", "wb") as fh:
+            pickle.dump(aug[i], fh)
+        files.append(str(tmp_path / "aug" / f"q{i}.pkl"))
+    ext = Audfprint_peaks(None)
+    pk = ext.wavfile2peaks(files[0])
+    assert pk == ext.find_peaks(aug[0])[0] and len(pk) > 0
+    mask, wav, sg = ext.wavfile2peaks(files[1], get_masks_waveforms=True)
+    assert mask.shape == (256, 63) and sg.shape == (257, 63) and torch.equal(wav, torch.from_numpy(aug[1]))
+    h = ext.wavfile2hashes(files[2])
+    uq, n = ext.hashes_batch(torch.from_numpy(aug[2:3]).cuda())
+    np.testing.assert_array_equal(h, uq[0, : int(n[0])].cpu().numpy())
+    wavfile.write(tmp_path / "a.wav", 8000, (aug[0] * 32767).astype(np.int16))
+    assert len(ext.wavfile2peaks(str(tmp_path / "a.wav"))) > 0
+    assert len(ext.wavfile2peaks(files[0], shifts=4)) == 4
+    got = compute_peaks_metrics_files(files, str(tmp_path / "cleans"), ext, ext)
+    want = compute_peaks_metrics(torch.from_numpy(clean), torch.from_numpy(aug), ext, ext)
+    assert got == want
+    with pytest.raises(NotImplementedError):
+        ext.wavfile2peaks("x.mp3")
