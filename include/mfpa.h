@@ -343,6 +343,10 @@ int mfpa_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
  *   mode 0: + bias, optional ReLU (relu = 1);  mode 2: additionally + addend[b*strideAdd + m*ldadd + n]
  *           (relu = 1: after the addition, relu = 2: before it -- `relu(convT(x)) + skip`, model.py:316)
  *   mode 1: GLU -- each 64-row tile of W holds 32 value rows then their 32 gate rows; N = output columns
+ *   mode 3: (acc + bias) * (addend[...] > 0) -- the input gradient of a layer whose input was a ReLU output `addend`
+ *   C2 (optional, training): mode 1 also stores the pre-activations (bias included) in the packed tile order, row pitch
+ *           ldc2 >= npad; relu = 2 also stores relu(acc + bias) before the addition, mode 3 the unmasked acc + bias
+ *           (same indexing as C)
  */
 typedef struct mfpa_gemm_desc {
   const float* A; long long lda, strideA;
@@ -355,6 +359,7 @@ typedef struct mfpa_gemm_desc {
    * mfpa_conv1d_c1_relu -- A[b][m][c] = relu(c1_b[c] + sum_j c1_w[j][c] * c1_x[b][4m + j]), c1_x (batch, c1_lin), c1_w (8, K) --
    * so its (B, L, K) output never exists in HBM (model.py:231-238); A may then be NULL. */
   const float* c1_x; long long c1_lin; const float* c1_w; const float* c1_b;
+  float* C2; long long ldc2, strideC2;
 } mfpa_gemm_desc;
 int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream);
 
@@ -369,8 +374,14 @@ int mfpa_downsample2(const float* x, int B, int T, const float* kernel112, float
 /* First encoder layer Conv1d(1->C, k8, s4)+ReLU: x (B,Lin) -> y (B,Lout,C), w (8,C) tap-major. */
 int mfpa_conv1d_c1_relu(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, float* y,
                         void* stream);
+/* The same without the ReLU when relu == 0 (bias may be NULL): with x = the gradient of the last ConvTranspose1d's output
+ * and w = its (8, C) taps this is that layer's input gradient. */
+int mfpa_conv1d_c1(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, int relu, float* y,
+                   void* stream);
 /* Last decoder layer ConvTranspose1d(C->1, k8, s4): P (B,L+2,C) with zero first/last rows -> y (B, 4(L+1)), w (8,C). */
 int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float bias, float* y, void* stream);
+/* The same with the bias read from device memory (training: the optimiser updates it there). */
+int mfpa_convT1d_c1_dev(const float* P, int B, int L, int C, const float* w, const float* bias_dev, float* y, void* stream);
 /* LSTM cell (gate order i,f,g,o; model.py:91-110 via nn.LSTM): gates (B,4H) rows ldg apart, c (B,H) in/out,
  * hout rows ldh apart; optional hsum = h + addend (the first decoder skip). */
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
@@ -382,6 +393,48 @@ int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, fl
  * bf16x3 products, fp32 accumulate.  H multiple of 128. */
 int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp, float* c,
                    int B, int H, float* hout, long long ldh, float* hsum, const float* addend, long long ldadd, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Demucs training step (training/train.py:275-312, input_type "audio": loss.backward() through training/model.py:290-326).
+ * Input gradients are mfpa_gemm_mfma calls on re-laid-out weights (a Conv1d's input gradient is a ConvTranspose1d of the
+ * output gradient and vice versa); the entries below are the rest of the backward pass.  csrc/demucs_train.hip. */
+/* mfpa_lstm_step that also keeps what the backward step needs: the gate activations [sig i | sig f | tanh g | sig o] of this
+ * step in gsave (B rows ldgs apart; may alias xp) and c_t in cout; the previous cell state is read from cprev (NULL = 0). */
+int mfpa_lstm_step_train(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp,
+                         const float* cprev, long long ldcp, float* cout, long long ldco, int B, int H, float* hout, long long ldh,
+                         float* hsum, const float* addend, long long ldadd, float* gsave, long long ldgs, void* stream);
+/* One LSTM backward time step in one launch: dh = dhout + dgnext W_hh (dgnext = the gate gradients of step t+1, NULL at the
+ * last step; whhT = W_hh^T (H, 4H)), then the cell backward: `gates` (the activations mfpa_lstm_step_train saved for step t)
+ * is overwritten with the gate pre-activation gradients [di | df | dg | do]; dcstate (B, H) carries dc between steps (zero it
+ * before the last step).  ct / cprev: c_t and c_{t-1} (cprev NULL at t = 0).  bf16x3 products.  H multiple of 128. */
+int mfpa_lstm_step_bwd(const float* dgnext, long long ldgn, const float* whhT, float* gates, long long ldg, const float* ct,
+                       long long ldct, const float* cprev, long long ldcp, const float* dhout, long long lddh, float* dcstate, int B,
+                       int H, void* stream);
+/* Weight-gradient GEMM: C[m][n] += sum_{b < batch, r < R} A[b*strideA + r*lda + m] * Bm[b*strideB + r*ldb + n]  (C is
+ * ACCUMULATED into: zero it first).  Rows are time steps: A = an output gradient (B, L, M), Bm = the layer's input as
+ * (possibly overlapping) row windows -- ldb = 4*Cin, N = 8*Cin for the k8/s4 convolutions.  fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: both operands are K-major in HBM, which is that instruction's fragment order), K split over
+ * workgroups, float atomics.  M, N, lda, ldb multiples of 4. */
+typedef struct mfpa_gemm_tn_desc {
+  const float* A; long long lda, strideA;
+  const float* Bm; long long ldb, strideB;
+  float* C; long long ldc;
+  int batch, R, M, N;
+  int precision;   /* 0: fp32 MFMA */
+} mfpa_gemm_tn_desc;
+int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream);
+/* GLU backward (nn.GLU(1), model.py:237,246): u (rows, npad) holds the packed pre-activations mfpa_gemm_mfma stored through C2;
+ * in place u <- dL/du given dg (rows, N) = dL/d(glu output), row pitch ldg. */
+int mfpa_glu_bwd(float* u, long long rows, int npad, int N, const float* dg, long long ldg, void* stream);
+/* out[c] += sum_r x[r*ld + c] (bias gradients; out is accumulated into).  C multiple of 4, <= 8192. */
+int mfpa_colsum_any(const float* x, long long rows, int C, long long ld, float* out, void* stream);
+/* Weight gradient of the two one-channel convolutions (encoder.0.0 and the last ConvTranspose1d), w (8, C) tap-major:
+ * dw[j][c] += sum_{b, t < L} x[b*ldx + 4t + j] * g[b*strideG + t*ldg + c].  C <= 256. */
+int mfpa_c1_wgrad(const float* x, long long ldx, const float* g, long long ldg, long long strideG, int B, int L, int C, float* dw,
+                  void* stream);
+/* Adjoint of mfpa_downsample2: dy (B rows ldy apart, nout gradients each, scaled by scale[b] like the forward) -> dx (B, T). */
+int mfpa_downsample2_adjoint(const float* dy, int B, int ldy, int nout, const float* kernel112, const float* scale, int T, float* dx,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Waveform-domain spectral losses of the Demucs branch, training/loss.py:10-186 (MultiResolutionSTFTLoss; forward).

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class MfpaError(RuntimeError):
@@ -70,6 +70,7 @@ _SIGNATURES = {
     "mfpa_downsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
     "mfpa_conv1d_c1_relu": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_convT1d_c1": ([c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
+    "mfpa_convT1d_c1_dev": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_loss_blocks": ([], c_int),
     "mfpa_reflect_pad": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_dft_mag": ([c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_void_p], c_int),
@@ -81,6 +82,17 @@ _SIGNATURES = {
                         c_void_p, c_void_p, c_longlong, c_void_p], c_int),
     "mfpa_lstm_cell": ([c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,
                         c_longlong, c_void_p], c_int),
+    "mfpa_conv1d_c1": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_lstm_step_train": ([c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong,
+                              c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong,
+                              c_void_p], c_int),
+    "mfpa_lstm_step_bwd": ([c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong,
+                            c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p], c_int),
+    "mfpa_gemm_tn": ([c_void_p, c_void_p], c_int),
+    "mfpa_glu_bwd": ([c_void_p, c_longlong, c_int, c_int, c_void_p, c_longlong, c_void_p], c_int),
+    "mfpa_colsum_any": ([c_void_p, c_longlong, c_int, c_longlong, c_void_p, c_void_p], c_int),
+    "mfpa_c1_wgrad": ([c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_downsample2_adjoint": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_red_blocks": ([], c_int),
     "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
@@ -131,7 +143,16 @@ class GemmDesc(ctypes.Structure):
                 ("C", c_void_p), ("ldc", c_longlong), ("strideC", c_longlong),
                 ("batch", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("npad", c_int), ("mode", c_int),
                 ("relu", c_int), ("precision", c_int),
-                ("c1_x", c_void_p), ("c1_lin", c_longlong), ("c1_w", c_void_p), ("c1_b", c_void_p)]
+                ("c1_x", c_void_p), ("c1_lin", c_longlong), ("c1_w", c_void_p), ("c1_b", c_void_p),
+                ("C2", c_void_p), ("ldc2", c_longlong), ("strideC2", c_longlong)]
+
+
+class GemmTnDesc(ctypes.Structure):
+    """mfpa_gemm_tn_desc of include/mfpa.h."""
+    _fields_ = [("A", c_void_p), ("lda", c_longlong), ("strideA", c_longlong),
+                ("Bm", c_void_p), ("ldb", c_longlong), ("strideB", c_longlong),
+                ("C", c_void_p), ("ldc", c_longlong),
+                ("batch", c_int), ("R", c_int), ("M", c_int), ("N", c_int), ("precision", c_int)]
 
 
 class WgradDesc(ctypes.Structure):

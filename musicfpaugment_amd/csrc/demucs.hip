@@ -31,7 +31,9 @@ struct GemmArgs {
   const float* bias;                           // [Npad] or null
   const float* addend; long long ldadd, strideAdd;   // mode 2: y += addend[b*strideAdd + m*ldadd + n]
   float* C; long long ldc, strideC;
-  int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend
+  float* C2; long long ldc2, strideC2;         // training: second output (mode 1: the packed GLU pre-activations; relu 2: relu(y) before the addition)
+  int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend;
+                                               // 3: * (addend > 0) -- the ReLU backward mask of the layer that produced addend
   // fp32 kernel only: A is not read but COMPUTED while it is staged -- the first encoder layer Conv1d(1 -> K, k8, s4) + ReLU
   // (conv1d_c1_kernel) of the waveform: A[b][m][c] = relu(c1_b[c] + sum_j c1_w[j][c] * c1_x[b][4 m + j])
   const float* c1_x; long long c1_lin;         // (batch, c1_lin) samples
@@ -50,14 +52,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, floatx16 (&acc)
     float v0 = acc[0][r] + bias0, v1 = acc[1][r] + bias1;
     if (a.mode == 1) {                         // GLU: value * sigmoid(gate); output column = (tile index) * 32 + li
       const int n = (n0 / 64) * 32 + li;
+      if (a.C2) {                              // the pre-activations in the packed [32 values | 32 gates] tile order
+        float* c2 = a.C2 + (size_t)b * a.strideC2 + (size_t)m * a.ldc2 + n0 + li;
+        c2[0] = v0; c2[32] = v1;
+      }
       if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0 * (1.f / (1.f + __expf(-v1)));
     } else {
       const int n = n0 + li;
-      if (a.relu == 2) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }   // ReLU before the skip addition
+      if (a.relu == 2) {                       // ReLU before the skip addition
+        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+        if (a.C2) {
+          float* c2 = a.C2 + (size_t)b * a.strideC2 + (size_t)m * a.ldc2;
+          if (n < a.N) c2[n] = v0;
+          if (n + 32 < a.N) c2[n + 32] = v1;
+        }
+      }
       if (a.mode == 2) {
         const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
         if (n < a.N) v0 += ad[n];
         if (n + 32 < a.N) v1 += ad[n + 32];
+      } else if (a.mode == 3) {
+        const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
+        if (a.C2) {                            // the unmasked gradient as well (it is also the skip connection's gradient)
+          float* c2 = a.C2 + (size_t)b * a.strideC2 + (size_t)m * a.ldc2;
+          if (n < a.N) c2[n] = v0;
+          if (n + 32 < a.N) c2[n + 32] = v1;
+        }
+        if (n < a.N) v0 = ad[n] > 0.f ? v0 : 0.f;
+        if (n + 32 < a.N) v1 = ad[n + 32] > 0.f ? v1 : 0.f;
       }
       if (a.relu == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
       if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0;
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(256) void downsample2_kernel(const float* __restric
 // First encoder conv: Conv1d(1 -> C, k=8, s=4) + ReLU on (B, Lin) -> (B, Lout, C).  w [8][C] (tap-major), bias [C].
 __global__ __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict__ x, int Lin, int Lout, int C,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        float* __restrict__ y) {
+                                                        float* __restrict__ y, int relu) {
   const int b = blockIdx.y, C4 = C / 4;
   const float* xb = x + (size_t)b * Lin;
   float* yb = y + (size_t)b * Lout * C;
@@ -441,15 +463,17 @@ __global__ __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict_
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int cq = (int)(e % C4);
     const int t = (int)(e / C4);
-    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
+    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = xb[4 * t + j];
       const f32x4 ww = *reinterpret_cast<const f32x4*>(w + j * C + 4 * cq);
       acc += v * ww;
     }
+    if (relu) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : 0.f;
+      for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : 0.f;
+    }
     *reinterpret_cast<f32x4*>(yb + (size_t)t * C + 4 * cq) = acc;
   }
 }
@@ -457,8 +481,10 @@ __global__ __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict_
 // Last decoder layer: ConvTranspose1d(C -> 1, k=8, s=4) on the zero-padded GLU output P (B, L+2, C):
 // out[4t + j] = bias + sum_c P[t+1][c] w[c][j] + P[t][c] w[c][j+4],  t = 0..L, j = 0..3.   w [8][C] (tap-major).
 __global__ __launch_bounds__(256) void convT1d_c1_kernel(const float* __restrict__ P, int L, int C,
-                                                         const float* __restrict__ w, float bias, float* __restrict__ y) {
+                                                         const float* __restrict__ w, float bias, const float* __restrict__ biasp,
+                                                         float* __restrict__ y) {
   const int b = blockIdx.y;
+  if (biasp) bias = biasp[0];
   const float* Pb = P + (size_t)b * (L + 2) * C;
   float* yb = y + (size_t)b * 4 * (L + 1);
   const int total = 4 * (L + 1);
@@ -514,10 +540,12 @@ constexpr int LBM = 64, LU = 16;         // clips x hidden units per workgroup
 constexpr int LTHREADS = 512;   // 8 waves: (clip half) x (gate-column half) x (k-step half of every chunk)
 
 __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __restrict__ hprev, long long ldhp,
-                                                           const float* __restrict__ whh, const float* __restrict__ xp,
-                                                           long long ldxp, float* __restrict__ c, int B, int H,
+                                                           const float* __restrict__ whh, const float* xp,
+                                                           long long ldxp, const float* cin, long long ldci, float* cout,
+                                                           long long ldco, int B, int H,
                                                            float* __restrict__ hout, long long ldh, float* __restrict__ hsum,
-                                                           const float* __restrict__ addend, long long ldadd, int mtiles) {
+                                                           const float* __restrict__ addend, long long ldadd, int mtiles,
+                                                           float* gsave, long long ldgs) {
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   char* As = lsm;                            // [2][64][LROW]
   char* Bs = lsm + 2 * LBM * LROW;           // [2][64][LROW]
@@ -623,17 +651,26 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
     const float* xr = xp + (size_t)m * ldxp;
     const f32x4 xi = *reinterpret_cast<const f32x4*>(xr + u0), xf = *reinterpret_cast<const f32x4*>(xr + H + u0);
     const f32x4 xg = *reinterpret_cast<const f32x4*>(xr + 2 * H + u0), xo = *reinterpret_cast<const f32x4*>(xr + 3 * H + u0);
-    const f32x4 cp = *reinterpret_cast<const f32x4*>(c + (size_t)m * H + u0);
+    const f32x4 cp = cin ? *reinterpret_cast<const f32x4*>(cin + (size_t)m * ldci + u0) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* g = G + clip * GLDW + 4 * uq;
-    f32x4 cn, hn;
+    f32x4 cn, hn, vi, vf, vg, vo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gi = g[k] + xi[k], gf = g[16 + k] + xf[k], gg = g[32 + k] + xg[k], go = g[48 + k] + xo[k];
       const float si = 1.f / (1.f + expf(-gi)), sf = 1.f / (1.f + expf(-gf)), so = 1.f / (1.f + expf(-go));
-      cn[k] = sf * cp[k] + si * tanhf(gg);
+      const float tg = tanhf(gg);
+      cn[k] = sf * cp[k] + si * tg;
       hn[k] = so * tanhf(cn[k]);
+      vi[k] = si; vf[k] = sf; vg[k] = tg; vo[k] = so;
     }
-    *reinterpret_cast<f32x4*>(c + (size_t)m * H + u0) = cn;
+    if (gsave) {                               // training: the gate activations the backward step needs (may alias xp)
+      float* gr = gsave + (size_t)m * ldgs;
+      *reinterpret_cast<f32x4*>(gr + u0) = vi;
+      *reinterpret_cast<f32x4*>(gr + H + u0) = vf;
+      *reinterpret_cast<f32x4*>(gr + 2 * H + u0) = vg;
+      *reinterpret_cast<f32x4*>(gr + 3 * H + u0) = vo;
+    }
+    *reinterpret_cast<f32x4*>(cout + (size_t)m * ldco + u0) = cn;
     *reinterpret_cast<f32x4*>(hout + (size_t)m * ldh + u0) = hn;
     if (hsum) {
       const f32x4 ad = *reinterpret_cast<const f32x4*>(addend + (size_t)m * ldadd + u0);
@@ -652,13 +689,14 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if ((!d->A && !d->c1_x) || !d->W || !d->C || d->batch < 0 || d->M < 0 || d->N < 1 || d->K < GKC || d->K % GKC) return MFPA_EINVAL;
   if (d->c1_x && (!d->c1_w || !d->c1_b || d->K > 256 || (d->precision == 1 && d->K >= 256) || d->c1_lin < 4 * ((long long)d->M - 1) + 8 ||
                   d->c1_lin % 4)) return MFPA_EINVAL;
-  if (d->npad < 64 || d->npad % 64 || d->mode < 0 || d->mode > 2 || (d->mode == 2 && !d->addend)) return MFPA_EINVAL;
+  if (d->npad < 64 || d->npad % 64 || d->mode < 0 || d->mode > 3 || (d->mode >= 2 && !d->addend)) return MFPA_EINVAL;
   if (d->lda % 4 || d->strideA % 4) return MFPA_EINVAL;   // float4 row loads
   if (d->mode == 1 ? (d->N > d->npad / 2) : (d->N > d->npad)) return MFPA_EINVAL;
   GemmArgs a{};
   a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.W = d->W; a.bias = d->bias;
   a.addend = d->addend; a.ldadd = d->ldadd; a.strideAdd = d->strideAdd;
   a.C = d->C; a.ldc = d->ldc; a.strideC = d->strideC;
+  a.C2 = d->C2; a.ldc2 = d->ldc2; a.strideC2 = d->strideC2;
   a.M = d->M; a.N = d->N; a.K = d->K; a.mode = d->mode; a.relu = d->relu;
   a.c1_x = d->c1_x; a.c1_lin = d->c1_lin; a.c1_w = d->c1_w; a.c1_b = d->c1_b;
   dim3 grid(d->npad / GBN, (d->M + GBM - 1) / GBM, d->batch);
@@ -711,21 +749,36 @@ int mfpa_downsample2(const float* x, int B, int T, const float* kernel112, float
   return MFPA_OK;
 }
 
-int mfpa_conv1d_c1_relu(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, float* y,
-                        void* stream) {
+int mfpa_conv1d_c1(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, int relu, float* y,
+                   void* stream) {
   if (B == 0) return MFPA_OK;
-  if (!x || !w || !bias || !y || B < 0 || B > 65535 || C < 4 || C % 4 || Lout < 1 || Lin < 4 * (Lout - 1) + 8) return MFPA_EINVAL;
+  if (!x || !w || !y || B < 0 || B > 65535 || C < 4 || C % 4 || Lout < 1 || Lin < 4 * (Lout - 1) + 8) return MFPA_EINVAL;
   long long blocks = ((long long)Lout * (C / 4) + 255) / 256; if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(conv1d_c1_kernel, dim3((unsigned)blocks, B), dim3(256), 0, mfpa_stream(stream), x, Lin, Lout, C, w, bias, y);
+  hipLaunchKernelGGL(conv1d_c1_kernel, dim3((unsigned)blocks, B), dim3(256), 0, mfpa_stream(stream), x, Lin, Lout, C, w, bias, y, relu);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
+}
+
+int mfpa_conv1d_c1_relu(const float* x, int B, int Lin, int Lout, int C, const float* w, const float* bias, float* y,
+                        void* stream) {
+  if (B != 0 && !bias) return MFPA_EINVAL;
+  return mfpa_conv1d_c1(x, B, Lin, Lout, C, w, bias, 1, y, stream);
 }
 
 int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float bias, float* y, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!P || !w || !y || B < 0 || B > 65535 || L < 1 || C < 4 || C % 4) return MFPA_EINVAL;
   int gx = (4 * (L + 1) + 255) / 256; if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(convT1d_c1_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), P, L, C, w, bias, y);
+  hipLaunchKernelGGL(convT1d_c1_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), P, L, C, w, bias, (const float*)nullptr, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_convT1d_c1_dev(const float* P, int B, int L, int C, const float* w, const float* bias_dev, float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!P || !w || !bias_dev || !y || B < 0 || B > 65535 || L < 1 || C < 4 || C % 4) return MFPA_EINVAL;
+  int gx = (4 * (L + 1) + 255) / 256; if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(convT1d_c1_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), P, L, C, w, 0.f, bias_dev, y);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -740,8 +793,25 @@ int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped,
   if (total > 0x7fffff) return MFPA_EINVAL;
   const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
   const size_t lds = (size_t)4 * LBM * LROW;
-  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, c, B,
-                     H, hout, ldh, hsum, addend, ldadd, mtiles);
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, c,
+                     (long long)H, c, (long long)H, B, H, hout, ldh, hsum, addend, ldadd, mtiles, (float*)nullptr, 0LL);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_lstm_step_train(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp,
+                         const float* cprev, long long ldcp, float* cout, long long ldco, int B, int H, float* hout, long long ldh,
+                         float* hsum, const float* addend, long long ldadd, float* gsave, long long ldgs, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!whh_grouped || !xp || !cout || !hout || !gsave || B < 0 || H < LKC || H % LKC) return MFPA_EINVAL;
+  if (ldhp % 4 || ldxp % 4 || ldh % 4 || ldadd % 4 || ldcp % 4 || ldco % 4 || ldgs % 4 || (hsum && !addend)) return MFPA_EINVAL;
+  const int mtiles = (B + LBM - 1) / LBM;
+  const long long total = (long long)(H / LU) * mtiles;
+  if (total > 0x7fffff) return MFPA_EINVAL;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  const size_t lds = (size_t)4 * LBM * LROW;
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, cprev,
+                     ldcp, cout, ldco, B, H, hout, ldh, hsum, addend, ldadd, mtiles, gsave, ldgs);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

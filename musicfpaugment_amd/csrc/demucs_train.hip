@@ -1,0 +1,486 @@
+// Demucs training step, backward-pass kernels for MI355X (gfx950) -- SURVEY.md §8f-2 ("+ MRSTFT loss train step").
+// Reference: training/train.py:275-312 (input_type == "audio": L1 + MultiResolutionSTFTLoss, loss.backward(), Adam) over
+// training/model.py:163-326.  torch autograd is not used: every layer's adjoint is written out.
+//
+// Activations are time-major (B, L, C) like the forward (csrc/demucs.hip).  Input gradients of every Conv1d /
+// ConvTranspose1d / 1x1 / LSTM projection are again strided-window GEMMs served by mfpa_gemm_mfma (a Conv1d's input
+// gradient is a ConvTranspose1d of the output gradient and vice versa); its epilogue applies the ReLU mask of the layer
+// below (mode 3).  This file holds what that kernel cannot express:
+//   gemm_tn_kernel        weight gradients  dW[m][n] += sum_rows dY[row][m] * Xwin[row][n]  (K = every time step of the batch)
+//   glu_bwd_kernel        GLU backward on the packed [32 values | 32 gates] pre-activation tiles the forward saved
+//   lstm_step_bwd_kernel  one backward time step: dh_rec = dgates[t+1] W_hh, then the cell backward, in one launch
+//   downsample2 adjoint, the two 1-channel convolutions' weight gradients, column sums (bias gradients)
+#include "mfpa_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 t_bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------- weight-gradient GEMM ("TN")
+// C[m][n] += sum_{b < batch} sum_{r < R} A[b*strideA + r*lda + m] * Bm[b*strideB + r*ldb + n]
+// Both operands are K-major in memory (a row = one time step), which is exactly the fragment order of
+// v_mfma_f32_32x32x2_f32: lane (i, k) of the A operand holds A[k][i], so the tiles are staged as they lie in HBM
+// ([k][m] rows, 32-float pad so the two k rows a wave reads fall on disjoint banks) and read with ds_read_b32.
+// K is split over blockIdx.y (row ranges that never straddle a clip); partial tiles are added with float atomics.
+struct TnArgs {
+  const float* A; long long lda, strideA;
+  const float* Bm; long long ldb, strideB;
+  float* C; long long ldc;
+  int R, M, N;
+  int rs, spb;                 // rows per split, splits per clip
+};
+
+constexpr int TKC = 16;
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDA_ = BM + 32, LDB_ = BN + 32;
+  constexpr int QA = BM / 4, QB = BN / 4;                // float4 per staged row
+  constexpr int FA = TKC * QA / 256, FB = TKC * QB / 256;  // float4 per thread per chunk (TM, TN)
+  __shared__ __attribute__((aligned(16))) float As[2][TKC * LDA_];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TKC * LDB_];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int ntn = (a.N + BN - 1) / BN;
+  const int n0 = (blockIdx.x % ntn) * BN, m0 = (blockIdx.x / ntn) * BM;
+  const int b = blockIdx.y / a.spb;
+  const int rbeg = (blockIdx.y % a.spb) * a.rs;
+  const int rend = rbeg + a.rs < a.R ? rbeg + a.rs : a.R;
+  const float* Ab = a.A + (size_t)b * a.strideA;
+  const float* Bb = a.Bm + (size_t)b * a.strideB;
+  const int nk = (rend - rbeg + TKC - 1) / TKC;
+
+  f32x4 ar[FA], br[FB];
+  auto load = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+      const int idx = tid + 256 * i, row = idx / QA, q = idx % QA;
+      const int r = rbeg + kc * TKC + row, m = m0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rend && m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)r * a.lda + m);
+      ar[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int idx = tid + 256 * i, row = idx / QB, q = idx % QB;
+      const int r = rbeg + kc * TKC + row, n = n0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rend && n < a.N) v = *reinterpret_cast<const f32x4*>(Bb + (size_t)r * a.ldb + n);
+      br[i] = v;
+    }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&As[buf][(idx / QA) * LDA_ + 4 * (idx % QA)]) = ar[i];
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&Bs[buf][(idx / QB) * LDB_ + 4 * (idx % QB)]) = br[i];
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < nk) store(buf ^ 1);
+      if (kc + 2 < nk) load(kc + 2);
+      const float* Ap = &As[buf][lh * LDA_ + wm * 32 * TM + li];
+      const float* Bp = &Bs[buf][lh * LDB_ + wn * 32 * TN + li];
+#pragma unroll
+      for (int s = 0; s < TKC / 2; ++s) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = Ap[2 * s * LDA_ + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = Bp[2 * s * LDB_ + 32 * j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 32 * TN + 32 * j + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < a.M && n < a.N) unsafeAtomicAdd(a.C + (size_t)m * a.ldc + n, acc[i][j][r]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------- GLU backward
+// u (rows, npad): packed pre-activations, tile t = [32 values | 32 gates] of output columns 32 t .. 32 t + 31 (< N).
+// In place: u <- d(loss)/du given dg (rows, N columns, row pitch ldg).
+__global__ __launch_bounds__(256) void glu_bwd_kernel(float* __restrict__ u, long long rows, int npad, int N,
+                                                      const float* __restrict__ dg, long long ldg) {
+  const int tiles = npad / 64;
+  const long long total = rows * tiles * 8;              // one thread = 4 consecutive outputs of a tile
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int q = (int)(e & 7);
+    const long long rt = e >> 3;
+    const int t = (int)(rt % tiles);
+    const long long row = rt / tiles;
+    float* up = u + row * npad + t * 64 + 4 * q;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(up), s = *reinterpret_cast<const f32x4*>(up + 32);
+    const int n = t * 32 + 4 * q;
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) d = *reinterpret_cast<const f32x4*>(dg + row * ldg + n);   // N is a multiple of 4
+    f32x4 dv, ds;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sg = 1.f / (1.f + __expf(-s[k]));
+      dv[k] = d[k] * sg;
+      ds[k] = d[k] * v[k] * sg * (1.f - sg);
+    }
+    *reinterpret_cast<f32x4*>(up) = dv;
+    *reinterpret_cast<f32x4*>(up + 32) = ds;
+  }
+}
+
+// ---------------------------------------------------------------------------------- column sums (bias gradients)
+// out[c] += sum_r x[r*ld + c], any C that is a multiple of 4 (48, 96, ... 3072): LDS accumulators with ds_add_f32.
+__global__ __launch_bounds__(256) void colsum_any_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
+                                                         float* __restrict__ out, long long rows_per_block) {
+  extern __shared__ float accs[];
+  const int tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) accs[c] = 0.f;
+  __syncthreads();
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  const int Q = C / 4;
+  const long long total = (r1 - r0) * Q;
+  for (long long e = tid; e < total; e += 256) {
+    const long long r = r0 + e / Q;
+    const int q = (int)(e % Q);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&accs[4 * q + k], v[k]);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) unsafeAtomicAdd(out + c, accs[c]);
+}
+
+// ---------------------------------------------------------------------------------- 1-channel convolutions' weight gradients
+// dw[j][c] += sum_{b,t} x[b*ldx + 4t + j] * g[b*strideG + t*ldg + c],  j < 8, t < L   (w (8, C) tap-major)
+// serves encoder.0.0 (x = the upsampled input, g = the masked gradient of its ReLU output) and the last
+// ConvTranspose1d (x = the gradient of its output, g = the GLU output it consumed).
+__global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g,
+                                                       long long ldg, long long strideG, int L, int C, float* __restrict__ dw,
+                                                       int rows_per_block) {
+  __shared__ float accs[8 * 256];                        // C <= 256
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < 8 * C; i += 256) accs[i] = 0.f;
+  __syncthreads();
+  const int Q = C / 4, lanes = 256 / Q;                  // row lanes per pass (Q = 12 for C = 48 -> 21 row lanes)
+  const int q = tid % Q, rl = tid / Q;
+  const int t0 = blockIdx.x * rows_per_block;
+  const int t1 = t0 + rows_per_block < L ? t0 + rows_per_block : L;
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes) {
+    const float* xb = x + (size_t)b * ldx;
+    const float* gb = g + (size_t)b * strideG;
+    for (int t = t0 + rl; t < t1; t += lanes) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + (size_t)t * ldg + 4 * q);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)t), x1 = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)t + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += x0[j] * gv; acc[4 + j] += x1[j] * gv; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(&accs[j * C + 4 * q + k], acc[j][k]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 8 * C; i += 256) unsafeAtomicAdd(dw + i, accs[i]);
+}
+
+// ---------------------------------------------------------------------------------- downsample2 adjoint
+// forward (model.py:69-88): out[i] = sc * 0.5 * (x[2i] + sum_k xodd[i + k - 56] ker[k]), i < nout, xodd[j] = x[2j+1].
+// adjoint: dx[2i] = g[i], dx[2j+1] = sum_k g[j + 56 - k] ker[k] with g[i] = 0.5 * sc * dy[i] (0 for i >= nout).
+__global__ __launch_bounds__(256) void downsample2_adj_kernel(const float* __restrict__ dy, int ldy, int nout, const float* __restrict__ ker,
+                                                              const float* __restrict__ scale, int T, float* __restrict__ dx) {
+  __shared__ float kk[112];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 112) kk[tid] = ker[tid];
+  __syncthreads();
+  const float sc = 0.5f * (scale ? scale[b] : 1.f);
+  const float* dyb = dy + (size_t)b * ldy;
+  float* dxb = dx + (size_t)b * T;
+  for (int p = blockIdx.x * 256 + tid; p < T; p += gridDim.x * 256) {
+    float v;
+    if ((p & 1) == 0) {
+      const int i = p >> 1;
+      v = i < nout ? dyb[i] : 0.f;
+    } else {
+      const int j = p >> 1;
+      float s = 0.f;
+      for (int k = 0; k < 112; ++k) {
+        const int i = j + 56 - k;
+        if (i >= 0 && i < nout) s += dyb[i] * kk[k];
+      }
+      v = s;
+    }
+    dxb[p] = sc * v;
+  }
+}
+
+// ---------------------------------------------------------------------------------- LSTM backward time step
+// One launch per step t (t = T-1 .. 0):
+//   dh    = dhout[t] + dgates[t+1] W_hh                      (GEMM, K = 4H; skipped at t = T-1)
+//   do = dh tanh(c_t) o (1-o);  dc = dc_next + dh o (1 - tanh^2 c_t);  di = dc g i (1-i);  df = dc c_{t-1} f (1-f);
+//   dg = dc i (1-g^2);  dc_next <- dc f;   dgates[t] overwrites the saved gate activations [i | f | g | o] of step t.
+// A workgroup owns 64 clips x 32 hidden units: B operand = rows u of W_hh^T (H, 4H).  8 waves = (clip half) x (K quarter of
+// every 128-wide chunk); bf16x3 products like the forward step; workgroup id -> (XCD, slot) so that an XCD's three unit
+// groups keep their 1.2 MB of W_hh^T in that XCD's L2 for all steps.
+constexpr int BKC = 128;
+constexpr int BROW = 4 * BKC + 16;       // LDS row bytes [128 hi | 128 lo | pad]
+constexpr int BBM = 64, BU = 32;
+constexpr int BTHREADS = 512;
+
+__global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float* __restrict__ dgnext, long long ldgn,
+                                                                    const float* __restrict__ whhT, float* gs, long long ldgs,
+                                                                    const float* __restrict__ ct, long long ldct,
+                                                                    const float* __restrict__ cprev, long long ldcp,
+                                                                    const float* __restrict__ dhout, long long lddh,
+                                                                    float* __restrict__ dcstate, int B, int H, int mtiles) {
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  char* As = lsm;                            // [2][64][BROW]
+  char* Bs = lsm + 2 * BBM * BROW;           // [2][32][BROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wk = wave >> 1;   // wk: k-steps 2 wk, 2 wk + 1 of each chunk
+  const int ngroups = H / BU;
+  int grp, mt;
+  {
+    const int id = blockIdx.x, total = ngroups * mtiles;
+    const int per_xcd = (total + 7) / 8;
+    const int lin = (id % 8) * per_xcd + id / 8;
+    if (lin >= total) return;                // uniform per workgroup, before any barrier
+    grp = lin / mtiles; mt = lin % mtiles;
+  }
+  const int m0 = mt * BBM;
+  const int K = 4 * H;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  if (dgnext != nullptr) {
+    const float* Wg = whhT + (size_t)grp * BU * K;
+    const int nk = K / BKC;
+    f32x4 ar[4], br[2];
+    const int q = tid & 31, r0 = tid >> 5;             // column quad, first row; rows r0 + 16 i
+    auto load = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 16 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < B) v = *reinterpret_cast<const f32x4*>(dgnext + (size_t)m * ldgn + kc * BKC + 4 * q);
+        ar[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) br[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(r0 + 16 * i) * K + kc * BKC + 4 * q);
+    };
+    auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
+      t_bf16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (__bf16)v[k];
+        lo[k] = (__bf16)(v[k] - (float)hi[k]);
+      }
+      *reinterpret_cast<t_bf16x4*>(row + 8 * q) = hi;
+      *reinterpret_cast<t_bf16x4*>(row + 2 * BKC + 8 * q) = lo;
+    };
+    auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) split_store(As + (buf * BBM + r0 + 16 * i) * BROW, ar[i]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) split_store(Bs + (buf * BU + r0 + 16 * i) * BROW, br[i]);
+    };
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < nk) store(buf ^ 1);
+      if (kc + 2 < nk) load(kc + 2);
+      const char* Ap = As + (buf * BBM + wm * 32 + li) * BROW + 16 * lh;
+      const char* Bp = Bs + (buf * BU + li) * BROW + 16 * lh;
+#pragma unroll
+      for (int s = 2 * wk; s < 2 * wk + 2; ++s) {
+        const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8*>(Ap + 32 * s);
+        const t_bf16x8 al = *reinterpret_cast<const t_bf16x8*>(Ap + 2 * BKC + 32 * s);
+        const t_bf16x8 bh = *reinterpret_cast<const t_bf16x8*>(Bp + 32 * s);
+        const t_bf16x8 bl = *reinterpret_cast<const t_bf16x8*>(Bp + 2 * BKC + 32 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  // the four K quarters -> LDS slabs [4][64 clips][36], summed by the cell threads
+  float* G = reinterpret_cast<float*>(lsm);
+  constexpr int GLDW = 36;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    G[(wk * BBM + m) * GLDW + li] = acc[r];
+  }
+  __syncthreads();
+  const int clip = tid >> 3, uq = tid & 7;
+  const int m = m0 + clip;
+  if (m < B) {
+    const int u0 = grp * BU + 4 * uq;
+    f32x4 dh = *reinterpret_cast<const f32x4*>(dhout + (size_t)m * lddh + u0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) dh += *reinterpret_cast<const f32x4*>(G + (w * BBM + clip) * GLDW + 4 * uq);
+    float* gr = gs + (size_t)m * ldgs;
+    const f32x4 vi = *reinterpret_cast<const f32x4*>(gr + u0), vf = *reinterpret_cast<const f32x4*>(gr + H + u0);
+    const f32x4 vg = *reinterpret_cast<const f32x4*>(gr + 2 * H + u0), vo = *reinterpret_cast<const f32x4*>(gr + 3 * H + u0);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(ct + (size_t)m * ldct + u0);
+    const f32x4 cp = cprev ? *reinterpret_cast<const f32x4*>(cprev + (size_t)m * ldcp + u0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dcs = *reinterpret_cast<const f32x4*>(dcstate + (size_t)m * H + u0);
+    f32x4 di, df, dg, dO;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float tc = tanhf(c[k]);
+      dO[k] = dh[k] * tc * vo[k] * (1.f - vo[k]);
+      const float dc = dcs[k] + dh[k] * vo[k] * (1.f - tc * tc);
+      di[k] = dc * vg[k] * vi[k] * (1.f - vi[k]);
+      df[k] = dc * cp[k] * vf[k] * (1.f - vf[k]);
+      dg[k] = dc * vi[k] * (1.f - vg[k] * vg[k]);
+      dcs[k] = dc * vf[k];
+    }
+    *reinterpret_cast<f32x4*>(gr + u0) = di;
+    *reinterpret_cast<f32x4*>(gr + H + u0) = df;
+    *reinterpret_cast<f32x4*>(gr + 2 * H + u0) = dg;
+    *reinterpret_cast<f32x4*>(gr + 3 * H + u0) = dO;
+    *reinterpret_cast<f32x4*>(dcstate + (size_t)m * H + u0) = dcs;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
+  if (!d) return MFPA_EINVAL;
+  if (d->batch == 0 || d->R == 0) return MFPA_OK;
+  if (!d->A || !d->Bm || !d->C || d->batch < 0 || d->R < 0 || d->M < 4 || d->N < 4 || d->M % 4 || d->N % 4) return MFPA_EINVAL;
+  if (d->lda % 4 || d->ldb % 4 || d->strideA % 4 || d->strideB % 4 || d->ldc < d->N) return MFPA_EINVAL;   // float4 row loads
+  if (d->precision != 0) return MFPA_EINVAL;
+  const bool big = d->M > 64 && d->N > 64;
+  const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+  const long long tiles = (long long)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  // rows per K split: about 2048 workgroups in all, at least 64 rows each, never across clips
+  long long want = 2048 / tiles; if (want < 1) want = 1;
+  long long rs = ((long long)d->batch * d->R + want - 1) / want;
+  if (rs < 64) rs = 64;
+  rs = (rs + TKC - 1) / TKC * TKC;
+  long long spb = (d->R + rs - 1) / rs;
+  while (spb * d->batch > 65535) { rs *= 2; spb = (d->R + rs - 1) / rs; }
+  if (tiles > 0x7fffffffLL) return MFPA_EINVAL;
+  TnArgs a{};
+  a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.Bm = d->Bm; a.ldb = d->ldb; a.strideB = d->strideB;
+  a.C = d->C; a.ldc = d->ldc; a.R = d->R; a.M = d->M; a.N = d->N; a.rs = (int)rs; a.spb = (int)spb;
+  dim3 grid((unsigned)tiles, (unsigned)(spb * d->batch));
+  if (big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, mfpa_stream(stream), a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), grid, dim3(256), 0, mfpa_stream(stream), a);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_glu_bwd(float* u, long long rows, int npad, int N, const float* dg, long long ldg, void* stream) {
+  if (rows == 0) return MFPA_OK;
+  if (!u || !dg || rows < 0 || npad < 64 || npad % 64 || N < 4 || N % 4 || N > npad / 2 || ldg < N || ldg % 4) return MFPA_EINVAL;
+  const long long total = rows * (npad / 64) * 8;
+  long long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), u, rows, npad, N, dg, ldg);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_colsum_any(const float* x, long long rows, int C, long long ld, float* out, void* stream) {
+  if (rows == 0) return MFPA_OK;
+  if (!x || !out || rows < 0 || C < 4 || C % 4 || C > 8192 || ld < C || ld % 4) return MFPA_EINVAL;
+  long long blocks = (rows * (C / 4) + 256 * 64 - 1) / (256 * 64);      // about 64 float4 per thread
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  const long long rpb = (rows + blocks - 1) / blocks;
+  blocks = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_any_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * sizeof(float), mfpa_stream(stream), x, rows, C,
+                     ld, out, rpb);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_c1_wgrad(const float* x, long long ldx, const float* g, long long ldg, long long strideG, int B, int L, int C, float* dw,
+                  void* stream) {
+  if (B == 0 || L == 0) return MFPA_OK;
+  if (!x || !g || !dw || B < 0 || B > 65535 || L < 0 || C < 4 || C % 4 || C > 256 || ldx % 4 || ldg % 4 || strideG % 4 ||
+      ldx < 4 * ((long long)L - 1) + 8) return MFPA_EINVAL;
+  int gx = (L + 2047) / 2048; if (gx > 64) gx = 64;
+  const int rpb = (L + gx - 1) / gx;
+  gx = (L + rpb - 1) / rpb;
+  hipLaunchKernelGGL(c1_wgrad_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), x, ldx, g, ldg, strideG, L, C, dw, rpb);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_downsample2_adjoint(const float* dy, int B, int ldy, int nout, const float* kernel112, const float* scale, int T, float* dx,
+                             void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!dy || !kernel112 || !dx || B < 0 || B > 65535 || T < 2 || nout < 1 || nout > (T + 1) / 2 || ldy < nout) return MFPA_EINVAL;
+  int gx = (T + 255) / 256; if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(downsample2_adj_kernel, dim3(gx, B), dim3(256), 0, mfpa_stream(stream), dy, ldy, nout, kernel112, scale, T, dx);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_lstm_step_bwd(const float* dgnext, long long ldgn, const float* whhT, float* gates, long long ldg, const float* ct,
+                       long long ldct, const float* cprev, long long ldcp, const float* dhout, long long lddh, float* dcstate, int B,
+                       int H, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!whhT || !gates || !ct || !dhout || !dcstate || B < 0 || H < BKC || H % BKC) return MFPA_EINVAL;
+  if (ldgn % 4 || ldg % 4 || ldct % 4 || ldcp % 4 || lddh % 4) return MFPA_EINVAL;
+  const int mtiles = (B + BBM - 1) / BBM;
+  const long long total = (long long)(H / BU) * mtiles;
+  if (total > 0x7fffff) return MFPA_EINVAL;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  const size_t lds = (size_t)2 * (BBM + BU) * BROW;
+  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg, ct, ldct,
+                     cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // extern "C"

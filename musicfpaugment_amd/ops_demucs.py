@@ -102,11 +102,12 @@ PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (
 
 
 def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mode=0, relu=0, addend: int = 0, ldadd=0,
-         strideAdd=0, precision=None, c1=None):
-    """C[b][m][:N] = epi(A-window[b][m] @ W^T + bias); A, C, addend are device addresses, strides in floats."""
+         strideAdd=0, precision=None, c1=None, C2: int = 0, ldc2=0, strideC2=0):
+    """C[b][m][:N] = epi(A-window[b][m] @ W^T + bias); A, C, addend, C2 are device addresses, strides in floats."""
     d = GemmDesc(A=A, lda=lda, strideA=strideA, W=ptr(W), bias=ptr(bias), addend=addend, ldadd=ldadd,
                  strideAdd=strideAdd, C=C, ldc=ldc, strideC=strideC, batch=batch, M=M, N=N, K=W.shape[1], npad=W.shape[0],
-                 mode=mode, relu=int(relu), precision=PRECISION if precision is None else precision)
+                 mode=mode, relu=int(relu), precision=PRECISION if precision is None else precision,
+                 C2=C2, ldc2=ldc2, strideC2=strideC2)
     if c1 is not None:                 # (x (B, Lin), w (8, K), b (K)): A is the first encoder layer, computed in the loader
         d.c1_x, d.c1_lin, d.c1_w, d.c1_b = ptr(c1[0]), c1[0].shape[1], ptr(c1[1]), ptr(c1[2])
     t0 = _K._TIMER.start() if _K._TIMER is not None else None

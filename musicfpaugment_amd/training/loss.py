@@ -192,14 +192,16 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         return self.factor_sc * sc_loss, self.factor_mag * mag_loss
 
     @torch.no_grad()
-    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor):
+    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
         """(sc_loss, mag_loss, d(sc_loss + mag_loss) / dx): the two terms training/train.py:297 adds to the L1 loss, and their
-        gradient with respect to the predicted waveform x (what the reference's autograd hands to the Demucs backward pass)."""
+        gradient with respect to the predicted waveform x (what the reference's autograd hands to the Demucs backward pass).
+        With `dx` given and `accumulate`, the gradient is ADDED to dx (which then already holds the L1 term's gradient)."""
         n = len(self.stft_losses)
-        dx = torch.empty_like(x, dtype=torch.float32)
+        if dx is None:
+            dx, accumulate = torch.empty_like(x, dtype=torch.float32), False
         sc_loss, mag_loss = 0.0, 0.0
         for i, f in enumerate(self.stft_losses):
-            sc_l, mag_l = f.value_and_grad(x, y, self.factor_sc / n, self.factor_mag / n, dx, accumulate=i > 0)
+            sc_l, mag_l = f.value_and_grad(x, y, self.factor_sc / n, self.factor_mag / n, dx, accumulate=accumulate or i > 0)
             sc_loss = sc_loss + sc_l
             mag_loss = mag_loss + mag_l
         return self.factor_sc * sc_loss / n, self.factor_mag * mag_loss / n, dx

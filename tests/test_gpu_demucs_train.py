@@ -1,0 +1,198 @@
+"""GPU parity: Demucs training step (forward with kept activations, L1 + MultiResolutionSTFTLoss, hand-written backward,
+Adam) against torch autograd through the CPU oracle (oracle/demucs.py, oracle/loss.py) -- training/train.py:275-312."""
+import numpy as np
+import pytest
+import torch
+
+from musicfpaugment_amd import synth
+from musicfpaugment_amd.training.demucs_weights import formula_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).abs().sum() / b.double().abs().sum().clamp_min(1e-30))
+
+
+def test_gemm_tn_window_weight_gradient():
+    """dW[co][j*cin + c] = sum_{b,t} dy[b][t][co] * x[b][4t + j][c]: the Conv1d(k8, s4) weight gradient as one TN GEMM."""
+    from musicfpaugment_amd import ops_demucs_train as T
+    g = torch.Generator().manual_seed(1)
+    for (B, L, cin, cout) in [(3, 37, 48, 96), (2, 130, 96, 192), (2, 9, 48, 48)]:
+        Lin = 4 * (L - 1) + 8
+        x = torch.randn(B, Lin, cin, generator=g)
+        dy = torch.randn(B, L, cout, generator=g)
+        win = torch.stack([x[:, 4 * t:4 * t + 8, :].reshape(B, -1) for t in range(L)], dim=1)        # (B, L, 8 cin)
+        want = torch.einsum("btm,btn->mn", dy.double(), win.double())
+        out = torch.zeros(cout, 8 * cin, device="cuda")
+        xd, dyd = x.cuda(), dy.cuda()
+        T.gemm_tn(T._p(dyd), cout, L * cout, T._p(xd), 4 * cin, Lin * cin, out, 8 * cin, B, L, cout, 8 * cin)
+        assert _rel(out.cpu(), want) < 1e-5
+        bias = torch.zeros(cout, device="cuda")
+        T.colsum(T._p(dyd), B * L, cout, cout, bias)
+        assert _rel(bias.cpu(), dy.double().sum((0, 1))) < 1e-5
+
+
+def test_glu_bwd_and_mask_epilogue():
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd import ops_demucs_train as T
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(2)
+    B, L, C = 2, 50, 48
+    a = torch.relu(torch.randn(B, L, C, generator=g)).requires_grad_(True)
+    wg = (torch.randn(2 * C, C, generator=g) / np.sqrt(C)).requires_grad_(True)
+    bg = torch.randn(2 * C, generator=g).requires_grad_(True)
+    h = F.glu(a @ wg.t() + bg, dim=-1)
+    dh = torch.randn(B, L, C, generator=g)
+    h.backward(dh)
+    wgp, bgp = D._pack_glu(wg.detach(), bg.detach())
+    npad = wgp.shape[0]
+    ad = a.detach().cuda()
+    u = torch.empty(B, L, npad, device="cuda")
+    hd = torch.empty(B, L, C, device="cuda")
+    wgd, bgd = wgp.cuda(), bgp.cuda()
+    D.gemm(D._p(ad), C, L * C, B, L, wgd, bgd, C, D._p(hd), C, L * C, mode=1, C2=D._p(u), ldc2=npad, strideC2=L * npad)
+    assert _rel(hd.cpu(), h.detach()) < 1e-5
+    dhd = dh.cuda()
+    check(lib().mfpa_glu_bwd(ptr(u), B * L, npad, C, ptr(dhd), C, stream()), "glu_bwd")
+    dwp = torch.zeros(npad, C, device="cuda")
+    T.gemm_tn(T._p(u), npad, 0, T._p(ad), C, 0, dwp, C, 1, B * L, npad, C)
+    dbp = torch.zeros(npad, device="cuda")
+    T.colsum(T._p(u), B * L, npad, npad, dbp)
+    dw, db = T.DemucsTrainEngine._unpack_glu(dwp, dbp, C)
+    assert _rel(dw.cpu(), wg.grad) < 1e-5 and _rel(db.cpu(), bg.grad) < 1e-5
+    # input gradient, masked by the ReLU that produced `a` (mode 3), unmasked copy through C2
+    da, da_raw = torch.empty(B, L, C, device="cuda"), torch.empty(B, L, C, device="cuda")
+    gwT = T._t_pad(wgd, C)
+    D.gemm(D._p(u), npad, L * npad, B, L, gwT, None, C, D._p(da), C, L * C, mode=3, addend=D._p(ad), ldadd=C,
+           strideAdd=L * C, C2=D._p(da_raw), ldc2=C, strideC2=L * C)
+    assert _rel(da_raw.cpu(), a.grad) < 1e-5
+    assert _rel(da.cpu(), a.grad * (a.detach() > 0)) < 1e-5
+
+
+def test_downsample_adjoint_and_c1_kernels():
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    from oracle import demucs as od
+    g = torch.Generator().manual_seed(3)
+    B, T_, keep = 2, 1001, 400
+    x = torch.randn(B, T_, generator=g).requires_grad_(True)
+    sc = torch.rand(B, generator=g) + 0.5
+    y = od.downsample2(x)[:, :keep] * sc[:, None]
+    dy = torch.randn(B, keep, generator=g)
+    y.backward(dy)
+    dx = torch.empty(B, T_, device="cuda")
+    dyd, scd, ker = dy.cuda(), sc.cuda(), D.sinc_kernel("cuda")          # keep the device copies alive across the launch
+    check(lib().mfpa_downsample2_adjoint(ptr(dyd), B, keep, keep, ptr(ker), ptr(scd), T_, ptr(dx), stream()), "adj")
+    assert _rel(dx.cpu(), x.grad) < 1e-5
+    # weight gradient of the 1 -> C convolution
+    L, C = 333, 48
+    Lin = 4 * (L - 1) + 8
+    xs = torch.randn(B, Lin, generator=g)
+    gr = torch.randn(B, L, C, generator=g)
+    want = torch.stack([torch.einsum("bt,btc->c", xs[:, j:j + 4 * L:4].double(), gr.double()) for j in range(8)])
+    dw = torch.zeros(8, C, device="cuda")
+    xsd, grd = xs.cuda(), gr.cuda()
+    check(lib().mfpa_c1_wgrad(ptr(xsd), Lin, ptr(grd), C, L * C, B, L, C, ptr(dw), stream()), "c1_wgrad")
+    assert _rel(dw.cpu(), want) < 1e-5
+
+
+def test_lstm_train_step_pair():
+    """mfpa_lstm_step_train / mfpa_lstm_step_bwd over a short sequence vs autograd through the oracle's LSTM layer."""
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(4)
+    B, Tn, H = 3, 5, 768
+    wih = (torch.randn(4 * H, H, generator=g) * 0.03).requires_grad_(True)
+    whh = (torch.randn(4 * H, H, generator=g) * 0.03).requires_grad_(True)
+    b = (torch.randn(4 * H, generator=g) * 0.03).requires_grad_(True)
+    x = torch.randn(B, Tn, H, generator=g).requires_grad_(True)
+    h = torch.zeros(B, H); c = torch.zeros(B, H)
+    outs = []
+    for t in range(Tn):
+        gt = x[:, t] @ wih.t() + b + h @ whh.t()
+        i, f, gg, o = gt.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    hs = torch.stack(outs, dim=1)
+    dh = torch.randn(B, Tn, H, generator=g)
+    hs.backward(dh)
+    L = lib()
+    dev = "cuda"
+    gates = (x.detach() @ wih.detach().t() + b.detach()).contiguous().to(dev)            # input projection (B, Tn, 4H)
+    whh_d = whh.detach().to(dev)
+    grouped = whh_d.view(4, H // 16, 16, H).permute(1, 0, 2, 3).reshape(4 * H, H).contiguous()
+    hseq, cseq = torch.empty(B, Tn, H, device=dev), torch.empty(B, Tn, H, device=dev)
+    p = lambda t_, off=0: ptr(t_) + 4 * off
+    for t in range(Tn):
+        check(L.mfpa_lstm_step_train(p(hseq, (t - 1) * H) if t else 0, Tn * H, ptr(grouped), p(gates, t * 4 * H), Tn * 4 * H,
+                                     p(cseq, (t - 1) * H) if t else 0, Tn * H, p(cseq, t * H), Tn * H, B, H, p(hseq, t * H), Tn * H,
+                                     0, 0, 0, p(gates, t * 4 * H), Tn * 4 * H, stream()), "step_train")
+    assert _rel(hseq.cpu(), hs.detach()) < 2e-5
+    whhT = whh_d.t().contiguous()
+    dc = torch.zeros(B, H, device=dev)
+    dhd = dh.to(dev)
+    for t in range(Tn - 1, -1, -1):
+        check(L.mfpa_lstm_step_bwd(p(gates, (t + 1) * 4 * H) if t + 1 < Tn else 0, Tn * 4 * H, ptr(whhT), p(gates, t * 4 * H),
+                                   Tn * 4 * H, p(cseq, t * H), Tn * H, p(cseq, (t - 1) * H) if t else 0, Tn * H, p(dhd, t * H),
+                                   Tn * H, ptr(dc), B, H, stream()), "step_bwd")
+    dg = gates.cpu().double()                                                               # now d loss / d gate pre-activations
+    assert _rel(dg.sum((0, 1)), b.grad) < 1e-4
+    assert _rel(torch.einsum("btg,bti->gi", dg, x.detach().double()), wih.grad) < 1e-4
+    assert _rel(torch.einsum("btg,bti->gi", dg[:, 1:], hs.detach().double()[:, :-1]), whh.grad) < 1e-4
+    assert _rel(dg @ wih.detach().double(), x.grad) < 1e-4
+
+
+def _oracle_step(sd, clean, aug):
+    from oracle import demucs as od
+    from oracle import loss as ol
+    params = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    pred = od.forward(aug.double(), params)[:, 0]
+    l1 = torch.nn.functional.l1_loss(pred, clean.double())
+    sc, mag, _ = ol.multi_resolution_stft_loss(pred, clean.double())
+    (l1 + sc + mag).backward()
+    return pred.detach(), (float(l1.detach()), float(sc.detach()), float(mag.detach())), {k: p.grad for k, p in params.items()}
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 2e-3), (1, 2e-3)])
+def test_train_step_gradients_vs_autograd(precision, tol):
+    """Every parameter gradient of one step (B = 2, 0.5 s clips) vs float64 autograd through the oracle; then the Adam update."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    sd = formula_state_dict(0)
+    n = 4000
+    clean = torch.from_numpy(synth.batch(2, seed=31, n=n))
+    aug = (clean + 0.05 * torch.from_numpy(synth.batch(2, seed=77, n=n))).float()
+    pred_w, (l1_w, sc_w, mag_w), grads = _oracle_step(sd, clean, aug)
+    eng = DemucsTrainEngine(sd, "cuda", precision=precision)
+    # the engine's state_dict round-trips the reference layout
+    back = eng.state_dict()
+    assert all(torch.equal(back[k].cpu(), sd[k]) for k in sd)
+    pred = eng.forward(aug.cuda())
+    assert _rel(pred.cpu(), pred_w) < 1e-4
+    l1, sc, mag, dpred = eng.loss_and_grad(pred, clean.cuda())
+    np.testing.assert_allclose([float(l1), float(sc), float(mag)], [l1_w, sc_w, mag_w], rtol=1e-3)
+    eng.backward(dpred)
+    got = eng.grad_dict()
+    worst = {}
+    for k in sd:
+        worst[k] = _rel(got[k].cpu(), grads[k])
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, f"gradient mismatch: {bad}"
+    # Adam: first step moves every parameter by -lr * sign(g) (bias-corrected m / sqrt(v) = g / |g|)
+    before = eng.flat_p.clone()
+    eng.adam_step()
+    delta = (eng.flat_p - before).cpu()
+    gflat = eng.flat_g.cpu()
+    nz = gflat.abs() > 1e-6
+    assert torch.allclose(delta[nz], -1e-3 * torch.sign(gflat[nz]), atol=2e-5)
+    assert float(delta[gflat == 0].abs().max()) == 0.0          # zero-padded rows stay zero
+
+
+def test_train_step_runs_and_reduces_loss():
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    eng = DemucsTrainEngine(formula_state_dict(0), "cuda", lr=3e-4, precision=1)
+    clean = torch.from_numpy(synth.batch(4, seed=5, n=8000)).cuda()
+    aug = (clean + 0.05 * torch.from_numpy(synth.batch(4, seed=9, n=8000)).cuda()).contiguous()
+    losses = [float(eng.train_step(clean, aug)) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
