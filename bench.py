@@ -237,6 +237,72 @@ def bench_metrics(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def bench_demucs_train(args, rank, world, dev, dist):
+    """SURVEY.md §8f-2, training branch: one Demucs training step (training/train.py:275-312): forward, L1 +
+    MultiResolutionSTFTLoss(0.5, 0.5), backward, Adam(5e-4) on synthetic clean / noisy waveform pairs; data-parallel with one
+    all-reduce of the 18.9 M fp32 gradients."""
+    from musicfpaugment_amd import ops_unet, synth
+    from musicfpaugment_amd.constants import DEMUCS_LEARNING_RATE, FACTOR_MAG, FACTOR_SC
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    from musicfpaugment_amd.training.loss import MultiResolutionSTFTLoss
+
+    B = args.clips if args.scaling == "weak" else max(1, args.clips // world)
+    n = int(args.seconds * 8000)
+    eng = DemucsTrainEngine(demucs_formula(0), dev, lr=DEMUCS_LEARNING_RATE, precision=1 if args.precision == "bf16x3" else 0,
+                            mrstft=MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG).to(dev))
+    base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank, n=n)
+    noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, n=n, tonal=False)
+    reps = (B + len(base) - 1) // len(base)
+    clean = torch.from_numpy(np.concatenate([base] * reps)[:B].copy()).to(dev)
+    aug = torch.from_numpy(np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * reps)[:B].copy()).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = eng.train_step(clean, aug)
+    barrier()
+    timer = ops_unet.KernelTimer()
+    ops_unet.set_timer(timer)
+    eng.phases = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.train_step(clean, aug)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops_unet.set_timer(None)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    if rank == 0:
+        gemm_ms = timer.total_ms()
+        gflop = 3 * 20.13 * n / 64000.0                  # forward + input gradients + weight gradients, per clip
+        achieved = gflop * 1e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12
+        phases = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in eng.phases.items()}
+        print(json.dumps({
+            "metric": f"{args.seconds:g}s/8kHz clips/sec (Demucs train step: fwd + L1 + MRSTFT loss + bwd + Adam)",
+            "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": ("bf16x3 forward / input-gradient GEMMs and LSTM steps, f32 weight-gradient GEMMs, f32/f64 reductions and Adam"
+                      if args.precision == "bf16x3" else "f32 GEMMs (the LSTM steps are bf16x3)"), "data": "synthetic",
+            "config": {"workload": f"Demucs() train step, L1 + MultiResolutionSTFTLoss(0.5, 0.5), Adam(5e-4), {args.seconds:g} s clips, "
+                                   f"{args.precision} GEMMs, pre-mixed noisy clips", "clips_per_gpu_per_step": B,
+                       "loss_last": float(loss), "phase_ms_per_step": phases,
+                       "parallelism": f"data-parallel x{world}, one RCCL all-reduce of 18.9 M fp32 gradients"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_bf16x3_kernel / gemm_mfma_kernel (forward, input gradients) + gemm_tn_kernel (weight "
+                                   "gradients) + lstm_step(_bwd)_kernel", "launches": timer.launches(),
+                         "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_train(args, rank, world, dev, dist):
     """BASELINE config 4: full UNet train step on synthetic clean/augmented 8 s clips, Dropout(0.05) as the reference
     trains (training/train.py:646).  Default arithmetic: bf16x3 products on the bf16 matrix cores (BASELINE config 4 says
@@ -355,7 +421,8 @@ def main():
                     help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
     ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
-    ap.add_argument("--mode", choices=["infer", "train", "demucs", "metrics"], default="infer",
+    ap.add_argument("--seconds", type=float, default=8.0, help="demucs-train mode: clip length (the reference trains on 3 s)")
+    ap.add_argument("--mode", choices=["infer", "train", "demucs", "demucs-train", "metrics"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick")
@@ -392,6 +459,8 @@ def main():
         return bench_train(args, rank, world, dev, dist)
     if args.mode == "demucs":
         return bench_demucs(args, rank, world, dev, dist)
+    if args.mode == "demucs-train":
+        return bench_demucs_train(args, rank, world, dev, dist)
     if args.mode == "metrics":
         return bench_metrics(args, rank, world, dev, dist)
 

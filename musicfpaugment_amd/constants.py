@@ -17,3 +17,6 @@ FACTOR = 0.1
 EARLY_STOP = 20
 NB_EPOCHS = 500
 DURATION = 3
+FACTOR_SC = 0.5      # MultiResolutionSTFTLoss factors of the Demucs branch (training/parameters.py:29-30)
+FACTOR_MAG = 0.5
+DEMUCS_LEARNING_RATE = 5e-4   # training/train.py:632

@@ -26,6 +26,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import ops_demucs as D
+from . import ops_unet as _K
 from ._lib import GemmTnDesc, check, lib, ptr, stream
 
 DEPTH, KERNEL, STRIDE, FLOOR = D.DEPTH, D.KERNEL, D.STRIDE, D.FLOOR
@@ -50,7 +51,10 @@ def gemm_tn(A: int, lda, strideA, Bm: int, ldb, strideB, C: torch.Tensor, ldc, b
     """C[m][n] += sum_{b, r} A[b][r][m] * Bm[b][r][n] (mfpa_gemm_tn); A, Bm device addresses, strides in floats."""
     d = GemmTnDesc(A=A, lda=lda, strideA=strideA, Bm=Bm, ldb=ldb, strideB=strideB, C=ptr(C), ldc=ldc, batch=batch, R=R, M=M, N=N,
                    precision=0)
+    t0 = _K._TIMER.start() if _K._TIMER is not None else None
     check(lib().mfpa_gemm_tn(ctypes.byref(d), stream()), "mfpa_gemm_tn")
+    if t0 is not None:
+        _K._TIMER.stop(t0)
 
 
 def colsum(x: int, rows, C, ld, out: torch.Tensor):
@@ -73,12 +77,32 @@ def _t_pad(w: torch.Tensor, rows: int) -> torch.Tensor:
     return out
 
 
+class _Phase:
+    """HIP-event stopwatch over a phase of the step (bench.py's breakdown); a no-op unless engine.phases is a dict."""
+
+    def __init__(self, eng, name):
+        self.eng, self.name = eng, name
+
+    def __enter__(self):
+        if self.eng.phases is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.eng.phases is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.eng.phases.setdefault(self.name, []).append((self.e0, e1))
+
+
 class DemucsTrainEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 precision: int = 1, mrstft=None, dist_group=None):
+                 precision: int = 1, mrstft=None, dist_group=None, module=None):
         self.device = torch.device(device)
+        self.module = module                  # optional training.model.Demucs whose parameters mirror the flat buffer
         self.lr, self.betas, self.eps, self.precision = lr, betas, eps, precision
         self.step_count = 0
+        self.phases: Optional[Dict[str, list]] = None
         self.mrstft = mrstft
         self.dist_group = dist_group
         # ---- flat layout
@@ -194,6 +218,14 @@ class DemucsTrainEngine:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return self._export(self.P)
 
+    def sync_to_module(self) -> None:
+        if self.module is not None:
+            self.module.load_state_dict(self.state_dict())
+
+    def load_from_module(self) -> None:
+        if self.module is not None:
+            self.load_state_dict(self.module.state_dict())
+
     def grad_dict(self) -> Dict[str, torch.Tensor]:
         return self._export(self.G)
 
@@ -273,12 +305,15 @@ class DemucsTrainEngine:
             last = layer == 1
             if last:
                 xsum = new(B, Tn, H)
+            t0 = _K._TIMER.start() if _K._TIMER is not None else None     # the whole recurrence as one timed group
             for t in range(Tn):
                 check(L.mfpa_lstm_step_train(_p(hseq, (t - 1) * H) if t else 0, Tn * H, ptr(W[f"lstm{layer}.whh_grouped"]),
                                              _p(gates, t * 4 * H), Tn * 4 * H, _p(cseq, (t - 1) * H) if t else 0, Tn * H,
                                              _p(cseq, t * H), Tn * H, B, H, _p(hseq, t * H), Tn * H,
                                              _p(xsum, t * H) if last else 0, _p(h_s[-1], t * H) if last else 0, Tn * H,
                                              _p(gates, t * 4 * H), Tn * 4 * H, stream()), "mfpa_lstm_step_train")
+            if t0 is not None:
+                _K._TIMER.stop(t0)
             lst.append((seq, gates, hseq, cseq))
             seq = hseq
         S["lstm"], S["Tn"] = lst, Tn
@@ -329,6 +364,10 @@ class DemucsTrainEngine:
         dev = dout.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        self._last_mark = None
+        if self.phases is not None:
+            self._last_mark = torch.cuda.Event(enable_timing=True)
+            self._last_mark.record()
         self.flat_g.zero_()
         Lfull, Lh = S["Lfull"], S["Lh"]
         dhalf = new(B, Lh)
@@ -375,17 +414,21 @@ class DemucsTrainEngine:
             dg = new(B, Lp, Cp)
             D.gemm(_p(dyc), 4 * C, Lcur * C, B, Lp, P[f"dec{d - 1}.w"], None, Cp, _p(dg), Cp, Lp * Cp, precision=prec)
         # ---- LSTM
+        self._mark("bwd_decoder")
         Tn = S["Tn"]
         dhout = dxsum
         dh_enc = None
         for layer in (1, 0):
             seq, gates, hseq, cseq = S["lstm"][layer]
             dc = zeros(B, H)
+            t0 = _K._TIMER.start() if _K._TIMER is not None else None
             for t in range(Tn - 1, -1, -1):
                 check(L.mfpa_lstm_step_bwd(_p(gates, (t + 1) * 4 * H) if t + 1 < Tn else 0, Tn * 4 * H, ptr(W[f"lstm{layer}.whhT"]),
                                            _p(gates, t * 4 * H), Tn * 4 * H, _p(cseq, t * H), Tn * H,
                                            _p(cseq, (t - 1) * H) if t else 0, Tn * H, _p(dhout, t * H), Tn * H, ptr(dc), B, H,
                                            stream()), "mfpa_lstm_step_bwd")
+            if t0 is not None:
+                _K._TIMER.stop(t0)
             colsum(ptr(gates), B * Tn, 4 * H, 4 * H, G[f"lstm{layer}.bih"])
             G[f"lstm{layer}.bhh"].copy_(G[f"lstm{layer}.bih"])
             gemm_tn(ptr(gates), 4 * H, 0, ptr(seq), H, 0, G[f"lstm{layer}.wih"], H, 1, B * Tn, 4 * H, H)
@@ -400,6 +443,7 @@ class DemucsTrainEngine:
                        addend=_p(dxsum), ldadd=H, strideAdd=0, precision=prec)
                 dh_enc = dx
         # ---- encoder
+        self._mark("bwd_lstm")
         Ls, a_s, u_s, h_s = S["L"], S["a"], S["u"], S["h"]
         dh = dh_enc
         for i in range(DEPTH - 1, -1, -1):
@@ -427,7 +471,18 @@ class DemucsTrainEngine:
             D.gemm(_p(dA), C, (Li + 2) * C, B, Li + 1, W[f"enc{i}.wT"], None, 4 * Cin, _p(dprev), 4 * Cin, Lprev * Cin, mode=2,
                    addend=_p(dskip[i - 1]), ldadd=4 * Cin, strideAdd=Lprev * Cin, precision=prec)
             dh = dprev
+        self._mark("bwd_encoder")
         self.S = None
+
+    def _mark(self, name: str) -> None:
+        """Phase boundary inside backward(): time since the previous mark (or since backward() began)."""
+        if self.phases is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if self._last_mark is not None:
+            self.phases.setdefault(name, []).append((self._last_mark, e))
+        self._last_mark = e
 
     # ------------------------------------------------------------------ loss + step
     @torch.no_grad()
@@ -459,9 +514,13 @@ class DemucsTrainEngine:
     @torch.no_grad()
     def train_step(self, clean: torch.Tensor, augmented: torch.Tensor) -> torch.Tensor:
         """One step of train.py:257-317 (audio branch) on (B, T) float32 waveforms; returns the loss (float64, on the device)."""
-        pred = self.forward(augmented.contiguous())
-        l1, sc, mag, dpred = self.loss_and_grad(pred, clean.contiguous())
-        self.backward(dpred)
-        self.adam_step()
+        with _Phase(self, "forward"):
+            pred = self.forward(augmented.contiguous())
+        with _Phase(self, "loss"):
+            l1, sc, mag, dpred = self.loss_and_grad(pred, clean.contiguous())
+        with _Phase(self, "backward"):
+            self.backward(dpred)
+        with _Phase(self, "adam"):
+            self.adam_step()
         self.last_losses = (l1, sc, mag)
         return l1 + sc.double() + mag.double()

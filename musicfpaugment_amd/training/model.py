@@ -4,7 +4,9 @@
 Same constructor defaults, module tree and state_dict keys (encoder.N.0/2, decoder.N.0/2, lstm.lstm.*), same
 ``forward((B, T) or (B, 1, T)) -> (B, 1, T)``, ``valid_length`` and ``total_stride``.  The torch layers are parameter
 containers; forward runs the gfx950 kernels of csrc/demucs.hip (fp32 MFMA GEMMs over time-major activations).
-Inference only: the reference's Demucs training branch (MultiResolutionSTFTLoss) and DemucsStreamer are not built.
+The module has no train/eval-dependent layer, so `forward` is the same in both modes; the training STEP (loss, backward,
+Adam -- training/train.py:275-312) is `ops_demucs_train.DemucsTrainEngine`, driven by `training.train.Trainer(input_type=
+"audio")`, not torch autograd.  DemucsStreamer is not built.
 """
 from __future__ import annotations
 
@@ -80,9 +82,6 @@ class Demucs(nn.Module):
     @torch.no_grad()
     def forward(self, mix: torch.Tensor) -> torch.Tensor:
         require_gpu(mix, "Demucs input")
-        if self.training:
-            raise NotImplementedError("Demucs training (MultiResolutionSTFTLoss branch, training/train.py:275-312) is not built; "
-                                      "call .eval()")
         if mix.dim() == 3:
             if mix.shape[1] != 1:
                 raise ValueError("expected (B, 1, T)")

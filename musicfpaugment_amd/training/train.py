@@ -1,4 +1,5 @@
-"""UNet `Trainer` / `EarlyStopping` on MI355X -- mirror of the spec branch of the reference's training/train.py.
+"""`Trainer` / `EarlyStopping` on MI355X -- mirror of the reference's training/train.py: the spec branch (UNet) and the audio
+branch (Demucs: L1 + MultiResolutionSTFTLoss, train.py:275-312, through ops_demucs_train.DemucsTrainEngine).
 
 Reference: Trainer.train_epoch (:245-359), validation_epoch (:361-468), EarlyStopping (:582-612),
 __main__ wiring (:645-667: UNet(1,1,rate), L1Loss, Adam(lr 1e-3, betas (0.9, 0.999)),
@@ -21,7 +22,7 @@ from typing import Any, Dict, Iterator, Optional, Tuple
 import torch
 
 from .. import ops
-from ..constants import LEARNING_RATE, TRAIN_STEPS, VAL_STEPS
+from ..constants import FACTOR_MAG, FACTOR_SC, LEARNING_RATE, TRAIN_STEPS, VAL_STEPS
 from ..ops_train import UNetTrainEngine
 from .unet import UNet
 
@@ -77,7 +78,7 @@ def _global_max(clip_max: torch.Tensor) -> torch.Tensor:
 
 
 class Trainer:
-    def __init__(self, model: UNet, train_loader: Iterator, val_loader: Optional[Iterator] = None,
+    def __init__(self, model, train_loader: Iterator, val_loader: Optional[Iterator] = None,
                  learning_rate: float = LEARNING_RATE, train_steps: int = TRAIN_STEPS, val_steps: int = VAL_STEPS,
                  device="cuda", ckpt_path: Optional[str] = None, input_type: str = "spec",
                  scheduler_factor: float = 0.1, scheduler_patience: int = 10, early_stop_patience: int = 20,
@@ -86,11 +87,20 @@ class Trainer:
         step rate; gradients deviate ~1e-2 relative from fp32 autograd, see tests/test_gpu_train.py).  `sync_bn` (multi-GPU):
         BatchNorm statistics over the global batch, so that N GPUs x B/N clips reproduce the reference's single-GPU step on
         B clips (tests/test_gpu_dist.py); default per-GPU statistics."""
-        if input_type != "spec":
-            raise NotImplementedError("input_type='audio' is the Demucs branch (next tier, SURVEY.md §8f-2)")
+        if input_type not in ("spec", "audio"):
+            raise ValueError("input_type must be 'spec' (UNet) or 'audio' (Demucs)")
+        self.input_type = input_type
         self.device = torch.device(device)
         self.model = model.to(self.device)
-        self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, precision=precision, sync_bn=sync_bn)
+        if input_type == "audio":
+            from ..ops_demucs_train import DemucsTrainEngine
+            from .loss import MultiResolutionSTFTLoss
+            self.mrsl = MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG).to(self.device)   # train.py:652-655
+            self.engine = DemucsTrainEngine(self.model.state_dict(), self.device, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8,
+                                            precision=precision, mrstft=self.mrsl, module=self.model)
+        else:
+            self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, precision=precision,
+                                          sync_bn=sync_bn)
         self.scheduler = ReduceLROnPlateau(self.engine, scheduler_factor, scheduler_patience)
         self.early_stopping = EarlyStopping(early_stop_patience)
         self.train_loader_iter, self.val_loader_iter = train_loader, val_loader
@@ -112,7 +122,17 @@ class Trainer:
         ops.normalize_(cm, _global_max(cmax).expand(B).contiguous(), per_clip=True)     # clean_specs, float64 target
         return am, _global_max(amax).expand(B).contiguous(), cm
 
+    def _waves(self, clean_audios: torch.Tensor, augmented_audios: torch.Tensor):
+        clean = clean_audios.to(self.device, torch.float32)
+        aug = augmented_audios.to(self.device, torch.float32)
+        clean = clean.squeeze(-1) if clean.dim() == 3 else clean          # (B,T,1) -> (B,T)   train.py:260-262
+        aug = aug.squeeze(-1) if aug.dim() == 3 else aug
+        return clean.contiguous(), aug.contiguous()
+
     def train_step(self, clean_audios, augmented_audios) -> torch.Tensor:
+        if self.input_type == "audio":
+            clean, aug = self._waves(clean_audios, augmented_audios)
+            return self.engine.train_step(clean, aug)
         am, aden, clean_spec = self._specs(clean_audios, augmented_audios)
         return self.engine.train_step(am, aden, clean_spec)
 
@@ -120,10 +140,17 @@ class Trainer:
     def train_epoch(self, epoch: int) -> Dict[str, Any]:
         self.model.train()
         total = torch.zeros(1, dtype=torch.float64, device=self.device)
+        parts = torch.zeros(3, dtype=torch.float64, device=self.device)
         for _ in range(1, self.train_steps):                    # reference quirk: steps-1 iterations (train.py:257)
             clean, aug = next(self.train_loader_iter)
             total += self.train_step(clean, aug)                # loss stays on the device: no per-step .item() sync
-        return {"loss": float(total.item()) / self.train_steps}  # ... divided by steps (train.py:341)
+            if self.input_type == "audio":
+                parts += torch.stack([v.double() for v in self.engine.last_losses])
+        out = {"loss": float(total.item()) / self.train_steps}  # ... divided by steps (train.py:341)
+        if self.input_type == "audio":                          # train.py:347-356
+            l1, sc, mag = (parts / self.train_steps).tolist()
+            out.update({"l1_loss": l1, "sc_loss": sc, "mag_loss": mag})
+        return out
 
     @torch.no_grad()
     def validation_epoch(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
@@ -133,6 +160,8 @@ class Trainer:
         self.model.eval()
         total = torch.zeros(1, dtype=torch.float64, device=self.device)
         psnr_total = 0.0
+        if self.input_type == "audio":
+            return self._validation_epoch_audio()
         for _ in range(1, self.val_steps):
             clean, aug = next(self.val_loader_iter)
             am, aden, clean_spec = self._specs(clean, aug)
@@ -146,6 +175,24 @@ class Trainer:
         self.scheduler.step(val_loss)                           # train.py:462
         self.model.train()
         return {"loss": val_loss}, {"psnr": psnr_total / self.val_steps}
+
+    def _validation_epoch_audio(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+        """train.py:418-445: predicted = model(augmented); L1 + sc + mag; PSNR on the waveforms."""
+        parts = torch.zeros(3, dtype=torch.float64, device=self.device)
+        psnr_total = 0.0
+        for _ in range(1, self.val_steps):
+            clean, aug = self._waves(*next(self.val_loader_iter))
+            pred = self.model(aug)[:, 0].contiguous()
+            l1, sc, mag, _ = self.engine.loss_and_grad(pred, clean)
+            parts += torch.stack([l1.double(), sc.double(), mag.double()])
+            mse = torch.mean((pred.double() - clean.double()) ** 2)
+            rng = clean.max() - clean.min()
+            psnr_total += float(10.0 * torch.log10(rng.double() ** 2 / mse))
+        l1, sc, mag = (parts / self.val_steps).tolist()
+        val_loss = l1 + sc + mag
+        self.scheduler.step(val_loss)
+        self.model.train()
+        return ({"loss": val_loss, "l1_loss": l1, "sc_loss": sc, "mag_loss": mag}, {"psnr": psnr_total / self.val_steps})
 
     # ------------------------------------------------------------------ checkpoints (train.py:197-221, :130-161)
     def save_checkpoint(self, val_loss: float) -> None:

@@ -196,3 +196,60 @@ def test_train_step_runs_and_reduces_loss():
     aug = (clean + 0.05 * torch.from_numpy(synth.batch(4, seed=9, n=8000)).cuda()).contiguous()
     losses = [float(eng.train_step(clean, aug)) for _ in range(6)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_train_step_golden_of_the_real_reference(golden):
+    """g12: one training step of the REAL reference (Demucs.train(), L1 + MultiResolutionSTFTLoss, Adam) -- losses, gradient
+    norms and the updated parameters."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    g = golden("g12_demucs_train_step")
+    n = int(g["n"])
+    clean = torch.from_numpy(synth.batch(2, seed=int(g["seed_clean"]), n=n))
+    aug = (clean + float(g["noise_gain"]) * torch.from_numpy(synth.batch(2, seed=int(g["seed_noise"]), n=n))).float()
+    sd = formula_state_dict(int(g["weight_seed"]))
+    eng = DemucsTrainEngine(sd, "cuda", lr=float(g["lr"]), precision=0)
+    before = eng.state_dict()
+    loss = eng.train_step(clean.cuda(), aug.cuda())
+    l1, sc, mag = (float(v) for v in eng.last_losses)
+    np.testing.assert_allclose([l1, sc, mag], [float(g["l1"]), float(g["sc"]), float(g["mag"])], rtol=1e-4)
+    assert abs(float(loss) - (float(g["l1"]) + float(g["sc"]) + float(g["mag"]))) < 1e-4
+    grads, after = eng.grad_dict(), eng.state_dict()
+    names = [str(k) for k in g["names"]]
+    gn = np.array([float(grads[k].double().norm()) for k in names])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=5e-3)
+    for r, k in enumerate(names):
+        m = min(8, sd[k].numel())
+        gh = g["grad_head"][r][:m]
+        big = np.abs(gh) > 1e-5                                    # Adam's first step is -lr * sign(g): compare where the sign is safe
+        got = after[k].reshape(-1)[:m].cpu().numpy()
+        np.testing.assert_array_equal(before[k].reshape(-1)[:m].cpu().numpy(), g["param_head_before"][r][:m])
+        np.testing.assert_allclose(got[big], g["param_head_after"][r][:m][big], rtol=0, atol=3e-6)
+
+
+def test_trainer_audio_branch():
+    """training.train.Trainer(input_type="audio") drives the engine; Demucs.train() forward goes through it too."""
+    from musicfpaugment_amd.training.model import Demucs
+    from musicfpaugment_amd.training.train import Trainer
+    net = Demucs()
+    net.load_state_dict(formula_state_dict(0))
+
+    def loader(seed0):
+        k = 0
+        while True:
+            clean = torch.from_numpy(synth.batch(2, seed=seed0 + k, n=4000))
+            aug = clean + 0.05 * torch.from_numpy(synth.batch(2, seed=seed0 + 500 + k, n=4000))
+            k += 1
+            yield clean.unsqueeze(-1), aug.float().unsqueeze(-1)           # (B, T, 1) like the reference's loader
+
+    tr = Trainer(net, loader(40), loader(90), train_steps=3, val_steps=2, device="cuda", input_type="audio", learning_rate=3e-4)
+    out = tr.train_epoch(1)
+    assert np.isfinite(out["loss"]) and set(out) == {"loss", "l1_loss", "sc_loss", "mag_loss"}
+    val, _ = tr.validation_epoch()
+    assert np.isfinite(val["loss"])
+    # the module's parameters follow the engine after a sync, and eval forward uses them
+    tr.engine.sync_to_module()
+    sd = net.state_dict()
+    assert not torch.equal(sd["encoder.0.0.weight"].cpu(), formula_state_dict(0)["encoder.0.0.weight"])
+    net.eval()
+    y = net(torch.from_numpy(synth.batch(1, seed=3, n=4000)).cuda())
+    assert y.shape == (1, 1, 4000) and bool(torch.isfinite(y).all())

@@ -207,3 +207,37 @@ def test_g11_multi_resolution_stft_loss(golden):
     np.testing.assert_array_equal(m0[0, ::7, ::9], g["mag0_sub"])
     zs, zm, _ = ol.multi_resolution_stft_loss(torch.zeros(2, 8000), y[:2, :8000])
     np.testing.assert_allclose([float(zs), float(zm)], [float(g["sc_silent"]), float(g["mag_silent"])], rtol=1e-6)
+
+
+def test_g12_demucs_train_step(golden):
+    """The oracle's forward + losses differentiated by torch autograd reproduce the REAL reference's training step
+    (training/train.py:275-312): losses, per-parameter gradient norms / leading entries, and the Adam update."""
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    from oracle import demucs as odm
+    from oracle import loss as ol
+    g = golden("g12_demucs_train_step")
+    n = int(g["n"])
+    clean = torch.from_numpy(synth.batch(2, seed=int(g["seed_clean"]), n=n))
+    aug = (clean + float(g["noise_gain"]) * torch.from_numpy(synth.batch(2, seed=int(g["seed_noise"]), n=n))).float()
+    sd = demucs_formula(int(g["weight_seed"]))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(4)
+    pred = odm.forward(aug, params)[:, 0]
+    l1 = torch.nn.functional.l1_loss(pred, clean)
+    sc, mag, _ = ol.multi_resolution_stft_loss(pred, clean)
+    (l1 + sc + mag).backward()
+    np.testing.assert_allclose(pred.detach().numpy()[:, ::8], g["pred_sub"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose([float(l1.detach()), float(sc.detach()), float(mag.detach())],
+                               [float(g["l1"]), float(g["sc"]), float(g["mag"])], rtol=2e-5)
+    names = [str(k) for k in g["names"]]
+    assert names == list(sd.keys())
+    gn = np.array([float(params[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-3)
+    lr = float(g["lr"])
+    for r, k in enumerate(names):
+        gh = params[k].grad.reshape(-1)[:8].numpy()
+        np.testing.assert_allclose(gh, g["grad_head"][r][:gh.size], rtol=5e-2, atol=2e-3 * g["grad_norm"][r] / np.sqrt(params[k].numel()))
+        # first Adam step: p - lr * g / (|g| + eps)
+        want = g["param_head_before"][r][:gh.size] - lr * gh / (np.abs(gh) + 1e-8)
+        big = np.abs(gh) > 1e-6
+        np.testing.assert_allclose(want[big], g["param_head_after"][r][:gh.size][big], rtol=0, atol=2e-6)

@@ -94,6 +94,55 @@ def save(name, **arrays):
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def g12_demucs_train_step(versions):
+    """G12: one training step of the audio branch (training/train.py:275-312) with the REAL reference: Demucs (train mode,
+    formula weights) -> L1 + MultiResolutionSTFTLoss -> backward -> Adam(lr 1e-3, betas (0.9, 0.999)) (train.py:661)."""
+    import torch
+    import training.loss as rloss
+    from training.model import Demucs
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+
+    real_stft = torch.stft
+
+    def stft_shim(x, n_fft, hop_length=None, win_length=None, window=None, **kw):
+        return torch.view_as_real(real_stft(x, n_fft, hop_length, win_length, window, return_complex=True, **kw))
+
+    n, seed_clean, seed_noise = 4000, 1500, 1501
+    clean = torch.from_numpy(synth.batch(2, seed=seed_clean, n=n))
+    aug = (clean + 0.05 * torch.from_numpy(synth.batch(2, seed=seed_noise, n=n))).float()
+    dm = Demucs()
+    dm.load_state_dict(demucs_formula(0))
+    dm.train()
+    opt = torch.optim.Adam(dm.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    torch.stft = stft_shim
+    try:
+        crit_l1 = torch.nn.L1Loss()
+        crit = rloss.MultiResolutionSTFTLoss(factor_sc=0.1, factor_mag=0.1)
+        pred = dm(aug.unsqueeze(1)).squeeze(1)                                     # train.py:262,276
+        l1 = crit_l1(pred, clean)
+        sc, mag = crit(pred, clean)
+        loss = l1 + sc + mag
+        opt.zero_grad()
+        loss.backward()
+    finally:
+        torch.stft = real_stft
+    def head(t):                                       # the first 8 entries (zero-padded: the last bias has one)
+        out = np.zeros(8, dtype=np.float32)
+        v = t.detach().reshape(-1)[:8].numpy()
+        out[:v.size] = v
+        return out
+
+    names = [k for k, _ in dm.named_parameters()]
+    gnorm = np.array([float(p.grad.double().norm()) for _, p in dm.named_parameters()])
+    ghead = np.stack([head(p.grad) for _, p in dm.named_parameters()])
+    before = np.stack([head(p) for _, p in dm.named_parameters()])
+    opt.step()
+    after = np.stack([head(p) for _, p in dm.named_parameters()])
+    save("g12_demucs_train_step", weight_seed=0, n=n, seed_clean=seed_clean, seed_noise=seed_noise, noise_gain=0.05, lr=1e-3,
+         l1=float(l1), sc=float(sc), mag=float(mag), pred_sub=pred.detach().numpy()[:, ::8].copy(), names=np.array(names),
+         grad_norm=gnorm, grad_head=ghead, param_head_before=before, param_head_after=after, versions=versions)
+
+
 def main():
     import scipy.signal
     import torch
@@ -106,6 +155,9 @@ def main():
     versions = np.array([f"torch {torch.__version__}", f"numpy {np.__version__}",
                          f"scipy {__import__('scipy').__version__}",
                          f"matplotlib {__import__('matplotlib').__version__}"])
+    if "--only-g12" in sys.argv:
+        g12_demucs_train_step(versions)
+        return
 
     # ---- G1 / G2: spectrogram() and audfprint stft on two 1-second clips -------------------
     wav = synth.batch(2, seed=1000, n=8000, tonal=True)
@@ -364,6 +416,7 @@ def main():
         torch.stft = real_stft
     save("g11_mrstft_loss", seed_x=1400, seed_noise=1401, n=24000, factor_sc=0.1, factor_mag=0.1, sc=float(sc), mag=float(mag), per_resolution=np.array(per),
          mag0_sub=m0[0, ::7, ::9].copy(), mag0_shape=np.array(m0.shape), sc_silent=float(zs), mag_silent=float(zm), versions=versions)
+    g12_demucs_train_step(versions)
     print("done")
 
 
