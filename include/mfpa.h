@@ -420,13 +420,14 @@ typedef struct mfpa_gemm_tn_desc {
   const float* Bm; long long ldb, strideB;
   float* C; long long ldc;
   int batch, R, M, N;
-  int precision;   /* 0: fp32 MFMA */
+  int precision;   /* 0: fp32 MFMA; 1: bf16x3 (3 bf16 MFMAs per product); 2: plain bf16 (one MFMA; the sum over every time
+                      step of the batch averages the 2^-9 product rounding) -- fragments via ds_read_b64_tr_b16 */
 } mfpa_gemm_tn_desc;
 int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream);
 /* GLU backward (nn.GLU(1), model.py:237,246): u (rows, npad) holds the packed pre-activations mfpa_gemm_mfma stored through C2;
  * in place u <- dL/du given dg (rows, N) = dL/d(glu output), row pitch ldg. */
 int mfpa_glu_bwd(float* u, long long rows, int npad, int N, const float* dg, long long ldg, void* stream);
-/* out[c] += sum_r x[r*ld + c] (bias gradients; out is accumulated into).  C multiple of 4, <= 8192. */
+/* out[c] += sum_r x[r*ld + c] (bias gradients; out is accumulated into).  C multiple of 4, <= 4096. */
 int mfpa_colsum_any(const float* x, long long rows, int C, long long ld, float* out, void* stream);
 /* Weight gradient of the two one-channel convolutions (encoder.0.0 and the last ConvTranspose1d), w (8, C) tap-major:
  * dw[j][c] += sum_{b, t < L} x[b*ldx + 4t + j] * g[b*strideG + t*ldg + c].  C <= 256. */

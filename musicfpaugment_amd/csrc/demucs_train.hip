@@ -134,6 +134,153 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     }
 }
 
+// The same product on the bf16 matrix cores (precision 1: bf16x3, precision 2: plain bf16).  K is the ROW index and rows are
+// what is contiguous in HBM, so the 8-consecutive-k fragments of v_mfma_f32_32x32x16_bf16 come from gfx950's transposing LDS
+// read ds_read_b64_tr_b16 (lane i of a 16-lane group receives column i of a 4-row x 16-column block): the tiles stay in their
+// natural [k][m] order.  LDS row = [BM bf16 hi | BM bf16 lo (bf16x3 only) | 64 B pad], which puts the four rows of a block on
+// bank offsets 0 / 64 / 128 / 192.  Plain bf16 is the default for training: a weight gradient sums over every time step of the
+// batch, so the 2^-9 product rounding averages out, and only the optimiser consumes the result (as for the UNet).
+typedef short t_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int HKC_T = 32;
+
+__device__ __forceinline__ t_bf16x8 tn_tr_frag(const char* p0, const char* p1) {
+  typedef t_s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const t_s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
+  const t_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p1));
+  union { short s[8]; t_bf16x8 b; } r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r.s[j] = u[j]; r.s[4 + j] = v[j]; }
+  return r.b;
+}
+
+template <int TM, int TN, bool PLAIN>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs a) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int ROWA = (PLAIN ? 2 : 4) * BM + 64, ROWB = (PLAIN ? 2 : 4) * BN + 64;     // bytes
+  constexpr int QA = BM / 4, QB = BN / 4;
+  constexpr int FA = HKC_T * QA / 256, FB = HKC_T * QB / 256;
+  extern __shared__ __attribute__((aligned(16))) char tsm[];
+  char* As = tsm;                                  // [2][HKC_T][ROWA]
+  char* Bs = tsm + 2 * HKC_T * ROWA;               // [2][HKC_T][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int ntn = (a.N + BN - 1) / BN;
+  const int n0 = (blockIdx.x % ntn) * BN, m0 = (blockIdx.x / ntn) * BM;
+  const int b = blockIdx.y / a.spb;
+  const int rbeg = (blockIdx.y % a.spb) * a.rs;
+  const int rend = rbeg + a.rs < a.R ? rbeg + a.rs : a.R;
+  const float* Ab = a.A + (size_t)b * a.strideA;
+  const float* Bb = a.Bm + (size_t)b * a.strideB;
+  const int nk = (rend - rbeg + HKC_T - 1) / HKC_T;
+  // transposing read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its block
+  const int gl = lane & 15, tq = gl >> 2, tp = gl & 3, gsel = (lane >> 4) & 1;
+  const int a_off = (8 * lh + tq) * ROWA + (wm * 32 * TM + 16 * gsel + 4 * tp) * 2;
+  const int b_off = (8 * lh + tq) * ROWB + (wn * 32 * TN + 16 * gsel + 4 * tp) * 2;
+
+  f32x4 ar[FA], br[FB];
+  auto load = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+      const int idx = tid + 256 * i, row = idx / QA, q = idx % QA;
+      const int r = rbeg + kc * HKC_T + row, m = m0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rend && m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)r * a.lda + m);
+      ar[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int idx = tid + 256 * i, row = idx / QB, q = idx % QB;
+      const int r = rbeg + kc * HKC_T + row, n = n0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rend && n < a.N) v = *reinterpret_cast<const f32x4*>(Bb + (size_t)r * a.ldb + n);
+      br[i] = v;
+    }
+  };
+  auto split_store = [&](char* row, int q, int lo_off, f32x4 v) __attribute__((always_inline)) {
+    t_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<t_bf16x4*>(row + 8 * q) = hi;
+    if (!PLAIN) *reinterpret_cast<t_bf16x4*>(row + lo_off + 8 * q) = lo;
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+      const int idx = tid + 256 * i;
+      split_store(As + (buf * HKC_T + idx / QA) * ROWA, idx % QA, 2 * BM, ar[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int idx = tid + 256 * i;
+      split_store(Bs + (buf * HKC_T + idx / QB) * ROWB, idx % QB, 2 * BN, br[i]);
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < nk) store(buf ^ 1);
+      if (kc + 2 < nk) load(kc + 2);
+      const char* Ap = As + buf * HKC_T * ROWA + a_off;
+      const char* Bp = Bs + buf * HKC_T * ROWB + b_off;
+#pragma unroll
+      for (int ks = 0; ks < HKC_T / 16; ++ks) {
+        t_bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const char* p = Ap + 16 * ks * ROWA + 64 * i;
+          ah[i] = tn_tr_frag(p, p + 4 * ROWA);
+          if (!PLAIN) al[i] = tn_tr_frag(p + 2 * BM, p + 4 * ROWA + 2 * BM);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const char* p = Bp + 16 * ks * ROWB + 64 * j;
+          bh[j] = tn_tr_frag(p, p + 4 * ROWB);
+          if (!PLAIN) bl[j] = tn_tr_frag(p + 2 * BN, p + 4 * ROWB + 2 * BN);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (!PLAIN) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 32 * TN + 32 * j + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < a.M && n < a.N) unsafeAtomicAdd(a.C + (size_t)m * a.ldc + n, acc[i][j][r]);
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------- GLU backward
 // u (rows, npad): packed pre-activations, tile t = [32 values | 32 gates] of output columns 32 t .. 32 t + 31 (< N).
 // In place: u <- d(loss)/du given dg (rows, N columns, row pitch ldg).
@@ -164,7 +311,10 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(float* __restrict__ u, lon
 }
 
 // ---------------------------------------------------------------------------------- column sums (bias gradients)
-// out[c] += sum_r x[r*ld + c], any C that is a multiple of 4 (48, 96, ... 3072): LDS accumulators with ds_add_f32.
+// out[c] += sum_r x[r*ld + c], any C that is a multiple of 4 (48, 96, ... 3072).  A thread keeps float4 register
+// accumulators for its column quad(s) and walks the rows of its block's range (four independent loads in flight); the
+// row lanes are combined once per block through LDS, then one global atomic per column and block.
+template <int NQ>
 __global__ __launch_bounds__(256) void colsum_any_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
                                                          float* __restrict__ out, long long rows_per_block) {
   extern __shared__ float accs[];
@@ -174,13 +324,42 @@ __global__ __launch_bounds__(256) void colsum_any_kernel(const float* __restrict
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   const int Q = C / 4;
-  const long long total = (r1 - r0) * Q;
-  for (long long e = tid; e < total; e += 256) {
-    const long long r = r0 + e / Q;
-    const int q = (int)(e % Q);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * q);
+  const int QT = Q < 256 ? Q : 256;
+  const int lanes = Q <= 256 ? 256 / Q : 1;
+  const int q0 = tid % QT, rl = tid / QT;
+  f32x4 acc[NQ];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(&accs[4 * q + k], v[k]);
+  for (int i = 0; i < NQ; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes) {
+    long long r = r0 + rl;
+    for (; r + 3LL * lanes < r1; r += 4LL * lanes) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int q = q0 + 256 * i;
+        if (q < Q) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * q);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + (r + lanes) * ld + 4 * q);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(x + (r + 2LL * lanes) * ld + 4 * q);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(x + (r + 3LL * lanes) * ld + 4 * q);
+          acc[i] += (v0 + v1) + (v2 + v3);
+        }
+      }
+    }
+    for (; r < r1; r += lanes) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int q = q0 + 256 * i;
+        if (q < Q) acc[i] += *reinterpret_cast<const f32x4*>(x + r * ld + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = q0 + 256 * i;
+      if (q < Q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&accs[4 * q + k], acc[i][k]);
+      }
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256) unsafeAtomicAdd(out + c, accs[c]);
@@ -397,7 +576,7 @@ int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
   if (d->batch == 0 || d->R == 0) return MFPA_OK;
   if (!d->A || !d->Bm || !d->C || d->batch < 0 || d->R < 0 || d->M < 4 || d->N < 4 || d->M % 4 || d->N % 4) return MFPA_EINVAL;
   if (d->lda % 4 || d->ldb % 4 || d->strideA % 4 || d->strideB % 4 || d->ldc < d->N) return MFPA_EINVAL;   // float4 row loads
-  if (d->precision != 0) return MFPA_EINVAL;
+  if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
   const bool big = d->M > 64 && d->N > 64;
   const int BM = big ? 128 : 64, BN = big ? 128 : 64;
   const long long tiles = (long long)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
@@ -405,7 +584,7 @@ int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
   long long want = 2048 / tiles; if (want < 1) want = 1;
   long long rs = ((long long)d->batch * d->R + want - 1) / want;
   if (rs < 64) rs = 64;
-  rs = (rs + TKC - 1) / TKC * TKC;
+  rs = (rs + HKC_T - 1) / HKC_T * HKC_T;
   long long spb = (d->R + rs - 1) / rs;
   while (spb * d->batch > 65535) { rs *= 2; spb = (d->R + rs - 1) / rs; }
   if (tiles > 0x7fffffffLL) return MFPA_EINVAL;
@@ -413,8 +592,18 @@ int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
   a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.Bm = d->Bm; a.ldb = d->ldb; a.strideB = d->strideB;
   a.C = d->C; a.ldc = d->ldc; a.R = d->R; a.M = d->M; a.N = d->N; a.rs = (int)rs; a.spb = (int)spb;
   dim3 grid((unsigned)tiles, (unsigned)(spb * d->batch));
-  if (big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, mfpa_stream(stream), a);
-  else hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), grid, dim3(256), 0, mfpa_stream(stream), a);
+  hipStream_t st = mfpa_stream(stream);
+  if (d->precision == 0) {
+    if (big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    const bool plain = d->precision == 2;
+    const size_t lds = (size_t)2 * HKC_T * 2 * ((plain ? 2 : 4) * BM + 64);      // BM == BN
+    if (big && plain) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, true>), grid, dim3(256), lds, st, a);
+    else if (big) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, false>), grid, dim3(256), lds, st, a);
+    else if (plain) hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 1, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gemm_tn_bf16_kernel<1, 1, false>), grid, dim3(256), lds, st, a);
+  }
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -431,14 +620,18 @@ int mfpa_glu_bwd(float* u, long long rows, int npad, int N, const float* dg, lon
 
 int mfpa_colsum_any(const float* x, long long rows, int C, long long ld, float* out, void* stream) {
   if (rows == 0) return MFPA_OK;
-  if (!x || !out || rows < 0 || C < 4 || C % 4 || C > 8192 || ld < C || ld % 4) return MFPA_EINVAL;
-  long long blocks = (rows * (C / 4) + 256 * 64 - 1) / (256 * 64);      // about 64 float4 per thread
-  if (blocks > 1024) blocks = 1024;
+  if (!x || !out || rows < 0 || C < 4 || C % 4 || C > 4096 || ld < C || ld % 4) return MFPA_EINVAL;
+  long long blocks = (rows * (C / 4) + 256 * 32 - 1) / (256 * 32);      // about 32 float4 per thread
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   const long long rpb = (rows + blocks - 1) / blocks;
   blocks = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL(colsum_any_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * sizeof(float), mfpa_stream(stream), x, rows, C,
-                     ld, out, rpb);
+  if (C <= 1024)
+    hipLaunchKernelGGL(colsum_any_kernel<1>, dim3((unsigned)blocks), dim3(256), (size_t)C * sizeof(float), mfpa_stream(stream), x, rows,
+                       C, ld, out, rpb);
+  else
+    hipLaunchKernelGGL(colsum_any_kernel<4>, dim3((unsigned)blocks), dim3(256), (size_t)C * sizeof(float), mfpa_stream(stream), x, rows,
+                       C, ld, out, rpb);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -47,10 +47,13 @@ def _p(t: torch.Tensor, off: int = 0) -> int:
     return ptr(t) + 4 * off
 
 
-def gemm_tn(A: int, lda, strideA, Bm: int, ldb, strideB, C: torch.Tensor, ldc, batch, R, M, N):
+WGRAD_PRECISION = 0   # module default of gemm_tn: 0 fp32 MFMA, 1 bf16x3, 2 plain bf16 (the engine passes its own)
+
+
+def gemm_tn(A: int, lda, strideA, Bm: int, ldb, strideB, C: torch.Tensor, ldc, batch, R, M, N, precision: Optional[int] = None):
     """C[m][n] += sum_{b, r} A[b][r][m] * Bm[b][r][n] (mfpa_gemm_tn); A, Bm device addresses, strides in floats."""
     d = GemmTnDesc(A=A, lda=lda, strideA=strideA, Bm=Bm, ldb=ldb, strideB=strideB, C=ptr(C), ldc=ldc, batch=batch, R=R, M=M, N=N,
-                   precision=0)
+                   precision=WGRAD_PRECISION if precision is None else precision)
     t0 = _K._TIMER.start() if _K._TIMER is not None else None
     check(lib().mfpa_gemm_tn(ctypes.byref(d), stream()), "mfpa_gemm_tn")
     if t0 is not None:
@@ -97,8 +100,11 @@ class _Phase:
 
 class DemucsTrainEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 precision: int = 1, mrstft=None, dist_group=None, module=None):
+                 precision: int = 1, mrstft=None, dist_group=None, module=None, wgrad_precision: Optional[int] = None):
+        """precision: forward / input-gradient GEMMs (0 exact fp32 products, 1 bf16x3).  wgrad_precision: weight-gradient GEMMs
+        (0 fp32, 1 bf16x3, 2 plain bf16); default 2 with precision 1 (like the UNet engine), else 0."""
         self.device = torch.device(device)
+        self.wgrad_precision = (2 if precision == 1 else 0) if wgrad_precision is None else wgrad_precision
         self.module = module                  # optional training.model.Demucs whose parameters mirror the flat buffer
         self.lr, self.betas, self.eps, self.precision = lr, betas, eps, precision
         self.step_count = 0
@@ -360,6 +366,8 @@ class DemucsTrainEngine:
         S, P, G, L = self.S, self.P, self.G, lib()
         W = S["W"]
         prec = self.precision
+        import functools
+        gemm_tn = functools.partial(globals()["gemm_tn"], precision=self.wgrad_precision)
         B, T = S["B"], S["T"]
         dev = dout.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)

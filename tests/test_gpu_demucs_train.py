@@ -14,11 +14,13 @@ def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a.double() - b.double()).abs().sum() / b.double().abs().sum().clamp_min(1e-30))
 
 
-def test_gemm_tn_window_weight_gradient():
-    """dW[co][j*cin + c] = sum_{b,t} dy[b][t][co] * x[b][4t + j][c]: the Conv1d(k8, s4) weight gradient as one TN GEMM."""
+@pytest.mark.parametrize("precision,tol", [(0, 1e-5), (1, 1e-4), (2, 1e-2)])
+def test_gemm_tn_window_weight_gradient(precision, tol):
+    """dW[co][j*cin + c] = sum_{b,t} dy[b][t][co] * x[b][4t + j][c]: the Conv1d(k8, s4) weight gradient as one TN GEMM
+    (fp32 MFMA / bf16x3 / plain bf16 through the transposing LDS reads)."""
     from musicfpaugment_amd import ops_demucs_train as T
     g = torch.Generator().manual_seed(1)
-    for (B, L, cin, cout) in [(3, 37, 48, 96), (2, 130, 96, 192), (2, 9, 48, 48)]:
+    for (B, L, cin, cout) in [(3, 37, 48, 96), (2, 130, 96, 192), (2, 9, 48, 48), (2, 1000, 192, 384)]:
         Lin = 4 * (L - 1) + 8
         x = torch.randn(B, Lin, cin, generator=g)
         dy = torch.randn(B, L, cout, generator=g)
@@ -26,8 +28,8 @@ def test_gemm_tn_window_weight_gradient():
         want = torch.einsum("btm,btn->mn", dy.double(), win.double())
         out = torch.zeros(cout, 8 * cin, device="cuda")
         xd, dyd = x.cuda(), dy.cuda()
-        T.gemm_tn(T._p(dyd), cout, L * cout, T._p(xd), 4 * cin, Lin * cin, out, 8 * cin, B, L, cout, 8 * cin)
-        assert _rel(out.cpu(), want) < 1e-5
+        T.gemm_tn(T._p(dyd), cout, L * cout, T._p(xd), 4 * cin, Lin * cin, out, 8 * cin, B, L, cout, 8 * cin, precision=precision)
+        assert _rel(out.cpu(), want) < tol
         bias = torch.zeros(cout, device="cuda")
         T.colsum(T._p(dyd), B * L, cout, cout, bias)
         assert _rel(bias.cpu(), dy.double().sum((0, 1))) < 1e-5
@@ -155,16 +157,17 @@ def _oracle_step(sd, clean, aug):
     return pred.detach(), (float(l1.detach()), float(sc.detach()), float(mag.detach())), {k: p.grad for k, p in params.items()}
 
 
-@pytest.mark.parametrize("precision,tol", [(0, 2e-3), (1, 2e-3)])
-def test_train_step_gradients_vs_autograd(precision, tol):
-    """Every parameter gradient of one step (B = 2, 0.5 s clips) vs float64 autograd through the oracle; then the Adam update."""
+@pytest.mark.parametrize("precision,wgrad,tol", [(0, 0, 2e-3), (1, 0, 2e-3), (1, 1, 2e-3), (1, 2, 2e-2)])
+def test_train_step_gradients_vs_autograd(precision, wgrad, tol):
+    """Every parameter gradient of one step (B = 2, 0.5 s clips) vs float64 autograd through the oracle; then the Adam update.
+    wgrad 2 = plain-bf16 weight-gradient products (the bench default): 2^-9 product rounding, averaged over the time steps."""
     from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
     sd = formula_state_dict(0)
     n = 4000
     clean = torch.from_numpy(synth.batch(2, seed=31, n=n))
     aug = (clean + 0.05 * torch.from_numpy(synth.batch(2, seed=77, n=n))).float()
     pred_w, (l1_w, sc_w, mag_w), grads = _oracle_step(sd, clean, aug)
-    eng = DemucsTrainEngine(sd, "cuda", precision=precision)
+    eng = DemucsTrainEngine(sd, "cuda", precision=precision, wgrad_precision=wgrad)
     # the engine's state_dict round-trips the reference layout
     back = eng.state_dict()
     assert all(torch.equal(back[k].cpu(), sd[k]) for k in sd)
@@ -177,7 +180,8 @@ def test_train_step_gradients_vs_autograd(precision, tol):
     worst = {}
     for k in sd:
         worst[k] = _rel(got[k].cpu(), grads[k])
-    bad = {k: v for k, v in worst.items() if v > tol}
+    bad = {k: v for k, v in worst.items() if v > (tol if k.endswith("weight") else 2e-3)}
+    print(f"precision {precision} wgrad {wgrad}: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
     assert not bad, f"gradient mismatch: {bad}"
     # Adam: first step moves every parameter by -lr * sign(g) (bias-corrected m / sqrt(v) = g / |g|)
     before = eng.flat_p.clone()
