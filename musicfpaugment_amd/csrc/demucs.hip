@@ -538,6 +538,10 @@ constexpr int LROW = 4 * LKC + 16;       // LDS row bytes: [128 hi | 128 lo | pa
 constexpr int LBM = 64, LU = 16;         // clips x hidden units per workgroup
 
 constexpr int LTHREADS = 512;   // 8 waves: (clip half) x (gate-column half) x (k-step half of every chunk)
+#ifndef MFPA_LSTM_PF
+#define MFPA_LSTM_PF 3
+#endif
+constexpr int LPF = MFPA_LSTM_PF;  // chunks of global loads in flight per thread (register ring)
 
 __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __restrict__ hprev, long long ldhp,
                                                            const float* __restrict__ whh, const float* xp,
@@ -571,17 +575,20 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
     const float* Wg = whh + (size_t)grp * 64 * H;
     const int nk = H / LKC;
     constexpr int F4 = LBM * (LKC / 4) / LTHREADS;       // float4 per thread per operand per chunk (4)
-    f32x4 ar[F4], br[F4];
+    // Register ring of LPF chunks: the recurrence is latency-bound (h[t-1] was written by the previous launch on other XCDs,
+    // so it comes from HBM / the Infinity Cache), and the MFMA block of a chunk is ~0.2 us -- with one chunk in flight every
+    // chunk exposed a full memory latency.  All LPF chunks' loads are issued before the first one is consumed.
+    f32x4 ar[LPF][F4], br[LPF][F4];
     const int q = tid % (LKC / 4), r0 = tid / (LKC / 4); // column quad, first row; rows r0 + 8 i
-    auto load = [&](int kc) __attribute__((always_inline)) {
+    auto load = [&](int kc, f32x4 (&a4)[F4], f32x4 (&b4)[F4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
         const int row = r0 + (LTHREADS / (LKC / 4)) * i;
         const int m = m0 + row;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < B) v = *reinterpret_cast<const f32x4*>(hprev + (size_t)m * ldhp + kc * LKC + 4 * q);
-        ar[i] = v;
-        br[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)row * H + kc * LKC + 4 * q);
+        a4[i] = v;
+        b4[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)row * H + kc * LKC + 4 * q);
       }
     };
     auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
@@ -594,36 +601,42 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
       *reinterpret_cast<l_bf16x4*>(row + 8 * q) = hi;
       *reinterpret_cast<l_bf16x4*>(row + 2 * LKC + 8 * q) = lo;
     };
-    auto store = [&](int buf) __attribute__((always_inline)) {
+    auto store = [&](int buf, f32x4 (&a4)[F4], f32x4 (&b4)[F4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < F4; ++i) {
         const int row = r0 + (LTHREADS / (LKC / 4)) * i;
-        split_store(As + (buf * LBM + row) * LROW, ar[i]);
-        split_store(Bs + (buf * LBM + row) * LROW, br[i]);
+        split_store(As + (buf * LBM + row) * LROW, a4[i]);
+        split_store(Bs + (buf * LBM + row) * LROW, b4[i]);
       }
     };
-    load(0);
-    store(0);
-    if (nk > 1) load(1);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-      const int buf = kc & 1;
-      if (kc + 1 < nk) store(buf ^ 1);
-      if (kc + 2 < nk) load(kc + 2);
-      const char* Ap = As + (buf * LBM + wm * 32 + li) * LROW + 16 * lh;
-      const char* Bp = Bs + (buf * LBM + wn * 32 + li) * LROW + 16 * lh;
 #pragma unroll
-      for (int s = 4 * wk; s < 4 * wk + 4; ++s) {
-        const l_bf16x8 ah = *reinterpret_cast<const l_bf16x8*>(Ap + 32 * s);
-        const l_bf16x8 al = *reinterpret_cast<const l_bf16x8*>(Ap + 2 * LKC + 32 * s);
-        const l_bf16x8 bh = *reinterpret_cast<const l_bf16x8*>(Bp + 32 * s);
-        const l_bf16x8 bl = *reinterpret_cast<const l_bf16x8*>(Bp + 2 * LKC + 32 * s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    for (int j = 0; j < LPF; ++j)
+      if (j < nk) load(j, ar[j], br[j]);
+    for (int base = 0; base < nk; base += LPF) {
+#pragma unroll
+      for (int j = 0; j < LPF; ++j) {
+        const int kc = base + j;
+        if (kc < nk) {                                   // uniform over the workgroup
+          const int buf = kc & 1;
+          store(buf, ar[j], br[j]);                      // buffer (kc & 1) was last read for chunk kc - 2, before the previous barrier
+          if (kc + LPF < nk) load(kc + LPF, ar[j], br[j]);
+          __syncthreads();
+          const char* Ap = As + (buf * LBM + wm * 32 + li) * LROW + 16 * lh;
+          const char* Bp = Bs + (buf * LBM + wn * 32 + li) * LROW + 16 * lh;
+#pragma unroll
+          for (int s = 4 * wk; s < 4 * wk + 4; ++s) {
+            const l_bf16x8 ah = *reinterpret_cast<const l_bf16x8*>(Ap + 32 * s);
+            const l_bf16x8 al = *reinterpret_cast<const l_bf16x8*>(Ap + 2 * LKC + 32 * s);
+            const l_bf16x8 bh = *reinterpret_cast<const l_bf16x8*>(Bp + 32 * s);
+            const l_bf16x8 bl = *reinterpret_cast<const l_bf16x8*>(Bp + 2 * LKC + 32 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+          }
+        }
       }
-      __syncthreads();
     }
+    __syncthreads();                                     // the gate tile below reuses the operand buffers
   }
   // gates of the tile -> LDS [64 clips][64 + 4], then one thread per (clip, 4 units) runs the cell
   float* G = reinterpret_cast<float*>(lsm);

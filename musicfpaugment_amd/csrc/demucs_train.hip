@@ -443,6 +443,10 @@ constexpr int BKC = 128;
 constexpr int BROW = 4 * BKC + 16;       // LDS row bytes [128 hi | 128 lo | pad]
 constexpr int BBM = 64, BU = 32;
 constexpr int BTHREADS = 512;
+#ifndef MFPA_LSTM_BPF
+#define MFPA_LSTM_BPF 6
+#endif
+constexpr int BPF = MFPA_LSTM_BPF;       // chunks of global loads in flight per thread
 
 __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float* __restrict__ dgnext, long long ldgn,
                                                                     const float* __restrict__ whhT, float* gs, long long ldgs,
@@ -474,18 +478,19 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
   if (dgnext != nullptr) {
     const float* Wg = whhT + (size_t)grp * BU * K;
     const int nk = K / BKC;
-    f32x4 ar[4], br[2];
+    // register ring of BPF chunks of global loads (the step is latency-bound: dgates[t+1] was written by the previous launch)
+    f32x4 ar[BPF][4], br[BPF][2];
     const int q = tid & 31, r0 = tid >> 5;             // column quad, first row; rows r0 + 16 i
-    auto load = [&](int kc) __attribute__((always_inline)) {
+    auto load = [&](int kc, f32x4 (&a4)[4], f32x4 (&b2)[2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + r0 + 16 * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < B) v = *reinterpret_cast<const f32x4*>(dgnext + (size_t)m * ldgn + kc * BKC + 4 * q);
-        ar[i] = v;
+        a4[i] = v;
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) br[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(r0 + 16 * i) * K + kc * BKC + 4 * q);
+      for (int i = 0; i < 2; ++i) b2[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(r0 + 16 * i) * K + kc * BKC + 4 * q);
     };
     auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
       t_bf16x4 hi, lo;
@@ -497,34 +502,40 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
       *reinterpret_cast<t_bf16x4*>(row + 8 * q) = hi;
       *reinterpret_cast<t_bf16x4*>(row + 2 * BKC + 8 * q) = lo;
     };
-    auto store = [&](int buf) __attribute__((always_inline)) {
+    auto store = [&](int buf, f32x4 (&a4)[4], f32x4 (&b2)[2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) split_store(As + (buf * BBM + r0 + 16 * i) * BROW, ar[i]);
+      for (int i = 0; i < 4; ++i) split_store(As + (buf * BBM + r0 + 16 * i) * BROW, a4[i]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) split_store(Bs + (buf * BU + r0 + 16 * i) * BROW, br[i]);
+      for (int i = 0; i < 2; ++i) split_store(Bs + (buf * BU + r0 + 16 * i) * BROW, b2[i]);
     };
-    load(0);
-    store(0);
-    if (nk > 1) load(1);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-      const int buf = kc & 1;
-      if (kc + 1 < nk) store(buf ^ 1);
-      if (kc + 2 < nk) load(kc + 2);
-      const char* Ap = As + (buf * BBM + wm * 32 + li) * BROW + 16 * lh;
-      const char* Bp = Bs + (buf * BU + li) * BROW + 16 * lh;
 #pragma unroll
-      for (int s = 2 * wk; s < 2 * wk + 2; ++s) {
-        const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8*>(Ap + 32 * s);
-        const t_bf16x8 al = *reinterpret_cast<const t_bf16x8*>(Ap + 2 * BKC + 32 * s);
-        const t_bf16x8 bh = *reinterpret_cast<const t_bf16x8*>(Bp + 32 * s);
-        const t_bf16x8 bl = *reinterpret_cast<const t_bf16x8*>(Bp + 2 * BKC + 32 * s);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    for (int j = 0; j < BPF; ++j)
+      if (j < nk) load(j, ar[j], br[j]);
+    for (int base = 0; base < nk; base += BPF) {
+#pragma unroll
+      for (int j = 0; j < BPF; ++j) {
+        const int kc = base + j;
+        if (kc < nk) {                                   // uniform over the workgroup
+          const int buf = kc & 1;
+          store(buf, ar[j], br[j]);                      // buffer (kc & 1) was last read for chunk kc - 2, before the previous barrier
+          if (kc + BPF < nk) load(kc + BPF, ar[j], br[j]);
+          __syncthreads();
+          const char* Ap = As + (buf * BBM + wm * 32 + li) * BROW + 16 * lh;
+          const char* Bp = Bs + (buf * BU + li) * BROW + 16 * lh;
+#pragma unroll
+          for (int s = 2 * wk; s < 2 * wk + 2; ++s) {
+            const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8*>(Ap + 32 * s);
+            const t_bf16x8 al = *reinterpret_cast<const t_bf16x8*>(Ap + 2 * BKC + 32 * s);
+            const t_bf16x8 bh = *reinterpret_cast<const t_bf16x8*>(Bp + 32 * s);
+            const t_bf16x8 bl = *reinterpret_cast<const t_bf16x8*>(Bp + 2 * BKC + 32 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+          }
+        }
       }
-      __syncthreads();
     }
+    __syncthreads();                                     // the slabs below reuse the operand buffers
   }
   // the four K quarters -> LDS slabs [4][64 clips][36], summed by the cell threads
   float* G = reinterpret_cast<float*>(lsm);

@@ -1,0 +1,45 @@
+"""Host logic of the Demucs training engine that needs no GPU: the flat master-layout buffer holds every reference parameter
+exactly once (plus zero padding), and the reference's state_dict round-trips through it."""
+import torch
+
+from musicfpaugment_amd.training.demucs_weights import formula_state_dict, state_dict_shapes
+
+
+def test_flat_layout_round_trip_on_cpu():
+    from musicfpaugment_amd.ops_demucs_train import CH, DemucsTrainEngine
+    sd = formula_state_dict(3)
+    eng = DemucsTrainEngine(sd, "cpu")
+    back = eng.state_dict()
+    assert list(back.keys()) != [] and set(back.keys()) == set(state_dict_shapes().keys())
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    n_ref = sum(v.numel() for v in sd.values())
+    assert n_ref == 18_867_937
+    # every non-zero entry of the flat buffer is a reference parameter; the rest is GEMM row padding
+    assert int((eng.flat_p != 0).sum()) <= n_ref <= eng.n_params
+    assert eng.n_params - n_ref < 0.02 * n_ref
+    # padding rows of the 96-channel level (96 -> 128 rows) are zero and stay addressable as a W operand
+    assert eng.P["enc1.w"].shape == (128, 8 * CH[0]) and float(eng.P["enc1.w"][96:].abs().max()) == 0.0
+    # gradients exported through the same mapping
+    eng.flat_g.copy_(eng.flat_p)
+    gd = eng.grad_dict()
+    assert all(torch.equal(gd[k], sd[k]) for k in sd)
+
+
+def test_derived_operands_match_the_inference_packing():
+    """The per-step re-layouts (forward ConvTranspose1d operand, grouped W_hh) equal what ops_demucs.pack_demucs_weights builds
+    from the reference layout, so the training forward and the inference forward read identical weights."""
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    sd = formula_state_dict(1)
+    eng = DemucsTrainEngine(sd, "cpu")
+    W = eng._derive()
+    pw = D.pack_demucs_weights(sd, "cpu")
+    for d in range(4):
+        assert torch.equal(W[f"dec{d}.wf"], pw[f"dec{d}.w"])
+        assert torch.equal(W[f"dec{d}.bf"], pw[f"dec{d}.b"])
+        assert torch.equal(eng.P[f"dec{d}.gw"], pw[f"dec{d}.gw"])
+    for i in range(1, 5):
+        assert torch.equal(eng.P[f"enc{i}.w"], pw[f"enc{i}.w"])
+    for layer in range(2):
+        assert torch.equal(W[f"lstm{layer}.whh_grouped"], pw[f"lstm{layer}.whh_grouped"])
+        assert torch.equal(W[f"lstm{layer}.b"], pw[f"lstm{layer}.b"])

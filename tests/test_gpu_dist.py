@@ -134,3 +134,35 @@ def test_two_rank_sync_batchnorm_step_equals_the_single_gpu_step():
     diff = np.abs(got[0]["params"] - want)                                       # Adam's first step is lr * sign-like: see above
     assert np.quantile(diff, 0.999) <= 1e-6, np.quantile(diff, 0.999)
     assert float(np.mean(diff > 1e-5)) < 1e-4 and diff.max() <= 2.1e-3
+
+
+def test_two_rank_demucs_train_step():
+    """Data-parallel Demucs step: the summed (all-reduced) gradients of two ranks and the 1/world scaling in Adam against an
+    in-process emulation of the two shards.  Each rank's loss is over its own shard (as under DDP)."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29537", os.path.join(ROOT, "tests", "_dist_demucs_worker.py"), tmp]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        _check(r)
+        got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]
+    np.testing.assert_array_equal(got[0]["params"], got[1]["params"])            # the replicas stay in sync
+    np.testing.assert_array_equal(got[0]["grads"], got[1]["grads"])              # ... on the same summed gradients
+    clean = synth.batch(4, seed=910, n=4000)
+    aug = (clean + 0.05 * synth.batch(4, seed=911, n=4000)).astype(np.float32)
+    gsum = None
+    for k in range(2):
+        eng = DemucsTrainEngine(demucs_formula(0), "cuda", lr=1e-3, precision=0)
+        pred = eng.forward(torch.from_numpy(aug[2 * k:2 * k + 2]).cuda())
+        _, _, _, dpred = eng.loss_and_grad(pred, torch.from_numpy(clean[2 * k:2 * k + 2]).cuda())
+        eng.backward(dpred)
+        gsum = eng.flat_g.clone() if gsum is None else gsum + eng.flat_g
+    g = gsum.cpu().numpy().astype(np.float64)
+    rel = np.abs(got[0]["grads"] - g).sum() / np.abs(g).sum()
+    assert rel < 1e-4, rel                                                       # float atomics: not bit-reproducible
+    # one Adam step on the AVERAGED gradient: -lr * sign(g) wherever the sign is safe
+    p0 = eng.flat_p.cpu().numpy()                                                # untouched initial parameters
+    big = np.abs(g) > 1e-5
+    np.testing.assert_allclose((got[0]["params"] - p0)[big], -1e-3 * np.sign(g[big]), atol=2e-5)
