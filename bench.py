@@ -288,7 +288,7 @@ def bench_demucs_train(args, rank, world, dev, dist):
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": ("bf16x3 forward / input-gradient GEMMs and LSTM steps, f32 weight-gradient GEMMs, f32/f64 reductions and Adam"
+            "dtype": ("bf16x3 forward / input-gradient GEMMs and LSTM steps, plain-bf16 weight-gradient GEMMs, f32/f64 reductions and Adam"
                       if args.precision == "bf16x3" else "f32 GEMMs (the LSTM steps are bf16x3)"), "data": "synthetic",
             "config": {"workload": f"Demucs() train step, L1 + MultiResolutionSTFTLoss(0.5, 0.5), Adam(5e-4), {args.seconds:g} s clips, "
                                    f"{args.precision} GEMMs, pre-mixed noisy clips", "clips_per_gpu_per_step": B,
@@ -296,8 +296,8 @@ def bench_demucs_train(args, rank, world, dev, dist):
                        "parallelism": f"data-parallel x{world}, one RCCL all-reduce of 18.9 M fp32 gradients"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_bf16x3_kernel / gemm_mfma_kernel (forward, input gradients) + gemm_tn_kernel (weight "
-                                   "gradients) + lstm_step(_bwd)_kernel", "launches": timer.launches(),
+                         "kernel": "gemm_bf16x3_kernel / gemm_mfma_kernel (forward, input gradients, the loss's DFT GEMMs) + "
+                                   "gemm_tn(_bf16)_kernel (weight gradients) + lstm_step(_bwd)_kernel", "launches": timer.launches(),
                          "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
