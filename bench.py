@@ -250,7 +250,8 @@ def bench_demucs_train(args, rank, world, dev, dist):
     B = args.clips if args.scaling == "weak" else max(1, args.clips // world)
     n = int(args.seconds * 8000)
     eng = DemucsTrainEngine(demucs_formula(0), dev, lr=DEMUCS_LEARNING_RATE, precision=1 if args.precision == "bf16x3" else 0,
-                            mrstft=MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG).to(dev))
+                            mrstft=MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG,
+                                                           precision=1 if args.precision == "bf16x3" else 0).to(dev))
     base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank, n=n)
     noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, n=n, tonal=False)
     reps = (B + len(base) - 1) // len(base)

@@ -45,7 +45,7 @@ def _dft_matrix(fft_size: int, win_length: int, device) -> Tuple[torch.Tensor, i
     if key not in _DFT_CACHE:
         bins = fft_size // 2 + 1
         off = (fft_size - win_length) // 2
-        kpad = (win_length + 15) // 16 * 16
+        kpad = (win_length + 31) // 32 * 32           # K of the GEMM: a multiple of 32 so that the bf16x3 kernel can take it
         im_off = (bins + 63) // 64 * 64
         npad = (im_off + bins + 63) // 64 * 64
         j = np.arange(win_length, dtype=np.float64)
@@ -58,7 +58,7 @@ def _dft_matrix(fft_size: int, win_length: int, device) -> Tuple[torch.Tensor, i
     return _DFT_CACHE[key]
 
 
-def _dft_rows(x: torch.Tensor, fft_size: int, hop_size: int, win_length: int):
+def _dft_rows(x: torch.Tensor, fft_size: int, hop_size: int, win_length: int, precision: int = 0):
     """(B, T) float32 on the GPU -> GEMM output C (B, frames, npad) float32 with re at [:bins], im at [im_off:im_off+bins]."""
     require_gpu(x, "signal")
     if x.dim() != 2 or x.dtype != torch.float32:
@@ -81,17 +81,17 @@ def _dft_rows(x: torch.Tensor, fft_size: int, hop_size: int, win_length: int):
     check(L.mfpa_reflect_pad(ptr(x), B, T, pad, 0, Lout, ptr(xp), stream()), "mfpa_reflect_pad")
     C = torch.empty((B, frames, npad), dtype=torch.float32, device=dev)
     if hop_size % 4 == 0:
-        gemm(ptr(xp) + 4 * off, hop_size, Lout, B, frames, W, None, npad, ptr(C), npad, frames * npad, precision=0)
+        gemm(ptr(xp) + 4 * off, hop_size, Lout, B, frames, W, None, npad, ptr(C), npad, frames * npad, precision=precision)
     else:
         # odd frames start at off + hop (2 mod 4 floats): read them from a copy shifted by 2 samples so that every row
         # of both GEMMs is 16-byte aligned; even / odd frames interleave in C through the row pitch 2 * npad
         xs = torch.empty((B, Lout), dtype=torch.float32, device=dev)
         check(L.mfpa_reflect_pad(ptr(x), B, T, pad, 2, Lout, ptr(xs), stream()), "mfpa_reflect_pad")
         n_even, n_odd = (frames + 1) // 2, frames // 2
-        gemm(ptr(xp) + 4 * off, 2 * hop_size, Lout, B, n_even, W, None, npad, ptr(C), 2 * npad, frames * npad, precision=0)
+        gemm(ptr(xp) + 4 * off, 2 * hop_size, Lout, B, n_even, W, None, npad, ptr(C), 2 * npad, frames * npad, precision=precision)
         if n_odd:
             gemm(ptr(xs) + 4 * (off + hop_size - 2), 2 * hop_size, Lout, B, n_odd, W, None, npad, ptr(C) + 4 * npad, 2 * npad,
-                 frames * npad, precision=0)
+                 frames * npad, precision=precision)
     return C, bins, im_off, frames
 
 
@@ -115,8 +115,12 @@ def stft(x: torch.Tensor, fft_size: int, hop_size: int, win_length: int, window:
 class STFTLoss(torch.nn.Module):
     """loss.py:86-125."""
 
-    def __init__(self, fft_size: int = 1024, shift_size: int = 120, win_length: int = 600, window: str = "hann_window") -> None:
+    def __init__(self, fft_size: int = 1024, shift_size: int = 120, win_length: int = 600, window: str = "hann_window",
+                 precision: int = 0) -> None:
+        """`precision` (not in the reference): arithmetic of the DFT GEMMs -- 0 exact fp32 products (default), 1 bf16x3 (relative
+        error ~1e-6 on the loss values; what the training step uses)."""
         super().__init__()
+        self.precision = precision
         if window != "hann_window":
             raise NotImplementedError("only hann_window (the reference's default and only use)")
         self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
@@ -126,8 +130,8 @@ class STFTLoss(torch.nn.Module):
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if x.shape != y.shape:
             raise ValueError("predicted and groundtruth signals must have the same shape")
-        Cx, bins, im_off, frames = _dft_rows(x, self.fft_size, self.shift_size, self.win_length)
-        Cy, _, _, _ = _dft_rows(y, self.fft_size, self.shift_size, self.win_length)
+        Cx, bins, im_off, frames = _dft_rows(x, self.fft_size, self.shift_size, self.win_length, self.precision)
+        Cy, _, _, _ = _dft_rows(y, self.fft_size, self.shift_size, self.win_length, self.precision)
         rows = x.shape[0] * frames
         L = lib()
         out = torch.empty(3, dtype=torch.float64, device=x.device)
@@ -145,8 +149,8 @@ class STFTLoss(torch.nn.Module):
         if x.shape != y.shape or dx.shape != x.shape or dx.dtype != torch.float32:
             raise ValueError("x, y and dx must be float32 tensors of one shape")
         fs, hop, wl = self.fft_size, self.shift_size, self.win_length
-        Cx, bins, im_off, frames = _dft_rows(x, fs, hop, wl)
-        Cy, _, _, _ = _dft_rows(y, fs, hop, wl)
+        Cx, bins, im_off, frames = _dft_rows(x, fs, hop, wl, self.precision)
+        Cy, _, _, _ = _dft_rows(y, fs, hop, wl, self.precision)
         B, T = x.shape
         rows, npad = B * frames, Cx.shape[2]
         L = lib()
@@ -158,7 +162,7 @@ class STFTLoss(torch.nn.Module):
         Wt = _dft_matrix_t(fs, wl, x.device)
         kp = Wt.shape[0]
         dfr = torch.empty((B, frames, kp), dtype=torch.float32, device=x.device)
-        gemm(ptr(Cx), npad, frames * npad, B, frames, Wt, None, kp, ptr(dfr), kp, frames * kp, precision=0)
+        gemm(ptr(Cx), npad, frames * npad, B, frames, Wt, None, kp, ptr(dfr), kp, frames * kp, precision=self.precision)
         pad, off = fs // 2, (fs - wl) // 2
         Lp = T + 2 * pad
         dxp = torch.empty((B, Lp), dtype=torch.float32, device=x.device)
@@ -174,10 +178,10 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
 
     def __init__(self, fft_sizes: List[int] = [1024, 2048, 512], hop_sizes: List[int] = [120, 240, 50],
                  win_lengths: List[int] = [600, 1200, 240], window: str = "hann_window", factor_sc: float = 0.1,
-                 factor_mag: float = 0.1) -> None:
+                 factor_mag: float = 0.1, precision: int = 0) -> None:
         super().__init__()
         assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
-        self.stft_losses = torch.nn.ModuleList([STFTLoss(fs, ss, wl, window) for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths)])
+        self.stft_losses = torch.nn.ModuleList([STFTLoss(fs, ss, wl, window, precision) for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths)])
         self.factor_sc, self.factor_mag = factor_sc, factor_mag
 
     @torch.no_grad()

@@ -95,7 +95,7 @@ class Trainer:
         if input_type == "audio":
             from ..ops_demucs_train import DemucsTrainEngine
             from .loss import MultiResolutionSTFTLoss
-            self.mrsl = MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG).to(self.device)   # train.py:652-655
+            self.mrsl = MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG, precision=precision).to(self.device)   # train.py:652-655
             self.engine = DemucsTrainEngine(self.model.state_dict(), self.device, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8,
                                             precision=precision, mrstft=self.mrsl, module=self.model)
         else:
