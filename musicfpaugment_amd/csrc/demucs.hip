@@ -535,7 +535,7 @@ typedef __bf16 l_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 l_bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LKC = 128;                 // K chunk
 constexpr int LROW = 4 * LKC + 16;       // LDS row bytes: [128 hi | 128 lo | pad]
-constexpr int LBM = 64, LU = 16;         // clips x hidden units per workgroup
+constexpr int LU = 16;                   // hidden units per workgroup (64 gate columns)
 
 constexpr int LTHREADS = 512;   // 8 waves: (clip half) x (gate-column half) x (k-step half of every chunk)
 #ifndef MFPA_LSTM_PF
@@ -543,6 +543,10 @@ constexpr int LTHREADS = 512;   // 8 waves: (clip half) x (gate-column half) x (
 #endif
 constexpr int LPF = MFPA_LSTM_PF;  // chunks of global loads in flight per thread (register ring)
 
+// MT = 32-clip tiles per workgroup: 2 (64 clips; 8 waves = 2 clip halves x 2 gate-column halves x 2 k-step halves) or 1 (32
+// clips; 2 gate-column halves x 4 k-step quarters).  The step streams h[t-1] and its W_hh slice from memory every launch and is
+// bound by what the CUs that own it can pull, so small batches use the 32-clip form: twice the workgroups, half of h[t-1] each.
+template <int MT>
 __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __restrict__ hprev, long long ldhp,
                                                            const float* __restrict__ whh, const float* xp,
                                                            long long ldxp, const float* cin, long long ldci, float* cout,
@@ -550,12 +554,15 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
                                                            float* __restrict__ hout, long long ldh, float* __restrict__ hsum,
                                                            const float* __restrict__ addend, long long ldadd, int mtiles,
                                                            float* gsave, long long ldgs) {
+  constexpr int BMT = 32 * MT;               // clips per workgroup
+  constexpr int WK = 4 / MT;                 // k-step groups
+  constexpr int KS = 8 / WK;                 // k-steps of 16 per wave and 128-wide chunk
   extern __shared__ __attribute__((aligned(16))) char lsm[];
-  char* As = lsm;                            // [2][64][LROW]
-  char* Bs = lsm + 2 * LBM * LROW;           // [2][64][LROW]
+  char* As = lsm;                            // [2][BMT][LROW]
+  char* Bs = lsm + 2 * BMT * LROW;           // [2][64][LROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave & 1, wn = (wave >> 1) & 1, wk = wave >> 2;   // wk: k-steps 4 wk .. 4 wk + 3 of each 128-wide chunk
+  const int wm = wave % MT, wn = (wave / MT) & 1, wk = wave / (2 * MT);
   // XCD-aware decode: consecutive workgroup ids go round-robin over the 8 XCDs
   const int ngroups = H / LU;
   int grp, mt;
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
     if (lin >= total) return;                           // uniform per workgroup (before any barrier)
     grp = lin / mtiles; mt = lin % mtiles;
   }
-  const int m0 = mt * LBM;
+  const int m0 = mt * BMT;
   floatx16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -574,22 +581,22 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
   if (hprev != nullptr) {
     const float* Wg = whh + (size_t)grp * 64 * H;
     const int nk = H / LKC;
-    constexpr int F4 = LBM * (LKC / 4) / LTHREADS;       // float4 per thread per operand per chunk (4)
-    // Register ring of LPF chunks: the recurrence is latency-bound (h[t-1] was written by the previous launch on other XCDs,
-    // so it comes from HBM / the Infinity Cache), and the MFMA block of a chunk is ~0.2 us -- with one chunk in flight every
-    // chunk exposed a full memory latency.  All LPF chunks' loads are issued before the first one is consumed.
-    f32x4 ar[LPF][F4], br[LPF][F4];
-    const int q = tid % (LKC / 4), r0 = tid / (LKC / 4); // column quad, first row; rows r0 + 8 i
-    auto load = [&](int kc, f32x4 (&a4)[F4], f32x4 (&b4)[F4]) __attribute__((always_inline)) {
+    constexpr int FA = BMT * (LKC / 4) / LTHREADS;       // float4 per thread per chunk: h rows (2 MT)
+    constexpr int FB = 64 * (LKC / 4) / LTHREADS;        // ... and W_hh rows (4)
+    constexpr int RSTEP = LTHREADS / (LKC / 4);          // 16 rows per pass
+    // register ring of LPF chunks of global loads
+    f32x4 ar[LPF][FA], br[LPF][FB];
+    const int q = tid % (LKC / 4), r0 = tid / (LKC / 4); // column quad, first row; rows r0 + 16 i
+    auto load = [&](int kc, f32x4 (&a4)[FA], f32x4 (&b4)[FB]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < F4; ++i) {
-        const int row = r0 + (LTHREADS / (LKC / 4)) * i;
-        const int m = m0 + row;
+      for (int i = 0; i < FA; ++i) {
+        const int m = m0 + r0 + RSTEP * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < B) v = *reinterpret_cast<const f32x4*>(hprev + (size_t)m * ldhp + kc * LKC + 4 * q);
         a4[i] = v;
-        b4[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)row * H + kc * LKC + 4 * q);
       }
+#pragma unroll
+      for (int i = 0; i < FB; ++i) b4[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(r0 + RSTEP * i) * H + kc * LKC + 4 * q);
     };
     auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
       l_bf16x4 hi, lo;
@@ -601,13 +608,11 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
       *reinterpret_cast<l_bf16x4*>(row + 8 * q) = hi;
       *reinterpret_cast<l_bf16x4*>(row + 2 * LKC + 8 * q) = lo;
     };
-    auto store = [&](int buf, f32x4 (&a4)[F4], f32x4 (&b4)[F4]) __attribute__((always_inline)) {
+    auto store = [&](int buf, f32x4 (&a4)[FA], f32x4 (&b4)[FB]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < F4; ++i) {
-        const int row = r0 + (LTHREADS / (LKC / 4)) * i;
-        split_store(As + (buf * LBM + row) * LROW, a4[i]);
-        split_store(Bs + (buf * LBM + row) * LROW, b4[i]);
-      }
+      for (int i = 0; i < FA; ++i) split_store(As + (buf * BMT + r0 + RSTEP * i) * LROW, a4[i]);
+#pragma unroll
+      for (int i = 0; i < FB; ++i) split_store(Bs + (buf * 64 + r0 + RSTEP * i) * LROW, b4[i]);
     };
 #pragma unroll
     for (int j = 0; j < LPF; ++j)
@@ -621,10 +626,10 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
           store(buf, ar[j], br[j]);                      // buffer (kc & 1) was last read for chunk kc - 2, before the previous barrier
           if (kc + LPF < nk) load(kc + LPF, ar[j], br[j]);
           __syncthreads();
-          const char* Ap = As + (buf * LBM + wm * 32 + li) * LROW + 16 * lh;
-          const char* Bp = Bs + (buf * LBM + wn * 32 + li) * LROW + 16 * lh;
+          const char* Ap = As + (buf * BMT + wm * 32 + li) * LROW + 16 * lh;
+          const char* Bp = Bs + (buf * 64 + wn * 32 + li) * LROW + 16 * lh;
 #pragma unroll
-          for (int s = 4 * wk; s < 4 * wk + 4; ++s) {
+          for (int s = KS * wk; s < KS * wk + KS; ++s) {
             const l_bf16x8 ah = *reinterpret_cast<const l_bf16x8*>(Ap + 32 * s);
             const l_bf16x8 al = *reinterpret_cast<const l_bf16x8*>(Ap + 2 * LKC + 32 * s);
             const l_bf16x8 bh = *reinterpret_cast<const l_bf16x8*>(Bp + 32 * s);
@@ -636,42 +641,39 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
         }
       }
     }
-    __syncthreads();                                     // the gate tile below reuses the operand buffers
+    __syncthreads();                                     // the gate slabs below reuse the operand buffers
   }
-  // gates of the tile -> LDS [64 clips][64 + 4], then one thread per (clip, 4 units) runs the cell
+  // the WK partial gate tiles -> LDS slabs [WK][BMT clips][64 + 4], summed by the cell threads
   float* G = reinterpret_cast<float*>(lsm);
   constexpr int GLDW = 68;
-  if (wk == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      G[m * GLDW + wn * 32 + li] = acc[r];
-    }
-  }
-  __syncthreads();
-  if (wk == 1) {                                       // the other half of K
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      G[m * GLDW + wn * 32 + li] += acc[r];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    G[(wk * BMT + m) * GLDW + wn * 32 + li] = acc[r];
   }
   __syncthreads();
   const int clip = tid >> 2, uq = tid & 3;
   const int m = m0 + clip;
-  if (tid < 256 && m < B) {
+  if (clip < BMT && m < B) {
     const int u0 = grp * LU + 4 * uq;
     const float* xr = xp + (size_t)m * ldxp;
     const f32x4 xi = *reinterpret_cast<const f32x4*>(xr + u0), xf = *reinterpret_cast<const f32x4*>(xr + H + u0);
     const f32x4 xg = *reinterpret_cast<const f32x4*>(xr + 2 * H + u0), xo = *reinterpret_cast<const f32x4*>(xr + 3 * H + u0);
     const f32x4 cp = cin ? *reinterpret_cast<const f32x4*>(cin + (size_t)m * ldci + u0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* g = G + clip * GLDW + 4 * uq;
+    f32x4 gi4 = xi, gf4 = xf, gg4 = xg, go4 = xo;
+#pragma unroll
+    for (int w = 0; w < WK; ++w) {
+      const float* g = G + (w * BMT + clip) * GLDW + 4 * uq;
+      gi4 += *reinterpret_cast<const f32x4*>(g);
+      gf4 += *reinterpret_cast<const f32x4*>(g + 16);
+      gg4 += *reinterpret_cast<const f32x4*>(g + 32);
+      go4 += *reinterpret_cast<const f32x4*>(g + 48);
+    }
     f32x4 cn, hn, vi, vf, vg, vo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gi = g[k] + xi[k], gf = g[16 + k] + xf[k], gg = g[32 + k] + xg[k], go = g[48 + k] + xo[k];
-      const float si = 1.f / (1.f + expf(-gi)), sf = 1.f / (1.f + expf(-gf)), so = 1.f / (1.f + expf(-go));
-      const float tg = tanhf(gg);
+      const float si = 1.f / (1.f + expf(-gi4[k])), sf = 1.f / (1.f + expf(-gf4[k])), so = 1.f / (1.f + expf(-go4[k]));
+      const float tg = tanhf(gg4[k]);
       cn[k] = sf * cp[k] + si * tg;
       hn[k] = so * tanhf(cn[k]);
       vi[k] = si; vf[k] = sf; vg[k] = tg; vo[k] = so;
@@ -690,6 +692,29 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
       *reinterpret_cast<f32x4*>(hsum + (size_t)m * ldh + u0) = hn + ad;
     }
   }
+}
+
+// 32-clip tiles while they still leave the chip under-filled (<= 256 workgroups), 64-clip tiles for large batches
+static int lstm_launch(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp, const float* cin,
+                       long long ldci, float* cout, long long ldco, int B, int H, float* hout, long long ldh, float* hsum,
+                       const float* addend, long long ldadd, float* gsave, long long ldgs, void* stream) {
+  static const int force = getenv("MFPA_LSTM_MT") ? atoi(getenv("MFPA_LSTM_MT")) : 0;
+  const int groups = H / LU;
+  int MT = ((long long)groups * ((B + 31) / 32) <= 256) ? 1 : 2;
+  if (force == 1 || force == 2) MT = force;
+  const int mtiles = (B + 32 * MT - 1) / (32 * MT);
+  const long long total = (long long)groups * mtiles;
+  if (total > 0x7fffff) return MFPA_EINVAL;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  const size_t lds = (size_t)2 * (32 * MT + 64) * LROW;
+  if (MT == 1)
+    hipLaunchKernelGGL(lstm_step_kernel<1>, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, cin,
+                       ldci, cout, ldco, B, H, hout, ldh, hsum, addend, ldadd, mtiles, gsave, ldgs);
+  else
+    hipLaunchKernelGGL(lstm_step_kernel<2>, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, cin,
+                       ldci, cout, ldco, B, H, hout, ldh, hsum, addend, ldadd, mtiles, gsave, ldgs);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
 }
 
 }  // namespace
@@ -801,15 +826,8 @@ int mfpa_lstm_step(const float* hprev, long long ldhp, const float* whh_grouped,
   if (B == 0) return MFPA_OK;
   if (!whh_grouped || !xp || !c || !hout || B < 0 || H < LKC || H % LKC) return MFPA_EINVAL;
   if (ldhp % 4 || ldxp % 4 || ldh % 4 || ldadd % 4 || (hsum && !addend)) return MFPA_EINVAL;   // float4 rows
-  const int mtiles = (B + LBM - 1) / LBM;
-  const long long total = (long long)(H / LU) * mtiles;
-  if (total > 0x7fffff) return MFPA_EINVAL;
-  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-  const size_t lds = (size_t)4 * LBM * LROW;
-  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, c,
-                     (long long)H, c, (long long)H, B, H, hout, ldh, hsum, addend, ldadd, mtiles, (float*)nullptr, 0LL);
-  MFPA_CHECK_LAUNCH();
-  return MFPA_OK;
+  return lstm_launch(hprev, ldhp, whh_grouped, xp, ldxp, c, (long long)H, c, (long long)H, B, H, hout, ldh, hsum, addend, ldadd,
+                     nullptr, 0LL, stream);
 }
 
 int mfpa_lstm_step_train(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp,
@@ -818,15 +836,8 @@ int mfpa_lstm_step_train(const float* hprev, long long ldhp, const float* whh_gr
   if (B == 0) return MFPA_OK;
   if (!whh_grouped || !xp || !cout || !hout || !gsave || B < 0 || H < LKC || H % LKC) return MFPA_EINVAL;
   if (ldhp % 4 || ldxp % 4 || ldh % 4 || ldadd % 4 || ldcp % 4 || ldco % 4 || ldgs % 4 || (hsum && !addend)) return MFPA_EINVAL;
-  const int mtiles = (B + LBM - 1) / LBM;
-  const long long total = (long long)(H / LU) * mtiles;
-  if (total > 0x7fffff) return MFPA_EINVAL;
-  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-  const size_t lds = (size_t)4 * LBM * LROW;
-  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(LTHREADS), lds, mfpa_stream(stream), hprev, ldhp, whh_grouped, xp, ldxp, cprev,
-                     ldcp, cout, ldco, B, H, hout, ldh, hsum, addend, ldadd, mtiles, gsave, ldgs);
-  MFPA_CHECK_LAUNCH();
-  return MFPA_OK;
+  return lstm_launch(hprev, ldhp, whh_grouped, xp, ldxp, cprev, ldcp, cout, ldco, B, H, hout, ldh, hsum, addend, ldadd, gsave, ldgs,
+                     stream);
 }
 
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,

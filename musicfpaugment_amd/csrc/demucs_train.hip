@@ -11,6 +11,7 @@
 //   lstm_step_bwd_kernel  one backward time step: dh_rec = dgates[t+1] W_hh, then the cell backward, in one launch
 //   downsample2 adjoint, the two 1-channel convolutions' weight gradients, column sums (bias gradients)
 #include "mfpa_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -441,25 +442,30 @@ __global__ __launch_bounds__(256) void downsample2_adj_kernel(const float* __res
 // groups keep their 1.2 MB of W_hh^T in that XCD's L2 for all steps.
 constexpr int BKC = 128;
 constexpr int BROW = 4 * BKC + 16;       // LDS row bytes [128 hi | 128 lo | pad]
-constexpr int BBM = 64, BU = 32;
+constexpr int BU = 32;
 constexpr int BTHREADS = 512;
 #ifndef MFPA_LSTM_BPF
 #define MFPA_LSTM_BPF 6
 #endif
 constexpr int BPF = MFPA_LSTM_BPF;       // chunks of global loads in flight per thread
 
+template <int MT>   // 32-clip tiles per workgroup: 2 = (clip half) x (K quarter), 1 = K eighths (small batches: twice the workgroups)
 __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float* __restrict__ dgnext, long long ldgn,
                                                                     const float* __restrict__ whhT, float* gs, long long ldgs,
                                                                     const float* __restrict__ ct, long long ldct,
                                                                     const float* __restrict__ cprev, long long ldcp,
                                                                     const float* __restrict__ dhout, long long lddh,
                                                                     float* __restrict__ dcstate, int B, int H, int mtiles) {
+  constexpr int BBM = 32 * MT;               // clips per workgroup
+  constexpr int WK = 8 / MT;                 // k-step groups
+  constexpr int KS = 8 / WK;                 // k-steps of 16 per wave and chunk
+  constexpr int FA = BBM * 32 / BTHREADS;    // float4 per thread per chunk for the dgates rows (2 MT)
   extern __shared__ __attribute__((aligned(16))) char lsm[];
-  char* As = lsm;                            // [2][64][BROW]
+  char* As = lsm;                            // [2][BBM][BROW]
   char* Bs = lsm + 2 * BBM * BROW;           // [2][32][BROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave & 1, wk = wave >> 1;   // wk: k-steps 2 wk, 2 wk + 1 of each chunk
+  const int wm = wave % MT, wk = wave / MT;  // wk: k-steps KS wk .. of each chunk
   const int ngroups = H / BU;
   int grp, mt;
   {
@@ -479,11 +485,11 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
     const float* Wg = whhT + (size_t)grp * BU * K;
     const int nk = K / BKC;
     // register ring of BPF chunks of global loads (the step is latency-bound: dgates[t+1] was written by the previous launch)
-    f32x4 ar[BPF][4], br[BPF][2];
+    f32x4 ar[BPF][FA], br[BPF][2];
     const int q = tid & 31, r0 = tid >> 5;             // column quad, first row; rows r0 + 16 i
-    auto load = [&](int kc, f32x4 (&a4)[4], f32x4 (&b2)[2]) __attribute__((always_inline)) {
+    auto load = [&](int kc, f32x4 (&a4)[FA], f32x4 (&b2)[2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < FA; ++i) {
         const int m = m0 + r0 + 16 * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m < B) v = *reinterpret_cast<const f32x4*>(dgnext + (size_t)m * ldgn + kc * BKC + 4 * q);
@@ -502,9 +508,9 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
       *reinterpret_cast<t_bf16x4*>(row + 8 * q) = hi;
       *reinterpret_cast<t_bf16x4*>(row + 2 * BKC + 8 * q) = lo;
     };
-    auto store = [&](int buf, f32x4 (&a4)[4], f32x4 (&b2)[2]) __attribute__((always_inline)) {
+    auto store = [&](int buf, f32x4 (&a4)[FA], f32x4 (&b2)[2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) split_store(As + (buf * BBM + r0 + 16 * i) * BROW, a4[i]);
+      for (int i = 0; i < FA; ++i) split_store(As + (buf * BBM + r0 + 16 * i) * BROW, a4[i]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) split_store(Bs + (buf * BU + r0 + 16 * i) * BROW, b2[i]);
     };
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
           const char* Ap = As + (buf * BBM + wm * 32 + li) * BROW + 16 * lh;
           const char* Bp = Bs + (buf * BU + li) * BROW + 16 * lh;
 #pragma unroll
-          for (int s = 2 * wk; s < 2 * wk + 2; ++s) {
+          for (int s = KS * wk; s < KS * wk + KS; ++s) {
             const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8*>(Ap + 32 * s);
             const t_bf16x8 al = *reinterpret_cast<const t_bf16x8*>(Ap + 2 * BKC + 32 * s);
             const t_bf16x8 bh = *reinterpret_cast<const t_bf16x8*>(Bp + 32 * s);
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
     }
     __syncthreads();                                     // the slabs below reuse the operand buffers
   }
-  // the four K quarters -> LDS slabs [4][64 clips][36], summed by the cell threads
+  // the WK partial tiles -> LDS slabs [WK][BBM clips][36], summed by the cell threads
   float* G = reinterpret_cast<float*>(lsm);
   constexpr int GLDW = 36;
 #pragma unroll
@@ -548,11 +554,11 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
   __syncthreads();
   const int clip = tid >> 3, uq = tid & 7;
   const int m = m0 + clip;
-  if (m < B) {
+  if (clip < BBM && m < B) {
     const int u0 = grp * BU + 4 * uq;
     f32x4 dh = *reinterpret_cast<const f32x4*>(dhout + (size_t)m * lddh + u0);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) dh += *reinterpret_cast<const f32x4*>(G + (w * BBM + clip) * GLDW + 4 * uq);
+    for (int w = 0; w < WK; ++w) dh += *reinterpret_cast<const f32x4*>(G + (w * BBM + clip) * GLDW + 4 * uq);
     float* gr = gs + (size_t)m * ldgs;
     const f32x4 vi = *reinterpret_cast<const f32x4*>(gr + u0), vf = *reinterpret_cast<const f32x4*>(gr + H + u0);
     const f32x4 vg = *reinterpret_cast<const f32x4*>(gr + 2 * H + u0), vo = *reinterpret_cast<const f32x4*>(gr + 3 * H + u0);
@@ -676,13 +682,20 @@ int mfpa_lstm_step_bwd(const float* dgnext, long long ldgn, const float* whhT, f
   if (B == 0) return MFPA_OK;
   if (!whhT || !gates || !ct || !dhout || !dcstate || B < 0 || H < BKC || H % BKC) return MFPA_EINVAL;
   if (ldgn % 4 || ldg % 4 || ldct % 4 || ldcp % 4 || lddh % 4) return MFPA_EINVAL;
-  const int mtiles = (B + BBM - 1) / BBM;
+  static const int force = getenv("MFPA_LSTM_MT") ? atoi(getenv("MFPA_LSTM_MT")) : 0;
+  int MT = ((long long)(H / BU) * ((B + 31) / 32) <= 256) ? 1 : 2;   // 32-clip tiles while they leave the chip under-filled
+  if (force == 1 || force == 2) MT = force;
+  const int mtiles = (B + 32 * MT - 1) / (32 * MT);
   const long long total = (long long)(H / BU) * mtiles;
   if (total > 0x7fffff) return MFPA_EINVAL;
   const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-  const size_t lds = (size_t)2 * (BBM + BU) * BROW;
-  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg, ct, ldct,
-                     cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
+  const size_t lds = (size_t)2 * (32 * MT + BU) * BROW;
+  if (MT == 1)
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg, ct,
+                       ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
+  else
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg, ct,
+                       ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -109,6 +109,7 @@ class DemucsTrainEngine:
         self.lr, self.betas, self.eps, self.precision = lr, betas, eps, precision
         self.step_count = 0
         self.phases: Optional[Dict[str, list]] = None
+        self.debug: Optional[Dict[str, torch.Tensor]] = None     # set to {} to keep copies of the backward intermediates
         self.mrstft = mrstft
         self.dist_group = dist_group
         # ---- flat layout
@@ -395,6 +396,7 @@ class DemucsTrainEngine:
               "mfpa_c1_wgrad")
         dg = new(B, Lcur, C)
         check(L.mfpa_conv1d_c1(ptr(dy), B, Lfull, Lcur, C, ptr(P["decL.w"]), 0, 0, ptr(dg), stream()), "mfpa_conv1d_c1")
+        self._dbg("dy", dy); self._dbg("dg4", dg)
         dskip = [None] * DEPTH
         dxsum = None
         for d in range(DEPTH - 1, -1, -1):
@@ -402,6 +404,7 @@ class DemucsTrainEngine:
             npad = _npad_glu(C)
             ud = uds[d]
             check(L.mfpa_glu_bwd(ptr(ud), B * Lcur, npad, C, ptr(dg), C, stream()), "mfpa_glu_bwd")
+            self._dbg(f"du{d}", ud)
             colsum(ptr(ud), B * Lcur, npad, npad, G[f"dec{d}.gb"])
             gemm_tn(ptr(ud), npad, 0, ptr(xins[d]), C, 0, G[f"dec{d}.gw"], C, 1, B * Lcur, npad, C)
             dxin = new(B, Lcur, C)                                       # gradient of x + skip: both addends receive it
@@ -415,12 +418,14 @@ class DemucsTrainEngine:
             D.gemm(_p(ud), npad, Lcur * npad, B, Lcur, W[f"dec{d}.gwT"], None, C, _p(dyc), C, Lcur * C, mode=3,
                    addend=_p(rs[d - 1]), ldadd=C, strideAdd=Lcur * C, precision=prec, C2=_p(dxin), ldc2=C, strideC2=Lcur * C)
             dskip[DEPTH - 1 - d] = dxin
+            self._dbg(f"dyc{d}", dyc); self._dbg(f"dxin{d}", dxin)
             # ---- ConvTranspose1d of decoder d-1: (B, Lp, Cp) -> (B, Lcur, C)
             Cp, Lp = CH[DEPTH - d], Ld[d - 1]
             colsum(ptr(dyc), B * Lcur, C, C, G[f"dec{d - 1}.b"])
             gemm_tn(_p(Ps[d - 1], Cp), Cp, (Lp + 2) * Cp, ptr(dyc), 4 * C, Lcur * C, G[f"dec{d - 1}.w"], 8 * C, B, Lp, Cp, 8 * C)
             dg = new(B, Lp, Cp)
             D.gemm(_p(dyc), 4 * C, Lcur * C, B, Lp, P[f"dec{d - 1}.w"], None, Cp, _p(dg), Cp, Lp * Cp, precision=prec)
+            self._dbg(f"dg{d - 1}", dg)
         # ---- LSTM
         self._mark("bwd_decoder")
         Tn = S["Tn"]
@@ -481,6 +486,10 @@ class DemucsTrainEngine:
             dh = dprev
         self._mark("bwd_encoder")
         self.S = None
+
+    def _dbg(self, name: str, t: torch.Tensor) -> None:
+        if self.debug is not None:
+            self.debug[name] = t.detach().clone()
 
     def _mark(self, name: str) -> None:
         """Phase boundary inside backward(): time since the previous mark (or since backward() began)."""

@@ -157,31 +157,32 @@ def _oracle_step(sd, clean, aug):
     return pred.detach(), (float(l1.detach()), float(sc.detach()), float(mag.detach())), {k: p.grad for k, p in params.items()}
 
 
-@pytest.mark.parametrize("precision,wgrad,tol", [(0, 0, 2e-3), (1, 0, 2e-3), (1, 1, 2e-3), (1, 2, 2e-2)])
-def test_train_step_gradients_vs_autograd(precision, wgrad, tol):
-    """Every parameter gradient of one step (B = 2, 0.5 s clips) vs float64 autograd through the oracle; then the Adam update.
-    wgrad 2 = plain-bf16 weight-gradient products (the bench default): 2^-9 product rounding, averaged over the time steps."""
-    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
-    sd = formula_state_dict(0)
+def _inputs():
     n = 4000
     clean = torch.from_numpy(synth.batch(2, seed=31, n=n))
     aug = (clean + 0.05 * torch.from_numpy(synth.batch(2, seed=77, n=n))).float()
+    return clean, aug
+
+
+def test_train_step_gradients_vs_autograd():
+    """Every parameter gradient of one step (B = 2, 0.5 s clips, exact-fp32 products) vs float64 autograd through the oracle;
+    then the Adam update."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    sd = formula_state_dict(0)
+    clean, aug = _inputs()
     pred_w, (l1_w, sc_w, mag_w), grads = _oracle_step(sd, clean, aug)
-    eng = DemucsTrainEngine(sd, "cuda", precision=precision, wgrad_precision=wgrad)
-    # the engine's state_dict round-trips the reference layout
-    back = eng.state_dict()
+    eng = DemucsTrainEngine(sd, "cuda", precision=0)
+    back = eng.state_dict()                                              # the reference layout round-trips
     assert all(torch.equal(back[k].cpu(), sd[k]) for k in sd)
     pred = eng.forward(aug.cuda())
-    assert _rel(pred.cpu(), pred_w) < 1e-4
+    assert _rel(pred.cpu(), pred_w) < 1e-5
     l1, sc, mag, dpred = eng.loss_and_grad(pred, clean.cuda())
     np.testing.assert_allclose([float(l1), float(sc), float(mag)], [l1_w, sc_w, mag_w], rtol=1e-3)
     eng.backward(dpred)
     got = eng.grad_dict()
-    worst = {}
-    for k in sd:
-        worst[k] = _rel(got[k].cpu(), grads[k])
-    bad = {k: v for k, v in worst.items() if v > (tol if k.endswith("weight") else 2e-3)}
-    print(f"precision {precision} wgrad {wgrad}: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
+    worst = {k: _rel(got[k].cpu(), grads[k]) for k in sd}
+    print(f"fp32: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
+    bad = {k: v for k, v in worst.items() if v > 1e-3}
     assert not bad, f"gradient mismatch: {bad}"
     # Adam: first step moves every parameter by -lr * sign(g) (bias-corrected m / sqrt(v) = g / |g|)
     before = eng.flat_p.clone()
@@ -191,6 +192,51 @@ def test_train_step_gradients_vs_autograd(precision, wgrad, tol):
     nz = gflat.abs() > 1e-6
     assert torch.allclose(delta[nz], -1e-3 * torch.sign(gflat[nz]), atol=2e-5)
     assert float(delta[gflat == 0].abs().max()) == 0.0          # zero-padded rows stay zero
+
+
+@pytest.mark.parametrize("precision,wgrad,tol", [(1, 0, 1e-4), (1, 1, 1e-4), (1, 2, 1e-2)])
+def test_backward_arithmetic_variants_on_one_forward_state(precision, wgrad, tol):
+    """The backward pass is linear in dpred GIVEN the forward state (ReLU masks, gates).  On one fp32 forward state, the bf16x3
+    input-gradient GEMMs (precision 1) and the bf16x3 / plain-bf16 weight-gradient GEMMs (wgrad 1 / 2: 2^-9 product rounding,
+    averaged over the time steps) are compared with the exact-fp32 backward."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    sd = formula_state_dict(0)
+    clean, aug = _inputs()
+
+    def grads(prec, wg):
+        eng = DemucsTrainEngine(sd, "cuda", precision=0, wgrad_precision=0)
+        pred = eng.forward(aug.cuda())
+        _, _, _, dpred = eng.loss_and_grad(pred, clean.cuda())
+        eng.precision, eng.wgrad_precision = prec, wg               # arithmetic of the backward GEMMs only
+        eng.backward(dpred)
+        return eng.grad_dict()
+
+    want, got = grads(0, 0), grads(precision, wgrad)
+    worst = {k: _rel(got[k], want[k]) for k in want}
+    print(f"backward precision {precision} wgrad {wgrad}: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
+    bad = {k: v for k, v in worst.items() if v > (tol if "weight" in k else 1e-4)}
+    assert not bad, f"gradient mismatch: {bad}"
+
+
+def test_bf16x3_forward_step_vs_autograd():
+    """The whole step with bf16x3 forward GEMMs (the bench default).  The prediction stays within 1e-4; a gradient can differ
+    from float64 autograd by more than the product rounding where a ReLU pre-activation lies within that rounding of zero and
+    its mask flips (one flipped unit of the 768-channel level moves the deep layers' gradients by ~5e-3 on this 2-clip batch) --
+    hence the looser bound here and the exact comparison of the backward arithmetic on a fixed forward state above."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    sd = formula_state_dict(0)
+    clean, aug = _inputs()
+    pred_w, (l1_w, sc_w, mag_w), grads = _oracle_step(sd, clean, aug)
+    eng = DemucsTrainEngine(sd, "cuda", precision=1)
+    pred = eng.forward(aug.cuda())
+    assert _rel(pred.cpu(), pred_w) < 1e-4
+    l1, sc, mag, dpred = eng.loss_and_grad(pred, clean.cuda())
+    np.testing.assert_allclose([float(l1), float(sc), float(mag)], [l1_w, sc_w, mag_w], rtol=1e-3)
+    eng.backward(dpred)
+    got = eng.grad_dict()
+    worst = {k: _rel(got[k].cpu(), grads[k]) for k in sd}
+    print(f"bf16x3 step: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
+    assert max(worst.values()) < 3e-2
 
 
 def test_train_step_runs_and_reduces_loss():
