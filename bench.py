@@ -258,20 +258,33 @@ def bench_demucs_train(args, rank, world, dev, dist):
     clean = torch.from_numpy(np.concatenate([base] * reps)[:B].copy()).to(dev)
     aug = torch.from_numpy(np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * reps)[:B].copy()).to(dev)
 
+    af = None
+    if args.augment:                                   # the AugmentFP chain on the device inside every step (training/dataset.py:143)
+        import random
+        from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
+        random.seed(100 + rank)
+        torch.manual_seed(100 + rank)
+        irs, noises = synthetic_banks(rank)
+        af = AugmentFP(None, 8000, ir_bank=irs, noise_bank=noises, device=dev)
+
+    def step():
+        a = af.batch_augment(clean[:, None, :])[:, 0].contiguous() if af is not None else aug
+        return eng.train_step(clean, a)
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        loss = eng.train_step(clean, aug)
+        loss = step()
     barrier()
     timer = ops_unet.KernelTimer()
     ops_unet.set_timer(timer)
     eng.phases = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = eng.train_step(clean, aug)
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     ops_unet.set_timer(None)
@@ -292,7 +305,8 @@ def bench_demucs_train(args, rank, world, dev, dist):
             "dtype": ("bf16x3 forward / input-gradient GEMMs and LSTM steps, plain-bf16 weight-gradient GEMMs, f32/f64 reductions and Adam"
                       if args.precision == "bf16x3" else "f32 GEMMs (the LSTM steps are bf16x3)"), "data": "synthetic",
             "config": {"workload": f"Demucs() train step, L1 + MultiResolutionSTFTLoss(0.5, 0.5), Adam(5e-4), {args.seconds:g} s clips, "
-                                   f"{args.precision} GEMMs, pre-mixed noisy clips", "clips_per_gpu_per_step": B,
+                                   f"{args.precision} GEMMs, " + ("AugmentFP chain on the device inside the step" if af is not None
+                                                                   else "pre-mixed noisy clips"), "clips_per_gpu_per_step": B,
                        "loss_last": float(loss), "phase_ms_per_step": phases,
                        "parallelism": f"data-parallel x{world}, one RCCL all-reduce of 18.9 M fp32 gradients"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -422,6 +436,7 @@ def main():
                     help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
     ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
+    ap.add_argument("--unet-pass", type=int, default=0, help="infer mode: clips per UNet pass (0 = the module default)")
     ap.add_argument("--seconds", type=float, default=8.0, help="demucs-train mode: clip length (the reference trains on 3 s)")
     ap.add_argument("--mode", choices=["infer", "train", "demucs", "demucs-train", "metrics"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
@@ -477,6 +492,8 @@ def main():
         net.load_state_dict(formula_state_dict(0))
         net = net.to(dev).eval()
         net.precision = 1 if args.precision == "bf16x3" else 0
+        if args.unet_pass > 0:
+            net.max_clips_per_pass = args.unet_pass
     hot = HotPath(net, device=dev)
 
     # synthetic clips of SURVEY.md §8d: 32 distinct generated clips per rank, tiled to B with a sign/gain variation

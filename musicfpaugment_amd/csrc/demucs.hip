@@ -353,6 +353,123 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
 }
 
+// Short-K layers with bf16x3 products (K = 48 and 96: the full-rate outer levels of the network; measured on 256 clips: forward
+// 50.1 -> 46.8 ms with these two; the same form for K = 128 / 192 was slower than the fp32 kernel and is not instantiated).  With exact fp32 products
+// these launches are bound by the fp32 MFMA rate (64 cycles per 32x32x2), not by HBM: e.g. the 1x1 + GLU of level 0 is 151 GFLOP
+// per 256 clips = 1.2 ms of fp32 MFMA against 0.8 ms of HBM traffic.  Here EVERY global load of the workgroup (all NCH chunks
+// of both tiles, up to 36 float4 per thread) is issued before anything is consumed; the chunks are then split to bf16 hi / lo and
+// staged one at a time through a single small LDS buffer (40 .. 77 KB, two workgroups per CU), 3 x v_mfma_f32_32x32x16_bf16 per
+// product.  Same tile (128 x 64, four 32 x 64 wave tiles) and epilogue as the other GEMM kernels.
+template <bool C1SRC, int K, int KCW>
+__global__ __launch_bounds__(256, 2) void gemm_shortk_bf16x3_kernel(GemmArgs a) {
+  static_assert(K % KCW == 0 && KCW % 16 == 0 && (!C1SRC || K == KCW), "chunking");
+  constexpr int NCH = K / KCW, QPR = KCW / 4, ROW = 4 * KCW + 16;   // LDS row bytes: [KCW hi | KCW lo | pad], conflict-free b128 reads
+  constexpr int A_F4 = (GBM * QPR + 255) / 256, B_F4 = (GBN * QPR + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char sksm[];
+  char* As = sksm;                                                      // [GBM][ROW]
+  char* Bs = sksm + GBM * ROW;                                          // [GBN][ROW]
+  float* W1s = reinterpret_cast<float*>(sksm + (GBM + GBN) * ROW);      // C1SRC: [8][K] taps then [K] bias
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;
+  f32x4 ar[NCH][A_F4], br[NCH][B_F4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + 256 * i;
+      br[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < GBN * QPR) br[c][i] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + idx / QPR) * K + c * KCW + 4 * (idx % QPR));
+    }
+  if (C1SRC) {
+    f32x4 x0[A_F4], x1[A_F4];
+    const float* xb = a.c1_x + (size_t)b * a.c1_lin;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + 256 * i, m = m0 + idx / QPR;
+      x0[i] = x1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < GBM * QPR && m < a.M) {
+        x0[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)m);
+        x1[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)m + 4);
+      }
+    }
+    for (int i = tid; i < 8 * K; i += 256) W1s[i] = a.c1_w[i];
+    for (int i = tid; i < K; i += 256) W1s[8 * K + i] = a.c1_b[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {              // conv1d_c1_kernel's arithmetic, same order: bias, then taps 0..7
+      const int idx = tid + 256 * i, c = 4 * (idx % QPR);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < GBM * QPR && m0 + idx / QPR < a.M) {
+        v = *reinterpret_cast<const f32x4*>(&W1s[8 * K + c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += x0[i][j] * *reinterpret_cast<const f32x4*>(&W1s[j * K + c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += x1[i][j] * *reinterpret_cast<const f32x4*>(&W1s[(4 + j) * K + c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      }
+      ar[0][i] = v;
+    }
+  } else {
+    const float* Ab = a.A + (size_t)b * a.strideA;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        const int idx = tid + 256 * i, m = m0 + idx / QPR;
+        ar[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < GBM * QPR && m < a.M) ar[c][i] = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + c * KCW + 4 * (idx % QPR));
+      }
+  }
+  auto split_store = [&](char* row, int q, f32x4 v) __attribute__((always_inline)) {
+    g_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
+    *reinterpret_cast<g_bf16x4*>(row + 2 * KCW + 8 * q) = lo;
+  };
+  floatx16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  const char* Ap = As + (wave * 32 + li) * ROW + 16 * lh;
+  const char* Bp = Bs + li * ROW + 16 * lh;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c > 0) __syncthreads();                  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < GBM * QPR) split_store(As + (idx / QPR) * ROW, idx % QPR, ar[c][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < GBN * QPR) split_store(Bs + (idx / QPR) * ROW, idx % QPR, br[c][i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KCW / 16; ++s) {
+      const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(Ap + 32 * s);
+      const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(Ap + 2 * KCW + 32 * s);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * ROW + 32 * s);
+        const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * ROW + 2 * KCW + 32 * s);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+      }
+    }
+  }
+  gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
+}
+
 // ---------------------------------------------------------------------------------- small kernels
 // mix / (floor + std), zero-padded to VL samples; std = unbiased std over time (model.py:293-301).
 __global__ __launch_bounds__(256) void demucs_prep_kernel(const float* __restrict__ wav, int T, int VL, float floor_,
@@ -721,6 +838,7 @@ static int lstm_launch(const float* hprev, long long ldhp, const float* whh_grou
 
 extern "C" {
 
+#define SK_LDS(KCW) ((size_t)(GBM + GBN) * (4 * (KCW) + 16))
 int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if (!d) return MFPA_EINVAL;
   if (d->batch == 0 || d->M == 0) return MFPA_OK;
@@ -742,8 +860,16 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   // Short-K layers (K < 256: the outer, full-rate encoder / decoder levels) are HBM-bound; the fp32 kernel's smaller
   // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_gemm_calls.md).
+  static const int shortk = getenv("MFPA_SHORTK") ? atoi(getenv("MFPA_SHORTK")) : 1;   // 0: the fp32-MFMA kernels for K < 256 (experiments)
+  hipStream_t st = mfpa_stream(stream);
   if (d->precision == 1 && d->K % HKC == 0 && d->K >= 256) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
+  } else if (d->precision == 1 && shortk && d->K == 48 && d->c1_x) {
+    hipLaunchKernelGGL((gemm_shortk_bf16x3_kernel<true, 48, 48>), grid, dim3(256), SK_LDS(48) + 9 * 48 * 4, st, a);
+  } else if (d->precision == 1 && shortk && d->K == 48) {
+    hipLaunchKernelGGL((gemm_shortk_bf16x3_kernel<false, 48, 48>), grid, dim3(256), SK_LDS(48), st, a);
+  } else if (d->precision == 1 && shortk && d->K == 96 && !d->c1_x) {
+    hipLaunchKernelGGL((gemm_shortk_bf16x3_kernel<false, 96, 48>), grid, dim3(256), SK_LDS(48), st, a);
   } else if (d->K == 48 && d->c1_x) {
     hipLaunchKernelGGL((gemm_smallk_kernel<true, 48>), grid, dim3(256), 0, mfpa_stream(stream), a);
   } else if (d->K == 48) {

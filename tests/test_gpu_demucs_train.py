@@ -221,7 +221,8 @@ def test_backward_arithmetic_variants_on_one_forward_state(precision, wgrad, tol
 def test_bf16x3_forward_step_vs_autograd():
     """The whole step with bf16x3 forward GEMMs (the bench default).  The prediction stays within 1e-4; a gradient can differ
     from float64 autograd by more than the product rounding where a ReLU pre-activation lies within that rounding of zero and
-    its mask flips (one flipped unit of the 768-channel level moves the deep layers' gradients by ~5e-3 on this 2-clip batch) --
+    its mask flips (one flipped unit of the 768-channel level moves the deep layers' gradients by ~5e-3 on this 2-clip batch; a few
+    flips by a few percent) --
     hence the looser bound here and the exact comparison of the backward arithmetic on a fixed forward state above."""
     from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
     sd = formula_state_dict(0)
@@ -235,8 +236,12 @@ def test_bf16x3_forward_step_vs_autograd():
     eng.backward(dpred)
     got = eng.grad_dict()
     worst = {k: _rel(got[k].cpu(), grads[k]) for k in sd}
-    print(f"bf16x3 step: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
-    assert max(worst.values()) < 3e-2
+    cos = {k: float(torch.nn.functional.cosine_similarity(got[k].cpu().double().reshape(1, -1), grads[k].reshape(1, -1))) for k in sd}
+    print(f"bf16x3 step: worst relative L1 {max(worst.values()):.2e} ({max(worst, key=worst.get)}), "
+          f"lowest cosine {min(cos.values()):.6f} ({min(cos, key=cos.get)})")
+    # which units flip depends on the last bits of the forward (it moved from 5.8e-3 to 4.5e-2 when the K = 48 / 96 layers went
+    # from fp32 to bf16x3 products): bound the direction tightly and the size loosely
+    assert min(cos.values()) > 0.995 and max(worst.values()) < 0.15
 
 
 def test_train_step_runs_and_reduces_loss():
