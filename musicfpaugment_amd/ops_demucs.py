@@ -77,6 +77,14 @@ def pack_demucs_weights(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.
         if d == DEPTH - 1:
             pw["decL.w"] = w[:, 0, :].t().contiguous()         # (8, h): rows j (current row taps 0..3) and j+4 (previous row)
             pw["decL.b"] = float(f(f"decoder.{d}.2.bias")[0])
+            # the same layer as a strided-window GEMM (row t = [g[t-1] | g[t]], K = 2h, N = 4 outputs, padded to one 64-row tile)
+            wg = torch.zeros((64, 2 * h), dtype=torch.float32, device=w.device)
+            wg[:4, :h] = w[:, 0, 4:8].t()
+            wg[:4, h:] = w[:, 0, 0:4].t()
+            pw["decL.wg"] = wg
+            bg = torch.zeros(64, dtype=torch.float32, device=w.device)
+            bg[:4] = f(f"decoder.{d}.2.bias")[0]
+            pw["decL.bg"] = bg
         else:
             # row n = j*cout + co, K = [previous row g[t-1] -> tap j+4 | current row g[t] -> tap j]
             wt = torch.cat([w[:, :, 4:8].permute(2, 1, 0), w[:, :, 0:4].permute(2, 1, 0)], dim=2)   # (4, cout, 2h)
@@ -98,6 +106,7 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
 
 
 FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
+LAST_LAYER_GEMM = True    # False: the stand-alone VALU kernel mfpa_convT1d_c1 for the last ConvTranspose1d
 PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (3 bf16 MFMAs per product, fp32 accumulate)
 
 
@@ -191,6 +200,11 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
             y = new(B, Lnext, cout)                              # row t = [g[t-1] | g[t]] -> positions 4t .. 4t+3
             gemm_p(_p(P), C, (Lcur + 2) * C, B, Lcur + 1, pw[f"dec{d}.w"], pw[f"dec{d}.b"], 4 * cout, _p(y), 4 * cout,
                  Lnext * cout, mode=2, relu=2, addend=_p(skip), ldadd=4 * cout, strideAdd=Lnext * cout)
+        elif LAST_LAYER_GEMM and precision == 1:
+            # ConvTranspose1d(48 -> 1) as the same strided-window GEMM (K = 96, four output columns): the VALU kernel reads every
+            # row of P eight times (2.2 ms per 256 clips), the short-K bf16x3 GEMM streams it once (1.2 ms)
+            y = new(B, Lnext)
+            gemm_p(_p(P), C, (Lcur + 2) * C, B, Lcur + 1, pw["decL.wg"], pw["decL.bg"], 4, _p(y), 4, Lnext)
         else:
             y = new(B, Lnext)
             check(L.mfpa_convT1d_c1(ptr(P), B, Lcur, C, ptr(pw["decL.w"]), pw["decL.b"], ptr(y), stream()), "mfpa_convT1d_c1")
