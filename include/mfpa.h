@@ -437,6 +437,15 @@ int mfpa_c1_wgrad(const float* x, long long ldx, const float* g, long long ldg, 
 int mfpa_downsample2_adjoint(const float* dy, int B, int ldy, int nout, const float* kernel112, const float* scale, int T, float* dx,
                              void* stream);
 
+/* Whole-layer forms (one call across the ABI for the Tn launches): (B, Tn, .) contiguous buffers.  mfpa_lstm_layer: xp (B,Tn,4H)
+ * input projections incl. biases; inference (train = 0): cstate (B,H) scratch, cseq unused; train = 1: cseq (B,Tn,H) receives
+ * c_t and xp is overwritten with the gate activations; xsum / skip as in mfpa_lstm_step (NULL for the first layer).
+ * mfpa_lstm_layer_bwd: gates <- gate pre-activation gradients, dcstate (B,H) scratch. */
+int mfpa_lstm_layer(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
+                    const float* skip, int train, void* stream);
+int mfpa_lstm_layer_bwd(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
+                        void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Waveform-domain spectral losses of the Demucs branch, training/loss.py:10-186 (MultiResolutionSTFTLoss; forward).
  * The STFT of a resolution is mfpa_reflect_pad + mfpa_gemm_mfma (precision 0) with a windowed DFT matrix

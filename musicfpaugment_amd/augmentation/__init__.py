@@ -31,6 +31,16 @@ from .constants import DEFAULT_PARAMETERS, IMPULSE_RESPONSE_DIR  # noqa: F401
 ZEROS = 8
 
 
+
+def _up(t: torch.Tensor, dev) -> torch.Tensor:
+    """Host tensor -> device WITHOUT a stream synchronisation: pinned staging buffer + asynchronous copy.  A pageable
+    `.to(device)` waits for everything queued on the stream; with ~25 small parameter uploads per batch that stalled the launch
+    queue of the training step that follows (Demucs step: 1500 launches; 70 -> 58 ms per 64-clip step with this)."""
+    if t.is_cuda:
+        return t
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+
+
 def _mels(f: torch.Tensor) -> torch.Tensor:          # augmentation/utils.py:36-42
     return 2595.0 * torch.log10(1.0 + f / 700.0)
 
@@ -214,14 +224,14 @@ class AugmentFP(object):
         dev = x.device
         ntaps = [2 * h + 1 for h in half]
         tap_off = np.concatenate([[0], np.cumsum(ntaps)]).astype(np.int64)          # ragged: a 0.5 Hz cut-off has 128 001 taps
-        cutoff_d = torch.tensor([f if s else 0.25 for f, s in zip(frac, should.tolist())], dtype=torch.float32, device=dev)
-        half_d = torch.tensor(half, dtype=torch.int32, device=dev)
-        ntaps_d = torch.tensor(ntaps, dtype=torch.int32, device=dev)
-        off_d = torch.from_numpy(tap_off[:-1].copy()).to(dev)
+        cutoff_d = _up(torch.tensor([f if s else 0.25 for f, s in zip(frac, should.tolist())], dtype=torch.float32), dev)
+        half_d = _up(torch.tensor(half, dtype=torch.int32), dev)
+        ntaps_d = _up(torch.tensor(ntaps, dtype=torch.int32), dev)
+        off_d = _up(torch.from_numpy(tap_off[:-1].copy()), dev)
         taps = torch.empty((int(tap_off[-1]),), dtype=torch.float32, device=dev)
         check(lib().mfpa_lowpass_taps(ptr(cutoff_d), ptr(half_d), ptr(off_d), B, ptr(taps), stream()), "mfpa_lowpass_taps")
         y = torch.empty_like(x)
-        apply_d = should.to(dev, torch.uint8)
+        apply_d = _up(should.to(torch.uint8), dev)
         check(lib().mfpa_fir(ptr(x), B, T, T, ptr(taps), ptr(off_d), ptr(ntaps_d), ptr(half_d), ptr(apply_d), 0,
                              1 if highpass else 0, ptr(y), 0, stream()), "mfpa_fir")
         return y
@@ -235,7 +245,7 @@ class AugmentFP(object):
         if B * T == 0:
             return waveforms
         dev, L, p = x.device, lib(), self.parameters
-        u8 = lambda m: m.to(dev, torch.uint8)
+        u8 = lambda m: _up(m.to(torch.uint8), dev)
         # 1 HighPass(0-150 Hz)
         self.t_hp1.gate(B)
         x = self._filter(x, self.t_hp1, self._cutoffs(self.t_hp1, p["min_cutoff_freq1"], p["max_cutoff_freq1"], B), True)
@@ -247,9 +257,9 @@ class AugmentFP(object):
         nmax = max(nlen)
         self.t_ir.transform_parameters["ir"] = irs
         self.t_ir.draws = {"ir": irs}
-        n_d = torch.tensor(nlen, dtype=torch.int32, device=dev)
+        n_d = _up(torch.tensor(nlen, dtype=torch.int32), dev)
         off_d = n_d - 1                                              # y[t] = sum_k ir[n-1-k] x[t + k - (n-1)]
-        toff_d = torch.from_numpy(self._ir_off[pick]).to(dev)
+        toff_d = _up(torch.from_numpy(self._ir_off[pick]), dev)
         y, peak, on_d = torch.empty_like(x), torch.empty((B,), dtype=torch.float32, device=dev), u8(should)
         check(L.mfpa_fir(ptr(x), B, T, T + nmax - 1, ptr(self._ir_dev), ptr(toff_d), ptr(n_d), ptr(off_d), ptr(on_d), 1, 2, ptr(y),
                          ptr(peak), stream()), "mfpa_fir")
@@ -263,15 +273,15 @@ class AugmentFP(object):
         for b, pc in enumerate(pieces):
             for j, (scene, k, off, n) in enumerate(pc):
                 src[b, j], ln[b, j] = self._noise_off[(scene, k)] + off, n
-        src_d, ln_d = torch.from_numpy(src).to(dev), torch.from_numpy(ln).to(dev)
+        src_d, ln_d = _up(torch.from_numpy(src), dev), _up(torch.from_numpy(ln), dev)
         noise = torch.empty((B, T), dtype=torch.float32, device=dev)
         check(L.mfpa_gather_background(ptr(self._noise_dev), ptr(src_d), ptr(ln_d), B, P, T, ptr(noise), stream()),
               "mfpa_gather_background")
         snr = torch.distributions.Uniform(torch.tensor(float(p["min_snr_in_db"])), torch.tensor(float(p["max_snr_in_db"]))).sample((B,))
-        sel = torch.nonzero(should).flatten().to(dev)          # host-known indices: no device-side nonzero, no sync
+        sel = _up(torch.nonzero(should).flatten(), dev)          # host-known indices: no device-side nonzero, no sync
         self.t_bg.transform_parameters.update(background=noise.index_select(0, sel), snr_in_db=snr[should])
         self.t_bg.draws = {"background": noise, "snr_in_db": snr, "pieces": pieces}
-        y, snr_d, on_d = torch.empty_like(x), snr.to(dev), u8(should)
+        y, snr_d, on_d = torch.empty_like(x), _up(snr, dev), u8(should)
         check(L.mfpa_mix_background(ptr(x), B, T, ptr(noise), ptr(snr_d), ptr(on_d), ptr(y), stream()), "mfpa_mix_background")
         x = y
         # 4 gain (gain.py:44-70)
@@ -281,7 +291,7 @@ class AugmentFP(object):
         self.t_gain.transform_parameters["gain_factors"] = fac[should].unsqueeze(1).unsqueeze(1)
         self.t_gain.draws = {"gain_in_db": gdb}
         y = torch.empty_like(x)
-        fac_d, on_d = fac.to(dev), u8(should)
+        fac_d, on_d = _up(fac, dev), u8(should)
         check(L.mfpa_scale_rows(ptr(x), B, T, ptr(fac_d), ptr(on_d), 0, ptr(y), stream()), "mfpa_scale_rows")
         x = y
         # 5 clipping at per-example quantiles (clipping.py:40-100)
@@ -290,7 +300,7 @@ class AugmentFP(object):
         self.t_clip.transform_parameters["percentile_threshold"] = pct[should].unsqueeze(1)
         self.t_clip.draws = {"percentile_threshold": pct}
         y = torch.empty_like(x)
-        pct_d, on_d = pct.to(dev), u8(should)
+        pct_d, on_d = _up(pct, dev), u8(should)
         check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct_d), ptr(on_d), ptr(y), stream()), "mfpa_clip_quantile")
         x = y
         # 6 LowPass(3000-3999 Hz), 7 HighPass(30-150 Hz)

@@ -171,17 +171,14 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
     for layer in range(2):
         xp = new(B, Tn, 4 * H)                                   # input projection of every step at once
         gemm_p(_p(seq), H, 0, 1, B * Tn, pw[f"lstm{layer}.wih"], pw[f"lstm{layer}.b"], 4 * H, _p(xp), 4 * H, 0)
-        hseq = new(B, Tn, H)
-        c = torch.zeros((B, H), dtype=torch.float32, device=dev)
+        hseq, c = new(B, Tn, H), new(B, H)
         last = layer == 1
         if last:
             xsum = new(B, Tn, H)
         t0 = _K._TIMER.start() if _K._TIMER is not None else None     # the whole recurrence as one timed group
-        for t in range(Tn):                                      # gates = h[t-1] @ W_hh^T + xp[:, t], cell, in one launch
-            check(L.mfpa_lstm_step(_p(hseq, (t - 1) * H) if t else 0, Tn * H, ptr(pw[f"lstm{layer}.whh_grouped"]),
-                                   _p(xp, t * 4 * H), Tn * 4 * H, ptr(c), B, H, _p(hseq, t * H), Tn * H,
-                                   _p(xsum, t * H) if last else 0, _p(skips[-1], t * H) if last else 0, Tn * H, stream()),
-                  "mfpa_lstm_step")
+        # gates = h[t-1] @ W_hh^T + xp[:, t] and the cell, one launch per time step, all Tn launched by one C call
+        check(L.mfpa_lstm_layer(ptr(pw[f"lstm{layer}.whh_grouped"]), ptr(xp), ptr(hseq), 0, ptr(c), B, Tn, H,
+                                ptr(xsum) if last else 0, ptr(skips[-1]) if last else 0, 0, stream()), "mfpa_lstm_layer")
         if t0 is not None:
             _K._TIMER.stop(t0)
         seq = hseq

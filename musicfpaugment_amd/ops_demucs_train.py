@@ -313,12 +313,8 @@ class DemucsTrainEngine:
             if last:
                 xsum = new(B, Tn, H)
             t0 = _K._TIMER.start() if _K._TIMER is not None else None     # the whole recurrence as one timed group
-            for t in range(Tn):
-                check(L.mfpa_lstm_step_train(_p(hseq, (t - 1) * H) if t else 0, Tn * H, ptr(W[f"lstm{layer}.whh_grouped"]),
-                                             _p(gates, t * 4 * H), Tn * 4 * H, _p(cseq, (t - 1) * H) if t else 0, Tn * H,
-                                             _p(cseq, t * H), Tn * H, B, H, _p(hseq, t * H), Tn * H,
-                                             _p(xsum, t * H) if last else 0, _p(h_s[-1], t * H) if last else 0, Tn * H,
-                                             _p(gates, t * 4 * H), Tn * 4 * H, stream()), "mfpa_lstm_step_train")
+            check(L.mfpa_lstm_layer(ptr(W[f"lstm{layer}.whh_grouped"]), ptr(gates), ptr(hseq), ptr(cseq), 0, B, Tn, H,
+                                    ptr(xsum) if last else 0, ptr(h_s[-1]) if last else 0, 1, stream()), "mfpa_lstm_layer")
             if t0 is not None:
                 _K._TIMER.stop(t0)
             lst.append((seq, gates, hseq, cseq))
@@ -433,13 +429,10 @@ class DemucsTrainEngine:
         dh_enc = None
         for layer in (1, 0):
             seq, gates, hseq, cseq = S["lstm"][layer]
-            dc = zeros(B, H)
+            dc = new(B, H)
             t0 = _K._TIMER.start() if _K._TIMER is not None else None
-            for t in range(Tn - 1, -1, -1):
-                check(L.mfpa_lstm_step_bwd(_p(gates, (t + 1) * 4 * H) if t + 1 < Tn else 0, Tn * 4 * H, ptr(W[f"lstm{layer}.whhT"]),
-                                           _p(gates, t * 4 * H), Tn * 4 * H, _p(cseq, t * H), Tn * H,
-                                           _p(cseq, (t - 1) * H) if t else 0, Tn * H, _p(dhout, t * H), Tn * H, ptr(dc), B, H,
-                                           stream()), "mfpa_lstm_step_bwd")
+            check(L.mfpa_lstm_layer_bwd(ptr(W[f"lstm{layer}.whhT"]), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, stream()),
+                  "mfpa_lstm_layer_bwd")
             if t0 is not None:
                 _K._TIMER.stop(t0)
             colsum(ptr(gates), B * Tn, 4 * H, 4 * H, G[f"lstm{layer}.bih"])
