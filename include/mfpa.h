@@ -420,6 +420,8 @@ typedef struct mfpa_gemm_tn_desc {
   const float* Bm; long long ldb, strideB;
   float* C; long long ldc;
   int batch, R, M, N;
+  float* colsum;   /* optional (M): colsum[m] += the sum over every row of A[.][m] -- the bias gradient, read off the tiles the
+                      workgroups of the first column tile stage anyway */
   int precision;   /* 0: fp32 MFMA; 1: bf16x3 (3 bf16 MFMAs per product); 2: plain bf16 (one MFMA; the sum over every time
                       step of the batch averages the 2^-9 product rounding) -- fragments via ds_read_b64_tr_b16 */
 } mfpa_gemm_tn_desc;

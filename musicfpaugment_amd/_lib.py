@@ -155,7 +155,7 @@ class GemmTnDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_longlong), ("strideA", c_longlong),
                 ("Bm", c_void_p), ("ldb", c_longlong), ("strideB", c_longlong),
                 ("C", c_void_p), ("ldc", c_longlong),
-                ("batch", c_int), ("R", c_int), ("M", c_int), ("N", c_int), ("precision", c_int)]
+                ("batch", c_int), ("R", c_int), ("M", c_int), ("N", c_int), ("colsum", c_void_p), ("precision", c_int)]
 
 
 class WgradDesc(ctypes.Structure):

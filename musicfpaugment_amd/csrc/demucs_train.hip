@@ -30,9 +30,28 @@ struct TnArgs {
   const float* A; long long lda, strideA;
   const float* Bm; long long ldb, strideB;
   float* C; long long ldc;
+  float* colsum;               // optional: colsum[m] += sum over all rows of A[.][m] (the bias gradient), by the n-tile-0 workgroups
   int R, M, N;
   int rs, spb;                 // rows per split, splits per clip
 };
+
+// column sums of the A tiles a workgroup staged (every thread keeps the same column quad for all of its loads): combine the row
+// lanes through LDS, one atomic per column
+template <int QA>
+__device__ __forceinline__ void tn_colsum_flush(float* red, f32x4 csum, int tid, int m0, int M, float* __restrict__ out) {
+  __syncthreads();                                   // the operand buffers are free
+  const int q = tid % QA, rl = tid / QA;
+  *reinterpret_cast<f32x4*>(red + (rl * QA + q) * 4) = csum;
+  __syncthreads();
+  if (tid < QA * 4) {
+    const int qq = tid >> 2, k = tid & 3;
+    float sacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 256 / QA; ++r) sacc += red[(r * QA + qq) * 4 + k];
+    const int m = m0 + 4 * qq + k;
+    if (m < M) unsafeAtomicAdd(out + m, sacc);
+  }
+}
 
 constexpr int TKC = 16;
 
@@ -57,6 +76,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
   const int nk = (rend - rbeg + TKC - 1) / TKC;
 
   f32x4 ar[FA], br[FB];
+  const bool do_colsum = a.colsum != nullptr && n0 == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto load = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
@@ -80,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     for (int i = 0; i < FA; ++i) {
       const int idx = tid + 256 * i;
       *reinterpret_cast<f32x4*>(&As[buf][(idx / QA) * LDA_ + 4 * (idx % QA)]) = ar[i];
+      if (do_colsum) csum += ar[i];
     }
 #pragma unroll
     for (int i = 0; i < FB; ++i) {
@@ -122,6 +144,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
       __syncthreads();
     }
   }
+  if (do_colsum) tn_colsum_flush<QA>(&As[0][0], csum, tid, m0, a.M, a.colsum);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -180,6 +203,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs a) {
   const int b_off = (8 * lh + tq) * ROWB + (wn * 32 * TN + 16 * gsel + 4 * tp) * 2;
 
   f32x4 ar[FA], br[FB];
+  const bool do_colsum = a.colsum != nullptr && n0 == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   auto load = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
@@ -213,6 +238,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs a) {
     for (int i = 0; i < FA; ++i) {
       const int idx = tid + 256 * i;
       split_store(As + (buf * HKC_T + idx / QA) * ROWA, idx % QA, 2 * BM, ar[i]);
+      if (do_colsum) csum += ar[i];
     }
 #pragma unroll
     for (int i = 0; i < FB; ++i) {
@@ -269,6 +295,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs a) {
       __syncthreads();
     }
   }
+  if (do_colsum) tn_colsum_flush<QA>(reinterpret_cast<float*>(tsm), csum, tid, m0, a.M, a.colsum);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -607,7 +634,7 @@ int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
   if (tiles > 0x7fffffffLL) return MFPA_EINVAL;
   TnArgs a{};
   a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.Bm = d->Bm; a.ldb = d->ldb; a.strideB = d->strideB;
-  a.C = d->C; a.ldc = d->ldc; a.R = d->R; a.M = d->M; a.N = d->N; a.rs = (int)rs; a.spb = (int)spb;
+  a.C = d->C; a.ldc = d->ldc; a.colsum = d->colsum; a.R = d->R; a.M = d->M; a.N = d->N; a.rs = (int)rs; a.spb = (int)spb;
   dim3 grid((unsigned)tiles, (unsigned)(spb * d->batch));
   hipStream_t st = mfpa_stream(stream);
   if (d->precision == 0) {

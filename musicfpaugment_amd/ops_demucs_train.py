@@ -50,10 +50,12 @@ def _p(t: torch.Tensor, off: int = 0) -> int:
 WGRAD_PRECISION = 0   # module default of gemm_tn: 0 fp32 MFMA, 1 bf16x3, 2 plain bf16 (the engine passes its own)
 
 
-def gemm_tn(A: int, lda, strideA, Bm: int, ldb, strideB, C: torch.Tensor, ldc, batch, R, M, N, precision: Optional[int] = None):
-    """C[m][n] += sum_{b, r} A[b][r][m] * Bm[b][r][n] (mfpa_gemm_tn); A, Bm device addresses, strides in floats."""
+def gemm_tn(A: int, lda, strideA, Bm: int, ldb, strideB, C: torch.Tensor, ldc, batch, R, M, N, precision: Optional[int] = None,
+            colsum: Optional[torch.Tensor] = None):
+    """C[m][n] += sum_{b, r} A[b][r][m] * Bm[b][r][n] (mfpa_gemm_tn); A, Bm device addresses, strides in floats.
+    colsum (M): += the column sums of A over all rows (the bias gradient), computed from the tiles the kernel stages anyway."""
     d = GemmTnDesc(A=A, lda=lda, strideA=strideA, Bm=Bm, ldb=ldb, strideB=strideB, C=ptr(C), ldc=ldc, batch=batch, R=R, M=M, N=N,
-                   precision=WGRAD_PRECISION if precision is None else precision)
+                   colsum=ptr(colsum), precision=WGRAD_PRECISION if precision is None else precision)
     t0 = _K._TIMER.start() if _K._TIMER is not None else None
     check(lib().mfpa_gemm_tn(ctypes.byref(d), stream()), "mfpa_gemm_tn")
     if t0 is not None:
@@ -401,8 +403,7 @@ class DemucsTrainEngine:
             ud = uds[d]
             check(L.mfpa_glu_bwd(ptr(ud), B * Lcur, npad, C, ptr(dg), C, stream()), "mfpa_glu_bwd")
             self._dbg(f"du{d}", ud)
-            colsum(ptr(ud), B * Lcur, npad, npad, G[f"dec{d}.gb"])
-            gemm_tn(ptr(ud), npad, 0, ptr(xins[d]), C, 0, G[f"dec{d}.gw"], C, 1, B * Lcur, npad, C)
+            gemm_tn(ptr(ud), npad, 0, ptr(xins[d]), C, 0, G[f"dec{d}.gw"], C, 1, B * Lcur, npad, C, colsum=G[f"dec{d}.gb"])
             dxin = new(B, Lcur, C)                                       # gradient of x + skip: both addends receive it
             if d == 0:
                 D.gemm(_p(ud), npad, Lcur * npad, B, Lcur, W[f"dec{d}.gwT"], None, C, _p(dxin), C, Lcur * C, precision=prec)
@@ -435,9 +436,8 @@ class DemucsTrainEngine:
                   "mfpa_lstm_layer_bwd")
             if t0 is not None:
                 _K._TIMER.stop(t0)
-            colsum(ptr(gates), B * Tn, 4 * H, 4 * H, G[f"lstm{layer}.bih"])
+            gemm_tn(ptr(gates), 4 * H, 0, ptr(seq), H, 0, G[f"lstm{layer}.wih"], H, 1, B * Tn, 4 * H, H, colsum=G[f"lstm{layer}.bih"])
             G[f"lstm{layer}.bhh"].copy_(G[f"lstm{layer}.bih"])
-            gemm_tn(ptr(gates), 4 * H, 0, ptr(seq), H, 0, G[f"lstm{layer}.wih"], H, 1, B * Tn, 4 * H, H)
             if Tn > 1:
                 gemm_tn(_p(gates, 4 * H), 4 * H, Tn * 4 * H, ptr(hseq), H, Tn * H, G[f"lstm{layer}.whh"], H, B, Tn - 1, 4 * H, H)
             dx = new(B, Tn, H)
@@ -457,8 +457,7 @@ class DemucsTrainEngine:
             npad = _npad_glu(C)
             u = u_s[i]
             check(L.mfpa_glu_bwd(ptr(u), B * Li, npad, C, ptr(dh), C, stream()), "mfpa_glu_bwd")
-            colsum(ptr(u), B * Li, npad, npad, G[f"enc{i}.gb"])
-            gemm_tn(ptr(u), npad, 0, ptr(a_s[i]), C, 0, G[f"enc{i}.gw"], C, 1, B * Li, npad, C)
+            gemm_tn(ptr(u), npad, 0, ptr(a_s[i]), C, 0, G[f"enc{i}.gw"], C, 1, B * Li, npad, C, colsum=G[f"enc{i}.gb"])
             if i == 0:
                 da = new(B, Li, C)
                 D.gemm(_p(u), npad, Li * npad, B, Li, W[f"enc{i}.gwT"], None, C, _p(da), C, Li * C, mode=3, addend=_p(a_s[i]),
@@ -470,9 +469,9 @@ class DemucsTrainEngine:
             dA = zeros(B, Li + 2, C)                                     # rows 0 and Li + 1 stay zero
             D.gemm(_p(u), npad, Li * npad, B, Li, W[f"enc{i}.gwT"], None, C, _p(dA, C), C, (Li + 2) * C, mode=3, addend=_p(a_s[i]),
                    ldadd=C, strideAdd=Li * C, precision=prec)
-            colsum(ptr(dA), B * (Li + 2), C, C, G[f"enc{i}.b"][:C])
             Cin, Lprev = CH[i - 1], Ls[i - 1]
-            gemm_tn(_p(dA, C), C, (Li + 2) * C, ptr(h_s[i - 1]), 4 * Cin, Lprev * Cin, G[f"enc{i}.w"], 8 * Cin, B, Li, C, 8 * Cin)
+            gemm_tn(_p(dA, C), C, (Li + 2) * C, ptr(h_s[i - 1]), 4 * Cin, Lprev * Cin, G[f"enc{i}.w"], 8 * Cin, B, Li, C, 8 * Cin,
+                    colsum=G[f"enc{i}.b"][:C])
             dprev = new(B, Lprev, Cin)                                   # ConvTranspose1d form + the decoder skip's gradient
             D.gemm(_p(dA), C, (Li + 2) * C, B, Li + 1, W[f"enc{i}.wT"], None, 4 * Cin, _p(dprev), 4 * Cin, Lprev * Cin, mode=2,
                    addend=_p(dskip[i - 1]), ldadd=4 * Cin, strideAdd=Lprev * Cin, precision=prec)

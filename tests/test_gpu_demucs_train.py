@@ -28,8 +28,11 @@ def test_gemm_tn_window_weight_gradient(precision, tol):
         want = torch.einsum("btm,btn->mn", dy.double(), win.double())
         out = torch.zeros(cout, 8 * cin, device="cuda")
         xd, dyd = x.cuda(), dy.cuda()
-        T.gemm_tn(T._p(dyd), cout, L * cout, T._p(xd), 4 * cin, Lin * cin, out, 8 * cin, B, L, cout, 8 * cin, precision=precision)
+        fused = torch.zeros(cout, device="cuda")                  # the bias gradient read off the staged dy tiles
+        T.gemm_tn(T._p(dyd), cout, L * cout, T._p(xd), 4 * cin, Lin * cin, out, 8 * cin, B, L, cout, 8 * cin, precision=precision,
+                  colsum=fused)
         assert _rel(out.cpu(), want) < tol
+        assert _rel(fused.cpu(), dy.double().sum((0, 1))) < 1e-5
         bias = torch.zeros(cout, device="cuda")
         T.colsum(T._p(dyd), B * L, cout, cout, bias)
         assert _rel(bias.cpu(), dy.double().sum((0, 1))) < 1e-5
