@@ -40,52 +40,81 @@ struct GemmArgs {
   const float* c1_w; const float* c1_b;        // (8, K), (K)
 };
 
-// epilogue shared by both precisions: D[row = m][col = n]; a lane holds column li of both 32-wide n tiles
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, floatx16 (&acc)[2], int m0, int n0, int b, int wave, int li, int lh) {
+// epilogue shared by all GEMM kernels: D[row = m][col = n]; a lane holds column li of both 32-wide n tiles.
+// The short-K launches are bound by vector-instruction issue, and the first form of this epilogue was most of it (64-bit
+// address arithmetic and an exec-mask branch per element, an IEEE division in the sigmoid): here every offset is a 32-bit byte
+// offset from a per-clip scalar base (the host checks that a clip's tile fits 4 GB), full row tiles skip the row bounds checks
+// (FULL), column predicates are hoisted out of the row loop, and the sigmoid uses v_rcp_f32.
+__device__ __forceinline__ float gemm_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ void st_f32(char* base, unsigned boff, float v) { *reinterpret_cast<float*>(base + boff) = v; }
+__device__ __forceinline__ float ld_f32(const char* base, unsigned boff) { return *reinterpret_cast<const float*>(base + boff); }
+
+template <bool FULL>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& a, floatx16 (&acc)[2], int m0, int n0, int b, int wave, int li, int lh) {
   const float bias0 = a.bias ? a.bias[n0 + li] : 0.f;
   const float bias1 = a.bias ? a.bias[n0 + 32 + li] : 0.f;
-  float* Cb = a.C + (size_t)b * a.strideC;
+  char* Cb = reinterpret_cast<char*>(a.C + (size_t)b * a.strideC);
+  char* C2b = a.C2 ? reinterpret_cast<char*>(a.C2 + (size_t)b * a.strideC2) : nullptr;
+  const unsigned ldc = (unsigned)a.ldc, ldc2 = (unsigned)a.ldc2;
+  const int mbase = m0 + wave * 32 + 4 * lh;
+  if (a.mode == 1) {                           // GLU: value * sigmoid(gate); output column = (tile index) * 32 + li
+    const int n = (n0 / 64) * 32 + li;
+    const bool ok = n < a.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + (r & 3) + 8 * (r >> 2);
+      if (!FULL && m >= a.M) continue;
+      const float v0 = acc[0][r] + bias0, v1 = acc[1][r] + bias1;
+      if (C2b) {                               // the pre-activations in the packed [32 values | 32 gates] tile order
+        const unsigned o = ((unsigned)m * ldc2 + (unsigned)(n0 + li)) * 4u;
+        st_f32(C2b, o, v0);
+        st_f32(C2b, o + 128u, v1);
+      }
+      if (ok) st_f32(Cb, ((unsigned)m * ldc + (unsigned)n) * 4u, v0 * gemm_sigmoid(v1));
+    }
+    return;
+  }
+  const int n = n0 + li;
+  const bool ok0 = n < a.N, ok1 = n + 32 < a.N;
+  const char* Adb = a.mode >= 2 ? reinterpret_cast<const char*>(a.addend + (size_t)b * a.strideAdd) : nullptr;
+  const unsigned ldadd = (unsigned)a.ldadd;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (m >= a.M) continue;
+    const int m = mbase + (r & 3) + 8 * (r >> 2);
+    if (!FULL && m >= a.M) continue;
     float v0 = acc[0][r] + bias0, v1 = acc[1][r] + bias1;
-    if (a.mode == 1) {                         // GLU: value * sigmoid(gate); output column = (tile index) * 32 + li
-      const int n = (n0 / 64) * 32 + li;
-      if (a.C2) {                              // the pre-activations in the packed [32 values | 32 gates] tile order
-        float* c2 = a.C2 + (size_t)b * a.strideC2 + (size_t)m * a.ldc2 + n0 + li;
-        c2[0] = v0; c2[32] = v1;
+    const unsigned o = ((unsigned)m * ldc + (unsigned)n) * 4u;
+    if (a.relu == 2) {                         // ReLU before the skip addition
+      v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f);
+      if (C2b) {
+        const unsigned o2 = ((unsigned)m * ldc2 + (unsigned)n) * 4u;
+        if (ok0) st_f32(C2b, o2, v0);
+        if (ok1) st_f32(C2b, o2 + 128u, v1);
       }
-      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0 * (1.f / (1.f + __expf(-v1)));
-    } else {
-      const int n = n0 + li;
-      if (a.relu == 2) {                       // ReLU before the skip addition
-        v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
-        if (a.C2) {
-          float* c2 = a.C2 + (size_t)b * a.strideC2 + (size_t)m * a.ldc2;
-          if (n < a.N) c2[n] = v0;
-          if (n + 32 < a.N) c2[n + 32] = v1;
-        }
-      }
-      if (a.mode == 2) {
-        const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
-        if (n < a.N) v0 += ad[n];
-        if (n + 32 < a.N) v1 += ad[n + 32];
-      } else if (a.mode == 3) {
-        const float* ad = a.addend + (size_t)b * a.strideAdd + (size_t)m * a.ldadd;
-        if (a.C2) {                            // the unmasked gradient as well (it is also the skip connection's gradient)
-          float* c2 = a.C2 + (size_t)b * a.strideC2 + (size_t)m * a.ldc2;
-          if (n < a.N) c2[n] = v0;
-          if (n + 32 < a.N) c2[n + 32] = v1;
-        }
-        if (n < a.N) v0 = ad[n] > 0.f ? v0 : 0.f;
-        if (n + 32 < a.N) v1 = ad[n + 32] > 0.f ? v1 : 0.f;
-      }
-      if (a.relu == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-      if (n < a.N) Cb[(size_t)m * a.ldc + n] = v0;
-      if (n + 32 < a.N) Cb[(size_t)m * a.ldc + n + 32] = v1;
     }
+    if (a.mode == 2) {
+      const unsigned oa = ((unsigned)m * ldadd + (unsigned)n) * 4u;
+      if (ok0) v0 += ld_f32(Adb, oa);
+      if (ok1) v1 += ld_f32(Adb, oa + 128u);
+    } else if (a.mode == 3) {
+      const unsigned oa = ((unsigned)m * ldadd + (unsigned)n) * 4u;
+      if (C2b) {                               // the unmasked gradient as well (it is also the skip connection's gradient)
+        const unsigned o2 = ((unsigned)m * ldc2 + (unsigned)n) * 4u;
+        if (ok0) st_f32(C2b, o2, v0);
+        if (ok1) st_f32(C2b, o2 + 128u, v1);
+      }
+      if (ok0) v0 = ld_f32(Adb, oa) > 0.f ? v0 : 0.f;
+      if (ok1) v1 = ld_f32(Adb, oa + 128u) > 0.f ? v1 : 0.f;
+    }
+    if (a.relu == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+    if (ok0) st_f32(Cb, o, v0);
+    if (ok1) st_f32(Cb, o + 128u, v1);
   }
+}
+
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, floatx16 (&acc)[2], int m0, int n0, int b, int wave, int li, int lh) {
+  if (m0 + GBM <= a.M) gemm_epilogue_t<true>(a, acc, m0, n0, b, wave, li, lh);
+  else gemm_epilogue_t<false>(a, acc, m0, n0, b, wave, li, lh);
 }
 
 template <bool C1SRC>
@@ -847,6 +876,11 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
                   d->c1_lin % 4)) return MFPA_EINVAL;
   if (d->npad < 64 || d->npad % 64 || d->mode < 0 || d->mode > 3 || (d->mode >= 2 && !d->addend)) return MFPA_EINVAL;
   if (d->lda % 4 || d->strideA % 4) return MFPA_EINVAL;   // float4 row loads
+  {   // the epilogue addresses a clip's outputs with 32-bit byte offsets
+    const long long lim = 0x3fffffffLL;      // floats
+    if ((long long)d->M * d->ldc + d->npad > lim || (d->C2 && (long long)d->M * d->ldc2 + d->npad > lim) ||
+        (d->mode >= 2 && (long long)d->M * d->ldadd + d->npad > lim)) return MFPA_EINVAL;
+  }
   if (d->mode == 1 ? (d->N > d->npad / 2) : (d->N > d->npad)) return MFPA_EINVAL;
   GemmArgs a{};
   a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.W = d->W; a.bias = d->bias;
