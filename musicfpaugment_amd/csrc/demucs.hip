@@ -76,8 +76,22 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& a, floatx16 (&ac
   }
   const int n = n0 + li;
   const bool ok0 = n < a.N, ok1 = n + 32 < a.N;
-  const char* Adb = a.mode >= 2 ? reinterpret_cast<const char*>(a.addend + (size_t)b * a.strideAdd) : nullptr;
   const unsigned ldadd = (unsigned)a.ldadd;
+  // modes 2 / 3: ALL of this lane's addend values are loaded before the first store -- the addend may alias C as far as the
+  // compiler knows, so loads interleaved with the stores were serialised into 16 exposed memory round trips per wave (PMC: the
+  // transposed-convolution launches spent 57 .. 70 % of their wave cycles in s_waitcnt)
+  float ad0[16], ad1[16];
+  if (a.mode >= 2) {
+    const char* Adb = reinterpret_cast<const char*>(a.addend + (size_t)b * a.strideAdd);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + (r & 3) + 8 * (r >> 2);
+      const unsigned oa = ((unsigned)m * ldadd + (unsigned)n) * 4u;
+      const bool rowok = FULL || m < a.M;
+      ad0[r] = (rowok && ok0) ? ld_f32(Adb, oa) : 0.f;
+      ad1[r] = (rowok && ok1) ? ld_f32(Adb, oa + 128u) : 0.f;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -93,18 +107,15 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& a, floatx16 (&ac
       }
     }
     if (a.mode == 2) {
-      const unsigned oa = ((unsigned)m * ldadd + (unsigned)n) * 4u;
-      if (ok0) v0 += ld_f32(Adb, oa);
-      if (ok1) v1 += ld_f32(Adb, oa + 128u);
+      v0 += ad0[r]; v1 += ad1[r];
     } else if (a.mode == 3) {
-      const unsigned oa = ((unsigned)m * ldadd + (unsigned)n) * 4u;
       if (C2b) {                               // the unmasked gradient as well (it is also the skip connection's gradient)
         const unsigned o2 = ((unsigned)m * ldc2 + (unsigned)n) * 4u;
         if (ok0) st_f32(C2b, o2, v0);
         if (ok1) st_f32(C2b, o2 + 128u, v1);
       }
-      if (ok0) v0 = ld_f32(Adb, oa) > 0.f ? v0 : 0.f;
-      if (ok1) v1 = ld_f32(Adb, oa + 128u) > 0.f ? v1 : 0.f;
+      v0 = ad0[r] > 0.f ? v0 : 0.f;
+      v1 = ad1[r] > 0.f ? v1 : 0.f;
     }
     if (a.relu == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
     if (ok0) st_f32(Cb, o, v0);
