@@ -354,7 +354,7 @@ typedef struct mfpa_gemm_desc {
   const float* addend; long long ldadd, strideAdd;
   float* C; long long ldc, strideC;
   int batch, M, N, K, npad, mode, relu;
-  int precision;   /* 0: fp32 MFMA (K multiple of 16); 1: bf16x3 where K >= 256 is a multiple of 32 or K is 48 / 96 (fp32 MFMA otherwise) */
+  int precision;   /* 0: fp32 MFMA (K multiple of 16); 1: bf16x3 where K >= 128 is a multiple of 32 or K is 48 / 96 (fp32 MFMA otherwise) */
   /* optional (K <= 256, fp32 kernel): A is COMPUTED while it is staged as the first encoder layer of
    * mfpa_conv1d_c1_relu -- A[b][m][c] = relu(c1_b[c] + sum_j c1_w[j][c] * c1_x[b][4m + j]), c1_x (batch, c1_lin), c1_w (8, K) --
    * so its (B, L, K) output never exists in HBM (model.py:231-238); A may then be NULL. */

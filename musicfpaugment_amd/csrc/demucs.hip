@@ -883,7 +883,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if (!d) return MFPA_EINVAL;
   if (d->batch == 0 || d->M == 0) return MFPA_OK;
   if ((!d->A && !d->c1_x) || !d->W || !d->C || d->batch < 0 || d->M < 0 || d->N < 1 || d->K < GKC || d->K % GKC) return MFPA_EINVAL;
-  if (d->c1_x && (!d->c1_w || !d->c1_b || d->K > 256 || (d->precision == 1 && d->K >= 256) || d->c1_lin < 4 * ((long long)d->M - 1) + 8 ||
+  if (d->c1_x && (!d->c1_w || !d->c1_b || d->K > 256 || (d->precision == 1 && d->K >= 128) || d->c1_lin < 4 * ((long long)d->M - 1) + 8 ||
                   d->c1_lin % 4)) return MFPA_EINVAL;
   if (d->npad < 64 || d->npad % 64 || d->mode < 0 || d->mode > 3 || (d->mode >= 2 && !d->addend)) return MFPA_EINVAL;
   if (d->lda % 4 || d->strideA % 4) return MFPA_EINVAL;   // float4 row loads
@@ -903,11 +903,12 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   dim3 grid(d->npad / GBN, (d->M + GBM - 1) / GBM, d->batch);
   if (grid.y > 65535 || grid.z > 65535) return MFPA_EINVAL;
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
-  // Short-K layers (K < 256: the outer, full-rate encoder / decoder levels) are HBM-bound; the fp32 kernel's smaller
-  // LDS footprint keeps more workgroups (memory requests) in flight there, and measured faster (profiles/r01c_demucs_gemm_calls.md).
+  // K >= 128: the chunked bf16x3 kernel.  (At first the K = 128 / 192 levels ran faster on the fp32 kernel; that was the
+  // epilogue's serialised addend loads and 64-bit addressing, not the arithmetic: with those fixed the fp32 MFMA rate is what
+  // bounds them -- PMC: 2.2 of 4.0 ms MFMA-busy on the K = 192 transposed convolution -- and bf16x3 is 10 % faster end to end.)
   static const int shortk = getenv("MFPA_SHORTK") ? atoi(getenv("MFPA_SHORTK")) : 1;   // 0: the fp32-MFMA kernels for K < 256 (experiments)
   hipStream_t st = mfpa_stream(stream);
-  if (d->precision == 1 && d->K % HKC == 0 && d->K >= 256) {
+  if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
   } else if (d->precision == 1 && shortk && d->K == 48 && d->c1_x) {
     hipLaunchKernelGGL((gemm_shortk_bf16x3_kernel<true, 48, 48>), grid, dim3(256), SK_LDS(48) + 9 * 48 * 4, st, a);
