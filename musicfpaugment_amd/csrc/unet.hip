@@ -370,24 +370,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
       }
   }
   if (a.y != nullptr) {
+    // 32-bit byte offsets from a scalar per-clip base (the host checks that one clip's output fits 4 GB), the pixel offset
+    // computed once for all of a lane's channels, and no bounds checks on interior tiles: the first form of this loop (64-bit
+    // index arithmetic and an exec-mask branch per element) was up to 13 % of the 64-channel layers
+    const unsigned oW = (MODE == 1) ? 2u * (unsigned)a.W : (unsigned)a.yW;
+    const unsigned oH = (MODE == 1) ? 2u * (unsigned)a.H : (unsigned)a.yH;
+    char* yb = reinterpret_cast<char*>(a.y + (size_t)b * oH * oW * a.Cout);
+    const unsigned cout = (unsigned)a.Cout;
+    const unsigned nb = (unsigned)(n0 + wn * (NT * 32) + li) * 4u;
+    const bool interior = (y0 + PH <= a.yH) && (x0p + PW <= a.yW);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + wn * (NT * 32) + nt * 32 + li;
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = y0 + m / PW, gx = x0p + m % PW;
+        if (interior || (gy < a.yH && gx < a.yW)) {
+          unsigned pix;
+          if (MODE != 1) pix = (unsigned)gy * oW + (unsigned)gx;
+          else pix = (unsigned)(2 * gy + (ct_tap >> 1)) * oW + (unsigned)(2 * gx + (ct_tap & 1));
+          char* yp = yb + (pix * cout * 4u + nb);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int gy = y0 + m / PW, gx = x0p + m % PW;
-          if (gy < a.yH && gx < a.yW && !((a.dbg & 4) && v_never(acc[mt][nt][r]))) {
-            const float v = acc[mt][nt][r];
-            if (MODE != 1) {
-              a.y[(((size_t)b * a.yH + gy) * a.yW + gx) * a.Cout + n] = v;
-            } else {
-              const int oy = 2 * gy + (ct_tap >> 1), ox = 2 * gx + (ct_tap & 1);
-              a.y[(((size_t)b * (2 * a.H) + oy) * (2 * a.W) + ox) * a.Cout + n] = v;
-            }
-          }
+          for (int nt = 0; nt < NT; ++nt)
+            if (!((a.dbg & 4) && v_never(acc[mt][nt][r]))) *reinterpret_cast<float*>(yp + nt * 128) = acc[mt][nt][r];
         }
       }
     }
@@ -833,6 +838,7 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->mode < 0 || d->mode > 2) return MFPA_EINVAL;
   if (d->C1 > 0 && (d->mode != 0 || !d->x1 || d->H1 < 1 || d->W1 < 1 || d->H1 > d->H || d->W1 > d->W)) return MFPA_EINVAL;
   if ((d->in_scale0 == nullptr) != (d->in_shift0 == nullptr)) return MFPA_EINVAL;
+  if (4LL * d->H * d->W * d->Cout * 4 > 0xffffffffLL) return MFPA_EINVAL;   // the epilogue addresses one clip's output with 32-bit byte offsets
   ConvArgs a{};
   a.x0 = d->x0; a.in_scale0 = d->in_scale0; a.in_shift0 = d->in_shift0;
   a.x1 = d->C1 ? d->x1 : nullptr; a.w = d->w; a.scale = d->out_scale; a.shift = d->out_shift; a.y = d->y;
