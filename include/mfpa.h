@@ -447,6 +447,13 @@ int mfpa_lstm_layer(const float* whh_grouped, float* xp, float* hseq, float* cse
                     const float* skip, int train, void* stream);
 int mfpa_lstm_layer_bwd(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
                         void* stream);
+/* The same for the time steps [t0, t1) only (backward: t1-1 down to t0), so that the two layers can run as a pipeline on two
+ * streams: layer 1 works on chunk k while layer 0 is already on chunk k+1 (backward: the other way round).  The state buffers
+ * (cstate / dcstate) are zeroed by the call that holds the first step of the recurrence. */
+int mfpa_lstm_layer_range(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H,
+                          float* xsum, const float* skip, int train, int t0, int t1, void* stream);
+int mfpa_lstm_layer_bwd_range(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn,
+                              int H, int t0, int t1, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Waveform-domain spectral losses of the Demucs branch, training/loss.py:10-186 (MultiResolutionSTFTLoss; forward).

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class MfpaError(RuntimeError):
@@ -91,6 +91,10 @@ _SIGNATURES = {
     "mfpa_lstm_layer": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
                         c_int),
     "mfpa_lstm_layer_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
+    "mfpa_lstm_layer_range": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                               c_int, c_void_p], c_int),
+    "mfpa_lstm_layer_bwd_range": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                                  c_int),
     "mfpa_gemm_tn": ([c_void_p, c_void_p], c_int),
     "mfpa_glu_bwd": ([c_void_p, c_longlong, c_int, c_int, c_void_p, c_longlong, c_void_p], c_int),
     "mfpa_colsum_any": ([c_void_p, c_longlong, c_int, c_longlong, c_void_p, c_void_p], c_int),

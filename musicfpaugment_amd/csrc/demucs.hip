@@ -1014,14 +1014,14 @@ int mfpa_lstm_step_train(const float* hprev, long long ldhp, const float* whh_gr
 
 /* A whole LSTM layer: the Tn time steps of mfpa_lstm_step / mfpa_lstm_step_train launched from one host loop (one call across
  * the ABI instead of Tn: the Python-side cost of 2 x 248 launches was a third of a 16-clip training step). */
-int mfpa_lstm_layer(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
-                    const float* skip, int train, void* stream) {
-  if (B == 0 || Tn == 0) return MFPA_OK;
-  if (!whh_grouped || !xp || !hseq || B < 0 || Tn < 0 || H < LKC || H % LKC || (xsum && !skip)) return MFPA_EINVAL;
+int mfpa_lstm_layer_range(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H,
+                          float* xsum, const float* skip, int train, int t0, int t1, void* stream) {
+  if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
+  if (!whh_grouped || !xp || !hseq || B < 0 || Tn < 0 || H < LKC || H % LKC || (xsum && !skip) || t0 < 0 || t1 > Tn) return MFPA_EINVAL;
   if (train ? !cseq : !cstate) return MFPA_EINVAL;
   const long long ldh = (long long)Tn * H, ldx = (long long)Tn * 4 * H;
-  if (!train) MFPA_HIP(hipMemsetAsync(cstate, 0, (size_t)B * H * sizeof(float), mfpa_stream(stream)));
-  for (int t = 0; t < Tn; ++t) {
+  if (!train && t0 == 0) MFPA_HIP(hipMemsetAsync(cstate, 0, (size_t)B * H * sizeof(float), mfpa_stream(stream)));
+  for (int t = t0; t < t1; ++t) {
     const float* hprev = t ? hseq + (size_t)(t - 1) * H : nullptr;
     float* xt = xp + (size_t)t * 4 * H;
     int rc;
@@ -1035,6 +1035,11 @@ int mfpa_lstm_layer(const float* whh_grouped, float* xp, float* hseq, float* cse
     if (rc != MFPA_OK) return rc;
   }
   return MFPA_OK;
+}
+
+int mfpa_lstm_layer(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
+                    const float* skip, int train, void* stream) {
+  return mfpa_lstm_layer_range(whh_grouped, xp, hseq, cseq, cstate, B, Tn, H, xsum, skip, train, 0, Tn, stream);
 }
 
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,

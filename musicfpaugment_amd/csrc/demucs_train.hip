@@ -729,19 +729,24 @@ int mfpa_lstm_step_bwd(const float* dgnext, long long ldgn, const float* whhT, f
 
 /* The backward recurrence of a whole LSTM layer: mfpa_lstm_step_bwd for t = Tn-1 .. 0 from one host loop.  gates / cseq / dhout
  * are (B, Tn, .) as mfpa_lstm_layer(train = 1) left them; dcstate (B, H) scratch (zeroed here). */
-int mfpa_lstm_layer_bwd(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
-                        void* stream) {
-  if (B == 0 || Tn == 0) return MFPA_OK;
-  if (!whhT || !gates || !cseq || !dhout || !dcstate || B < 0 || Tn < 0) return MFPA_EINVAL;
-  MFPA_HIP(hipMemsetAsync(dcstate, 0, (size_t)B * H * sizeof(float), mfpa_stream(stream)));
+int mfpa_lstm_layer_bwd_range(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn,
+                              int H, int t0, int t1, void* stream) {
+  if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
+  if (!whhT || !gates || !cseq || !dhout || !dcstate || B < 0 || Tn < 0 || t0 < 0 || t1 > Tn) return MFPA_EINVAL;
+  if (t1 == Tn) MFPA_HIP(hipMemsetAsync(dcstate, 0, (size_t)B * H * sizeof(float), mfpa_stream(stream)));
   const long long ldg = (long long)Tn * 4 * H, ldh = (long long)Tn * H;
-  for (int t = Tn - 1; t >= 0; --t) {
+  for (int t = t1 - 1; t >= t0; --t) {
     const int rc = mfpa_lstm_step_bwd(t + 1 < Tn ? gates + (size_t)(t + 1) * 4 * H : nullptr, ldg, whhT, gates + (size_t)t * 4 * H, ldg,
                                       cseq + (size_t)t * H, ldh, t ? cseq + (size_t)(t - 1) * H : nullptr, ldh, dhout + (size_t)t * H, ldh,
                                       dcstate, B, H, stream);
     if (rc != MFPA_OK) return rc;
   }
   return MFPA_OK;
+}
+
+int mfpa_lstm_layer_bwd(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
+                        void* stream) {
+  return mfpa_lstm_layer_bwd_range(whhT, gates, cseq, dhout, dcstate, B, Tn, H, 0, Tn, stream);
 }
 
 }  // extern "C"

@@ -125,6 +125,74 @@ def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mo
         _K._TIMER.stop(t0)
 
 
+
+PIPELINE_LSTM = True      # False: the two LSTM layers one after the other on the current stream
+PIPELINE_MAX_CLIPS = 96   # above this a step fills the chip on its own: forward 7.1 -> 5.5 ms at 16 clips, 13.6 -> 12.6 at 64, 21.3 -> 22.0 at 128
+LSTM_CHUNK = 31           # time steps per pipeline stage (248 = 8 x 31)
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[idx]
+
+
+def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped, precision: int, train: bool):
+    """Both LSTM layers (model.py:91-110) on x (B, Tn, H): returns (xsum = h1 + skip, saved) with saved = per layer
+    (input, gates-or-projections, hseq, cseq-or-None).
+
+    A time step of one layer occupies 48-96 of the 256 CUs (it is bound by what those CUs can stream), so the two
+    layers run as a PIPELINE on two streams: while layer 0 works on chunk k+1 of the sequence on the current stream, a side
+    stream projects chunk k of its output (h0 W_ih1^T) and runs layer 1 on it.  Joined before returning."""
+    B, Tn, H = x.shape
+    dev = x.device
+    L = lib()
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    xp = [new(B, Tn, 4 * H), new(B, Tn, 4 * H)]
+    hs = [new(B, Tn, H), new(B, Tn, H)]
+    cs = [new(B, Tn, H), new(B, Tn, H)] if train else [None, None]
+    cstate = [None, None] if train else [new(B, H), new(B, H)]
+    xsum = new(B, Tn, H)
+    t0ev = _K._TIMER.start() if _K._TIMER is not None else None        # projection + recurrence of both layers as one timed group
+    timer, _K._TIMER = _K._TIMER, None
+    try:
+        gemm(_p(x), H, 0, 1, B * Tn, wih[0], bias[0], 4 * H, _p(xp[0]), 4 * H, 0, precision=precision)
+
+        def layer(k, a, b):
+            check(L.mfpa_lstm_layer_range(ptr(whh_grouped[k]), ptr(xp[k]), ptr(hs[k]), ptr(cs[k]) if train else 0,
+                                          0 if train else ptr(cstate[k]), B, Tn, H, ptr(xsum) if k == 1 else 0,
+                                          ptr(skip) if k == 1 else 0, int(train), a, b, stream()), "mfpa_lstm_layer_range")
+
+        def project(a, b):                                               # xp1[:, a:b] = h0[:, a:b] W_ih1^T + bias
+            gemm(_p(hs[0], a * H), H, Tn * H, B, b - a, wih[1], bias[1], 4 * H, _p(xp[1], a * 4 * H), 4 * H, Tn * 4 * H,
+                 precision=precision)
+
+        if not PIPELINE_LSTM or Tn <= LSTM_CHUNK or B > PIPELINE_MAX_CLIPS:
+            layer(0, 0, Tn)
+            gemm(_p(hs[0]), H, 0, 1, B * Tn, wih[1], bias[1], 4 * H, _p(xp[1]), 4 * H, 0, precision=precision)
+            layer(1, 0, Tn)
+        else:
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(main)
+            for a in range(0, Tn, LSTM_CHUNK):
+                b = min(Tn, a + LSTM_CHUNK)
+                layer(0, a, b)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    project(a, b)
+                    layer(1, a, b)
+            main.wait_stream(side)
+    finally:
+        _K._TIMER = timer
+    if t0ev is not None:
+        _K._TIMER.stop(t0ev)
+    return xsum, [(x, xp[0], hs[0], cs[0]), (hs[0], xp[1], hs[1], cs[1])]
+
+
 def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: int = PRECISION) -> torch.Tensor:
     """(B, T) float32 on the GPU -> (B, T) denoised waveform.  model.py:290-326.  `precision` selects the GEMM arithmetic
     (the fused LSTM step is always bf16x3)."""
@@ -167,21 +235,8 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
         Lin = Lout
     # ---- LSTM: 2 layers, unidirectional, zero initial state (model.py:91-110); the last layer also emits h + skip
     Tn, H = Lin, chans[-1]
-    seq, xsum = h, None
-    for layer in range(2):
-        xp = new(B, Tn, 4 * H)                                   # input projection of every step at once
-        gemm_p(_p(seq), H, 0, 1, B * Tn, pw[f"lstm{layer}.wih"], pw[f"lstm{layer}.b"], 4 * H, _p(xp), 4 * H, 0)
-        hseq, c = new(B, Tn, H), new(B, H)
-        last = layer == 1
-        if last:
-            xsum = new(B, Tn, H)
-        t0 = _K._TIMER.start() if _K._TIMER is not None else None     # the whole recurrence as one timed group
-        # gates = h[t-1] @ W_hh^T + xp[:, t] and the cell, one launch per time step, all Tn launched by one C call
-        check(L.mfpa_lstm_layer(ptr(pw[f"lstm{layer}.whh_grouped"]), ptr(xp), ptr(hseq), 0, ptr(c), B, Tn, H,
-                                ptr(xsum) if last else 0, ptr(skips[-1]) if last else 0, 0, stream()), "mfpa_lstm_layer")
-        if t0 is not None:
-            _K._TIMER.stop(t0)
-        seq = hseq
+    xsum, _ = lstm_two_layers(h, skips[-1], [pw["lstm0.wih"], pw["lstm1.wih"]], [pw["lstm0.b"], pw["lstm1.b"]],
+                              [pw["lstm0.whh_grouped"], pw["lstm1.whh_grouped"]], precision, train=False)
     # ---- decoder: (x + skip) -> Conv1d(1x1) + GLU -> ConvTranspose1d(k8,s4) [+ ReLU], next skip added in the epilogue
     x = xsum
     skips.pop()

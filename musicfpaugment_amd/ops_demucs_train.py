@@ -305,22 +305,8 @@ class DemucsTrainEngine:
         S["L"], S["a"], S["u"], S["h"] = Ls, a_s, u_s, h_s
         # ---- LSTM
         Tn = Lin
-        seq, xsum = h, None
-        lst = []
-        for layer in range(2):
-            gates = new(B, Tn, 4 * H)                                   # input projections, overwritten by the gate activations
-            D.gemm(_p(seq), H, 0, 1, B * Tn, P[f"lstm{layer}.wih"], W[f"lstm{layer}.b"], 4 * H, _p(gates), 4 * H, 0, precision=prec)
-            hseq, cseq = new(B, Tn, H), new(B, Tn, H)
-            last = layer == 1
-            if last:
-                xsum = new(B, Tn, H)
-            t0 = _K._TIMER.start() if _K._TIMER is not None else None     # the whole recurrence as one timed group
-            check(L.mfpa_lstm_layer(ptr(W[f"lstm{layer}.whh_grouped"]), ptr(gates), ptr(hseq), ptr(cseq), 0, B, Tn, H,
-                                    ptr(xsum) if last else 0, ptr(h_s[-1]) if last else 0, 1, stream()), "mfpa_lstm_layer")
-            if t0 is not None:
-                _K._TIMER.stop(t0)
-            lst.append((seq, gates, hseq, cseq))
-            seq = hseq
+        xsum, lst = D.lstm_two_layers(h, h_s[-1], [P["lstm0.wih"], P["lstm1.wih"]], [W["lstm0.b"], W["lstm1.b"]],
+                                      [W["lstm0.whh_grouped"], W["lstm1.whh_grouped"]], prec, train=True)
         S["lstm"], S["Tn"] = lst, Tn
         # ---- decoder
         x = xsum
@@ -426,28 +412,49 @@ class DemucsTrainEngine:
         # ---- LSTM
         self._mark("bwd_decoder")
         Tn = S["Tn"]
-        dhout = dxsum
-        dh_enc = None
-        for layer in (1, 0):
-            seq, gates, hseq, cseq = S["lstm"][layer]
-            dc = new(B, H)
-            t0 = _K._TIMER.start() if _K._TIMER is not None else None
-            check(L.mfpa_lstm_layer_bwd(ptr(W[f"lstm{layer}.whhT"]), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, stream()),
-                  "mfpa_lstm_layer_bwd")
-            if t0 is not None:
-                _K._TIMER.stop(t0)
+        (seq0, g0, hseq0, cseq0), (seq1, g1, hseq1, cseq1) = S["lstm"]
+        dc0, dc1, dx1 = new(B, H), new(B, H), new(B, Tn, H)
+        t0 = _K._TIMER.start() if _K._TIMER is not None else None
+        timer, _K._TIMER = _K._TIMER, None
+
+        def bwd(whhT, gates, cseq, dhout, dc, a, b):
+            check(L.mfpa_lstm_layer_bwd_range(ptr(whhT), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, a, b, stream()),
+                  "mfpa_lstm_layer_bwd_range")
+
+        def dx_chunk(a, b):                                              # dL/d(h0)[:, a:b] = dgates1[:, a:b] W_ih1
+            D.gemm(_p(g1, a * 4 * H), 4 * H, Tn * 4 * H, B, b - a, W["lstm1.wihT"], None, H, _p(dx1, a * H), H, Tn * H, precision=prec)
+
+        try:
+            if not D.PIPELINE_LSTM or Tn <= D.LSTM_CHUNK or B > D.PIPELINE_MAX_CLIPS:
+                bwd(W["lstm1.whhT"], g1, cseq1, dxsum, dc1, 0, Tn)
+                dx_chunk(0, Tn)
+                bwd(W["lstm0.whhT"], g0, cseq0, dx1, dc0, 0, Tn)
+            else:       # layer 1 runs backwards through the chunks on this stream, layer 0 follows one chunk behind on the side stream
+                main, side = torch.cuda.current_stream(dev), D._side_stream(dev)
+                side.wait_stream(main)
+                starts = list(range(0, Tn, D.LSTM_CHUNK))
+                for a in reversed(starts):
+                    b = min(Tn, a + D.LSTM_CHUNK)
+                    bwd(W["lstm1.whhT"], g1, cseq1, dxsum, dc1, a, b)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        dx_chunk(a, b)
+                        bwd(W["lstm0.whhT"], g0, cseq0, dx1, dc0, a, b)
+                main.wait_stream(side)
+        finally:
+            _K._TIMER = timer
+        if t0 is not None:
+            _K._TIMER.stop(t0)
+        for layer, (seq, gates, hseq) in enumerate(((seq0, g0, hseq0), (seq1, g1, hseq1))):
             gemm_tn(ptr(gates), 4 * H, 0, ptr(seq), H, 0, G[f"lstm{layer}.wih"], H, 1, B * Tn, 4 * H, H, colsum=G[f"lstm{layer}.bih"])
             G[f"lstm{layer}.bhh"].copy_(G[f"lstm{layer}.bih"])
             if Tn > 1:
                 gemm_tn(_p(gates, 4 * H), 4 * H, Tn * 4 * H, ptr(hseq), H, Tn * H, G[f"lstm{layer}.whh"], H, B, Tn - 1, 4 * H, H)
-            dx = new(B, Tn, H)
-            if layer == 1:
-                D.gemm(_p(gates), 4 * H, 0, 1, B * Tn, W[f"lstm{layer}.wihT"], None, H, _p(dx), H, 0, precision=prec)
-                dhout = dx
-            else:                                                        # + the first decoder skip's gradient
-                D.gemm(_p(gates), 4 * H, 0, 1, B * Tn, W[f"lstm{layer}.wihT"], None, H, _p(dx), H, 0, mode=2,
-                       addend=_p(dxsum), ldadd=H, strideAdd=0, precision=prec)
-                dh_enc = dx
+        dh_enc = new(B, Tn, H)                                           # dL/d(h_4) = layer 0's input gradient + the first decoder skip's
+        D.gemm(_p(g0), 4 * H, 0, 1, B * Tn, W["lstm0.wihT"], None, H, _p(dh_enc), H, 0, mode=2, addend=_p(dxsum), ldadd=H, strideAdd=0,
+               precision=prec)
         # ---- encoder
         self._mark("bwd_lstm")
         Ls, a_s, u_s, h_s = S["L"], S["a"], S["u"], S["h"]
