@@ -494,6 +494,7 @@ def main():
         net.precision = 1 if args.precision == "bf16x3" else 0
         if args.unet_pass > 0:
             net.max_clips_per_pass = args.unet_pass
+        net.two_streams = bool(int(os.environ.get("MFPA_UNET_TWO_STREAMS", "0")))
     hot = HotPath(net, device=dev)
 
     # synthetic clips of SURVEY.md §8d: 32 distinct generated clips per rank, tiled to B with a sign/gain variation

@@ -103,6 +103,14 @@ class KernelTimer:
 
 
 _TIMER = None
+_SIDE = {}
+
+
+def side_stream(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE:
+        _SIDE[idx] = torch.cuda.Stream(device=dev)
+    return _SIDE[idx]
 
 
 def set_timer(timer):

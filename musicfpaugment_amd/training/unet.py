@@ -87,6 +87,7 @@ class UNet(nn.Module):
         self.outc = OutConv(64, n_classes)
 
         self.max_clips_per_pass = 64       # activations of one pass: ~0.12 GB per 8 s clip
+        self.two_streams = False           # experiment: alternate the passes of a batch on two streams
         # inference arithmetic of the MFMA convolutions: 0 = fp32 MFMA (exact fp32 products, rel. L1 ~1e-6 vs the
         # reference), 1 = bf16x3 split (3 bf16 MFMAs per product, rel. L1 ~2e-5; tolerance is 1e-4)
         self.precision = 0
@@ -137,7 +138,21 @@ class UNet(nn.Module):
         if not per_clip:
             clip_max = clip_max.max().expand(B).contiguous()
         outs = []
-        for s in range(0, B, self.max_clips_per_pass):
-            e = min(B, s + self.max_clips_per_pass)
-            outs.append(K.unet_forward_eval(pw, spec64=spec64[s:e], denom=clip_max[s:e].contiguous()))
+        ranges = [(s, min(B, s + self.max_clips_per_pass)) for s in range(0, B, self.max_clips_per_pass)]
+        if self.two_streams and len(ranges) > 1:
+            # alternate passes on two streams: the tail of one pass's launches (the last wave of workgroups, the 16 x 15 levels)
+            # overlaps the other pass's kernels
+            main = torch.cuda.current_stream(spec64.device)
+            side = K.side_stream(spec64.device)
+            side.wait_stream(main)
+            for i, (s, e) in enumerate(ranges):
+                if i % 2:
+                    with torch.cuda.stream(side):
+                        outs.append(K.unet_forward_eval(pw, spec64=spec64[s:e], denom=clip_max[s:e].contiguous()))
+                else:
+                    outs.append(K.unet_forward_eval(pw, spec64=spec64[s:e], denom=clip_max[s:e].contiguous()))
+            main.wait_stream(side)
+        else:
+            for s, e in ranges:
+                outs.append(K.unet_forward_eval(pw, spec64=spec64[s:e], denom=clip_max[s:e].contiguous()))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
