@@ -393,6 +393,98 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
 }
 
+// The same with a 128 x 128 workgroup tile of four 64 x 64 wave tiles (2 x 2 MFMA tiles per wave): a wave reads 8 fragments per
+// 12 MFMAs instead of 6 per 6 -- the 32 x 64 wave tile above keeps the LDS pipe as busy as the matrix pipe (PMC: 30 % of the wave
+// cycles issue-stalled on the mid-level launches).  Used when the padded N is a multiple of 128.  73.7 KB of LDS, two workgroups
+// per CU.
+constexpr int WBN = 128;
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  char* As = wsm;                                    // [2][GBM][HROW]
+  char* Bs = wsm + 2 * GBM * HROW;                   // [2][WBN][HROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int n0 = blockIdx.x * WBN, m0 = blockIdx.y * GBM, b = blockIdx.z;
+  const float* Ab = a.A + (size_t)b * a.strideA;
+  const int nk = a.K / HKC;
+
+  f32x4 ar[4], br[4];
+  const int q = tid & 7, r0 = tid >> 3;                  // rows r0 + 32 i
+  auto load = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M) v = *reinterpret_cast<const f32x4*>(Ab + (size_t)m * a.lda + kc * HKC + 4 * q);
+      ar[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      br[i] = *reinterpret_cast<const f32x4*>(a.W + (size_t)(n0 + r0 + 32 * i) * a.K + kc * HKC + 4 * q);
+  };
+  auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
+    g_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
+    *reinterpret_cast<g_bf16x4*>(row + 64 + 8 * q) = lo;
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store(As + (buf * GBM + r0 + 32 * i) * HROW, ar[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store(Bs + (buf * WBN + r0 + 32 * i) * HROW, br[i]);
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  load(0);
+  store(0);
+  if (nk > 1) load(1);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) store(buf ^ 1);
+    if (kc + 2 < nk) load(kc + 2);
+    const char* Ap = As + (buf * GBM + wm * 64 + li) * HROW + 16 * lh;
+    const char* Bp = Bs + (buf * WBN + wn * 64 + li) * HROW + 16 * lh;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      g_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *reinterpret_cast<const g_bf16x8*>(Ap + t * 32 * HROW + 32 * s);
+        al[t] = *reinterpret_cast<const g_bf16x8*>(Ap + t * 32 * HROW + 64 + 32 * s);
+        bh[t] = *reinterpret_cast<const g_bf16x8*>(Bp + t * 32 * HROW + 32 * s);
+        bl[t] = *reinterpret_cast<const g_bf16x8*>(Bp + t * 32 * HROW + 64 + 32 * s);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // the shared epilogue takes a 32-row x 64-column wave tile at row (wave index) * 32: two calls per wave
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) gemm_epilogue(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+}
+
 // Short-K layers with bf16x3 products (K = 48 and 96: the full-rate outer levels of the network; measured on 256 clips: forward
 // 50.1 -> 46.8 ms with these two; the same form for K = 128 / 192 was slower than the fp32 kernel and is not instantiated).  With exact fp32 products
 // these launches are bound by the fp32 MFMA rate (64 cycles per 32x32x2), not by HBM: e.g. the 1x1 + GLU of level 0 is 151 GFLOP
@@ -908,7 +1000,11 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   // bounds them -- PMC: 2.2 of 4.0 ms MFMA-busy on the K = 192 transposed convolution -- and bf16x3 is 10 % faster end to end.)
   static const int shortk = getenv("MFPA_SHORTK") ? atoi(getenv("MFPA_SHORTK")) : 1;   // 0: the fp32-MFMA kernels for K < 256 (experiments)
   hipStream_t st = mfpa_stream(stream);
-  if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128) {
+  static const int wide = getenv("MFPA_GEMM_WIDE") ? atoi(getenv("MFPA_GEMM_WIDE")) : 1;   // 0: always the 128 x 64 tile (experiments)
+  if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128 && wide && d->npad % WBN == 0) {
+    dim3 gw(d->npad / WBN, grid.y, grid.z);
+    hipLaunchKernelGGL(gemm_bf16x3_wide_kernel, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);
+  } else if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
   } else if (d->precision == 1 && shortk && d->K == 48 && d->c1_x) {
     hipLaunchKernelGGL((gemm_shortk_bf16x3_kernel<true, 48, 48>), grid, dim3(256), SK_LDS(48) + 9 * 48 * 4, st, a);
