@@ -1,5 +1,7 @@
 """GPU parity: Demucs training step (forward with kept activations, L1 + MultiResolutionSTFTLoss, hand-written backward,
 Adam) against torch autograd through the CPU oracle (oracle/demucs.py, oracle/loss.py) -- training/train.py:275-312."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -311,3 +313,15 @@ def test_trainer_audio_branch():
     net.eval()
     y = net(torch.from_numpy(synth.batch(1, seed=3, n=4000)).cuda())
     assert y.shape == (1, 1, 4000) and bool(torch.isfinite(y).all())
+    # checkpoints with the reference's keys (train.py:197-221) round-trip the parameters and the optimiser state
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        tr.ckpt_path = tmp
+        tr.save_checkpoint(val["loss"])
+        ck = torch.load(os.path.join(tmp, "best_epoch.pt"))
+        assert set(ck["model_state_dict"].keys()) == set(formula_state_dict(0).keys())
+        net2 = Demucs()
+        tr2 = Trainer(net2, loader(40), loader(90), train_steps=3, val_steps=2, device="cuda", input_type="audio", ckpt_path=tmp)
+        assert tr2.load_checkpoint()
+        assert torch.equal(tr2.engine.flat_p, tr.engine.flat_p) and torch.equal(tr2.engine.flat_m, tr.engine.flat_m)
+        assert tr2.engine.step_count == tr.engine.step_count
