@@ -4,6 +4,7 @@ Reference: Demucs.forward, training/model.py:290-326.  Activations are (B, L, C)
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Dict
 
@@ -128,7 +129,7 @@ def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mo
 
 PIPELINE_LSTM = True      # False: the two LSTM layers one after the other on the current stream
 PIPELINE_MAX_CLIPS = 96   # above this a step fills the chip on its own: forward 7.1 -> 5.5 ms at 16 clips, 13.6 -> 12.6 at 64, 21.3 -> 22.0 at 128
-LSTM_CHUNK = 31           # time steps per pipeline stage (248 = 8 x 31)
+LSTM_CHUNK = int(os.environ.get("MFPA_LSTM_CHUNK", "31"))   # time steps per pipeline stage (248 = 8 x 31)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
