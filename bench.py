@@ -335,8 +335,9 @@ def bench_train(args, rank, world, dev, dist):
     wprec = {"fp32": 0, "bf16x3": 1, "bf16": 2}[args.wgrad]
     eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0, wgrad_precision=wprec,
                           sync_bn=args.sync_bn)
-    base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank)
-    noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False)
+    nsamp = int(args.seconds * 8000)
+    base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank, n=nsamp)
+    noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False, n=nsamp)
     reps = (B + len(base) - 1) // len(base)
     clean = np.concatenate([base] * reps)[:B]
     aug = np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * reps)[:B]
@@ -382,19 +383,19 @@ def bench_train(args, rank, world, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
     if rank == 0:
-        mfma_gflop = 280.1 - 3 * 0.082               # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU)
+        mfma_gflop = (280.1 - 3 * 0.082) * (1 + nsamp // 256) / 251.0   # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU); scales with the frames
         conv_ms = timer.total_ms()
         achieved = mfma_gflop * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12
         issue_x = 2.0 + {"bf16x3": 3, "bf16": 1, "fp32": 0}[args.wgrad] / 3.0      # fp32 weight gradients run on the fp32 cores
         print(json.dumps({
-            "metric": "8s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
+            "metric": f"{args.seconds:g}s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": (f"bf16x3 forward and input-gradient convolutions (fp32 operands split into bf16 hi+lo, fp32 accumulate), "
                       f"{args.wgrad} weight gradients, fp32/fp64 reductions and Adam") if args.precision == "bf16x3"
                      else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
-            "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), 8 s clips 257x251, {args.precision} MFMA, "
+            "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), {args.seconds:g} s clips 257x{1 + nsamp // 256}, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "loss_last": float(loss),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
@@ -437,7 +438,7 @@ def main():
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
     ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
     ap.add_argument("--unet-pass", type=int, default=0, help="infer mode: clips per UNet pass (0 = the module default)")
-    ap.add_argument("--seconds", type=float, default=8.0, help="demucs-train mode: clip length (the reference trains on 3 s)")
+    ap.add_argument("--seconds", type=float, default=8.0, help="train / demucs-train modes: clip length (the reference trains on 3 s)")
     ap.add_argument("--mode", choices=["infer", "train", "demucs", "demucs-train", "metrics"], default="infer",
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
