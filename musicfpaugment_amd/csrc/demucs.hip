@@ -31,6 +31,7 @@ struct GemmArgs {
   const float* bias;                           // [Npad] or null
   const float* addend; long long ldadd, strideAdd;   // mode 2: y += addend[b*strideAdd + m*ldadd + n]
   float* C; long long ldc, strideC;
+  int nx, ny, nz, xcd;                         // tile grid (n tiles, m tiles, clips) of the 1-D launch; xcd = 1: XCD-aware tile order
   float* C2; long long ldc2, strideC2;         // training: second output (mode 1: the packed GLU pre-activations; relu 2: relu(y) before the addition)
   int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend;
                                                // 3: * (addend > 0) -- the ReLU backward mask of the layer that produced addend
@@ -39,6 +40,25 @@ struct GemmArgs {
   const float* c1_x; long long c1_lin;         // (batch, c1_lin) samples
   const float* c1_w; const float* c1_b;        // (8, K), (K)
 };
+
+// Tile of a workgroup in the 1-D launch.  Consecutive workgroup ids are dealt round-robin over the 8 XCDs, each with its own L2:
+// with the plain order the n tiles that share an A tile land on 8 different XCDs and every one of them fetches that A tile from
+// memory (PMC: the mid-level launches fetched 2.7x what they wrote).  Here XCD k owns a contiguous range of the (clip, m tile,
+// n tile) order, n fastest, so the workgroups sharing an A tile run back to back on ONE XCD.
+__device__ __forceinline__ bool gemm_tile(const GemmArgs& a, int& bx, int& by, int& bz) {
+  const unsigned total = (unsigned)a.nx * a.ny * a.nz;
+  unsigned lin = blockIdx.x;
+  if (a.xcd) {
+    const unsigned per = (total + 7) / 8;
+    lin = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  }
+  if (lin >= total) return false;              // uniform over the workgroup, before any barrier
+  bx = lin % a.nx;
+  const unsigned rest = lin / a.nx;
+  by = rest % a.ny;
+  bz = rest / a.ny;
+  return true;
+}
 
 // epilogue shared by all GEMM kernels: D[row = m][col = n]; a lane holds column li of both 32-wide n tiles.
 // The short-K launches are bound by vector-instruction issue, and the first form of this epilogue was most of it (64-bit
@@ -135,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float W1s[C1SRC ? 9 * 256 : 4];      // C1SRC: [8][K] taps then [K] bias, K <= 256
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;   // n tiles fastest: the workgroups that share an A tile run together
+  int bx, by, b;
+  if (!gemm_tile(a, bx, by, b)) return;
+  const int n0 = bx * GBN, m0 = by * GBM;
   const float* Ab = a.A + (size_t)b * a.strideA;
   const int nk = a.K / GKC;
 
@@ -234,7 +256,9 @@ __global__ __launch_bounds__(256, 3) void gemm_smallk_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float W1s[C1SRC ? 9 * K : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;
+  int bx, by, b;
+  if (!gemm_tile(a, bx, by, b)) return;
+  const int n0 = bx * GBN, m0 = by * GBM;
   f32x4 ar[A_F4], br[B_F4], x0[C1SRC ? A_F4 : 1], x1[C1SRC ? A_F4 : 1];
 #pragma unroll
   for (int i = 0; i < B_F4; ++i) {
@@ -323,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) char Bs[2][GBN * HROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;   // n tiles fastest: the workgroups that share an A tile run together
+  int bx, by, b;
+  if (!gemm_tile(a, bx, by, b)) return;
+  const int n0 = bx * GBN, m0 = by * GBM;
   const float* Ab = a.A + (size_t)b * a.strideA;
   const int nk = a.K / HKC;
 
@@ -406,7 +432,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
-  const int n0 = blockIdx.x * WBN, m0 = blockIdx.y * GBM, b = blockIdx.z;
+  int bx, by, b;
+  if (!gemm_tile(a, bx, by, b)) return;
+  const int n0 = bx * WBN, m0 = by * GBM;
   const float* Ab = a.A + (size_t)b * a.strideA;
   const int nk = a.K / HKC;
 
@@ -503,7 +531,9 @@ __global__ __launch_bounds__(256, 2) void gemm_shortk_bf16x3_kernel(GemmArgs a) 
   float* W1s = reinterpret_cast<float*>(sksm + (GBM + GBN) * ROW);      // C1SRC: [8][K] taps then [K] bias
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM, b = blockIdx.z;
+  int bx, by, b;
+  if (!gemm_tile(a, bx, by, b)) return;
+  const int n0 = bx * GBN, m0 = by * GBM;
   f32x4 ar[NCH][A_F4], br[NCH][B_F4];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -992,8 +1022,11 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   a.C2 = d->C2; a.ldc2 = d->ldc2; a.strideC2 = d->strideC2;
   a.M = d->M; a.N = d->N; a.K = d->K; a.mode = d->mode; a.relu = d->relu;
   a.c1_x = d->c1_x; a.c1_lin = d->c1_lin; a.c1_w = d->c1_w; a.c1_b = d->c1_b;
-  dim3 grid(d->npad / GBN, (d->M + GBM - 1) / GBM, d->batch);
-  if (grid.y > 65535 || grid.z > 65535) return MFPA_EINVAL;
+  static const int xcd_env = getenv("MFPA_GEMM_XCD") ? atoi(getenv("MFPA_GEMM_XCD")) : 1;   // 0: plain tile order (experiments)
+  a.ny = (d->M + GBM - 1) / GBM; a.nz = d->batch; a.nx = d->npad / GBN; a.xcd = xcd_env;
+  if ((long long)a.nx * a.ny * a.nz > 0x3fffffffLL) return MFPA_EINVAL;
+  auto grid1d = [&](int nx) { a.nx = nx; return dim3((unsigned)((((long long)nx * a.ny * a.nz + 7) / 8) * 8)); };
+  dim3 grid = grid1d(d->npad / GBN);
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   // K >= 128: the chunked bf16x3 kernel.  (At first the K = 128 / 192 levels ran faster on the fp32 kernel; that was the
   // epilogue's serialised addend loads and 64-bit addressing, not the arithmetic: with those fixed the fp32 MFMA rate is what
@@ -1002,7 +1035,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   hipStream_t st = mfpa_stream(stream);
   static const int wide = getenv("MFPA_GEMM_WIDE") ? atoi(getenv("MFPA_GEMM_WIDE")) : 1;   // 0: always the 128 x 64 tile (experiments)
   if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128 && wide && d->npad % WBN == 0) {
-    dim3 gw(d->npad / WBN, grid.y, grid.z);
+    dim3 gw = grid1d(d->npad / WBN);
     hipLaunchKernelGGL(gemm_bf16x3_wide_kernel, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);
   } else if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
