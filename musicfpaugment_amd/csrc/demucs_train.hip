@@ -33,7 +33,24 @@ struct TnArgs {
   float* colsum;               // optional: colsum[m] += sum over all rows of A[.][m] (the bias gradient), by the n-tile-0 workgroups
   int R, M, N;
   int rs, spb;                 // rows per split, splits per clip
+  int tiles, nsplit, xcd;      // 1-D launch: tiles x nsplit workgroups; xcd = 1: XCD-aware order
 };
+
+// (tile, split) of a workgroup.  Every tile of one K split reads the same rows of A and Bm; consecutive workgroup ids go round-robin
+// over the 8 XCDs (one L2 each), so in the plain order each XCD fetched every split's rows.  Here XCD k owns a contiguous range
+// of the (split, tile) order, tiles fastest: the tiles of a split run back to back on ONE XCD.
+__device__ __forceinline__ bool tn_tile(const TnArgs& a, int& tile, int& split) {
+  const unsigned total = (unsigned)a.tiles * a.nsplit;
+  unsigned lin = blockIdx.x;
+  if (a.xcd) {
+    const unsigned per = (total + 7) / 8;
+    lin = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  }
+  if (lin >= total) return false;
+  tile = lin % a.tiles;
+  split = lin / a.tiles;
+  return true;
+}
 
 // column sums of the A tiles a workgroup staged (every thread keeps the same column quad for all of its loads): combine the row
 // lanes through LDS, one atomic per column
@@ -67,9 +84,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
   const int ntn = (a.N + BN - 1) / BN;
-  const int n0 = (blockIdx.x % ntn) * BN, m0 = (blockIdx.x / ntn) * BM;
-  const int b = blockIdx.y / a.spb;
-  const int rbeg = (blockIdx.y % a.spb) * a.rs;
+  int tile, split;
+  if (!tn_tile(a, tile, split)) return;              // uniform, before any barrier
+  const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
+  const int b = split / a.spb;
+  const int rbeg = (split % a.spb) * a.rs;
   const int rend = rbeg + a.rs < a.R ? rbeg + a.rs : a.R;
   const float* Ab = a.A + (size_t)b * a.strideA;
   const float* Bb = a.Bm + (size_t)b * a.strideB;
@@ -190,9 +209,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
   const int ntn = (a.N + BN - 1) / BN;
-  const int n0 = (blockIdx.x % ntn) * BN, m0 = (blockIdx.x / ntn) * BM;
-  const int b = blockIdx.y / a.spb;
-  const int rbeg = (blockIdx.y % a.spb) * a.rs;
+  int tile, split;
+  if (!tn_tile(a, tile, split)) return;              // uniform, before any barrier
+  const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
+  const int b = split / a.spb;
+  const int rbeg = (split % a.spb) * a.rs;
   const int rend = rbeg + a.rs < a.R ? rbeg + a.rs : a.R;
   const float* Ab = a.A + (size_t)b * a.strideA;
   const float* Bb = a.Bm + (size_t)b * a.strideB;
@@ -630,12 +651,14 @@ int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
   if (rs < 64) rs = 64;
   rs = (rs + HKC_T - 1) / HKC_T * HKC_T;
   long long spb = (d->R + rs - 1) / rs;
-  while (spb * d->batch > 65535) { rs *= 2; spb = (d->R + rs - 1) / rs; }
   if (tiles > 0x7fffffffLL) return MFPA_EINVAL;
   TnArgs a{};
   a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.Bm = d->Bm; a.ldb = d->ldb; a.strideB = d->strideB;
   a.C = d->C; a.ldc = d->ldc; a.colsum = d->colsum; a.R = d->R; a.M = d->M; a.N = d->N; a.rs = (int)rs; a.spb = (int)spb;
-  dim3 grid((unsigned)tiles, (unsigned)(spb * d->batch));
+  static const int xcd_env = getenv("MFPA_GEMM_XCD") ? atoi(getenv("MFPA_GEMM_XCD")) : 1;
+  a.tiles = (int)tiles; a.nsplit = (int)(spb * d->batch); a.xcd = xcd_env;
+  if (tiles * a.nsplit > 0x3fffffffLL) return MFPA_EINVAL;
+  dim3 grid((unsigned)(((tiles * a.nsplit + 7) / 8) * 8));
   hipStream_t st = mfpa_stream(stream);
   if (d->precision == 0) {
     if (big) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, st, a);
