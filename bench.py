@@ -100,6 +100,15 @@ def cpu_baseline(budget_s: float, seed: int):
                       f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
 
 
+def _demucs_traffic(B):
+    """HBM bytes per step of the Demucs forward's GEMM family from the committed rocprofv3 --pmc passes, scaled to B clips."""
+    pmc = os.path.join(ROOT, "profiles", "r01e_pmc_traffic_demucs.json")
+    if not os.path.exists(pmc):
+        return None
+    with open(pmc) as fh:
+        return json.load(fh)["per_256_clip_step_bytes"] * B / 256.0
+
+
 def bench_demucs(args, rank, world, dev, dist):
     """BASELINE config 5 (next tier): Demucs forward on the waveform, then STFT + Audfprint peak-pick of the denoised clip
     (wavfile2peaks with denoising_model="demucs", afp/audfprint/peak_extractor.py:369-376,406)."""
@@ -154,10 +163,11 @@ def bench_demucs(args, rank, world, dev, dist):
                                    "Audfprint peak-pick, 8 s clips", "clips_per_gpu_per_step": B, "peaks_last_step_rank0": int(npeaks.sum()),
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": _demucs_traffic(B),
+                          "traffic_source": "profiles/r01e_pmc_traffic_demucs.json (offline PMC passes, FETCH_SIZE x2 + WRITE_SIZE of the GEMM and LSTM-step launches, scaled to the batch)",
                           "mfma_flops_issued_per_algorithmic_flop": 3,
                           "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                          "kernel": "gemm_bf16x3_kernel + lstm_step_kernel (the 2 x 248 recurrent steps timed as two groups)",
+                          "kernel": "gemm_bf16x3(_wide)_kernel + gemm_shortk_bf16x3_kernel + lstm_step_kernel (the recurrence timed as one group)",
                           "launches": timer.launches(), "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}
                          if args.precision == "bf16x3" else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

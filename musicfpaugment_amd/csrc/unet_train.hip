@@ -329,6 +329,7 @@ struct WgradArgs {
   int tiles_x, tiles_y;
   unsigned drop_seed, drop_thresh;
   float drop_scale;
+  int xcd;                  // bf16 kernels: XCD-aware (patch group, tile) order
 };
 
 constexpr int WG_PH = 2, WG_PW = 32, WG_PIX = 64, WG_T = 64;
@@ -500,7 +501,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int cot = wave & 1, cit = (wave >> 1) & 1, ph = wave >> 2;   // ph: the patch's upper / lower 64 pixels (NW = 8)
-  const int co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T;
+  // (co tile, ci tile, patch group) of this workgroup.  Every tile of one patch group reads the same dz / x patches; consecutive
+  // workgroup ids are dealt round-robin over the 8 XCDs (one L2 each), so with the plain order every XCD fetched every patch.
+  // When the grid size is a multiple of 8, XCD k owns a contiguous range of the (group, tile) order instead, tiles fastest.
+  unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  {
+    const unsigned tiles = gridDim.x * gridDim.y, total = tiles * gridDim.z;
+    if (a.xcd && total % 8 == 0) {
+      const unsigned hw = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned lin = (hw % 8) * (total / 8) + hw / 8;
+      const unsigned tile = lin % tiles;
+      bzi = lin / tiles; bxi = tile % gridDim.x; byi = tile / gridDim.x;
+    }
+  }
+  const int co0 = bxi * WG_T, ci0 = byi * WG_T;
   const int Cin = a.C0 + a.C1;
   const bool from0 = ci0 < a.C0;
   const bool affine = from0 && a.in_scale0 != nullptr;
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   };
 
   int b = 0, y0 = 0, x0p = 0;
-  long long patch = blockIdx.z;
+  long long patch = bzi;
   if (patch < npatch) {
     decode(patch, b, y0, x0p);
     load_x(b, y0, x0p);
@@ -1050,6 +1064,8 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
     if (split_b < 1) split_b = 1;
     if (split_b > 65535) split_b = 65535;
     grid.z = (unsigned)split_b;
+    static const int xcd_env = getenv("MFPA_GEMM_XCD") ? atoi(getenv("MFPA_GEMM_XCD")) : 1;   // 0: plain order (experiments)
+    a.xcd = xcd_env;
     const bool plain = d->precision == 2;
     const size_t lds = (size_t)(plain ? 192 : WGB_ROW) * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
     const dim3 blk(64 * nw);
