@@ -502,17 +502,21 @@ class DemucsTrainEngine:
 
     # ------------------------------------------------------------------ loss + step
     @torch.no_grad()
-    def loss_and_grad(self, pred: torch.Tensor, clean: torch.Tensor):
-        """loss = L1(pred, clean) + sc + mag (train.py:292-297) and d loss / d pred.  Returns (l1, sc, mag, dpred)."""
+    def _mrstft(self):
+        if self.mrstft is None:
+            from .training.loss import MultiResolutionSTFTLoss
+            self.mrstft = MultiResolutionSTFTLoss().to(self.device)
+        return self.mrstft
+
+    def loss_and_grad(self, pred: torch.Tensor, clean: torch.Tensor, Cys=None):
+        """loss = L1(pred, clean) + sc + mag (train.py:292-297) and d loss / d pred.  Returns (l1, sc, mag, dpred).
+        Cys: the target's DFT rows per resolution if they were computed ahead (train_step does, on a side stream)."""
         n = pred.numel()
         dpred = torch.empty_like(pred)
         check(lib().mfpa_l1_loss(ptr(pred), ptr(clean.double().contiguous()), n, ptr(dpred), ptr(self.loss_buf), ptr(self.l1_ws),
                                  stream()), "mfpa_l1_loss")
         l1 = self.loss_buf.clone()[0]
-        if self.mrstft is None:
-            from .training.loss import MultiResolutionSTFTLoss
-            self.mrstft = MultiResolutionSTFTLoss().to(self.device)
-        sc, mag, _ = self.mrstft.value_and_grad(pred, clean, dx=dpred, accumulate=True)
+        sc, mag, _ = self._mrstft().value_and_grad(pred, clean, dx=dpred, accumulate=True, Cys=Cys)
         return l1, sc, mag, dpred
 
     @torch.no_grad()
@@ -530,10 +534,19 @@ class DemucsTrainEngine:
     @torch.no_grad()
     def train_step(self, clean: torch.Tensor, augmented: torch.Tensor) -> torch.Tensor:
         """One step of train.py:257-317 (audio branch) on (B, T) float32 waveforms; returns the loss (float64, on the device)."""
+        clean = clean.contiguous()
+        # the clean signal's three STFTs do not depend on the model: a side stream computes them while the forward pass runs
+        main, side = torch.cuda.current_stream(clean.device), D._side_stream(clean.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            Cys = self._mrstft().target_transforms(clean)
+        for c in Cys:
+            c.record_stream(main)
         with _Phase(self, "forward"):
             pred = self.forward(augmented.contiguous())
+        main.wait_stream(side)
         with _Phase(self, "loss"):
-            l1, sc, mag, dpred = self.loss_and_grad(pred, clean.contiguous())
+            l1, sc, mag, dpred = self.loss_and_grad(pred, clean, Cys)
         with _Phase(self, "backward"):
             self.backward(dpred)
         with _Phase(self, "adam"):

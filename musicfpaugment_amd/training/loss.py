@@ -143,14 +143,21 @@ class STFTLoss(torch.nn.Module):
         return sc.to(torch.float32), mag.to(torch.float32)
 
     @torch.no_grad()
-    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor, w_sc: float, w_mag: float, dx: torch.Tensor, accumulate: bool):
+    def target_transform(self, y: torch.Tensor) -> torch.Tensor:
+        """The DFT rows of the target signal alone (it does not depend on the model: the training step computes it on a side stream
+        while the forward pass runs); pass the result to value_and_grad(..., Cy=...)."""
+        return _dft_rows(y, self.fft_size, self.shift_size, self.win_length, self.precision)[0]
+
+    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor, w_sc: float, w_mag: float, dx: torch.Tensor, accumulate: bool,
+                       Cy: Optional[torch.Tensor] = None):
         """(sc, mag) and d(w_sc * sc + w_mag * mag) / dx written (or added) to dx (B, T): the adjoint chain of the forward --
         loss gradient on (re, im), GEMM with the transposed DFT matrix, overlap-add of the frames, reflect-padding adjoint."""
         if x.shape != y.shape or dx.shape != x.shape or dx.dtype != torch.float32:
             raise ValueError("x, y and dx must be float32 tensors of one shape")
         fs, hop, wl = self.fft_size, self.shift_size, self.win_length
         Cx, bins, im_off, frames = _dft_rows(x, fs, hop, wl, self.precision)
-        Cy, _, _, _ = _dft_rows(y, fs, hop, wl, self.precision)
+        if Cy is None:
+            Cy, _, _, _ = _dft_rows(y, fs, hop, wl, self.precision)
         B, T = x.shape
         rows, npad = B * frames, Cx.shape[2]
         L = lib()
@@ -196,7 +203,11 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         return self.factor_sc * sc_loss, self.factor_mag * mag_loss
 
     @torch.no_grad()
-    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
+    def target_transforms(self, y: torch.Tensor) -> List[torch.Tensor]:
+        return [f.target_transform(y) for f in self.stft_losses]
+
+    def value_and_grad(self, x: torch.Tensor, y: torch.Tensor, dx: Optional[torch.Tensor] = None, accumulate: bool = False,
+                       Cys: Optional[List[torch.Tensor]] = None):
         """(sc_loss, mag_loss, d(sc_loss + mag_loss) / dx): the two terms training/train.py:297 adds to the L1 loss, and their
         gradient with respect to the predicted waveform x (what the reference's autograd hands to the Demucs backward pass).
         With `dx` given and `accumulate`, the gradient is ADDED to dx (which then already holds the L1 term's gradient)."""
@@ -205,7 +216,8 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
             dx, accumulate = torch.empty_like(x, dtype=torch.float32), False
         sc_loss, mag_loss = 0.0, 0.0
         for i, f in enumerate(self.stft_losses):
-            sc_l, mag_l = f.value_and_grad(x, y, self.factor_sc / n, self.factor_mag / n, dx, accumulate=accumulate or i > 0)
+            sc_l, mag_l = f.value_and_grad(x, y, self.factor_sc / n, self.factor_mag / n, dx, accumulate=accumulate or i > 0,
+                                           Cy=None if Cys is None else Cys[i])
             sc_loss = sc_loss + sc_l
             mag_loss = mag_loss + mag_l
         return self.factor_sc * sc_loss / n, self.factor_mag * mag_loss / n, dx
