@@ -86,6 +86,28 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert h.mfpa_reflect_pad(1, 1, 100, 100, 0, 400, 1, None) == lib.EINVAL              # pad >= T
     assert h.mfpa_stft_loss_sums(1, 1, 10, 513, 1000, 576, 1, 1, None) == lib.EINVAL      # ldc < im_off + bins
     assert h.mfpa_loss_blocks() > 0
+    # Demucs training entry points
+    assert h.mfpa_gemm_tn(None, None) == lib.EINVAL
+    t = lib.GemmTnDesc(A=1, lda=48, strideA=0, Bm=1, ldb=48, strideB=0, C=1, ldc=48, batch=1, R=10, M=46, N=48, precision=0)
+    assert h.mfpa_gemm_tn(ctypes.byref(t), None) == lib.EINVAL                            # M % 4
+    t = lib.GemmTnDesc(A=1, lda=48, strideA=0, Bm=1, ldb=48, strideB=0, C=1, ldc=48, batch=1, R=10, M=48, N=48, precision=3)
+    assert h.mfpa_gemm_tn(ctypes.byref(t), None) == lib.EINVAL                            # precision
+    t = lib.GemmTnDesc(A=1, lda=48, strideA=0, Bm=1, ldb=48, strideB=0, C=1, ldc=48, batch=1, R=0, M=48, N=48)
+    assert h.mfpa_gemm_tn(ctypes.byref(t), None) == 0                                     # no rows: a no-op
+    assert h.mfpa_glu_bwd(1, 10, 100, 48, 1, 48, None) == lib.EINVAL                      # npad % 64
+    assert h.mfpa_glu_bwd(1, 10, 128, 96, 1, 96, None) == lib.EINVAL                      # N > npad / 2
+    assert h.mfpa_colsum_any(1, 10, 46, 48, 1, None) == lib.EINVAL                        # C % 4
+    assert h.mfpa_c1_wgrad(1, 100, 1, 48, 4800, 1, 100, 48, 1, None) == lib.EINVAL        # ldx too short for L windows
+    assert h.mfpa_downsample2_adjoint(1, 1, 10, 600, 1, None, 1001, 1, None) == lib.EINVAL   # nout > ceil(T / 2) / ldy < nout
+    assert h.mfpa_lstm_step_bwd(None, 0, 1, 1, 3072, 1, 768, None, 0, 1, 768, 1, 4, 760, None) == lib.EINVAL   # H % 128
+    assert h.mfpa_lstm_layer(1, 1, 1, None, None, 4, 10, 768, None, None, 0, None) == lib.EINVAL    # inference needs cstate
+    assert h.mfpa_lstm_layer(1, 1, 1, None, None, 4, 10, 768, None, None, 1, None) == lib.EINVAL    # training needs cseq
+    assert h.mfpa_lstm_layer_range(1, 1, 1, 1, None, 4, 10, 768, None, None, 1, 5, 11, None) == lib.EINVAL   # t1 > Tn
+    assert h.mfpa_lstm_layer_bwd(1, 1, 1, 1, None, 4, 10, 768, None) == lib.EINVAL        # dcstate
+    m = lib.GemmDesc(A=1, lda=48, strideA=0, W=1, C=1, ldc=1 << 29, strideC=0, batch=1, M=16, N=64, K=48, npad=64)
+    assert h.mfpa_gemm_mfma(ctypes.byref(m), None) == lib.EINVAL                          # a clip's output beyond 32-bit byte offsets
+    m = lib.GemmDesc(A=1, lda=48, strideA=0, W=1, C=1, ldc=64, strideC=0, batch=1, M=16, N=64, K=48, npad=64, mode=3)
+    assert h.mfpa_gemm_mfma(ctypes.byref(m), None) == lib.EINVAL                          # mode 3 needs the addend (the ReLU output)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
