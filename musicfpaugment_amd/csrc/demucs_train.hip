@@ -497,7 +497,10 @@ constexpr int BTHREADS = 512;
 #endif
 constexpr int BPF = MFPA_LSTM_BPF;       // chunks of global loads in flight per thread
 
-template <int MT>   // 32-clip tiles per workgroup: 2 = (clip half) x (K quarter), 1 = K eighths (small batches: twice the workgroups)
+// MT: 32-clip tiles per workgroup: 2 = (clip half) x (K quarter), 1 = K eighths (small batches: twice the workgroups).
+// BUT: hidden units per workgroup, 32 or 16 (16: the matrix tile is half empty, but the step is bound by the bytes a workgroup
+// streams -- 32 x 3072 gate gradients + BUT x 3072 weights -- and twice as many CUs pull them).
+template <int MT, int BUT>
 __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float* __restrict__ dgnext, long long ldgn,
                                                                     const float* __restrict__ whhT, float* gs, long long ldgs,
                                                                     const float* __restrict__ ct, long long ldct,
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave % MT, wk = wave / MT;  // wk: k-steps KS wk .. of each chunk
-  const int ngroups = H / BU;
+  const int ngroups = H / BUT;
   int grp, mt;
   {
     const int id = blockIdx.x, total = ngroups * mtiles;
@@ -530,12 +533,19 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   if (dgnext != nullptr) {
-    const float* Wg = whhT + (size_t)grp * BU * K;
+    const float* Wg = whhT + (size_t)grp * BUT * K;
     const int nk = K / BKC;
+    constexpr int FB = BUT / 16;                       // float4 per thread per chunk for the weight rows
+    if (BUT < 32) {                                    // rows BUT .. 31 of both weight buffers are never staged: keep them zero
+      for (int i = tid; i < 2 * (32 - BUT) * (BROW / 16); i += BTHREADS) {
+        const int buf = i / ((32 - BUT) * (BROW / 16)), rem = i % ((32 - BUT) * (BROW / 16));
+        *reinterpret_cast<f32x4*>(Bs + (buf * 32 + BUT + rem / (BROW / 16)) * BROW + 16 * (rem % (BROW / 16))) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     // register ring of BPF chunks of global loads (the step is latency-bound: dgates[t+1] was written by the previous launch)
-    f32x4 ar[BPF][FA], br[BPF][2];
+    f32x4 ar[BPF][FA], br[BPF][FB];
     const int q = tid & 31, r0 = tid >> 5;             // column quad, first row; rows r0 + 16 i
-    auto load = [&](int kc, f32x4 (&a4)[FA], f32x4 (&b2)[2]) __attribute__((always_inline)) {
+    auto load = [&](int kc, f32x4 (&a4)[FA], f32x4 (&b2)[FB]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < FA; ++i) {
         const int m = m0 + r0 + 16 * i;
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
         a4[i] = v;
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) b2[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(r0 + 16 * i) * K + kc * BKC + 4 * q);
+      for (int i = 0; i < FB; ++i) b2[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(r0 + 16 * i) * K + kc * BKC + 4 * q);
     };
     auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
       t_bf16x4 hi, lo;
@@ -556,11 +566,11 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
       *reinterpret_cast<t_bf16x4*>(row + 8 * q) = hi;
       *reinterpret_cast<t_bf16x4*>(row + 2 * BKC + 8 * q) = lo;
     };
-    auto store = [&](int buf, f32x4 (&a4)[FA], f32x4 (&b2)[2]) __attribute__((always_inline)) {
+    auto store = [&](int buf, f32x4 (&a4)[FA], f32x4 (&b2)[FB]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < FA; ++i) split_store(As + (buf * BBM + r0 + 16 * i) * BROW, a4[i]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) split_store(Bs + (buf * BU + r0 + 16 * i) * BROW, b2[i]);
+      for (int i = 0; i < FB; ++i) split_store(Bs + (buf * 32 + r0 + 16 * i) * BROW, b2[i]);
     };
 #pragma unroll
     for (int j = 0; j < BPF; ++j)
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
           if (kc + BPF < nk) load(kc + BPF, ar[j], br[j]);
           __syncthreads();
           const char* Ap = As + (buf * BBM + wm * 32 + li) * BROW + 16 * lh;
-          const char* Bp = Bs + (buf * BU + li) * BROW + 16 * lh;
+          const char* Bp = Bs + (buf * 32 + li) * BROW + 16 * lh;
 #pragma unroll
           for (int s = KS * wk; s < KS * wk + KS; ++s) {
             const t_bf16x8 ah = *reinterpret_cast<const t_bf16x8*>(Ap + 32 * s);
@@ -600,10 +610,11 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
     G[(wk * BBM + m) * GLDW + li] = acc[r];
   }
   __syncthreads();
-  const int clip = tid >> 3, uq = tid & 7;
+  constexpr int UQ = BUT / 4;                  // unit quads per clip
+  const int clip = tid / UQ, uq = tid % UQ;
   const int m = m0 + clip;
   if (clip < BBM && m < B) {
-    const int u0 = grp * BU + 4 * uq;
+    const int u0 = grp * BUT + 4 * uq;
     f32x4 dh = *reinterpret_cast<const f32x4*>(dhout + (size_t)m * lddh + u0);
 #pragma unroll
     for (int w = 0; w < WK; ++w) dh += *reinterpret_cast<const f32x4*>(G + (w * BBM + clip) * GLDW + 4 * uq);
@@ -733,19 +744,25 @@ int mfpa_lstm_step_bwd(const float* dgnext, long long ldgn, const float* whhT, f
   if (!whhT || !gates || !ct || !dhout || !dcstate || B < 0 || H < BKC || H % BKC) return MFPA_EINVAL;
   if (ldgn % 4 || ldg % 4 || ldct % 4 || ldcp % 4 || lddh % 4) return MFPA_EINVAL;
   static const int force = getenv("MFPA_LSTM_MT") ? atoi(getenv("MFPA_LSTM_MT")) : 0;
+  static const int force_bu = getenv("MFPA_LSTM_BU") ? atoi(getenv("MFPA_LSTM_BU")) : 0;
   int MT = ((long long)(H / BU) * ((B + 31) / 32) <= 256) ? 1 : 2;   // 32-clip tiles while they leave the chip under-filled
   if (force == 1 || force == 2) MT = force;
+  int but = (MT == 1 && (long long)(H / 16) * ((B + 31) / 32) <= 128) ? 16 : 32;   // 16-unit groups while even those leave half the chip free
+  if (force_bu == 16 || force_bu == 32) but = (MT == 1) ? force_bu : 32;
   const int mtiles = (B + 32 * MT - 1) / (32 * MT);
-  const long long total = (long long)(H / BU) * mtiles;
+  const long long total = (long long)(H / but) * mtiles;
   if (total > 0x7fffff) return MFPA_EINVAL;
   const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-  const size_t lds = (size_t)2 * (32 * MT + BU) * BROW;
-  if (MT == 1)
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg, ct,
-                       ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
+  const size_t lds = (size_t)2 * (32 * MT + 32) * BROW;
+  if (MT == 1 && but == 16)
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 16>), dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg,
+                       ct, ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
+  else if (MT == 1)
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 32>), dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg,
+                       ct, ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
   else
-    hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg, ct,
-                       ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<2, 32>), dim3(grid), dim3(BTHREADS), lds, mfpa_stream(stream), dgnext, ldgn, whhT, gates, ldg,
+                       ct, ldct, cprev, ldcp, dhout, lddh, dcstate, B, H, mtiles);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
