@@ -14,7 +14,7 @@ from ctypes import c_double, c_float, c_int, c_longlong, c_uint, c_void_p
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfpa.so")
+LIB_PATH = os.environ.get("MFPA_LIB", os.path.join(_HERE, "libmfpa.so"))    # MFPA_LIB: A/B experiments between two builds
 
 EINVAL = -22
 EHIP = -1000
