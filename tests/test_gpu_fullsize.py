@@ -101,3 +101,35 @@ def test_config3_train_step_64_clips_precisions_agree_and_loss_falls():
     # the first step sees identical weights and dropout masks: the two arithmetic paths give the same loss to 1e-4
     assert abs(losses[0][0] - losses[1][0]) <= 1e-4 * abs(losses[0][0]), losses
     assert abs(losses[0][-1] - losses[1][-1]) <= 2e-2 * abs(losses[0][-1]), losses
+
+
+def test_config5_demucs_forward_256_clips_within_tolerance_and_batch_invariant():
+    """BASELINE configs[4]: the Demucs waveform denoiser at 256 clips of 8 s.  Two sampled clips go through the oracle; the rest is
+    covered by determinism and by invariance to the batch composition -- a 37-clip shard runs other kernel shapes (32-clip LSTM
+    tiles, the two layers pipelined on two streams), so that comparison is to rounding, not bit for bit."""
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    from musicfpaugment_amd.training.model import Demucs
+    from oracle import demucs as od
+    from oracle.unet import relative_l1
+    B = 256
+    wav = np.stack([synth.clip(5000 + i, tonal=(i % 4 != 0)) for i in range(B)])
+    wav[31] = 0.0                                                      # a silent clip: std 0, output exactly 0
+    x = torch.from_numpy(wav).cuda()
+    net = Demucs()
+    sd = demucs_formula(0)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    y = net(x)
+    assert y.shape == (B, 1, 64000) and bool(torch.isfinite(y).all())
+    assert float(y[31].abs().max()) == 0.0
+    torch.set_num_threads(8)
+    for i in (0, 255):
+        with torch.no_grad():
+            want = od.forward(torch.from_numpy(wav[i:i + 1]), sd)
+        assert relative_l1(y[i:i + 1].cpu(), want) <= 1e-4
+    assert _digest(net(x)) == _digest(y)                               # no atomics on the forward path: bit-reproducible
+    idx = list(range(100, 137))
+    ys = net(x[idx].contiguous())
+    assert relative_l1(ys.cpu(), y[idx].cpu()) <= 1e-5
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    assert torch.equal(net(x[perm].contiguous()), y[perm])             # same batch size, other order: the same kernels, bit for bit
