@@ -133,3 +133,26 @@ def test_config5_demucs_forward_256_clips_within_tolerance_and_batch_invariant()
     assert relative_l1(ys.cpu(), y[idx].cpu()) <= 1e-5
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
     assert torch.equal(net(x[perm].contiguous()), y[perm])             # same batch size, other order: the same kernels, bit for bit
+
+
+def test_demucs_train_step_64_clips_precisions_agree_and_loss_falls():
+    """The Demucs training step at the bench shape (64 clips of 8 s): the first step's loss terms agree between exact-fp32 and
+    bf16x3 products, the loss falls over a few steps, and the parameters stay finite."""
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    B = 64
+    base = synth.batch(16, seed=6000)
+    noise = synth.batch(16, seed=6100, tonal=False)
+    clean = torch.from_numpy(np.concatenate([base] * 4)[:B].copy()).cuda()
+    aug = torch.from_numpy(np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * 4)[:B].copy()).cuda()
+    first = {}
+    for prec in (0, 1):
+        eng = DemucsTrainEngine(demucs_formula(0), "cuda", lr=3e-4, precision=prec)
+        losses = [float(eng.train_step(clean, aug)) for _ in range(4 if prec else 1)]
+        first[prec] = [float(v) for v in eng.last_losses] if not prec else None
+        if prec:
+            assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+            assert bool(torch.isfinite(eng.flat_p).all())
+            eng2 = DemucsTrainEngine(demucs_formula(0), "cuda", lr=3e-4, precision=1)
+            eng2.train_step(clean, aug)
+            np.testing.assert_allclose([float(v) for v in eng2.last_losses], first[0], rtol=2e-4)
