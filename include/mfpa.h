@@ -130,6 +130,11 @@ int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const doub
  */
 int mfpa_dejavu_prepare(const double* psd, int B, int F, int T, const double* denom, double scale,
                         int mean_order, double* arr, void* stream);
+/* The denoised branch (fingerprint.py:70-79): x is the UNet's float32 output (B, F, T) for the normalised spectrogram,
+ * a = x*x when square != 0, and max / floor / log / mean / subtraction are float32 operations as numpy performs them on a
+ * float32 array (the network output is C-contiguous: mean_order = 0); arr is that float32 result widened to float64. */
+int mfpa_dejavu_prepare_f32(const float* x, int B, int F, int T, int square, double scale, int mean_order, double* arr,
+                            void* stream);
 int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double amp_min,
                     uint8_t* mask, int32_t* npeaks, void* stream);
 

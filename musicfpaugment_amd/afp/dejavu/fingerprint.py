@@ -32,9 +32,29 @@ def get_2D_peaks(arr2D, plot: bool = False, amp_min: int = afp_settings["dejavu"
 
 
 def fingerprint_peaks_batch(wav: torch.Tensor, amp_min: float = afp_settings["dejavu"]["amp_min"],
-                            scale_in: float = 32767.0):
-    """(B, T) float32 on the GPU -> (mask (B,257,nF) uint8, npeaks (B,), specgram (B,257,nF) float64)."""
+                            scale_in: float = 32767.0, denoising: bool = False, denoising_model: str = "unet",
+                            unet=None, demucs=None):
+    """(B, T) float32 on the GPU -> (mask (B,257,nF) uint8, npeaks (B,), specgram (B,257,nF)).
+
+    ``denoising`` / ``denoising_model`` follow fingerprint.py:34-79 and dejavu.py:85-106: "unet" runs the spectrogram
+    denoiser on the max-normalised PSD (cast to float32), squares its output and keeps float32 for the log / mean steps
+    (specgram is then float32); "demucs" denoises the waveform before the x 32767 scaling, the rest is the float64 path.
+    The networks are passed in (``unet`` = training.unet.UNet in eval mode, ``demucs`` = training.model.Demucs); the
+    reference builds them at import time from checkpoint files."""
+    if denoising:
+        if denoising_model not in ("unet", "demucs"):
+            raise AssertionError("denoising_model must be 'unet' or 'demucs'")
+        net = unet if denoising_model == "unet" else demucs
+        if net is None:
+            raise ValueError(f"denoising_model={denoising_model!r} needs the {denoising_model} module")
+        if denoising_model == "demucs":
+            wav = demucs(wav)[:, 0]
     psd, cmax = ops.specgram_psd(wav, scale_in=scale_in)
+    if denoising and denoising_model == "unet":
+        y = unet.denoise_spectrogram(psd, cmax, per_clip=True)               # (B, 257, nF) float32
+        arr = ops.dejavu_prepare_f32(y, square=True, scale=10.0, mean_order=0)
+        mask, npeaks = ops.localmax2d(arr, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
+        return mask, npeaks, y * y
     arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=1)
     mask, npeaks = ops.localmax2d(arr, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
     return mask, npeaks, ops.normalize_(psd, cmax, per_clip=True)
@@ -62,9 +82,10 @@ def generate_hashes(peaks: List[Tuple[int, int]], fan_value: int = afp_settings[
 
 
 def fingerprint_batch(wav: torch.Tensor, amp_min: float = afp_settings["dejavu"]["amp_min"],
-                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096):
+                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096, **denoise):
     """fingerprint(...) for a batch (afp/dejavu/fingerprint.py:34-91): (digests (B,cap,10) uint8, t1 (B,cap), counts (B,),
-    peak mask, normalised specgram), everything on the device."""
-    mask, _, spec = fingerprint_peaks_batch(wav, amp_min)
+    peak mask, normalised specgram), everything on the device.  ``denoise``: the denoising arguments of
+    fingerprint_peaks_batch."""
+    mask, _, spec = fingerprint_peaks_batch(wav, amp_min, **denoise)
     dig, t1, counts = ops.dejavu_hashes(mask, cap=cap, peak_cap=cap, fan_value=fan_value)
     return dig, t1, counts, mask, spec

@@ -19,30 +19,38 @@ namespace {
 using namespace mfpa_np;
 constexpr int PREP_THREADS = 512;
 
-__global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const double* __restrict__ psd, int F, int T,
+// TIn = double: the un-denoised path (psd / max, float64 throughout).  TIn = float: the UNet path (fingerprint.py:70-79) --
+// the network's float32 output is squared and every later step (max, floor max / 1e6, 10 * log, mean, subtraction) stays in
+// float32 like numpy on a float32 array; the result is widened to float64 for the peak picker (comparisons are unchanged).
+template <typename TIn>
+__global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn* __restrict__ psd, int F, int T,
                                                                       const double* __restrict__ denom, double scale,
-                                                                      int mean_order, double* __restrict__ arr) {
+                                                                      int mean_order, int square, double* __restrict__ arr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* heap = reinterpret_cast<double*>(smem);
+  TIn* heap = reinterpret_cast<TIn*>(smem);
   __shared__ double red[PREP_THREADS / 64];
   __shared__ double bcast[2];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int N = F * T;
-  const double* x = psd + (size_t)b * N;
+  const TIn* x = psd + (size_t)b * N;
   double* L = arr + (size_t)b * N;
   const bool has_den = denom != nullptr;
   const double den = has_den ? denom[b] : 1.0;
+  auto value = [&](TIn v) __attribute__((always_inline)) -> TIn {
+    if (has_den) return (TIn)((double)v / den);
+    return square ? v * v : v;
+  };
 
   // 8 independent loads in flight per thread in every streaming pass (one workgroup per clip: memory-latency-bound otherwise)
   double m = -INFINITY;
   for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
-    double v[8];
+    TIn v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : 0.0;
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : (TIn)0;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u * PREP_THREADS < N) {
-        const double s = has_den ? v[u] / den : v[u];
+        const double s = (double)value(v[u]);
         m = s > m ? s : m;
       }
   }
@@ -55,29 +63,30 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const doub
     bcast[0] = mm;
   }
   __syncthreads();
-  const double floor_v = bcast[0] / 1e6;
+  const TIn floor_v = (TIn)bcast[0] / (TIn)1e6;
+  const TIn sc = (TIn)scale;
   for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
-    double v[8];
+    TIn v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : 1.0;
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : (TIn)1;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u * PREP_THREADS < N) {
-        double s = has_den ? v[u] / den : v[u];
+        TIn s = value(v[u]);
         s = s > floor_v ? s : floor_v;
-        L[i0 + u * PREP_THREADS] = scale * log(s);
+        L[i0 + u * PREP_THREADS] = (double)(sc * (TIn)log((double)s));   // float32: the float64 log rounded once (as audfprint.hip)
       }
   }
   __syncthreads();
-  const double total = block_numpy_sum<double>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
-  const double mean = total / (double)N;
+  const TIn total = block_numpy_sum<TIn>(L, N, F, T, mean_order, heap, &bcast[1], tid, PREP_THREADS);
+  const TIn mean = total / (TIn)N;
   for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? L[i0 + u * PREP_THREADS] : 0.0;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (i0 + u * PREP_THREADS < N) L[i0 + u * PREP_THREADS] = v[u] - mean;
+      if (i0 + u * PREP_THREADS < N) L[i0 + u * PREP_THREADS] = (double)((TIn)v[u] - mean);
   }
 }
 
@@ -206,8 +215,21 @@ int mfpa_dejavu_prepare(const double* psd, int B, int F, int T, const double* de
   const long long N = (long long)F * T;
   const long long nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
   if (nchunks > MAX_CHUNKS) return MFPA_EINVAL;
-  hipLaunchKernelGGL(dejavu_prepare_kernel, dim3(B), dim3(PREP_THREADS), sizeof(double) * nchunks * HEAP,
-                     mfpa_stream(stream), psd, F, T, denom, scale, mean_order, arr);
+  hipLaunchKernelGGL(dejavu_prepare_kernel<double>, dim3(B), dim3(PREP_THREADS), sizeof(double) * nchunks * HEAP,
+                     mfpa_stream(stream), psd, F, T, denom, scale, mean_order, 0, arr);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_dejavu_prepare_f32(const float* x, int B, int F, int T, int square, double scale, int mean_order, double* arr,
+                            void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !arr || B < 0 || F < 1 || T < 1) return MFPA_EINVAL;
+  const long long N = (long long)F * T;
+  const long long nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
+  if (nchunks > MAX_CHUNKS) return MFPA_EINVAL;
+  hipLaunchKernelGGL(dejavu_prepare_kernel<float>, dim3(B), dim3(PREP_THREADS), sizeof(double) * nchunks * HEAP,
+                     mfpa_stream(stream), x, F, T, (const double*)nullptr, scale, mean_order, square, arr);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

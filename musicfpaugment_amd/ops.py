@@ -209,6 +209,20 @@ def dejavu_prepare(psd: torch.Tensor, denom: Optional[torch.Tensor], scale: floa
     return arr
 
 
+def dejavu_prepare_f32(x: torch.Tensor, square: bool = True, scale: float = 10.0, mean_order: int = 0) -> torch.Tensor:
+    """The denoised branch of Dejavu's pre-processing (fingerprint.py:70-79): float32 (B, F, T) network output -> x**2 ->
+    10*log(max(., max/1e6)) - mean in float32, widened to float64 for the picker."""
+    require_gpu(x, "x")
+    if x.dim() != 3 or x.dtype != torch.float32:
+        raise ValueError("x must be (B, F, T) float32")
+    x = x.contiguous()
+    B, F, T = x.shape
+    arr = torch.empty((B, F, T), dtype=torch.float64, device=x.device)
+    check(lib().mfpa_dejavu_prepare_f32(ptr(x), B, F, T, int(bool(square)), float(scale), int(mean_order), ptr(arr),
+                                        stream()), "mfpa_dejavu_prepare_f32")
+    return arr
+
+
 def localmax2d(arr: torch.Tensor, radius: int = DEJAVU_RADIUS, amp_min: float = DEJAVU_AMP_MIN):
     require_gpu(arr, "arr2D")
     if arr.dim() != 3 or arr.dtype != torch.float64:

@@ -80,3 +80,25 @@ def fingerprint_peaks(samples: np.ndarray, amp_min: float = AMP_MIN):
     spec = psd / psd.max()
     coords, mask = get_2d_peaks(preprocess(psd), amp_min)
     return coords, mask, spec
+
+
+def preprocess_denoised(unet_out: np.ndarray) -> np.ndarray:
+    """fingerprint.py:74-79 after the UNet: the float32 output squared, then the same log / mean steps, which numpy keeps
+    in float32 (a C-contiguous array: np.mean sums bin-major)."""
+    a = np.ascontiguousarray(unet_out, dtype=np.float32) ** 2
+    spec = a.copy()
+    a = 10 * np.log(np.maximum(a, np.max(a) / 1e6))
+    return a - np.mean(a), spec
+
+
+def fingerprint_peaks_unet(samples: np.ndarray, unet_sd, amp_min: float = AMP_MIN):
+    """fingerprint(..., denoising=True, denoising_model="unet") up to the peak list (fingerprint.py:58-84): the normalised
+    PSD goes through the UNet as float32 (1, 1, 257, T); returns (coords, mask, specgram float32)."""
+    import torch
+    from . import unet as ounet
+    psd = ostft.specgram_psd(samples)
+    x = torch.tensor(psd / psd.max()).unsqueeze(0).unsqueeze(0).float()
+    y = ounet.forward(x, unet_sd).squeeze().numpy()
+    arr, spec = preprocess_denoised(y)
+    coords, mask = get_2d_peaks(arr, amp_min)
+    return coords, mask, spec

@@ -145,6 +145,99 @@ def test_dejavu_full_pipeline(ops, golden):
         np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
 
 
+def test_dejavu_prepare_float32_branch_bit_exact(ops):
+    """The denoised branch's arithmetic (fingerprint.py:74-79) on float32 network-like outputs, negatives and an all-equal
+    clip included: x**2 -> float32 floor / log / mean -> picker; masks identical to numpy's, values within a float32 ulp."""
+    from oracle import dejavu as od
+    rng = np.random.default_rng(13)
+    x = (rng.random((5, 257, 249)) ** 3).astype(np.float32)
+    x[1] -= 0.3
+    x[2] *= 1e-3
+    x[3, 100:, :] = 0.0
+    x[4] = 0.25
+    xd = torch.from_numpy(x).cuda()
+    arr = ops.dejavu_prepare_f32(xd, square=True, scale=10.0, mean_order=0)
+    for amp in (50.0, 5.0):
+        mask, npk = ops.localmax2d(arr, 10, amp)
+        for b in range(len(x)):
+            want_arr, spec = od.preprocess_denoised(x[b])
+            assert want_arr.dtype == np.float32
+            coords, want = od.get_2d_peaks(want_arr, amp)
+            np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
+            assert int(npk[b]) == len(coords)
+    got = arr.cpu().numpy()
+    for b in range(len(x)):
+        want_arr, _ = od.preprocess_denoised(x[b])
+        assert np.array_equal(got[b].astype(np.float32).astype(np.float64), got[b])          # float32 values, widened
+        np.testing.assert_allclose(got[b], want_arr.astype(np.float64), rtol=0, atol=1e-4)     # 10 x a 1-ulp float32 log difference
+    # odd shape, several 8192-element chunks plus a tail in the float32 pairwise mean
+    y = (rng.random((2, 37, 531)) ** 2).astype(np.float32)
+    arr = ops.dejavu_prepare_f32(torch.from_numpy(y).cuda())
+    mask, _ = ops.localmax2d(arr, 10, 3.0)
+    for b in range(2):
+        _, want = od.get_2d_peaks(od.preprocess_denoised(y[b])[0], 3.0)
+        np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
+    with pytest.raises(ValueError):
+        ops.dejavu_prepare_f32(xd.double())
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_dejavu_denoised_fingerprint_vs_reference(ops, golden, precision):
+    """fingerprint(denoising=True, denoising_model="unet") against the golden run of the real reference (g13): specgram
+    within the UNet tolerance (1e-4 relative L1), the amp_min=50 peak set identical, the dense amp_min=5 set to F1 >= 0.97
+    (a peak within 1e-5 of a neighbour may flip under MFMA summation order), and -- given the device's own network
+    output -- the picker bit-exact against numpy."""
+    from oracle import dejavu as od
+    from musicfpaugment_amd.afp.dejavu.fingerprint import fingerprint_peaks_batch
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict
+    g = golden("g13_dejavu_denoised")
+    net = UNet(1, 1, rate=0.05)
+    net.load_state_dict(formula_state_dict(0))
+    net = net.cuda().eval()
+    net.precision = precision
+    seeds = [int(s) for s in g["seeds"]]
+    wav = torch.from_numpy(np.stack([synth.clip(s, tonal=True) for s in seeds])).cuda()
+    mask, npk, spec = fingerprint_peaks_batch(wav, denoising=True, denoising_model="unet", unet=net)
+    assert spec.dtype == torch.float32 and tuple(mask.shape[1:]) == tuple(g["shape"])
+    amp_low = float(g["amp_min_low"])
+    mask_lo, _, _ = fingerprint_peaks_batch(wav, amp_min=amp_low, denoising=True, unet=net)
+    y = net.denoise_spectrogram(*ops.specgram_psd(wav, scale_in=32767.0), per_clip=True).cpu().numpy()
+    for i in range(len(seeds)):
+        sub, want_sub = spec[i].cpu().numpy()[::8, ::8], g[f"spec_sub{i}"]
+        assert np.abs(sub - want_sub).sum() / np.abs(want_sub).sum() <= 1e-4
+        f_idx, t_idx = np.nonzero(mask[i].cpu().numpy())
+        np.testing.assert_array_equal(np.stack([f_idx, t_idx], axis=1), g[f"coords{i}"])
+        assert int(npk[i]) == len(g[f"coords{i}"])
+        got = set(map(tuple, np.argwhere(mask_lo[i].cpu().numpy())))
+        want = set(map(tuple, g[f"coords_low{i}"]))
+        f1 = 2 * len(got & want) / (len(got) + len(want))
+        assert f1 >= 0.97, f"clip {seeds[i]}: F1 {f1:.4f} ({len(got)} vs {len(want)} peaks)"
+        _, want_own = od.get_2d_peaks(od.preprocess_denoised(y[i])[0], amp_low)
+        np.testing.assert_array_equal(mask_lo[i].cpu().numpy(), want_own.astype(np.uint8))
+
+
+def test_dejavu_demucs_branch_and_argument_checks(ops):
+    """denoising_model="demucs" (dejavu.py:100-106): the waveform goes through Demucs before the x 32767 scaling."""
+    from musicfpaugment_amd.afp.dejavu.fingerprint import fingerprint_batch, fingerprint_peaks_batch
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    from musicfpaugment_amd.training.model import Demucs
+    dm = Demucs()
+    dm.load_state_dict(demucs_formula(0))
+    dm = dm.cuda().eval()
+    wav = torch.from_numpy(synth.batch(3, seed=70, n=64000)).cuda()
+    mask, npk, spec = fingerprint_peaks_batch(wav, denoising=True, denoising_model="demucs", demucs=dm)
+    den = dm(wav)[:, 0].contiguous()
+    mask2, npk2, spec2 = fingerprint_peaks_batch(den)
+    assert torch.equal(mask, mask2) and torch.equal(npk, npk2) and torch.equal(spec, spec2) and spec.dtype == torch.float64
+    dig, t1, counts, mask3, _ = fingerprint_batch(wav, denoising=True, denoising_model="demucs", demucs=dm)
+    assert torch.equal(mask3, mask) and int(counts.min()) >= 0
+    with pytest.raises(AssertionError):
+        fingerprint_peaks_batch(wav, denoising=True, denoising_model="wavenet")
+    with pytest.raises(ValueError):
+        fingerprint_peaks_batch(wav, denoising=True, denoising_model="unet")
+
+
 def test_peak_metrics(ops, golden):
     from oracle import metrics as om
     g = golden("g5_metrics")
@@ -195,6 +288,49 @@ def test_peaks_metrics_harness_vs_oracle():
     sa = np.stack([(lambda m: m / m.max())(ostft.magnitude(c)) for c in aug])
     want_psnr = np.mean([10 * np.log10((sc[k].max() - sc[k].min()) ** 2 / np.mean((sa[k] - sc[k]) ** 2)) for k in range(n)])
     assert abs(res["psnr_no_den_spec"] - want_psnr) < 1e-9
+
+
+def test_dejavu_peaks_metrics_harness_vs_oracle():
+    """compute_peaks_metrics of testing/dejavu_exps.py:82-167 on synthetic queries: the un-denoised half and the denoised
+    half given the device's network output are exact against the oracle; the reference's key set (with its psnr_*_wav
+    entries filled from the spectrogram PSNR) is kept."""
+    from musicfpaugment_amd import ops
+    from musicfpaugment_amd.testing.dejavu_exps import DejavuPeaks, KEYS, compute_peaks_metrics
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict
+    from oracle import dejavu as od
+    from oracle import metrics as om
+    n = 5
+    clean = synth.batch(n, seed=810)
+    aug = (0.8 * clean + 0.2 * synth.batch(n, seed=910, tonal=False)).astype(np.float32)
+    net = UNet(1, 1, rate=0.05)
+    net.load_state_dict(formula_state_dict(0))
+    net = net.cuda().eval()
+    d0 = DejavuPeaks()
+    d0.settings["amp_min"] = 5                   # the formula-weight network leaves few bins 50 above the mean
+    d1 = DejavuPeaks(d0.settings, denoising=True, denoising_model="unet", unet=net)
+    res = compute_peaks_metrics(torch.from_numpy(clean), torch.from_numpy(aug), d0, d1, batch=2)
+    assert list(res.keys()) == KEYS
+    y = net.denoise_spectrogram(*ops.specgram_psd(torch.from_numpy(aug).cuda(), scale_in=32767.0), per_clip=True).cpu().numpy()
+    acc = np.zeros(8)
+    for k in range(n):
+        _, mc, sc = od.fingerprint_peaks(clean[k].astype(np.float64) * 32767.0, amp_min=5)
+        _, ma, sa = od.fingerprint_peaks(aug[k].astype(np.float64) * 32767.0, amp_min=5)
+        arr, sd_ = od.preprocess_denoised(y[k])
+        _, md = od.get_2d_peaks(arr, 5)
+        mc, ma, md = mc.T[None], ma.T[None], md.T[None]
+        psnr = lambda a, b: 10 * np.log10((b.max() - b.min()) ** 2 / np.mean((a.astype(np.float64) - b) ** 2))
+        acc += [om.precision(ma, mc), om.recall(ma, mc), om.f1score(ma, mc), psnr(sa, sc),
+                om.precision(md, mc), om.recall(md, mc), om.f1score(md, mc), psnr(sd_, sc)]
+    acc /= n
+    for key, want in zip(["precision_no_den", "recall_no_den", "f1_score_no_den"], acc[:3]):
+        assert abs(res[key] - want) < 1e-12, key
+    for key, want in zip(["prec_den", "rec_den", "f1_den"], acc[4:7]):
+        assert abs(res[key] - want) < 1e-12, key
+    assert abs(res["psnr_no_den_spec"] - acc[3]) < 1e-9 and abs(res["psnr_den_spec"] - acc[7]) < 1e-5
+    assert res["psnr_no_den_wav"] == res["psnr_no_den_spec"] and res["psnr_den_wav"] == res["psnr_den_spec"]
+    with pytest.raises(AssertionError):
+        DejavuPeaks(denoising=True, denoising_model="wavenet")
 
 
 def test_file_level_entry_points(tmp_path):

@@ -94,6 +94,24 @@ def test_g4_dejavu(golden):
     np.testing.assert_allclose(spec_f[::8, ::8], g["full_spec_sub"], rtol=1e-12, atol=0)
 
 
+def test_g13_dejavu_denoised(golden):
+    """fingerprint(denoising=True, denoising_model="unet") of the real reference: UNet on the normalised PSD, squared, float32
+    log / mean, picker -- peak sets identical at both thresholds, specgram within float32 conv rounding."""
+    from musicfpaugment_amd.training.weights import formula_state_dict
+    g = golden("g13_dejavu_denoised")
+    sd = formula_state_dict(0)
+    for i, seed in enumerate(g["seeds"]):
+        d = synth.clip(int(seed), tonal=True)
+        assert synth.digest(d) == str(g[f"wav_digest{i}"])
+        samples = d.astype(np.float64) * 32767.0
+        coords, mask, spec = od.fingerprint_peaks_unet(samples, sd)
+        assert spec.dtype == np.float32 and mask.shape == tuple(g["shape"])
+        np.testing.assert_allclose(spec[::8, ::8], g[f"spec_sub{i}"], rtol=2e-4, atol=1e-7)
+        assert np.array_equal(np.array(coords, dtype=np.int32).reshape(-1, 2), g[f"coords{i}"])
+        coords_lo, _, _ = od.fingerprint_peaks_unet(samples, sd, amp_min=float(g["amp_min_low"]))
+        assert np.array_equal(np.array(coords_lo, dtype=np.int32).reshape(-1, 2), g[f"coords_low{i}"])
+
+
 def test_g5_metrics(golden):
     g = golden("g5_metrics")
     pred, gt, prf = g["pred"].astype(np.float32), g["gt"].astype(np.float32), g["prf"]

@@ -143,6 +143,33 @@ def g12_demucs_train_step(versions):
          grad_norm=gnorm, grad_head=ghead, param_head_before=before, param_head_after=after, versions=versions)
 
 
+AMP_MIN_LOW = 5
+
+
+def g13_dejavu_denoised(fp, versions):
+    """G13: Dejavu's fingerprint() with denoising=True, denoising_model="unet" (afp/dejavu/fingerprint.py:58-84) on full
+    8-second clips; fp.unet holds the formula weights (seed 0) injected at import."""
+    out = {}
+    seeds = [61, 2061]
+    for i, s_ in enumerate(seeds):
+        d = synth.clip(s_, tonal=True)
+        _, mask, spec = fp.fingerprint((d.astype(np.float64) * 32767.0), denoising=True, denoising_model="unet",
+                                       get_masks=True)
+        assert spec.dtype == np.float32
+        f_idx, t_idx = np.nonzero(mask)
+        out[f"wav_digest{i}"] = synth.digest(d)
+        out[f"coords{i}"] = np.stack([f_idx, t_idx], axis=1).astype(np.int32)
+        out[f"spec_sub{i}"] = spec[::8, ::8].copy()
+        # the formula weights leave few bins 50 above the mean: a second run with a low threshold exercises the picker
+        _, mask_lo, _ = fp.fingerprint((d.astype(np.float64) * 32767.0), denoising=True, denoising_model="unet",
+                                       amp_min=AMP_MIN_LOW, get_masks=True)
+        fl, tl = np.nonzero(mask_lo)
+        out[f"coords_low{i}"] = np.stack([fl, tl], axis=1).astype(np.int32)
+        print(f"  dejavu + unet, clip {s_}: {len(f_idx)} peaks (amp_min 50), {len(fl)} (amp_min {AMP_MIN_LOW}), "
+              f"specgram max {spec.max():.4g}")
+    save("g13_dejavu_denoised", amp_min_low=AMP_MIN_LOW, seeds=np.array(seeds), shape=np.array(mask.shape), versions=versions, **out)
+
+
 def main():
     import scipy.signal
     import torch
@@ -157,6 +184,9 @@ def main():
                          f"matplotlib {__import__('matplotlib').__version__}"])
     if "--only-g12" in sys.argv:
         g12_demucs_train_step(versions)
+        return
+    if "--only-g13" in sys.argv:
+        g13_dejavu_denoised(fp, versions)
         return
 
     # ---- G1 / G2: spectrogram() and audfprint stft on two 1-second clips -------------------
@@ -417,6 +447,7 @@ def main():
     save("g11_mrstft_loss", seed_x=1400, seed_noise=1401, n=24000, factor_sc=0.1, factor_mag=0.1, sc=float(sc), mag=float(mag), per_resolution=np.array(per),
          mag0_sub=m0[0, ::7, ::9].copy(), mag0_shape=np.array(m0.shape), sc_silent=float(zs), mag_silent=float(zm), versions=versions)
     g12_demucs_train_step(versions)
+    g13_dejavu_denoised(fp, versions)
     print("done")
 
 
