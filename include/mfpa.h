@@ -518,6 +518,11 @@ int mfpa_mix_background(const float* x, int B, int T, const float* noise, const 
 /* Clipping (clipping.py:67-100) one example at a time, as AugmentFP.__call__ applies it: clamp to torch.quantile(x, p/2)
  * and torch.quantile(x, 1 - p/2) (linear interpolation), found by an in-LDS radix select. */
 int mfpa_clip_quantile(const float* x, int B, int T, const float* pct, const uint8_t* apply, float* y, void* stream);
+/* The same transform as the reference's batch_augment applies it to B > 1 examples (clipping.py:77-93: torch.quantile without
+ * a dim argument): example b is clamped to the pct[b]/2 and 1 - pct[b]/2 quantiles of ALL selected examples flattened
+ * together.  n_apply = number of non-zero entries of apply; n_apply * T <= 16 000 000 (torch.quantile's limit) else EINVAL. */
+int mfpa_clip_quantile_flat(const float* x, int B, int T, const float* pct, const uint8_t* apply, int n_apply, float* y,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class MfpaError(RuntimeError):
@@ -66,6 +66,7 @@ _SIGNATURES = {
     "mfpa_gather_background": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_mix_background": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_clip_quantile": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_clip_quantile_flat": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_demucs_prep": ([c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_upsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_downsample2": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),

@@ -11,8 +11,9 @@ Differences, on purpose:
     reference decodes and resamples a file per example with torchaudio (file I/O is out of scope, SURVEY.md §2);
   * the random draws use the same distributions (torch.distributions / random.choice) but are made for the whole batch
     on the host; the per-sample arithmetic runs in csrc/augment.hip;
-  * `batch_augment` treats every example like `__call__` does (the reference's Clipping takes its quantile over the
-    flattened selected sub-batch when B > 1, clipping.py:72-86 -- a quirk only its streamlit UI can trigger);
+  * by default `batch_augment` treats every example like `__call__` does, which is how the training data is made
+    (training/dataset.py:143); the reference's own batch_augment lets Clipping take its quantiles over the flattened
+    selected sub-batch (torch.quantile without a dim, clipping.py:77-93) -- `clipping_scope="batch"` reproduces that;
   * the windowed-sinc filters restate julius 0.2.7 (not in the reference tree): parity unpinned, property-tested.
 """
 from __future__ import annotations
@@ -140,7 +141,10 @@ class AugmentFP(object):
     def __init__(self, background_paths: Optional[Dict[str, List[str]]] = None, sample_rate: int = 8000,
                  parameters: Dict[str, float] = DEFAULT_PARAMETERS, impulse_response_dir: Optional[str] = None, *,
                  ir_bank: Optional[List[torch.Tensor]] = None, noise_bank: Optional[Dict[str, List[torch.Tensor]]] = None,
-                 device="cuda") -> None:
+                 device="cuda", clipping_scope: str = "example") -> None:
+        if clipping_scope not in ("example", "batch"):
+            raise ValueError("clipping_scope must be 'example' (like __call__) or 'batch' (the reference's batch_augment)")
+        self.clipping_scope = clipping_scope
         if ir_bank is None:
             if impulse_response_dir is None:
                 raise ValueError("pass `impulse_response_dir` (a directory of .wav files) or an in-memory `ir_bank`")
@@ -301,7 +305,11 @@ class AugmentFP(object):
         self.t_clip.draws = {"percentile_threshold": pct}
         y = torch.empty_like(x)
         pct_d, on_d = _up(pct, dev), u8(should)
-        check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct_d), ptr(on_d), ptr(y), stream()), "mfpa_clip_quantile")
+        if self.clipping_scope == "batch" and B > 1:
+            check(L.mfpa_clip_quantile_flat(ptr(x), B, T, ptr(pct_d), ptr(on_d), int(should.sum()), ptr(y), stream()),
+                  "mfpa_clip_quantile_flat")
+        else:
+            check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct_d), ptr(on_d), ptr(y), stream()), "mfpa_clip_quantile")
         x = y
         # 6 LowPass(3000-3999 Hz), 7 HighPass(30-150 Hz)
         self.t_lp.gate(B)

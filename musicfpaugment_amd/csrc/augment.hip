@@ -241,7 +241,11 @@ __device__ __forceinline__ float key2f(unsigned k) {
 // Clipping.apply_transform for ONE example per workgroup (clipping.py:67-100 as AugmentFP.__call__ uses it):
 // lo = quantile(x, p/2), hi = quantile(x, 1 - p/2) with torch.quantile's linear interpolation, y = clamp(x, lo, hi).
 // Four order statistics (floor/ceil ranks of both quantiles) are found together by a 3-pass (11/11/10 bit) radix select.
-__global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x, int T, const float* __restrict__ pct,
+// FLAT: the quantiles of example b are taken over ALL selected examples flattened together -- what the reference's
+// batch_augment computes, because its torch.quantile call has no dim argument (clipping.py:77-93); every workgroup then
+// walks the whole selected sub-batch (B' * T elements, at most torch.quantile's 16 000 000).
+template <bool FLAT>
+__global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x, int B, int T, const float* __restrict__ pct,
                                                     const uint8_t* __restrict__ apply, float* __restrict__ y) {
   __shared__ unsigned hist[4][2048];
   __shared__ unsigned prefix[4], want[4];
@@ -252,8 +256,14 @@ __global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x,
     for (int i = tid; i < T; i += 1024) yb[i] = xb[i];
     return;
   }
+  int nsel = 1;
+  if (FLAT) {
+    nsel = 0;
+    for (int r = 0; r < B; ++r) nsel += apply[r] != 0;
+  }
+  const long long n = (long long)nsel * T;
   const float qlo = pct[b] / 2.f, qhi = 1.f - qlo;
-  const float rlo = qlo * (float)(T - 1), rhi = qhi * (float)(T - 1);      // torch.quantile: rank = q * (n - 1), in float32
+  const float rlo = qlo * (float)(n - 1), rhi = qhi * (float)(n - 1);      // torch.quantile: rank = q * (n - 1), in float32
   const int ranks[4] = {(int)floorf(rlo), (int)ceilf(rlo), (int)floorf(rhi), (int)ceilf(rhi)};
   if (tid < 4) { prefix[tid] = 0; want[tid] = (unsigned)ranks[tid]; }
   const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
@@ -262,12 +272,16 @@ __global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x,
     for (int i = tid; i < 4 * 2048; i += 1024) (&hist[0][0])[i] = 0;
     __syncthreads();
     const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shifts[pass] + bits[pass]));
-    for (int i = tid; i < T; i += 1024) {
-      const unsigned k = f2key(xb[i]);
-      const unsigned digit = (k >> shifts[pass]) & (nb - 1);
+    for (int row = FLAT ? 0 : b; row < (FLAT ? B : b + 1); ++row) {
+      if (FLAT && !apply[row]) continue;
+      const float* xr = x + (size_t)row * T;
+      for (int i = tid; i < T; i += 1024) {
+        const unsigned k = f2key(xr[i]);
+        const unsigned digit = (k >> shifts[pass]) & (nb - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if ((k & himask) == prefix[r]) atomicAdd(&hist[r][digit], 1u);
+        for (int r = 0; r < 4; ++r)
+          if ((k & himask) == prefix[r]) atomicAdd(&hist[r][digit], 1u);
+      }
     }
     __syncthreads();
     if (tid < 4) {                                   // walk the histogram to the bin holding the wanted rank
@@ -348,7 +362,17 @@ int mfpa_mix_background(const float* x, int B, int T, const float* noise, const 
 int mfpa_clip_quantile(const float* x, int B, int T, const float* pct, const uint8_t* apply, float* y, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!x || !pct || !apply || !y || B < 0 || T < 2) return MFPA_EINVAL;
-  hipLaunchKernelGGL(clip_kernel, dim3(B), dim3(1024), 0, mfpa_stream(stream), x, T, pct, apply, y);
+  hipLaunchKernelGGL(clip_kernel<false>, dim3(B), dim3(1024), 0, mfpa_stream(stream), x, B, T, pct, apply, y);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_clip_quantile_flat(const float* x, int B, int T, const float* pct, const uint8_t* apply, int n_apply, float* y,
+                            void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !pct || !apply || !y || B < 0 || T < 2 || n_apply < 0 || n_apply > B) return MFPA_EINVAL;
+  if ((long long)n_apply * T > 16000000LL) return MFPA_EINVAL;       // torch.quantile's own input limit
+  hipLaunchKernelGGL(clip_kernel<true>, dim3(B), dim3(1024), 0, mfpa_stream(stream), x, B, T, pct, apply, y);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

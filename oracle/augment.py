@@ -99,6 +99,15 @@ def clipping(samples: torch.Tensor, percentile: torch.Tensor) -> torch.Tensor:
     return torch.stack(out)[:, None]
 
 
+def clipping_flat(samples: torch.Tensor, percentile: torch.Tensor) -> torch.Tensor:
+    """clipping.py:67-100 as batch_augment runs it on B > 1 selected examples: torch.quantile has no dim argument there, so
+    example b is clamped to the p_b/2 and 1 - p_b/2 quantiles of the whole flattened sub-batch."""
+    flat = samples[:, 0, :].reshape(-1)
+    lo = torch.quantile(flat, percentile.reshape(-1) / 2)
+    hi = torch.quantile(flat, 1 - percentile.reshape(-1) / 2)
+    return torch.clip(samples[:, 0, :], min=lo[:, None], max=hi[:, None]).unsqueeze(1)
+
+
 def peak_normalize(samples: torch.Tensor) -> torch.Tensor:
     peak = samples.abs().amax(dim=(1, 2), keepdim=True)
     return torch.where(peak > 0, samples / torch.where(peak > 0, peak, torch.ones_like(peak)), samples)

@@ -79,6 +79,8 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert h.mfpa_fir(1, 1, 100, 100, 1, 1, 1, 1, 1, 2, 0, 1, None, None) == lib.EINVAL   # pad_mode
     assert h.mfpa_fir(1, 1, 100, 100, 1, 1, 1, 1, 1, 0, 2, 1, None, None) == lib.EINVAL   # impulse-response mode needs `peak`
     assert h.mfpa_clip_quantile(None, 1, 100, 1, 1, 1, None) == lib.EINVAL
+    assert h.mfpa_clip_quantile_flat(1, 4, 100, 1, 1, 5, 1, None) == lib.EINVAL          # more selected than examples
+    assert h.mfpa_clip_quantile_flat(1, 300, 64000, 1, 1, 300, 1, None) == lib.EINVAL     # beyond torch.quantile's input limit
     assert h.mfpa_gather_background(1, 1, 1, 1, 0, 100, 1, None) == lib.EINVAL            # P < 1
     assert h.mfpa_lstm_step(None, 0, 1, 1, 3072, 1, 4, 760, 1, 768, None, None, 0, None) == lib.EINVAL   # H % 128
     assert h.mfpa_lstm_step(None, 0, 1, 1, 3072, 1, 0, 768, 1, 768, None, None, 0, None) == 0           # empty batch

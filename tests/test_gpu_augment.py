@@ -51,6 +51,14 @@ def test_ir_noise_gain_clip_peak_against_reference_golden(golden):
     pct = torch.from_numpy(g["percentile"]).cuda()
     check(L.mfpa_clip_quantile(ptr(x), B, T, ptr(pct), ptr(on), ptr(y), stream()), "clip")
     np.testing.assert_array_equal(y.cpu().numpy(), g["y_clip"][:, 0])
+    # ... and as the reference's batch_augment takes them: over the flattened selected sub-batch (clipping.py:77-93)
+    check(L.mfpa_clip_quantile_flat(ptr(x), B, T, ptr(pct), ptr(on), B, ptr(y), stream()), "clip_flat")
+    np.testing.assert_array_equal(y.cpu().numpy(), g["y_clip_batchquirk"][:, 0])
+    sel = torch.tensor([1, 0, 1], dtype=torch.uint8, device="cuda")                     # a gated-off example is left out of the pool
+    check(L.mfpa_clip_quantile_flat(ptr(x), B, T, ptr(pct), ptr(sel), 2, ptr(y), stream()), "clip_flat")
+    want = oau.clipping_flat(x.cpu()[[0, 2], None, :], torch.from_numpy(g["percentile"])[[0, 2]])[:, 0]
+    np.testing.assert_array_equal(y.cpu().numpy()[[0, 2]], want.numpy())
+    np.testing.assert_array_equal(y.cpu().numpy()[1], x.cpu().numpy()[1])
     # peak normalisation (a silent clip is left alone)
     xs = x * torch.from_numpy(g["peak_scale"]).cuda()[:, None]
     check(L.mfpa_mix_background(ptr(xs), B, T, 0, 0, 0, ptr(y), stream()), "peak")
@@ -157,7 +165,8 @@ def test_augmentfp_reads_wav_banks_like_the_reference_constructor(tmp_path):
         AugmentFP({"x": [str(tmp_path / "wrong_rate.wav")]}, 8000, impulse_response_dir=str(ir_dir))
 
 
-def test_batch_augment_replayed_on_the_oracle():
+@pytest.mark.parametrize("scope", ["example", "batch"])
+def test_batch_augment_replayed_on_the_oracle(scope):
     """The whole 8-stage chain: replay the draws of one batch_augment call through oracle/augment.py, stage by stage."""
     import random
     from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
@@ -170,7 +179,7 @@ def test_batch_augment_replayed_on_the_oracle():
     for k in par:
         if k.startswith("proba"):
             par[k] = 0.7                                                    # every stage on and off within one batch
-    af = AugmentFP(None, 8000, parameters=par, ir_bank=irs, noise_bank=noises)
+    af = AugmentFP(None, 8000, parameters=par, ir_bank=irs, noise_bank=noises, clipping_scope=scope)
     B, T = 12, 24000
     wav = torch.from_numpy(synth.batch(B, seed=1800, n=T))[:, None, :]
     out = af.batch_augment(wav).cpu()
@@ -193,7 +202,12 @@ def test_batch_augment_replayed_on_the_oracle():
     np.testing.assert_allclose(tr[2].draws["background"].cpu().numpy(), bg.numpy(), rtol=0, atol=2e-6)
     x = gated(x, gates[2], lambda v, b: oau.add_background(v, bg[b:b + 1], tr[2].draws["snr_in_db"][b:b + 1]))
     x = gated(x, gates[3], lambda v, b: oau.gain(v, tr[3].draws["gain_in_db"][b:b + 1]))
-    x = gated(x, gates[4], lambda v, b: oau.clipping(v, tr[4].draws["percentile_threshold"][b:b + 1]))
+    if scope == "example":
+        x = gated(x, gates[4], lambda v, b: oau.clipping(v, tr[4].draws["percentile_threshold"][b:b + 1]))
+    else:                                       # the reference's batch_augment: quantiles over the flattened selected sub-batch
+        sel = torch.nonzero(torch.as_tensor(gates[4])).flatten()
+        x = x.clone()
+        x[sel] = oau.clipping_flat(x[sel], tr[4].draws["percentile_threshold"][sel])
     x = gated(x, gates[5], lambda v, b: oau.lowpass(v[:, 0], float(tr[5].draws["cutoff_freq"][b]) / 8000)[:, None])
     x = gated(x, gates[6], lambda v, b: oau.highpass(v[:, 0], float(tr[6].draws["cutoff_freq"][b]) / 8000)[:, None])
     x = oau.peak_normalize(x)

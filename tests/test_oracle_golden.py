@@ -188,6 +188,7 @@ def test_g10_augment_transforms(golden):
     np.testing.assert_allclose(oau.add_background(x, noise, torch.from_numpy(g["snr"])).numpy(), g["y_bg"], rtol=0, atol=1e-6)
     np.testing.assert_array_equal(oau.gain(x, torch.from_numpy(g["gain_db"])).numpy(), g["y_gain"])
     np.testing.assert_array_equal(oau.clipping(x, torch.from_numpy(g["percentile"])).numpy(), g["y_clip"])
+    np.testing.assert_array_equal(oau.clipping_flat(x, torch.from_numpy(g["percentile"])).numpy(), g["y_clip_batchquirk"])
     xs = x * torch.from_numpy(g["peak_scale"]).view(3, 1, 1)
     np.testing.assert_array_equal(oau.peak_normalize(xs).numpy(), g["y_peak"])
 
