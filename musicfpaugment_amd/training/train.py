@@ -194,6 +194,37 @@ class Trainer:
         self.model.train()
         return ({"loss": val_loss, "l1_loss": l1, "sc_loss": sc, "mag_loss": mag}, {"psnr": psnr_total / self.val_steps})
 
+    @torch.no_grad()
+    def start_epoch(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+        """train.py:470-578: the losses and PSNR of the UN-denoised validation inputs (augmented vs clean) before training --
+        all `val_steps` batches, unlike the epochs' steps-1.  Monitoring only (plain device arithmetic, no model); the
+        reference prints the two dictionaries, this also returns them."""
+        if self.val_loader_iter is None:
+            raise ValueError("no validation loader")
+        total, parts, psnr_total = 0.0, [0.0, 0.0, 0.0], 0.0
+        for _ in range(self.val_steps):
+            clean, aug = next(self.val_loader_iter)
+            if self.input_type == "audio":
+                clean, aug = self._waves(clean, aug)
+                l1, sc, mag, _ = self.engine.loss_and_grad(aug, clean)
+                vals = [float(l1), float(sc), float(mag)]
+                parts = [p + v for p, v in zip(parts, vals)]
+                total += sum(vals)
+                a, c = aug.double(), clean.double()
+            else:
+                am, aden, c = self._specs(clean, aug)
+                a = am / aden[:, None, None]
+                total += float(torch.mean(torch.abs(a - c)))
+            rng = c.max() - c.min()
+            psnr_total += float(10.0 * torch.log10(rng * rng / torch.mean((a - c) ** 2)))
+        losses: Dict[str, Any] = {"loss": total / self.val_steps}
+        if self.input_type == "audio":
+            losses.update({k: v / self.val_steps for k, v in zip(["l1_loss", "sc_loss", "mag_loss"], parts)})
+        metrics = {"psnr": psnr_total / self.val_steps}
+        print(f"\nStart Loss: {losses}")
+        print(f"\nStart Metrics: {metrics}")
+        return losses, metrics
+
     # ------------------------------------------------------------------ checkpoints (train.py:197-221, :130-161)
     def save_checkpoint(self, val_loss: float) -> None:
         if self.ckpt_path is None:

@@ -320,6 +320,13 @@ def test_trainer_audio_branch():
             yield clean.unsqueeze(-1), aug.float().unsqueeze(-1)           # (B, T, 1) like the reference's loader
 
     tr = Trainer(net, loader(40), loader(90), train_steps=3, val_steps=2, device="cuda", input_type="audio", learning_rate=3e-4)
+    start, start_m = Trainer(net, loader(40), loader(90), val_steps=2, device="cuda", input_type="audio").start_epoch()
+    gen, want = loader(90), 0.0                               # train.py:470-578: un-denoised inputs, all val_steps batches
+    for _ in range(2):
+        c, a = next(gen)
+        want += float(torch.mean(torch.abs(a.double() - c.double()))) / 2
+    assert abs(start["l1_loss"] - want) < 1e-7 and np.isfinite(start_m["psnr"])
+    assert abs(start["loss"] - (start["l1_loss"] + start["sc_loss"] + start["mag_loss"])) < 1e-9
     out = tr.train_epoch(1)
     assert np.isfinite(out["loss"]) and set(out) == {"loss", "l1_loss", "sc_loss", "mag_loss"}
     val, _ = tr.validation_epoch()

@@ -173,6 +173,16 @@ def test_trainer_mirror_epoch_and_checkpoint(tmp_path):
     net = UNet(1, 1, rate=0.0)
     net.load_state_dict(formula_state_dict(3))
     tr = Trainer(net, loader(10), loader(10), learning_rate=1e-3, train_steps=5, val_steps=3, ckpt_path=str(tmp_path))
+    # start_epoch (train.py:470-578): L1 / PSNR of the un-denoised inputs over ALL val_steps batches, against the oracle
+    from oracle import stft as ostft
+    start, start_m = Trainer(net, loader(10), loader(10), val_steps=3).start_epoch()
+    gen, want_l1, want_psnr = loader(10), 0.0, 0.0
+    for _ in range(3):
+        c, a = next(gen)
+        sc_, sa_ = ostft.spectrogram(c[:, :, 0].numpy()), ostft.spectrogram(a[:, :, 0].numpy())
+        want_l1 += np.mean(np.abs(sa_ - sc_)) / 3
+        want_psnr += 10 * np.log10((sc_.max() - sc_.min()) ** 2 / np.mean((sa_ - sc_) ** 2)) / 3
+    assert abs(start["loss"] - want_l1) < 1e-12 and abs(start_m["psnr"] - want_psnr) < 1e-9
     l1 = tr.train_epoch(1)["loss"]
     l2 = tr.train_epoch(2)["loss"]
     assert l2 < l1
