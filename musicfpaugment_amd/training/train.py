@@ -82,7 +82,9 @@ class Trainer:
                  learning_rate: float = LEARNING_RATE, train_steps: int = TRAIN_STEPS, val_steps: int = VAL_STEPS,
                  device="cuda", ckpt_path: Optional[str] = None, input_type: str = "spec",
                  scheduler_factor: float = 0.1, scheduler_patience: int = 10, early_stop_patience: int = 20,
-                 precision: int = 0, sync_bn: bool = False):
+                 precision: int = 0, sync_bn: bool = False, factor_sc: float = FACTOR_SC, factor_mag: float = FACTOR_MAG,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, early_stop_min_delta: float = 0.0,
+                 nb_epochs: Optional[int] = None):
         """`precision` (not in the reference): 0 = exact fp32 products on the fp32 matrix cores, 1 = bf16x3 (2.4x the
         step rate; gradients deviate ~1e-2 relative from fp32 autograd, see tests/test_gpu_train.py).  `sync_bn` (multi-GPU):
         BatchNorm statistics over the global batch, so that N GPUs x B/N clips reproduce the reference's single-GPU step on
@@ -95,20 +97,52 @@ class Trainer:
         if input_type == "audio":
             from ..ops_demucs_train import DemucsTrainEngine
             from .loss import MultiResolutionSTFTLoss
-            self.mrsl = MultiResolutionSTFTLoss(factor_sc=FACTOR_SC, factor_mag=FACTOR_MAG, precision=precision).to(self.device)   # train.py:652-655
-            self.engine = DemucsTrainEngine(self.model.state_dict(), self.device, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8,
+            self.mrsl = MultiResolutionSTFTLoss(factor_sc=factor_sc, factor_mag=factor_mag, precision=precision).to(self.device)   # train.py:652-655
+            self.engine = DemucsTrainEngine(self.model.state_dict(), self.device, lr=learning_rate, betas=tuple(betas), eps=eps,
                                             precision=precision, mrstft=self.mrsl, module=self.model)
         else:
-            self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8, precision=precision,
+            self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=tuple(betas), eps=eps, precision=precision,
                                           sync_bn=sync_bn)
         self.scheduler = ReduceLROnPlateau(self.engine, scheduler_factor, scheduler_patience)
-        self.early_stopping = EarlyStopping(early_stop_patience)
+        self.early_stopping = EarlyStopping(early_stop_patience, early_stop_min_delta)
+        self.nb_epochs = nb_epochs
+        self.save = True                                        # from_reference: the reference's `save` flag
         self.train_loader_iter, self.val_loader_iter = train_loader, val_loader
         self.train_steps, self.val_steps = train_steps, val_steps
         self.ckpt_path = ckpt_path
         self.epoch = 0
         self.best_val_loss = float("inf")
         self.losses: Dict[str, list] = {"train": [], "val": []}
+
+    @classmethod
+    def from_reference(cls, model, train_loader, train_steps: int, val_loader, val_steps: int, criterion: Dict[str, Any],
+                       optimizer, scheduler, early_stopping, nb_epochs: int, device, metadatas: Optional[Dict[str, str]] = None,
+                       checkpoint: Optional[str] = None, monitoring: bool = False, save: bool = False,
+                       input_type: str = "audio", *, precision: int = 0, sync_bn: bool = False) -> "Trainer":
+        """The reference's constructor call (training/train.py:52-70, as `__main__` makes it, :676-693) mapped onto this class:
+        the torch objects are read for their hyper-parameters -- Adam's lr / betas / eps, ReduceLROnPlateau's factor / patience,
+        EarlyStopping's patience / min_delta, the MultiResolutionSTFTLoss factors -- because the optimiser step, the schedule
+        and the losses run on the engine's flat buffers, not on `model.parameters()`.  `monitoring` (TensorBoard) is not built;
+        checkpoints are written when `save` is set, and an existing `last_epoch.pt` under `checkpoint` is resumed (:130-161)."""
+        if monitoring:
+            raise NotImplementedError("TensorBoard monitoring is outside the hot path")
+        if type(optimizer).__name__ != "Adam":
+            raise ValueError("the reference trains with torch.optim.Adam (train.py:661); no other optimiser is built")
+        g = optimizer.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False):
+            raise ValueError("Adam with weight decay / amsgrad is not built (the reference uses neither)")
+        mrsl = criterion.get("mrsl") if criterion else None
+        ck = checkpoint if checkpoint and (save or os.path.exists(os.path.join(checkpoint, "last_epoch.pt"))) else None
+        self = cls(model, iter(train_loader), iter(val_loader) if val_loader is not None else None, learning_rate=float(g["lr"]),
+                   train_steps=train_steps, val_steps=val_steps, device=device, ckpt_path=ck, input_type=input_type,
+                   scheduler_factor=float(getattr(scheduler, "factor", 0.1)), scheduler_patience=int(getattr(scheduler, "patience", 10)),
+                   early_stop_patience=int(getattr(early_stopping, "patience", 20)),
+                   early_stop_min_delta=float(getattr(early_stopping, "min_delta", 0.0)), precision=precision, sync_bn=sync_bn,
+                   factor_sc=float(getattr(mrsl, "factor_sc", FACTOR_SC)), factor_mag=float(getattr(mrsl, "factor_mag", FACTOR_MAG)),
+                   betas=tuple(float(b) for b in g["betas"]), eps=float(g["eps"]), nb_epochs=int(nb_epochs))
+        self.metadatas = dict(metadatas or {})
+        self.save = bool(save)
+        return self
 
     # ------------------------------------------------------------------ one batch
     def _specs(self, clean_audios: torch.Tensor, augmented_audios: torch.Tensor):
@@ -227,7 +261,7 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints (train.py:197-221, :130-161)
     def save_checkpoint(self, val_loss: float) -> None:
-        if self.ckpt_path is None:
+        if self.ckpt_path is None or not self.save:
             return
         os.makedirs(self.ckpt_path, exist_ok=True)
         self.engine.sync_to_module()
@@ -254,8 +288,11 @@ class Trainer:
         self.epoch, self.losses, self.best_val_loss = ck["epoch"], ck["losses"], ck["best_val_loss"]
         return True
 
-    def training_loop(self, nb_epochs: int) -> None:
-        """train.py:171-243 without the logging side outputs."""
+    def training_loop(self, nb_epochs: Optional[int] = None) -> None:
+        """train.py:171-243 without the logging side outputs (`nb_epochs` defaults to the constructor's, as in the reference)."""
+        nb_epochs = self.nb_epochs if nb_epochs is None else nb_epochs
+        if nb_epochs is None:
+            raise ValueError("nb_epochs was given neither here nor to the constructor")
         self.load_checkpoint()
         while self.epoch < nb_epochs:
             self.epoch += 1

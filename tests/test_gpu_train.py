@@ -1,5 +1,7 @@
 """GPU parity: UNet training step (forward in train mode, L1, backward, Adam) vs torch autograd on the CPU
 and the golden step recorded from the real reference (tools/make_goldens.py, G7)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -199,6 +201,22 @@ def test_trainer_mirror_epoch_and_checkpoint(tmp_path):
     for v in (1.0, 1.1, 1.2):
         es(v)
     assert es.early_stop
+    # the reference's own constructor call (train.py:676-693) with torch objects for the hyper-parameters
+    net3 = UNet(1, 1, rate=0.0)
+    net3.load_state_dict(formula_state_dict(3))
+    opt = torch.optim.Adam(net3.parameters(), lr=2e-3, betas=(0.8, 0.99))
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", factor=0.5, patience=3)
+    tr3 = Trainer.from_reference(net3, loader(10), 3, loader(10), 2, {"l1": torch.nn.L1Loss(reduction="mean")}, opt, sched,
+                                 EarlyStopping(patience=7, min_delta=0.01), 2, "cuda", {"name": "t", "model": "unet"},
+                                 monitoring=False, save=False, checkpoint=str(tmp_path / "none"), input_type="spec")
+    assert tr3.engine.lr == 2e-3 and tuple(tr3.engine.betas) == (0.8, 0.99) and tr3.engine.eps == 1e-8
+    assert (tr3.scheduler.factor, tr3.scheduler.patience) == (0.5, 3)
+    assert (tr3.early_stopping.patience, tr3.early_stopping.min_delta) == (7, 0.01)
+    tr3.start_epoch()
+    tr3.training_loop()
+    assert tr3.epoch == 2 and len(tr3.losses["train"]) == 2 and not os.path.exists(tmp_path / "none")
+    with pytest.raises(ValueError):
+        Trainer.from_reference(net3, loader(10), 3, None, 2, {}, torch.optim.SGD(net3.parameters(), lr=0.1), sched, es, 1, "cuda")
 
 
 def _host_keep_mask(seed, thresh, scale, shape_nhwc):
