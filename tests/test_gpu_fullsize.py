@@ -156,3 +156,44 @@ def test_demucs_train_step_64_clips_precisions_agree_and_loss_falls():
             eng2 = DemucsTrainEngine(demucs_formula(0), "cuda", lr=3e-4, precision=1)
             eng2.train_step(clean, aug)
             np.testing.assert_allclose([float(v) for v in eng2.last_losses], first[0], rtol=2e-4)
+
+
+def test_config1_dejavu_picker_256_clips_bit_exact_and_batch_invariant(net):
+    """configs[1] with the second picker: mlab.specgram PSD -> /max -> 10 ln -> -mean -> 21x21 local
+    maxima on 256 clips; sampled clips through the oracle, the rest through batch-composition properties.  Then the denoised
+    branch (UNet on the normalised PSD, squared, float32 log / mean) on 64 of them: the picker is checked against numpy on
+    the device's own network output, and sub-batching must not change a bit."""
+    from musicfpaugment_amd import ops
+    from musicfpaugment_amd.afp.dejavu.fingerprint import fingerprint_peaks_batch
+    from oracle import dejavu as od
+    B = 256
+    wav = np.stack([synth.clip(5000 + i, tonal=(i % 4 != 0)) for i in range(B)])
+    wav[9, 40000:] = 0.0                                               # half-silent: exact-zero PSD background (erosion term)
+    x = torch.from_numpy(wav).cuda()
+    mask, npk, spec = fingerprint_peaks_batch(x)
+    assert mask.shape == (B, 257, 249) and spec.dtype == torch.float64
+    for i in (0, 9, 101, 255):
+        coords, want, want_spec = od.fingerprint_peaks(wav[i].astype(np.float64) * 32767.0)
+        np.testing.assert_array_equal(mask[i].cpu().numpy(), want.astype(np.uint8))
+        assert int(npk[i]) == len(coords)
+        np.testing.assert_allclose(spec[i].cpu().numpy(), want_spec, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(npk.cpu().numpy(), mask.reshape(B, -1).sum(dim=1).cpu().numpy())
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    assert torch.equal(fingerprint_peaks_batch(x[perm].contiguous())[0], mask[perm])
+    parts = torch.cat([fingerprint_peaks_batch(x[s:s + 53].contiguous())[0] for s in range(0, B, 53)])
+    assert torch.equal(parts, mask)
+    # denoised branch, 64 clips, low threshold so that the formula-weight network leaves peaks to compare
+    xd = x[:64].contiguous()
+    net.precision = 1
+    mask_d, npk_d, spec_d = fingerprint_peaks_batch(xd, amp_min=5, denoising=True, denoising_model="unet", unet=net)
+    assert spec_d.dtype == torch.float32 and int(npk_d.min()) > 0
+    y = net.denoise_spectrogram(*ops.specgram_psd(xd, scale_in=32767.0), per_clip=True)
+    assert torch.equal(spec_d, y * y)
+    for i in (0, 9, 63):
+        _, want = od.get_2d_peaks(od.preprocess_denoised(y[i].cpu().numpy())[0], 5)
+        np.testing.assert_array_equal(mask_d[i].cpu().numpy(), want.astype(np.uint8))
+    net.max_clips_per_pass = 16
+    mask_s, _, _ = fingerprint_peaks_batch(xd, amp_min=5, denoising=True, denoising_model="unet", unet=net)
+    net.max_clips_per_pass = 64
+    net.precision = 0
+    assert torch.equal(mask_s, mask_d)
