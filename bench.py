@@ -434,6 +434,8 @@ def main():
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
+    ap.add_argument("--picker", choices=["audfprint", "dejavu"], default="audfprint",
+                    help="infer mode: the peak picker after the UNet (dejavu: specgram PSD, UNet output squared, 21x21 local maxima)")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
@@ -492,7 +494,7 @@ def main():
         return bench_metrics(args, rank, world, dev, dist)
 
     from musicfpaugment_amd import ops_unet, synth
-    from musicfpaugment_amd.pipeline import UNET_MFMA_GFLOP_PER_CLIP, HotPath
+    from musicfpaugment_amd.pipeline import HotPath, unet_mfma_gflop
     from musicfpaugment_amd.training.unet import UNet
     from musicfpaugment_amd.training.weights import formula_state_dict
 
@@ -506,7 +508,8 @@ def main():
         if args.unet_pass > 0:
             net.max_clips_per_pass = args.unet_pass
         net.two_streams = bool(int(os.environ.get("MFPA_UNET_TWO_STREAMS", "0")))
-    hot = HotPath(net, device=dev)
+    hot = HotPath(net, device=dev, picker=args.picker)
+    UNET_MFMA_GFLOP_PER_CLIP = unet_mfma_gflop(257, 251 if args.picker == "audfprint" else 249)
 
     # synthetic clips of SURVEY.md §8d: 32 distinct generated clips per rank, tiled to B with a sign/gain variation
     base = synth.batch(min(B, 32), seed=synth.BASE_SEED + 1000 * rank)
@@ -552,7 +555,8 @@ def main():
     if rank == 0:
         clips = world * B * args.steps
         out = {
-            "metric": "8s/8kHz clips/sec (STFT+UNet+peak-pick)" if net is not None else "8s/8kHz clips/sec (STFT+peak-pick, no UNet)",
+            "metric": ("8s/8kHz clips/sec (STFT+UNet+peak-pick)" if net is not None else "8s/8kHz clips/sec (STFT+peak-pick, no UNet)")
+                      + (" [Dejavu picker]" if args.picker == "dejavu" else ""),
             "value": round(clips / dt_max, 3),
             "unit": "clips/s",
             "n_gpus": world,
@@ -566,7 +570,10 @@ def main():
                      if net is not None else "f64",
             "data": "synthetic",
             "config": {"workload": (f"STFT(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights) -> "
-                                    "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms") if net is not None else
+                                    "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms") if net is not None and args.picker == "audfprint" else
+                                   (f"mlab.specgram PSD(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights), squared -> "
+                                    "Dejavu 21x21 local-max pick; 8 s / 8 kHz clips, 257x249 spectrograms") if net is not None else
+                                   "mlab.specgram PSD -> /max -> 10 ln / mean -> Dejavu 21x21 local-max pick; 8 s / 8 kHz clips" if args.picker == "dejavu" else
                                    "STFT(512/256,f64) -> per-clip normalise -> log/mean/high-pass -> Audfprint forward+backward "
                                    "prune (BASELINE configs[1]); 8 s / 8 kHz clips",
                        "clips_per_gpu_per_step": B, "peaks_last_step_rank0": total_peaks,
@@ -601,16 +608,19 @@ def main():
             # fused STFT -> magnitude -> mask moves 578 284 algorithmic bytes per clip (256 000 B of samples in,
             # the float32 spectrogram out and back in, 64 256 B of mask out).  The chain is three short launches whose
             # pruner walks 251 frames sequentially per clip: at 256 clips it is latency-bound, not bandwidth-bound.
-            gbs = 578284.0 * B * args.steps / dt_max / 1e9
+            # Dejavu: 256 000 B of samples in, the float64 PSD out and back in (257 x 249 x 8 = 511 944 B), 63 993 B of mask out.
+            per_clip = 578284.0 if args.picker == "audfprint" else 256000.0 + 511944.0 + 63993.0
+            gbs = per_clip * B * args.steps / dt_max / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(gbs / 8000.0, 5), "traffic": None,
-                               "kernel": "stft_kernel + prepare_kernel + prune_kernel (whole chain, wall clock)"}
+                               "kernel": "stft_kernel + prepare_kernel + prune_kernel (whole chain, wall clock)" if args.picker == "audfprint"
+                               else "stft_kernel (PSD) + dejavu_prepare_kernel + localmax2d_kernel (whole chain, wall clock)"}
         if other is not None:
             oname = "fp32" if args.precision == "bf16x3" else "bf16x3"
             out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),
                                       "unit": "clips/s", "ms_per_step": round(1e3 * other[0] / args.steps, 3),
                                       "roofline": roofline(other[1], oname)}
-        if world == 1 and args.cpu_seconds > 0 and net is not None:
+        if world == 1 and args.cpu_seconds > 0 and net is not None and args.picker == "audfprint":   # the baseline times the Audfprint chain
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, synth.BASE_SEED)
         print(json.dumps(out), flush=True)
     if dist is not None:

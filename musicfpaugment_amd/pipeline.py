@@ -25,13 +25,39 @@ STFT_BYTES_PER_CLIP = 514028
 PRUNER_BYTES_PER_CLIP = 322284
 
 
+def unet_mfma_gflop(H: int, W: int) -> float:
+    """Algorithmic GFLOP of the UNet's MFMA launches (every 3x3 conv but inc.0, the four transposed convs; training/unet.py:77-108)
+    for one (H, W) spectrogram: 93.316 at 257 x 251, 92.986 at Dejavu's 257 x 249."""
+    hs = [(H, W)]
+    for _ in range(4):
+        hs.append((hs[-1][0] // 2, hs[-1][1] // 2))
+    ch = [64, 128, 256, 512, 1024]
+    macs = hs[0][0] * hs[0][1] * 9 * 64 * 64
+    for lvl in range(1, 5):
+        macs += hs[lvl][0] * hs[lvl][1] * 9 * (ch[lvl - 1] * ch[lvl] + ch[lvl] * ch[lvl])
+    for lvl in range(3, -1, -1):
+        macs += hs[lvl + 1][0] * hs[lvl + 1][1] * 4 * ch[lvl + 1] * ch[lvl]
+        macs += hs[lvl][0] * hs[lvl][1] * 9 * (2 * ch[lvl] * ch[lvl] + ch[lvl] * ch[lvl])
+    return 2.0 * macs / 1e9
+
+
 class HotPath:
-    def __init__(self, unet, device="cuda"):
+    """picker "audfprint": STFT -> /max -> [UNet] -> log / mean / high-pass -> decaying-threshold prune (peak_extractor.py:236-311);
+    picker "dejavu": specgram PSD -> /max -> [UNet, squared] -> 10 ln / mean -> 21 x 21 local maxima (fingerprint.py:56-171)."""
+
+    def __init__(self, unet, device="cuda", picker: str = "audfprint"):
+        if picker not in ("audfprint", "dejavu"):
+            raise ValueError("picker must be 'audfprint' or 'dejavu'")
+        self.picker, self.unet = picker, unet
         self.extractor = Audfprint_peaks(None, denoising=unet is not None, denoising_model="unet" if unet else None,
                                          unet=unet, device=device)
 
     @torch.no_grad()
     def __call__(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.picker == "dejavu":
+            from .afp.dejavu.fingerprint import fingerprint_peaks_batch
+            mask, npeaks, _ = fingerprint_peaks_batch(wav, denoising=self.unet is not None, denoising_model="unet", unet=self.unet)
+            return mask, npeaks
         mask, npeaks, _ = self.extractor.find_peaks_batch(wav)
         return mask, npeaks
 
