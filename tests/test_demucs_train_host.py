@@ -43,3 +43,12 @@ def test_derived_operands_match_the_inference_packing():
     for layer in range(2):
         assert torch.equal(W[f"lstm{layer}.whh_grouped"], pw[f"lstm{layer}.whh_grouped"])
         assert torch.equal(W[f"lstm{layer}.b"], pw[f"lstm{layer}.b"])
+
+
+def test_unet_flop_count_matches_the_survey_figure():
+    """pipeline.unet_mfma_gflop: the per-clip FLOPs the roofline figure is built from (93.398 GFLOP forward,
+    0.074 + 0.008 of it in the two one-channel VALU layers)."""
+    from musicfpaugment_amd.pipeline import UNET_MFMA_GFLOP_PER_CLIP, unet_mfma_gflop
+    assert abs(unet_mfma_gflop(257, 251) - UNET_MFMA_GFLOP_PER_CLIP) < 1e-3
+    assert abs(unet_mfma_gflop(257, 94) - (34.177 - 0.027 - 0.003)) < 5e-3       # the reference's 3 s training length
+    assert unet_mfma_gflop(257, 249) < unet_mfma_gflop(257, 251)
