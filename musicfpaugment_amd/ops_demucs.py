@@ -107,6 +107,7 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
 
 
 FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
+_PAD_ROWS_ONLY = bool(int(os.environ.get("MFPA_DEMUCS_PAD_ROWS_ONLY", "1")))   # zero only the two padding rows of the GLU output (0: memset the whole buffer)
 LAST_LAYER_GEMM = True    # False: the stand-alone VALU kernel mfpa_convT1d_c1 for the last ConvTranspose1d
 PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (3 bf16 MFMAs per product, fp32 accumulate)
 
@@ -244,7 +245,12 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
     Lcur = Tn
     for d in range(DEPTH):
         C = chans[DEPTH - 1 - d]
-        P = torch.zeros((B, Lcur + 2, C), dtype=torch.float32, device=dev)      # rows 0 and L+1 stay zero
+        if _PAD_ROWS_ONLY:
+            P = new(B, Lcur + 2, C)                                                # rows 0 and L+1 are the zero padding
+            P[:, 0].zero_()
+            P[:, Lcur + 1].zero_()
+        else:
+            P = torch.zeros((B, Lcur + 2, C), dtype=torch.float32, device=dev)      # rows 0 and L+1 stay zero
         gemm_p(_p(x), C, Lcur * C, B, Lcur, pw[f"dec{d}.gw"], pw[f"dec{d}.gb"], C, _p(P, C), C, (Lcur + 2) * C, mode=1)
         Lnext = 4 * (Lcur + 1)                                   # (L - 1) * 4 + 8
         if d < DEPTH - 1:
