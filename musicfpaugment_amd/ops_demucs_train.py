@@ -100,6 +100,16 @@ class _Phase:
             self.eng.phases.setdefault(self.name, []).append((self.e0, e1))
 
 
+def _padded(new, zeros, B: int, L: int, C: int) -> torch.Tensor:
+    """(B, L + 2, C) buffer whose rows 0 and L + 1 are zero; the L rows between are written by the GEMM that follows."""
+    if not D._PAD_ROWS_ONLY:
+        return zeros(B, L + 2, C)
+    t = new(B, L + 2, C)
+    t[:, 0].zero_()
+    t[:, L + 1].zero_()
+    return t
+
+
 class DemucsTrainEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  precision: int = 1, mrstft=None, dist_group=None, module=None, wgrad_precision: Optional[int] = None):
@@ -315,7 +325,7 @@ class DemucsTrainEngine:
         for d in range(DEPTH):
             C = CH[DEPTH - 1 - d]
             npad = _npad_glu(C)
-            Pd = zeros(B, Lcur + 2, C)
+            Pd = _padded(new, zeros, B, Lcur, C)
             ud = new(B, Lcur, npad)
             D.gemm(_p(x), C, Lcur * C, B, Lcur, P[f"dec{d}.gw"], P[f"dec{d}.gb"], C, _p(Pd, C), C, (Lcur + 2) * C, mode=1,
                    precision=prec, C2=_p(ud), ldc2=npad, strideC2=Lcur * npad)
@@ -473,7 +483,7 @@ class DemucsTrainEngine:
                 check(L.mfpa_c1_wgrad(ptr(S["xup"]), S["xup"].shape[1], ptr(da), C, Li * C, B, Li, C, ptr(G["enc0.w"]), stream()),
                       "mfpa_c1_wgrad")
                 break
-            dA = zeros(B, Li + 2, C)                                     # rows 0 and Li + 1 stay zero
+            dA = _padded(new, zeros, B, Li, C)                           # rows 0 and Li + 1 stay zero
             D.gemm(_p(u), npad, Li * npad, B, Li, W[f"enc{i}.gwT"], None, C, _p(dA, C), C, (Li + 2) * C, mode=3, addend=_p(a_s[i]),
                    ldadd=C, strideAdd=Li * C, precision=prec)
             Cin, Lprev = CH[i - 1], Ls[i - 1]
