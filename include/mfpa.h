@@ -334,6 +334,14 @@ int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, 
 int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dpred, double* loss,
                  double* workspace, void* stream);
 
+/* Operand image of a convolution's weights, rebuilt from the master fp32 parameters after every optimiser step (replaces the
+ * host-side flip / transpose / bf16 split of the packing code).  w: [taps][Co][Ci] fp32.  out: [taps][nrows][K] rows, K-contiguous,
+ * 32-element chunks as 32 floats (precision 0) or [32 bf16 hi | 32 bf16 lo] (precision 1).  flip_transpose = 0: rows = output
+ * channels row0 .. row0+nrows-1, K = Ci (forward operand).  flip_transpose = 1: rows = input channels row0 .. row0+nrows-1,
+ * K = Co, and for taps == 9 the kernel is flipped (tap t <- 8 - t): the input-gradient operand (training/unet.py's Conv2d /
+ * ConvTranspose2d backward).  Co, Ci, row0, nrows multiples of 32. */
+int mfpa_pack_conv_weights(const float* w, int taps, int Co, int Ci, int flip_transpose, int row0, int nrows, int precision,
+                           float* out, void* stream);
 /* torch.optim.Adam step (train.py:661: lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay) on flat
  * arrays; g is multiplied by grad_scale first (1/world_size after a SUM all-reduce). step >= 1. */
 int mfpa_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,

@@ -876,6 +876,42 @@ inline int grid_for(long long work, int per_block = 256, int cap = 256 * 16) {
   return (int)(b < 1 ? 1 : b);
 }
 
+// Convolution weights [tap][Co][Ci] (the master fp32 layout) -> the operand image a conv launch reads: rows n, K-contiguous,
+// every 32-element chunk of K either 32 floats (precision 0) or [32 bf16 hi | 32 bf16 lo] (precision 1: the LDS row format of the
+// bf16x3 kernels).  TR = false: n = co in [row0, row0 + nrows), k = ci (forward).  TR = true: the input-gradient operand --
+// tap t reads source tap taps-1-t when taps == 9 (the 3x3 kernel flipped; the 2x2 transposed conv keeps its tap), n = ci in
+// [row0, row0 + nrows), k = co.  One workgroup per 32 x 32 (n, k) tile and tap, transposed through LDS so both sides coalesce.
+template <bool TR>
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, int taps, int Co, int Ci, int row0,
+                                                                int nrows, int precision, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, t = blockIdx.z;
+  const int ts = (TR && taps == 9) ? taps - 1 - t : t;
+  const int K = TR ? Co : Ci;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    // source element (n = n0 + .., k = k0 + ..): TR: w[ts][co = k][ci = row0 + n], contiguous along n; else w[ts][co = row0 + n][ci = k]
+    if (TR) tile[r][tx] = w[((size_t)ts * Co + (k0 + r)) * Ci + row0 + n0 + tx];          // tile[k][n]
+    else tile[r][tx] = w[((size_t)ts * Co + (row0 + n0 + r)) * Ci + k0 + tx];             // tile[n][k]
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const float v = TR ? tile[tx][r] : tile[r][tx];                  // (n = n0 + r, k = k0 + tx)
+    float* orow = out + ((size_t)t * nrows + n0 + r) * K + k0;       // this row's 32-element chunk (128 bytes)
+    if (precision == 0) {
+      orow[tx] = v;
+    } else {
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      __bf16* ob = reinterpret_cast<__bf16*>(orow);
+      ob[tx] = hi;
+      ob[32 + tx] = lo;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1140,6 +1176,20 @@ int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dp
   hipLaunchKernelGGL(l1_kernel, dim3(nblk), dim3(256), 0, s, pred, target, n, dpred, workspace);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, s, workspace, nblk, n, loss);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_pack_conv_weights(const float* w, int taps, int Co, int Ci, int flip_transpose, int row0, int nrows, int precision,
+                            float* out, void* stream) {
+  if (!w || !out || taps < 1 || Co < 32 || Ci < 32 || Co % 32 || Ci % 32 || nrows < 32 || nrows % 32 || row0 < 0 || row0 % 32)
+    return MFPA_EINVAL;
+  if (precision != 0 && precision != 1) return MFPA_EINVAL;
+  if (row0 + nrows > (flip_transpose ? Ci : Co)) return MFPA_EINVAL;
+  const int K = flip_transpose ? Co : Ci;
+  dim3 grid(K / 32, nrows / 32, taps);
+  if (flip_transpose) hipLaunchKernelGGL(pack_conv_weights_kernel<true>, grid, dim3(256), 0, mfpa_stream(stream), w, taps, Co, Ci, row0, nrows, precision, out);
+  else hipLaunchKernelGGL(pack_conv_weights_kernel<false>, grid, dim3(256), 0, mfpa_stream(stream), w, taps, Co, Ci, row0, nrows, precision, out);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -12,6 +12,7 @@ backward, and Adam is one fused launch over the whole buffer.
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -50,12 +51,34 @@ def _drop(st):
     return st.drop if st is not None else (0, 0, 1.0)
 
 
+DEVICE_PACK = bool(int(os.environ.get("MFPA_DEVICE_PACK", "1")))    # operand images of the weights built by mfpa_pack_conv_weights (False: the torch flip / transpose / split ops)
+
+
+def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, row0: int = 0, nrows: Optional[int] = None):
+    """Master weights [taps][Co][Ci] -> the operand image of one conv launch (see mfpa_pack_conv_weights): forward operand, or with
+    flip_transpose the input-gradient operand [taps][ci in row0..row0+nrows][Co] (3x3 kernels flipped)."""
+    taps, Co, Ci = w.shape
+    if nrows is None:
+        nrows = (Ci if flip_transpose else Co) - row0
+    if not DEVICE_PACK:
+        if flip_transpose:
+            w = (w.flip(0) if taps == 9 else w).transpose(1, 2)[:, row0:row0 + nrows].contiguous()
+        else:
+            w = w[:, row0:row0 + nrows].contiguous()
+        return K.split_bf16x3(w) if precision == 1 else w
+    out = torch.empty((taps, nrows, Co if flip_transpose else Ci), dtype=torch.float32, device=w.device)
+    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, precision, ptr(out), stream()),
+          "mfpa_pack_conv_weights")
+    return out
+
+
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
-              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0):
+              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False):
     """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
-    `w` (fp32, kernel layout) is split into the bf16 hi|lo row format here."""
-    if precision == 1:
-        w = K.split_bf16x3(w)
+    `w` (fp32, kernel layout) is split into the bf16 hi|lo row format here unless it already is an operand image (`packed`)."""
+    if precision == 1 and not packed:
+        w = pack_weights(w, 1) if (DEVICE_PACK and w.is_contiguous() and w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0) \
+            else K.split_bf16x3(w)
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -356,8 +379,8 @@ class UNetTrainEngine:
         cout = r["z3"].shape[-1]
         dz3 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b")
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision)
-        wt3 = self.P[prefix + ".3.w"].flip(0).transpose(1, 2).contiguous()          # [tap'][ci][co]
-        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision)
+        wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True)   # [tap'][ci][co]
+        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True)
         del dz3
         dz0 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b")
         if r["first_input"] is not None:
@@ -371,14 +394,13 @@ class UNetTrainEngine:
         if not need_input_grad:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
-        wt0 = w0.flip(0).transpose(1, 2)                                            # (9, cin, cout) view
         c0 = r["src0"].shape[-1]
-        d0 = conv_mfma(dz0, wt0[:, :c0].contiguous(), c0, precision=self.precision)
+        d0 = conv_mfma(dz0, pack_weights(w0, self.precision, True, 0, c0), c0, precision=self.precision, packed=True)
         d1 = None
         if r["src1"] is not None:
             c1 = r["src1"].shape[-1]
-            d1 = conv_mfma(dz0, wt0[:, c0:].contiguous(), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
-                           precision=self.precision)
+            d1 = conv_mfma(dz0, pack_weights(w0, self.precision, True, c0, c1), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
+                           precision=self.precision, packed=True)
         return d0, d1
 
     def backward(self, dpred):
@@ -404,8 +426,8 @@ class UNetTrainEngine:
             prev = r["up_in"]
             wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"],
                        precision=self.wgrad_precision)
-            wt = self.P[name + ".up.w"].transpose(1, 2).contiguous()                # (4, cin, cout)
-            dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision)
+            wt = pack_weights(self.P[name + ".up.w"], self.precision, flip_transpose=True)   # (4, cin, cout), taps kept
+            dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision, packed=True)
             handles.append(self._reduce_bucket(name))
         for i in range(len(ENC) - 1, -1, -1):                                       # down4 ... inc
             name = ENC[i]

@@ -292,3 +292,20 @@ def test_train_step_bf16x3_forward_and_dgrad():
     # the plain-bf16 weight gradient adds little on top of what the bf16x3 input-gradient chain already carries
     extra = sorted(rel(out[2][2][k], out[1][2][k]) for k in out[0][2])
     assert extra[len(extra) // 2] < 1e-2, extra[len(extra) // 2]
+
+
+def test_device_weight_pack_equals_the_host_packing():
+    """mfpa_pack_conv_weights against the torch flip / transpose / bf16 split it replaces: forward and input-gradient operand
+    images, both precisions, 3x3 and 2x2 kernels, channel sub-ranges -- bit for bit."""
+    from musicfpaugment_amd import ops_train as T
+    g = torch.Generator().manual_seed(5)
+    for taps, co, ci in [(9, 64, 128), (9, 128, 64), (4, 64, 128), (9, 96, 32)]:
+        w = torch.randn(taps, co, ci, generator=g).cuda()
+        for prec in (0, 1):
+            for ft, row0, nrows in [(False, 0, None), (True, 0, None), (True, 32, ci - 32) if ci > 32 else (True, 0, 32)]:
+                T.DEVICE_PACK = True
+                got = T.pack_weights(w, prec, ft, row0, nrows)
+                T.DEVICE_PACK = False
+                want = T.pack_weights(w, prec, ft, row0, nrows)
+                T.DEVICE_PACK = True
+                assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), (taps, co, ci, prec, ft)
