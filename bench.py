@@ -2,16 +2,21 @@
 """Benchmark of the musicFPaugment hot path on MI355X.
 
 Metric (BASELINE.json): 8 s / 8 kHz clips per second through STFT + UNet + peak-pick.
-One "step" = one pass of the whole chain (fused STFT-magnitude -> UNet eval forward on fp32 MFMA
--> Audfprint log/high-pass + forward/backward pruning) over a batch of synthetic clips that is
-already resident in HBM.  N GPUs = N processes, each with its own batch (weak scaling; clips are
-independent, no data-path collective).
+One "step" = one pass of the whole chain (fused STFT-magnitude -> UNet eval forward, by default with
+bf16x3 products on the bf16 matrix cores (every fp32 product as three bf16 MFMAs, fp32 accumulate;
+--precision fp32 = exact fp32 MFMA) -> Audfprint log/high-pass + forward/backward pruning) over a
+batch of synthetic clips that is already resident in HBM.  N GPUs = N processes, each with its own
+batch (weak scaling; clips are independent, no data-path collective).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the MFMA implicit-GEMM
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(a child `python -m torch.distributed.run ...`, before this process touches the GPU) and relays rank 0's line.
+Rank 0 prints ONE JSON line; at N = 1 the headline line also carries `configs`: the other BASELINE.json
+configurations (STFT + peak-pick without the UNet for both pickers, the UNet train step, the Demucs forward)
+timed for a few steps each in the same process, each with its own `roofline`.  `roofline` is for the dominant kernel family (the MFMA implicit-GEMM
 convolutions of the UNet): algorithmic FLOPs / HIP-event time of those launches inside the timed
 region.  `cpu_baseline` times the CPU oracle (the numpy/torch-CPU restatement of the reference)
 on a bounded sample of the same workload on this box's host cores (N=1 only).
@@ -33,20 +38,18 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
+PMC_TRAFFIC_BF16X3 = "r01d_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
 
 
-def cpu_baseline(budget_s: float, seed: int):
-    """The oracle chain (reference algorithms on the CPU), one clip at a time like the reference, for about
-    `budget_s` seconds of wall time on this box's host cores -> clips/s.  torch's intra-op thread count is
-    calibrated first (batch-1 convolutions get SLOWER with hundreds of threads); `cores` = threads used."""
-    from musicfpaugment_amd import synth
+def _oracle_chain():
+    """The reference's per-clip chain on the CPU oracle (afp/audfprint/peak_extractor.py:236-311): numpy float64 STFT ->
+    torch-CPU fp32 UNet forward (batch 1) -> numpy log / high-pass + forward / backward prune.  Checker code, timed as the baseline."""
     from musicfpaugment_amd.training.weights import formula_state_dict
     from oracle import audfprint as oa
     from oracle import stft as ostft
     from oracle import unet as ou
 
     sd = formula_state_dict(0)
-    wav = synth.batch(8, seed=seed)
 
     def one(w):
         sg = ostft.magnitude(w)
@@ -54,8 +57,51 @@ def cpu_baseline(budget_s: float, seed: int):
         with torch.no_grad():
             den = ou.forward(torch.from_numpy(sg).float()[None, None], sd)[0, 0].numpy()
         return oa.find_peaks_from_sgram(den)[1]
+    return one
 
-    ncpu = os.cpu_count() or 1
+
+def _cpu_worker(barrier, queue, threads, seed, budget_s):
+    """One worker of the all-core CPU leg: warm up, meet the others at the barrier, then run clips for `budget_s` seconds."""
+    from musicfpaugment_amd import synth
+    torch.set_num_threads(threads)
+    one = _oracle_chain()
+    wav = synth.batch(4, seed=seed)
+    one(wav[0])
+    barrier.wait()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(wav[n % len(wav)])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    queue.put((n, dt))
+
+
+def _host_cores() -> int:
+    """Cores this process may use: the affinity mask, capped by the cgroup's CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(budget_s: float, seed: int):
+    """The oracle chain (reference algorithms on the CPU) on this box's host cores -> clips/s, two ways:
+    `value`: one clip at a time like the reference, torch's intra-op thread count calibrated first (batch-1 convolutions get
+    SLOWER with hundreds of threads), `cores` = the threads used; `all_core_value`: host cores // cores worker processes of that
+    thread count running the same per-clip chain side by side (what the same host delivers when every core is put to work)."""
+    import multiprocessing as mp
+    from musicfpaugment_amd import synth
+
+    one = _oracle_chain()
+    wav = synth.batch(8, seed=seed)
+    ncpu = _host_cores()
     best_thr, best_t = None, None
     for thr in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
         torch.set_num_threads(thr)
@@ -93,11 +139,39 @@ def cpu_baseline(budget_s: float, seed: int):
                     break
     except OSError:
         pass
-    return {"value": round(n / dt, 4), "unit": "clips/s", "cores": best_thr, "kind": "port",
-            "one_thread_value": round(one_thread, 4), "host_cpu_count": ncpu, "host_cpu_model": model,
-            "sample": f"{n} synthetic 8 s clips in {dt:.1f} s, one at a time like the reference "
-                      f"(peak_extractor.py:236-311): numpy float64 STFT -> torch-CPU fp32 UNet forward (batch 1, "
-                      f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
+    out = {"value": round(n / dt, 4), "unit": "clips/s", "cores": best_thr, "kind": "port",
+           "one_thread_value": round(one_thread, 4), "host_cpu_count": ncpu, "host_cpu_model": model,
+           "sample": f"{n} synthetic 8 s clips in {dt:.1f} s, one at a time like the reference "
+                     f"(peak_extractor.py:236-311): numpy float64 STFT -> torch-CPU fp32 UNet forward (batch 1, "
+                     f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
+    # every core at work: W processes x best_thr threads, started together (spawned before this process owns a GPU)
+    workers = max(1, min(32, ncpu // best_thr))
+    try:
+        ctx = mp.get_context("spawn")
+        barrier, queue = ctx.Barrier(workers), ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(barrier, queue, best_thr, seed + 100 * (k + 1), budget_s)) for k in range(workers)]
+        for p in procs:
+            p.start()
+        got, deadline = [], time.perf_counter() + 180 + 4 * budget_s
+        while len(got) < workers:
+            try:
+                got.append(queue.get(timeout=2.0))
+            except Exception:
+                if time.perf_counter() > deadline or any(p.exitcode not in (None, 0) for p in procs):
+                    raise RuntimeError("a CPU worker failed or timed out")
+        for p in procs:
+            p.join(timeout=30)
+        out["all_core_value"] = round(sum(c / t for c, t in got), 4)
+        out["all_core_cores"] = workers * best_thr
+        out["all_core_sample"] = (f"{workers} worker processes x {best_thr} threads, {sum(c for c, _ in got)} clips in "
+                                  f"{max(t for _, t in got):.1f} s, the same per-clip chain in every worker")
+    except Exception as e:                       # the batch-1 figure above stands on its own
+        out["all_core_value"] = None
+        out["all_core_sample"] = f"not measured: {type(e).__name__}: {e}"
+        for p in locals().get("procs", []):
+            if p.is_alive():
+                p.terminate()
+    return out
 
 
 def _demucs_traffic(B):
@@ -150,10 +224,11 @@ def bench_demucs(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    result = None
     if rank == 0:
         gemm_ms = timer.total_ms()
         achieved = 20.13e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12
-        print(json.dumps({
+        result = ({
             "metric": "8s/8kHz clips/sec (Demucs forward + STFT + peak-pick)", "value": round(world * B * args.steps / dt_max, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -173,9 +248,8 @@ def bench_demucs(args, rank, world, dev, dist):
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           "kernel": "gemm_mfma_kernel + lstm_step_kernel (bf16x3)", "launches": timer.launches(),
-                          "kernel_ms_per_step": round(gemm_ms / args.steps, 3)})}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+                          "kernel_ms_per_step": round(gemm_ms / args.steps, 3)})})
+    return result
 
 
 def bench_metrics(args, rank, world, dev, dist):
@@ -233,8 +307,9 @@ def bench_metrics(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    result = None
     if rank == 0:
-        print(json.dumps({
+        result = ({
             "metric": "queries/sec (peak-metrics experiment: 3 peak extractions + denoiser + P/R/F1/PSNR per query)",
             "value": round(N * args.steps / dt_max, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
@@ -242,9 +317,8 @@ def bench_metrics(args, rank, world, dev, dist):
             "config": {"workload": f"{N} synthetic 8 s queries (AugmentFP on the device), denoiser {args.denoiser}, Audfprint "
                                    "peaks, per-query precision/recall/F1/PSNR means", "queries": N,
                        "parallelism": f"queries sharded x{world}, one all-gather of the per-query rows"},
-            "result": {k: round(v, 6) for k, v in res.items()}}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+            "result": {k: round(v, 6) for k, v in res.items()}})
+    return result
 
 
 def bench_demucs_train(args, rank, world, dev, dist):
@@ -302,12 +376,13 @@ def bench_demucs_train(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    result = None
     if rank == 0:
         gemm_ms = timer.total_ms()
         gflop = 3 * 20.13 * n / 64000.0                  # forward + input gradients + weight gradients, per clip
         achieved = gflop * 1e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12
         phases = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in eng.phases.items()}
-        print(json.dumps({
+        result = ({
             "metric": f"{args.seconds:g}s/8kHz clips/sec (Demucs train step: fwd + L1 + MRSTFT loss + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
@@ -323,9 +398,8 @@ def bench_demucs_train(args, rank, world, dev, dist):
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "gemm_bf16x3_kernel / gemm_mfma_kernel (forward, input gradients, the loss's DFT GEMMs) + "
                                    "gemm_tn(_bf16)_kernel (weight gradients) + lstm_step(_bwd)_kernel", "launches": timer.launches(),
-                         "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+                         "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}})
+    return result
 
 
 def bench_train(args, rank, world, dev, dist):
@@ -344,7 +418,7 @@ def bench_train(args, rank, world, dev, dist):
     net = net.to(dev).train()
     wprec = {"fp32": 0, "bf16x3": 1, "bf16": 2}[args.wgrad]
     eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0, wgrad_precision=wprec,
-                          sync_bn=args.sync_bn)
+                          sync_bn=args.sync_bn, collectives_at_world_one=dist is not None)
     nsamp = int(args.seconds * 8000)
     base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank, n=nsamp)
     noise = synth.batch(min(B, 16), seed=7000 + 1000 * rank, tonal=False, n=nsamp)
@@ -382,6 +456,7 @@ def bench_train(args, rank, world, dev, dist):
     barrier()
     timer = ops_unet.KernelTimer()
     ops_unet.set_timer(timer)
+    comm0 = (eng.comm_calls, eng.comm_bytes)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -392,12 +467,16 @@ def bench_train(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    # collectives per step: the engine's gradient buckets (+ SyncBN sums) and the two scalar MAX all-reduces of the spectrogram maxima
+    ar_calls = (eng.comm_calls - comm0[0]) // args.steps + (2 if dist is not None else 0)
+    ar_bytes = (eng.comm_bytes - comm0[1]) // args.steps + (16 if dist is not None else 0)
+    result = None
     if rank == 0:
         mfma_gflop = (280.1 - 3 * 0.082) * (1 + nsamp // 256) / 251.0   # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU); scales with the frames
         conv_ms = timer.total_ms()
         achieved = mfma_gflop * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12
         issue_x = 2.0 + {"bf16x3": 3, "bf16": 1, "fp32": 0}[args.wgrad] / 3.0      # fp32 weight gradients run on the fp32 cores
-        print(json.dumps({
+        result = ({
             "metric": f"{args.seconds:g}s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
@@ -407,7 +486,8 @@ def bench_train(args, rank, world, dev, dist):
                      else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), {args.seconds:g} s clips 257x{1 + nsamp // 256}, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
-                       "clips_per_gpu_per_step": B, "loss_last": float(loss),
+                       "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "loss_last": float(loss),
+                       "allreduce_calls_per_step": ar_calls, "allreduce_bytes_per_step": ar_bytes,
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
                                       + ("synchronised (global-batch)" if eng.sync_bn else "per-GPU")
                                       + " BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
@@ -421,78 +501,12 @@ def bench_train(args, rank, world, dev, dist):
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           "kernel": "conv_mfma_kernel<PREC 0> + wgrad_mfma_kernel", "launches": timer.launches(),
-                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)})}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)})})
+    return result
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=256, help="clips per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
-    ap.add_argument("--picker", choices=["audfprint", "dejavu"], default="audfprint",
-                    help="infer mode: the peak picker after the UNet (dejavu: specgram PSD, UNet output squared, 21x21 local maxima)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
-                    help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
-                         "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
-                         "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
-    ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
-    ap.add_argument("--wgrad", choices=["fp32", "bf16x3", "bf16"], default=None,
-                    help="train mode: arithmetic of the weight-gradient kernel (default: bf16 with --precision bf16x3 -- one bf16 MFMA "
-                         "per product, the sum over all pixels averages the rounding: relative L1 2e-3 per layer -- else fp32)")
-    ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: BatchNorm statistics over the global batch")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
-    ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
-    ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
-    ap.add_argument("--unet-pass", type=int, default=0, help="infer mode: clips per UNet pass (0 = the module default)")
-    ap.add_argument("--seconds", type=float, default=8.0, help="train / demucs-train modes: clip length (the reference trains on 3 s)")
-    ap.add_argument("--mode", choices=["infer", "train", "demucs", "demucs-train", "metrics"], default="infer",
-                    help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
-                         "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
-                         "config 5's Demucs waveform denoiser forward + STFT + peak-pick")
-    args = ap.parse_args()
-    if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
-        args.precision = "bf16x3"
-    if args.wgrad is None:
-        args.wgrad = "bf16" if args.precision == "bf16x3" else "fp32"
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    backend = os.environ.get("MFPA_DIST_BACKEND", "nccl")          # "gloo": several ranks may share one GPU (tests only)
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
-        else:
-            dist.init_process_group(backend)
-
-    if args.mode == "train":
-        return bench_train(args, rank, world, dev, dist)
-    if args.mode == "demucs":
-        return bench_demucs(args, rank, world, dev, dist)
-    if args.mode == "demucs-train":
-        return bench_demucs_train(args, rank, world, dev, dist)
-    if args.mode == "metrics":
-        return bench_metrics(args, rank, world, dev, dist)
-
+def bench_infer(args, rank, world, dev, dist):
+    """The headline (BASELINE.json metric): STFT -> UNet eval forward -> peak-pick; --no-unet = BASELINE configs[1]."""
     from musicfpaugment_amd import ops_unet, synth
     from musicfpaugment_amd.pipeline import HotPath, unet_mfma_gflop
     from musicfpaugment_amd.training.unet import UNet
@@ -507,7 +521,7 @@ def main():
         net.precision = 1 if args.precision == "bf16x3" else 0
         if args.unet_pass > 0:
             net.max_clips_per_pass = args.unet_pass
-        net.two_streams = bool(int(os.environ.get("MFPA_UNET_TWO_STREAMS", "0")))
+        net.two_streams = bool(args.two_streams)
     hot = HotPath(net, device=dev, picker=args.picker)
     UNET_MFMA_GFLOP_PER_CLIP = unet_mfma_gflop(257, 251 if args.picker == "audfprint" else 249)
 
@@ -538,7 +552,7 @@ def main():
     barrier()
     dt, timer, (mask, npeaks) = timed(args.steps)
     other = None
-    if net is not None and world == 1:        # the other arithmetic, same run, for the record (not the headline)
+    if net is not None and world == 1 and not args.sub_config:   # the other arithmetic, same run, for the record (not the headline)
         net.precision = 1 - net.precision
         hot(wav)
         barrier()
@@ -552,77 +566,261 @@ def main():
     dt_max = float(t.item())
     total_peaks = int(npeaks.sum().item())
 
-    if rank == 0:
-        clips = world * B * args.steps
-        out = {
-            "metric": ("8s/8kHz clips/sec (STFT+UNet+peak-pick)" if net is not None else "8s/8kHz clips/sec (STFT+peak-pick, no UNet)")
-                      + (" [Dejavu picker]" if args.picker == "dejavu" else ""),
-            "value": round(clips / dt_max, 3),
-            "unit": "clips/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt_max / args.steps, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "f32")
-                     if net is not None else "f64",
-            "data": "synthetic",
-            "config": {"workload": (f"STFT(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights) -> "
-                                    "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms") if net is not None and args.picker == "audfprint" else
-                                   (f"mlab.specgram PSD(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights), squared -> "
-                                    "Dejavu 21x21 local-max pick; 8 s / 8 kHz clips, 257x249 spectrograms") if net is not None else
-                                   "mlab.specgram PSD -> /max -> 10 ln / mean -> Dejavu 21x21 local-max pick; 8 s / 8 kHz clips" if args.picker == "dejavu" else
-                                   "STFT(512/256,f64) -> per-clip normalise -> log/mean/high-pass -> Audfprint forward+backward "
-                                   "prune (BASELINE configs[1]); 8 s / 8 kHz clips",
-                       "clips_per_gpu_per_step": B, "peaks_last_step_rank0": total_peaks,
-                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        }
-        def roofline(tm, precision):
-            conv_ms = tm.total_ms()
-            flops = UNET_MFMA_GFLOP_PER_CLIP * 1e9 * B * args.steps
-            achieved = flops / (conv_ms * 1e-3) / 1e12        # ALGORITHMIC TFLOP/s of the MFMA conv launches
-            if precision == "fp32":
-                return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                        "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
-            traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01d_pmc_traffic_bf16x3.json")
-            if os.path.exists(pmc):      # HBM bytes per step from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                with open(pmc) as fh:    # (FETCH_SIZE x2 per MI355X_MICROARCH.md), scaled to this batch size
-                    traffic = json.load(fh)["per_256_clip_step_bytes"] * B / 256.0
-                tsrc = "profiles/r01d_pmc_traffic_bf16x3.json (offline PMC passes, bytes per step of all MFMA conv launches)"
-            return {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
-                    "mfma_flops_issued_per_algorithmic_flop": 3,
-                    "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "kernel": "conv_mfma_kernel<PREC 1> + convT_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 "
-                              "per fp32 product)",
-                    "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+    if rank != 0:
+        return None
+    clips = world * B * args.steps
+    out = {
+        "metric": ("8s/8kHz clips/sec (STFT+UNet+peak-pick)" if net is not None else "8s/8kHz clips/sec (STFT+peak-pick, no UNet)")
+                  + (" [Dejavu picker]" if args.picker == "dejavu" else ""),
+        "value": round(clips / dt_max, 3),
+        "unit": "clips/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt_max / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, fp32 accumulate)" if args.precision == "bf16x3" else "f32")
+                 if net is not None else "f64",
+        "data": "synthetic",
+        "config": {"workload": (f"STFT(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights) -> "
+                                "Audfprint peak-pick; 8 s / 8 kHz clips, 257x251 spectrograms") if net is not None and args.picker == "audfprint" else
+                               (f"mlab.specgram PSD(512/256,f64) -> UNet(1,1) eval forward ({args.precision} MFMA, formula weights), squared -> "
+                                "Dejavu 21x21 local-max pick; 8 s / 8 kHz clips, 257x249 spectrograms") if net is not None else
+                               "mlab.specgram PSD -> /max -> 10 ln / mean -> Dejavu 21x21 local-max pick; 8 s / 8 kHz clips" if args.picker == "dejavu" else
+                               "STFT(512/256,f64) -> per-clip normalise -> log/mean/high-pass -> Audfprint forward+backward "
+                               "prune (BASELINE configs[1]); 8 s / 8 kHz clips",
+                   "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "peaks_last_step_rank0": total_peaks,
+                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
+    }
 
-        if net is not None and timer.launches():
-            out["roofline"] = roofline(timer, args.precision)
-        if net is None:
-            # fused STFT -> magnitude -> mask moves 578 284 algorithmic bytes per clip (256 000 B of samples in,
-            # the float32 spectrogram out and back in, 64 256 B of mask out).  The chain is three short launches whose
-            # pruner walks 251 frames sequentially per clip: at 256 clips it is latency-bound, not bandwidth-bound.
-            # Dejavu: 256 000 B of samples in, the float64 PSD out and back in (257 x 249 x 8 = 511 944 B), 63 993 B of mask out.
-            per_clip = 578284.0 if args.picker == "audfprint" else 256000.0 + 511944.0 + 63993.0
-            gbs = per_clip * B * args.steps / dt_max / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(gbs / 8000.0, 5), "traffic": None,
-                               "kernel": "stft_kernel + prepare_kernel + prune_kernel (whole chain, wall clock)" if args.picker == "audfprint"
-                               else "stft_kernel (PSD) + dejavu_prepare_kernel + localmax2d_kernel (whole chain, wall clock)"}
-        if other is not None:
-            oname = "fp32" if args.precision == "bf16x3" else "bf16x3"
-            out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),
-                                      "unit": "clips/s", "ms_per_step": round(1e3 * other[0] / args.steps, 3),
-                                      "roofline": roofline(other[1], oname)}
-        if world == 1 and args.cpu_seconds > 0 and net is not None and args.picker == "audfprint":   # the baseline times the Audfprint chain
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, synth.BASE_SEED)
-        print(json.dumps(out), flush=True)
+    def roofline(tm, precision):
+        conv_ms = tm.total_ms()
+        flops = UNET_MFMA_GFLOP_PER_CLIP * 1e9 * B * args.steps
+        achieved = flops / (conv_ms * 1e-3) / 1e12        # ALGORITHMIC TFLOP/s of the MFMA conv launches
+        if precision == "fp32":
+            return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                    "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+        traffic, tsrc = None, None
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_BF16X3)
+        if os.path.exists(pmc):      # HBM bytes per step from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            with open(pmc) as fh:    # (FETCH_SIZE x2 per MI355X_MICROARCH.md), scaled to this batch size
+                traffic = json.load(fh)["per_256_clip_step_bytes"] * B / 256.0
+            tsrc = f"profiles/{PMC_TRAFFIC_BF16X3} (offline PMC passes, bytes per step of all MFMA conv launches)"
+        return {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "mfma_flops_issued_per_algorithmic_flop": 3,
+                "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                "kernel": "conv_mfma_kernel<PREC 1> + convT_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 "
+                          "per fp32 product)",
+                "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
+
+    if net is not None and timer.launches():
+        out["roofline"] = roofline(timer, args.precision)
+    if net is None:
+        # fused STFT -> magnitude -> mask moves 578 284 algorithmic bytes per clip (256 000 B of samples in,
+        # the float32 spectrogram out and back in, 64 256 B of mask out).  The chain is three short launches whose
+        # pruner walks 251 frames sequentially per clip: at 256 clips it is latency-bound, not bandwidth-bound.
+        # Dejavu: 256 000 B of samples in, the float64 PSD out and back in (257 x 249 x 8 = 511 944 B), 63 993 B of mask out.
+        per_clip = 578284.0 if args.picker == "audfprint" else 256000.0 + 511944.0 + 63993.0
+        gbs = per_clip * B * args.steps / dt_max / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(gbs / 8000.0, 5), "traffic": None,
+                           "kernel": "stft_kernel + prepare_kernel + prune_kernel (whole chain, wall clock)" if args.picker == "audfprint"
+                           else "stft_kernel (PSD) + dejavu_prepare_kernel + localmax2d_kernel (whole chain, wall clock)"}
+    if other is not None:
+        oname = "fp32" if args.precision == "bf16x3" else "bf16x3"
+        out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),
+                                  "unit": "clips/s", "ms_per_step": round(1e3 * other[0] / args.steps, 3),
+                                  "roofline": roofline(other[1], oname)}
+    return out
+
+
+def bench_launch_check(args, rank, world, dist):
+    """--mode launch-check (tests only): the launcher, the rendezvous, one MAX all-reduce of a host scalar and the one-line JSON
+    relay, with NO kernel launched -- it measures nothing and says so.  It lets the `python bench.py --gpus N` self-launch
+    path run where there is no GPU (the hot path itself has no CPU fallback)."""
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    if dist is not None:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    return {"metric": "launch-check (launcher / rendezvous / JSON relay only; no kernel ran, nothing was measured)", "value": None,
+            "unit": "clips/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+            "config": {"workload": "none", "max_rank_seen": int(t.item())}}
+
+
+def _sub_args(args, **kw):
+    a = argparse.Namespace(**vars(args))
+    a.sub_config = True
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def other_configs(args, dev):
+    """N = 1 only: the other BASELINE.json configurations, a few steps each in this same process, nested under `configs`
+    (each entry is the line its own mode would print, minus what only the headline carries)."""
+    import gc
+    out = {}
+    plan = [
+        ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
+        ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
+        ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=1, warmup=1, clips=512)),
+        ("config4_unet_train_step", bench_train, dict(mode="train", steps=3, warmup=1, clips=64, seconds=8.0)),
+        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=3, warmup=1, clips=256)),
+    ]
+    for name, fn, kw in plan:
+        t0 = time.perf_counter()
+        try:
+            r = fn(_sub_args(args, **kw), 0, 1, dev, None)
+        except Exception as e:                                  # a sub-config must never take the headline line down with it
+            r = {"error": f"{type(e).__name__}: {e}"}
+        if isinstance(r, dict):
+            for k in ("higher_is_better", "vs_baseline", "data", "n_gpus"):
+                r.pop(k, None)
+            r["wall_s_including_setup"] = round(time.perf_counter() - t0, 2)
+        out[name] = r
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def _self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a CHILD process tree -- this process has
+    not touched the GPU and never execs -- relay rank 0's JSON line on stdout, everything else on stderr, and return the child's code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        return proc.returncode
+    return 0 if line is not None else 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=None, help="clips per GPU per step (default 256; train / demucs-train 64)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of each CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1 infer mode: skip the `configs` block (the other BASELINE configurations)")
+    ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
+    ap.add_argument("--picker", choices=["audfprint", "dejavu"], default="audfprint",
+                    help="infer mode: the peak picker after the UNet (dejavu: specgram PSD, UNet output squared, 21x21 local maxima)")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
+                    help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
+                         "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
+                         "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
+    ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
+    ap.add_argument("--wgrad", choices=["fp32", "bf16x3", "bf16"], default=None,
+                    help="train mode: arithmetic of the weight-gradient kernel (default: bf16 with --precision bf16x3 -- one bf16 MFMA "
+                         "per product, the sum over all pixels averages the rounding: relative L1 2e-3 per layer -- else fp32)")
+    ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: BatchNorm statistics over the global batch")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
+    ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
+    ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
+    ap.add_argument("--unet-pass", type=int, default=0, help="infer mode: clips per UNet pass (0 = the module default)")
+    ap.add_argument("--two-streams", action="store_true", help="infer mode: alternate the UNet passes of a step on two streams")
+    ap.add_argument("--seconds", type=float, default=8.0, help="train / demucs-train modes: clip length (the reference trains on 3 s)")
+    ap.add_argument("--mode", choices=["infer", "train", "demucs", "demucs-train", "metrics", "launch-check"], default="infer",
+                    help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
+                         "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
+                         "config 5's Demucs waveform denoiser forward + STFT + peak-pick; launch-check: launcher plumbing only (tests)")
+    ap.add_argument("--lib", default=None, help="experiments only: bind another build of the library (e.g. musicfpaugment_amd/libmfpa_exp.so)")
+    args = ap.parse_args()
+    args.sub_config = False
+    if args.lib:
+        from musicfpaugment_amd import _lib
+        _lib.set_library_path(args.lib)
+    if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
+        args.precision = "bf16x3"
+    if args.wgrad is None:
+        args.wgrad = "bf16" if args.precision == "bf16x3" else "fp32"
+    if args.clips is None:
+        args.clips = 64 if args.mode in ("train", "demucs-train") else 256
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # before anything touches the GPU
+        raise SystemExit(_self_launch(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.gpus = world
+    backend = os.environ.get("MFPA_DIST_BACKEND", "nccl")          # "gloo": several ranks may share one GPU (tests only)
+
+    if args.mode == "launch-check":
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        result = bench_launch_check(args, rank, world, dist)
+        if result is not None:
+            print(json.dumps(result), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # CPU legs first (N = 1 headline only): they need no GPU and their worker processes are started before this process owns one
+    cpu = None
+    if world == 1 and args.mode == "infer" and args.cpu_seconds > 0 and not args.no_unet and args.picker == "audfprint":
+        if torch.cuda.device_count() < 1:
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        from musicfpaugment_amd import synth
+        cpu = cpu_baseline(args.cpu_seconds, synth.BASE_SEED)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or "WORLD_SIZE" in os.environ:                   # under torch.distributed.run even one rank goes through RCCL
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
+
+    fn = {"train": bench_train, "demucs": bench_demucs, "demucs-train": bench_demucs_train, "metrics": bench_metrics,
+          "infer": bench_infer}[args.mode]
+    result = fn(args, rank, world, dev, dist)
+    if rank == 0:
+        result["dist_backend"] = ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+        if world == 1 and args.mode == "infer" and not args.no_unet and not args.no_configs:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            result["configs"] = other_configs(args, dev)
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -14,7 +14,7 @@ from ctypes import c_double, c_float, c_int, c_longlong, c_uint, c_void_p
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MFPA_LIB", os.path.join(_HERE, "libmfpa.so"))    # MFPA_LIB: A/B experiments between two builds
+LIB_PATH = os.path.join(_HERE, "libmfpa.so")    # the environment cannot redirect it; tools/ A/B runs call set_library_path()
 
 EINVAL = -22
 EHIP = -1000
@@ -202,6 +202,15 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_library_path(path: str) -> None:
+    """tools/ and tests only: bind another build of the library (e.g. libmfpa_exp.so, the -DMFPA_EXPERIMENTS build) before the
+    first call.  The product path never calls this, and no environment variable redirects the library."""
+    global LIB_PATH, _lib
+    if _lib is not None:
+        raise MfpaError("set_library_path() must be called before the first libmfpa call")
+    LIB_PATH = os.path.abspath(path)
+
+
 def check(rc: int, what: str) -> None:
     if rc == 0:
         return
@@ -220,10 +229,15 @@ def ptr(t) -> int:
         raise MfpaError("libmfpa operates on GPU tensors only (no CPU fallback)")
     if not t.is_contiguous():
         raise MfpaError("libmfpa needs contiguous tensors")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream: a tensor of another GPU would fault or go through peer access
+        raise MfpaError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                        "call torch.cuda.set_device(...) (one process per GPU) or wrap the call in torch.cuda.device(t.device)")
     return t.data_ptr()
 
 
 def stream() -> int:
+    """HIP stream handle of torch's current stream on the current device (ptr() checks that every operand lives there)."""
     return torch.cuda.current_stream().cuda_stream
 
 

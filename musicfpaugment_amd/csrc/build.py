@@ -47,13 +47,17 @@ def _stamp(src: str, flags) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, experiments: bool = False, extra_flags=(), out: str = None) -> str:
+    """experiments=True: the A/B build of tools/ (-DMFPA_EXPERIMENTS: the environment switches of mfpa_common.h are live) ->
+    libmfpa_exp.so, which the package never loads on its own.  `extra_flags` / `out`: further tools-only variants."""
+    OUT = out or (os.path.join(PKG, "libmfpa_exp.so") if experiments else globals()["OUT"])
+    OBJ = os.path.join(HERE, "build" + ("_exp" if experiments else "") + ("_" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8] if extra_flags else ""))
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     objs = []
     for src in _sources():
-        flags = COMMON + PER_FILE.get(src, [])
+        flags = COMMON + PER_FILE.get(src, []) + (["-DMFPA_EXPERIMENTS"] if experiments else []) + list(extra_flags)
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         stamp_file = obj + ".stamp"
         stamp = _stamp(src, flags)
@@ -86,5 +90,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+def record(path: str = None) -> dict:
+    """Identity of a built library: sha256, size, hipcc version, flags (written to profiles/BUILD_rNN.txt by __graft_entry__.build())."""
+    path = path or OUT
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    src = hashlib.sha256()
+    for f in _sources() + sorted(x for x in os.listdir(HERE) if x.endswith(".h")) + ["../../include/mfpa.h"]:
+        with open(os.path.join(HERE, f), "rb") as fh:
+            src.update(f.encode() + b"\0" + fh.read())
+    return {"library": os.path.relpath(path, os.path.dirname(PKG)), "sha256": h.hexdigest(), "bytes": os.path.getsize(path),
+            "sources_sha256": src.hexdigest(), "hipcc": " | ".join(v for v in ver[:2]), "flags": " ".join(COMMON),
+            "per_file_flags": {k: " ".join(v) for k, v in PER_FILE.items()}}
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

@@ -977,7 +977,7 @@ __global__ __launch_bounds__(LTHREADS, 1) void lstm_step_kernel(const float* __r
 static int lstm_launch(const float* hprev, long long ldhp, const float* whh_grouped, const float* xp, long long ldxp, const float* cin,
                        long long ldci, float* cout, long long ldco, int B, int H, float* hout, long long ldh, float* hsum,
                        const float* addend, long long ldadd, float* gsave, long long ldgs, void* stream) {
-  static const int force = getenv("MFPA_LSTM_MT") ? atoi(getenv("MFPA_LSTM_MT")) : 0;
+  static const int force = MFPA_EXP_ENV("MFPA_LSTM_MT", 0);
   const int groups = H / LU;
   int MT = ((long long)groups * ((B + 31) / 32) <= 256) ? 1 : 2;
   if (force == 1 || force == 2) MT = force;
@@ -1022,7 +1022,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   a.C2 = d->C2; a.ldc2 = d->ldc2; a.strideC2 = d->strideC2;
   a.M = d->M; a.N = d->N; a.K = d->K; a.mode = d->mode; a.relu = d->relu;
   a.c1_x = d->c1_x; a.c1_lin = d->c1_lin; a.c1_w = d->c1_w; a.c1_b = d->c1_b;
-  static const int xcd_env = getenv("MFPA_GEMM_XCD") ? atoi(getenv("MFPA_GEMM_XCD")) : 1;   // 0: plain tile order (experiments)
+  static const int xcd_env = MFPA_EXP_ENV("MFPA_GEMM_XCD", 1);   // 0: plain tile order (experiments)
   a.ny = (d->M + GBM - 1) / GBM; a.nz = d->batch; a.nx = d->npad / GBN; a.xcd = xcd_env;
   if ((long long)a.nx * a.ny * a.nz > 0x3fffffffLL) return MFPA_EINVAL;
   auto grid1d = [&](int nx) { a.nx = nx; return dim3((unsigned)((((long long)nx * a.ny * a.nz + 7) / 8) * 8)); };
@@ -1031,9 +1031,9 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   // K >= 128: the chunked bf16x3 kernel.  (At first the K = 128 / 192 levels ran faster on the fp32 kernel; that was the
   // epilogue's serialised addend loads and 64-bit addressing, not the arithmetic: with those fixed the fp32 MFMA rate is what
   // bounds them -- PMC: 2.2 of 4.0 ms MFMA-busy on the K = 192 transposed convolution -- and bf16x3 is 10 % faster end to end.)
-  static const int shortk = getenv("MFPA_SHORTK") ? atoi(getenv("MFPA_SHORTK")) : 1;   // 0: the fp32-MFMA kernels for K < 256 (experiments)
+  static const int shortk = MFPA_EXP_ENV("MFPA_SHORTK", 1);   // 0: the fp32-MFMA kernels for K < 256 (experiments)
   hipStream_t st = mfpa_stream(stream);
-  static const int wide = getenv("MFPA_GEMM_WIDE") ? atoi(getenv("MFPA_GEMM_WIDE")) : 1;   // 0: always the 128 x 64 tile (experiments)
+  static const int wide = MFPA_EXP_ENV("MFPA_GEMM_WIDE", 1);   // 0: always the 128 x 64 tile (experiments)
   if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128 && wide && d->npad % WBN == 0) {
     dim3 gw = grid1d(d->npad / WBN);
     hipLaunchKernelGGL(gemm_bf16x3_wide_kernel, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);

@@ -666,7 +666,7 @@ int mfpa_gemm_tn(const mfpa_gemm_tn_desc* d, void* stream) {
   TnArgs a{};
   a.A = d->A; a.lda = d->lda; a.strideA = d->strideA; a.Bm = d->Bm; a.ldb = d->ldb; a.strideB = d->strideB;
   a.C = d->C; a.ldc = d->ldc; a.colsum = d->colsum; a.R = d->R; a.M = d->M; a.N = d->N; a.rs = (int)rs; a.spb = (int)spb;
-  static const int xcd_env = getenv("MFPA_GEMM_XCD") ? atoi(getenv("MFPA_GEMM_XCD")) : 1;
+  static const int xcd_env = MFPA_EXP_ENV("MFPA_GEMM_XCD", 1);
   a.tiles = (int)tiles; a.nsplit = (int)(spb * d->batch); a.xcd = xcd_env;
   if (tiles * a.nsplit > 0x3fffffffLL) return MFPA_EINVAL;
   dim3 grid((unsigned)(((tiles * a.nsplit + 7) / 8) * 8));
@@ -743,8 +743,8 @@ int mfpa_lstm_step_bwd(const float* dgnext, long long ldgn, const float* whhT, f
   if (B == 0) return MFPA_OK;
   if (!whhT || !gates || !ct || !dhout || !dcstate || B < 0 || H < BKC || H % BKC) return MFPA_EINVAL;
   if (ldgn % 4 || ldg % 4 || ldct % 4 || ldcp % 4 || lddh % 4) return MFPA_EINVAL;
-  static const int force = getenv("MFPA_LSTM_MT") ? atoi(getenv("MFPA_LSTM_MT")) : 0;
-  static const int force_bu = getenv("MFPA_LSTM_BU") ? atoi(getenv("MFPA_LSTM_BU")) : 0;
+  static const int force = MFPA_EXP_ENV("MFPA_LSTM_MT", 0);
+  static const int force_bu = MFPA_EXP_ENV("MFPA_LSTM_BU", 0);
   int MT = ((long long)(H / BU) * ((B + 31) / 32) <= 256) ? 1 : 2;   // 32-clip tiles while they leave the chip under-filled
   if (force == 1 || force == 2) MT = force;
   int but = (MT == 1 && (long long)(H / 16) * ((B + 31) / 32) <= 128) ? 16 : 32;   // 16-unit groups while even those leave half the chip free

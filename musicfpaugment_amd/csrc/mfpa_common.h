@@ -7,6 +7,18 @@
 
 #define MFPA_WAVE 64
 
+// Experiment switches (A/B timing runs of tools/, some of which skip work and give WRONG results) exist only in a library
+// built with -DMFPA_EXPERIMENTS (`python -m musicfpaugment_amd.csrc.build --experiments` -> libmfpa_exp.so, never loaded by the
+// package on its own).  The product library does not read the environment: every switch is its compile-time default.
+#ifdef MFPA_EXPERIMENTS
+#include <cstdlib>
+#define MFPA_EXP_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define MFPA_EXP_FLAG(word, bit) (((word) & (bit)) != 0)
+#else
+#define MFPA_EXP_ENV(name, dflt) (dflt)
+#define MFPA_EXP_FLAG(word, bit) false
+#endif
+
 #define MFPA_CHECK_LAUNCH()                                   \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \

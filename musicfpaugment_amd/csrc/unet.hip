@@ -52,7 +52,7 @@ struct ConvArgs {
   const float* w1x1;                 // optional fused OutConv 1x1 to one class (needs the whole Cout in one workgroup):
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
-  int dbg;                           // timing experiments only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA
+  int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA
   // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
   // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
   const float* c1_x32;               // (B,H,W) float32, or
@@ -319,18 +319,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     constexpr int cur = decltype(CUR)::value;
     const int tap = it % TAPS;
     const bool chunk_end = (tap == TAPS - 1);
-    if (!(a.dbg & 1)) {
+    if (!MFPA_EXP_FLAG(a.dbg, 1)) {
       if (it + 1 < nit) store_b(CUR, Bs0 + ((it + 1) & 1) * (BN * LDK));
       if (it + 2 < nit) load_b(it + 2, std::integral_constant<int, 1 - cur>{});
     }
     if (!A_PER_TAP && tap == 0 && it + TAPS < nit) load_a(it / TAPS + 1, 0);   // next chunk's halo, a whole chunk ahead
     if (A_PER_TAP && it + 1 < nit) load_a((it + 1) / TAPS, (it + 1) % TAPS);
-    if (!(a.dbg & 8)) compute(tap, Bs0 + (it & 1) * (BN * LDK));
+    if (!MFPA_EXP_FLAG(a.dbg, 8)) compute(tap, Bs0 + (it & 1) * (BN * LDK));
     if ((chunk_end || A_PER_TAP) && it + 1 < nit) {
-      if (!(a.dbg & 2)) __syncthreads();            // every wave is done reading As
+      if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();            // every wave is done reading As
       store_a((it + 1) / TAPS);
     }
-    if (!(a.dbg & 2)) __syncthreads();
+    if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();
   };
 
   if (C1SRC) {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
           char* yp = yb + (pix * cout * 4u + nb);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            if (!((a.dbg & 4) && v_never(acc[mt][nt][r]))) *reinterpret_cast<float*>(yp + nt * 128) = acc[mt][nt][r];
+            if (!(MFPA_EXP_FLAG(a.dbg, 4) && v_never(acc[mt][nt][r]))) *reinterpret_cast<float*>(yp + nt * 128) = acc[mt][nt][r];
         }
       }
     }
@@ -759,7 +759,7 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + PH - 1) / PH;
-  static const int dbg_env = getenv("MFPA_CONV_DBG") ? atoi(getenv("MFPA_CONV_DBG")) : 0;
+  static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
   const size_t lds = sizeof(float) * ((size_t)HP * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
@@ -777,11 +777,11 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
 //   W <= 16 (the 16x15 bottleneck): 8x16 patches.
 template <int MODE, int PREC>
 int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
-  static const int ct_old = getenv("MFPA_CONVT_OLD") ? atoi(getenv("MFPA_CONVT_OLD")) : 0;   // experiments: generic kernel
+  static const int ct_old = MFPA_EXP_ENV("MFPA_CONVT_OLD", 0);   // experiments: generic kernel
   if (MODE == 1 && !ct_old) return a.W > 16 ? launch_convT<4, 32, PREC>(a, s) : launch_convT<8, 16, PREC>(a, s);
   const int taps_y = (MODE == 1) ? 4 : 1;
   const bool bn128 = (a.Cout % 128 == 0);
-  static const int wm_env = getenv("MFPA_CONV_WM") ? atoi(getenv("MFPA_CONV_WM")) : 0;   // experiments
+  static const int wm_env = MFPA_EXP_ENV("MFPA_CONV_WM", 0);   // experiments
   const int cin = a.C0 + a.C1;
   const bool big = (wm_env == 4) || (wm_env == 0 && cin >= 256);
   if (MODE == 0 && (a.c1_x32 || a.c1_spec64)) {        // checked by the caller: C0 == 64, C1 == 0, Cout == 64, W > 16, H >= 8

@@ -1088,7 +1088,7 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
   if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
   if (d->precision >= 1) {
     // transposing LDS reads need every lane live (512-thread workgroups, no early exits) -- guaranteed by the kernel shape
-    static const int nw_env = getenv("MFPA_WGRAD_NW") ? atoi(getenv("MFPA_WGRAD_NW")) : 0;   // experiments: 4 or 8 waves
+    static const int nw_env = MFPA_EXP_ENV("MFPA_WGRAD_NW", 0);   // experiments: 4 or 8 waves
     const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : 8;
     const int pix = 16 * nw;
     const int pw = d->W <= 16 ? 16 : 32, phh = pix / pw;
@@ -1100,7 +1100,7 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
     if (split_b < 1) split_b = 1;
     if (split_b > 65535) split_b = 65535;
     grid.z = (unsigned)split_b;
-    static const int xcd_env = getenv("MFPA_GEMM_XCD") ? atoi(getenv("MFPA_GEMM_XCD")) : 1;   // 0: plain order (experiments)
+    static const int xcd_env = MFPA_EXP_ENV("MFPA_GEMM_XCD", 1);   // 0: plain order (experiments)
     a.xcd = xcd_env;
     const bool plain = d->precision == 2;
     const size_t lds = (size_t)(plain ? 192 : WGB_ROW) * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));

@@ -107,7 +107,7 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
 
 
 FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
-_PAD_ROWS_ONLY = bool(int(os.environ.get("MFPA_DEMUCS_PAD_ROWS_ONLY", "1")))   # zero only the two padding rows of the GLU output (0: memset the whole buffer)
+_PAD_ROWS_ONLY = True   # zero only the two padding rows of the GLU output (0: memset the whole buffer)
 LAST_LAYER_GEMM = True    # False: the stand-alone VALU kernel mfpa_convT1d_c1 for the last ConvTranspose1d
 PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (3 bf16 MFMAs per product, fp32 accumulate)
 
@@ -130,7 +130,7 @@ def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mo
 
 PIPELINE_LSTM = True      # False: the two LSTM layers one after the other on the current stream
 PIPELINE_MAX_CLIPS = 96   # above this a step fills the chip on its own: forward 7.1 -> 5.5 ms at 16 clips, 13.6 -> 12.6 at 64, 21.3 -> 22.0 at 128
-LSTM_CHUNK = int(os.environ.get("MFPA_LSTM_CHUNK", "31"))   # time steps per pipeline stage (248 = 8 x 31)
+LSTM_CHUNK = 31   # time steps per pipeline stage (248 = 8 x 31)
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 

@@ -51,7 +51,7 @@ def _drop(st):
     return st.drop if st is not None else (0, 0, 1.0)
 
 
-DEVICE_PACK = bool(int(os.environ.get("MFPA_DEVICE_PACK", "1")))    # operand images of the weights built by mfpa_pack_conv_weights (False: the torch flip / transpose / split ops)
+DEVICE_PACK = True    # operand images of the weights built by mfpa_pack_conv_weights (False: the torch flip / transpose / split ops)
 
 
 def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, row0: int = 0, nrows: Optional[int] = None):
@@ -161,8 +161,12 @@ class UNetTrainEngine:
     """Owns kernel-layout master parameters, gradients and Adam moments of a UNet(1, 1) and runs train steps."""
 
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, precision: int = 0,
-                 wgrad_precision: Optional[int] = None, sync_bn: bool = False):
+                 wgrad_precision: Optional[int] = None, sync_bn: bool = False, collectives_at_world_one: bool = False):
         self.module = module
+        # collectives_at_world_one: issue the gradient-bucket all-reduces even when the process group has a single rank (the
+        # RCCL path of a one-GPU box: tests/test_gpu_dist.py, `torchrun --nproc-per-node 1 bench.py --mode train`)
+        self.collectives_at_world_one = bool(collectives_at_world_one)
+        self.comm_calls, self.comm_bytes = 0, 0            # collectives issued by this engine / their payload bytes
         # arithmetic of the convolutions: 0 = fp32 MFMA, 1 = bf16x3 (3 bf16 MFMAs per fp32 product); `wgrad_precision`
         # overrides it for the weight-gradient kernel, which also offers 2 = plain bf16 products (a weight gradient sums over
         # every pixel of the batch: relative L1 ~2e-3).  Reductions, BatchNorm statistics, the loss and Adam are fp32/fp64.
@@ -177,7 +181,8 @@ class UNetTrainEngine:
         if self.device.type != "cuda":
             raise RuntimeError("the training engine runs on the MI355X only")
         self.rate = float(module.dropout.p)        # nn.Dropout(rate) on x2..x5 and up1's output (unet.py:83,99-103)
-        self.drop_seed = 0x5EED
+        # data-parallel ranks must not apply identical dropout masks to their shards: the rank is mixed into the seed
+        self.drop_seed = 0x5EED + 0x9E3779B1 * (_dist.get_rank(process_group) if _dist.is_available() and _dist.is_initialized() else 0) & 0x7FFFFFFF
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.group = process_group
@@ -278,6 +283,7 @@ class UNetTrainEngine:
     def _all_reduce_sums(self, sums_and_count: torch.Tensor) -> torch.Tensor:
         import torch.distributed as dist
         dist.all_reduce(sums_and_count, op=dist.ReduceOp.SUM, group=self.group)
+        self.comm_calls += 1; self.comm_bytes += sums_and_count.numel() * sums_and_count.element_size()
         return sums_and_count
 
     def _bn_stats(self, z, bn, g, b) -> Stats:
@@ -448,10 +454,13 @@ class UNetTrainEngine:
 
     def _reduce_bucket(self, name):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        if dist.get_world_size(self.group) == 1 and not self.collectives_at_world_one:
             return None
         for bname, s, e in self.buckets:
             if bname == name:
+                self.comm_calls += 1; self.comm_bytes += 4 * (e - s)
                 return dist.all_reduce(self.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
@@ -478,6 +487,7 @@ class UNetTrainEngine:
             import torch.distributed as dist
             nb = torch.tensor([float(aug_spec64.shape[0])], dtype=torch.float64, device=aug_spec64.device)
             dist.all_reduce(nb, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm_calls += 1; self.comm_bytes += 8
             self._global_over_local_batch = float(nb.item()) / float(aug_spec64.shape[0])
         pred = self.forward(spec64=aug_spec64, denom=aug_denom)
         loss, dpred = self.l1_loss(pred, clean_spec64)

@@ -26,9 +26,15 @@ _DFT_CACHE: Dict[Tuple[int, int, int, int], Tuple[torch.Tensor, int, int, int]] 
 _DFT_T_CACHE: Dict[Tuple[int, int, int], torch.Tensor] = {}
 
 
+def _dev_index(device) -> int:
+    """Resolved GPU index: an unindexed 'cuda' device means the CURRENT device, not cuda:0."""
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def _dft_matrix_t(fft_size: int, win_length: int, device) -> torch.Tensor:
     """The transposed windowed DFT matrix (rows = window samples, padded to a multiple of 64; K = npad) for the backward GEMM."""
-    key = (fft_size, win_length, device.index or 0)
+    key = (fft_size, win_length, _dev_index(device))
     if key not in _DFT_T_CACHE:
         W, _, _, kpad = _dft_matrix(fft_size, win_length, device)
         rows = (kpad + 63) // 64 * 64
@@ -41,7 +47,7 @@ def _dft_matrix_t(fft_size: int, win_length: int, device) -> torch.Tensor:
 def _dft_matrix(fft_size: int, win_length: int, device) -> Tuple[torch.Tensor, int, int, int]:
     """Rows [re bins | zeros | im bins] of hann(win_length, periodic) * exp(-2 pi i k (off + j) / fft_size), K padded to a
     multiple of 16 with zero columns.  Returns (W (npad, Kpad) float32, bins, im_off, Kpad).  Built in float64."""
-    key = (fft_size, win_length, device.index or 0, 0)
+    key = (fft_size, win_length, _dev_index(device), 0)
     if key not in _DFT_CACHE:
         bins = fft_size // 2 + 1
         off = (fft_size - win_length) // 2

@@ -82,3 +82,21 @@ def test_bucketed_allreduce_pattern_gloo_world2():
     for r in (0, 1):
         g, m = ret[r]
         assert set(g) == {3.0} and m == 1.0
+
+
+def test_bench_self_launches_its_ranks_when_called_with_gpus_2():
+    """`python bench.py --gpus 2` outside torch.distributed.run (the form of the driver's N = 1 command with N > 1): the parent starts
+    the two ranks as a child process tree, relays exactly one JSON line from rank 0 and returns the child's exit code.
+    --mode launch-check runs no kernel (there is no GPU here and the hot path has no CPU fallback)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["max_rank_seen"] == 1 and out["value"] is None

@@ -111,6 +111,47 @@ def test_bench_runs_under_torchrun_with_two_ranks(mode):
     assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 0.01 * out["value"]   # whole-job aggregate
 
 
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_self_launch_with_two_ranks(mode):
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (how the driver calls it): bench.py starts its own
+    ranks (child `python -m torch.distributed.run`), the parent relays one JSON line.  Two ranks share cuda:0 over gloo here."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MFPA_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8", "--mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    _check(r)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                             # exactly rank 0's line, nothing else on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["dist_backend"] == "gloo"
+    assert out["config"]["clips_per_gpu_per_step"] == 8
+    if mode == "train":
+        assert out["config"]["allreduce_bytes_per_step"] >= 31_036_481 * 4
+
+
+@pytest.mark.parametrize("mode", ["train", "infer"])
+def test_bench_on_rccl_at_world_size_one(mode):
+    """The RCCL leg at the only world size a one-GPU box allows: under torch.distributed.run with one rank bench.py still calls
+    init_process_group("nccl", device_id=...) -- RCCL on ROCm -- so the barriers, the MAX-over-ranks timing, and in train mode the
+    two scalar MAX all-reduces of the spectrogram maxima and the ten asynchronous gradient-bucket all-reduces issued between
+    ctypes-launched kernels (ops_train.UNetTrainEngine) all execute on RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k != "MFPA_DIST_BACKEND"}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29538", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips", "8",
+           "--mode", mode, "--cpu-seconds", "0", "--no-configs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    _check(r)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["dist_backend"].startswith("rccl")
+    if mode == "train":
+        assert out["config"]["allreduce_calls_per_step"] >= 12 and np.isfinite(out["config"]["loss_last"])
+
+
 def test_two_rank_sync_batchnorm_step_equals_the_single_gpu_step():
     """sync_bn=True: BatchNorm statistics over the global batch -- a 2 x 2-clip data-parallel step reproduces the 4-clip
     single-GPU step of the reference semantics (parameters, running statistics, mean loss)."""
