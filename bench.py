@@ -94,8 +94,9 @@ def _host_cores() -> int:
 def cpu_baseline(budget_s: float, seed: int):
     """The oracle chain (reference algorithms on the CPU) on this box's host cores -> clips/s, two ways:
     `value`: one clip at a time like the reference, torch's intra-op thread count calibrated first (batch-1 convolutions get
-    SLOWER with hundreds of threads), `cores` = the threads used; `all_core_value`: host cores // cores worker processes of that
-    thread count running the same per-clip chain side by side (what the same host delivers when every core is put to work)."""
+    SLOWER with hundreds of threads), `cores` = the threads used; `all_core_value`: one single-threaded worker process per host
+    core (at most 32), each running the same per-clip chain on its own clips side by side -- clip-level parallelism, the way the
+    same host delivers the most clips/s when every core is put to work (batch-1 convolutions scale poorly over threads)."""
     import multiprocessing as mp
     from musicfpaugment_amd import synth
 
@@ -144,12 +145,13 @@ def cpu_baseline(budget_s: float, seed: int):
            "sample": f"{n} synthetic 8 s clips in {dt:.1f} s, one at a time like the reference "
                      f"(peak_extractor.py:236-311): numpy float64 STFT -> torch-CPU fp32 UNet forward (batch 1, "
                      f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
-    # every core at work: W processes x best_thr threads, started together (spawned before this process owns a GPU)
-    workers = max(1, min(32, ncpu // best_thr))
+    # every core at work: one worker per core, started together (spawned before this process owns a GPU)
+    workers = max(1, min(32, ncpu))
+    wthr = max(1, ncpu // workers)
     try:
         ctx = mp.get_context("spawn")
         barrier, queue = ctx.Barrier(workers), ctx.Queue()
-        procs = [ctx.Process(target=_cpu_worker, args=(barrier, queue, best_thr, seed + 100 * (k + 1), budget_s)) for k in range(workers)]
+        procs = [ctx.Process(target=_cpu_worker, args=(barrier, queue, wthr, seed + 100 * (k + 1), budget_s)) for k in range(workers)]
         for p in procs:
             p.start()
         got, deadline = [], time.perf_counter() + 180 + 4 * budget_s
@@ -162,8 +164,8 @@ def cpu_baseline(budget_s: float, seed: int):
         for p in procs:
             p.join(timeout=30)
         out["all_core_value"] = round(sum(c / t for c, t in got), 4)
-        out["all_core_cores"] = workers * best_thr
-        out["all_core_sample"] = (f"{workers} worker processes x {best_thr} threads, {sum(c for c, _ in got)} clips in "
+        out["all_core_cores"] = workers * wthr
+        out["all_core_sample"] = (f"{workers} worker processes x {wthr} threads, {sum(c for c, _ in got)} clips in "
                                   f"{max(t for _, t in got):.1f} s, the same per-clip chain in every worker")
     except Exception as e:                       # the batch-1 figure above stands on its own
         out["all_core_value"] = None

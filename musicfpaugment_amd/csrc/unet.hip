@@ -28,10 +28,42 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MFPA_CONV_PIPE
+#define MFPA_CONV_PIPE 1      // 0: the round-1 main loop for the bf16x3 3x3 convolution too (A/B builds of tools/)
+#endif
+#ifndef MFPA_CONV_BIG_MIN_CIN
+#define MFPA_CONV_BIG_MIN_CIN 64    // 128-channel tiles: the 8-wave 256-pixel shape from this many input channels on (256: round 1's choice)
+#endif
+#ifndef MFPA_CONV_WN64
+#define MFPA_CONV_WN64 1
+#endif
+#ifndef MFPA_CONV_BOTTLENECK8
+#define MFPA_CONV_BOTTLENECK8 1     // the 16x15 level on the 8-wave shape with 16x16-pixel patches (0: round 1's 4-wave 8x16 shape)
+#endif
+
 constexpr int KC = 32;        // channels per K chunk
 constexpr int LDK = KC + 4;   // padded LDS row (floats): 144 B -> conflict-free b128 fragment reads
 
 __device__ __forceinline__ bool v_never(float v) { return v != 12345.678f; }  // keeps the accumulators live in the 'skip stores' experiment
+
+// sched_group_barrier pattern "one MFMA, then k LDS reads" with LEFT reads spread evenly over SLOTS MFMAs
+template <int SLOTS, int LEFT, int I = 0>
+__device__ __forceinline__ void pin_reads() {
+  if constexpr (I < SLOTS && LEFT > 0) {
+    constexpr int k = (LEFT + (SLOTS - I) - 1) / (SLOTS - I);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, k, 0);
+    pin_reads<SLOTS, LEFT - k, I + 1>();
+  }
+}
+constexpr int pin_read_slots(int slots, int left) {      // how many MFMAs pin_reads placed
+  int used = 0;
+  for (int i = 0; i < slots && left > 0; ++i) {
+    left -= (left + (slots - i) - 1) / (slots - i);
+    ++used;
+  }
+  return used;
+}
 
 struct ConvArgs {
   const float* x0;         // source 0: (B,H,W,C0) [mode 2: (B,2H,2W,C0)]
@@ -97,9 +129,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   constexpr int B_F4 = (BN * (KC / 4) + THREADS - 1) / THREADS;
   constexpr bool B_EXACT = (BN * (KC / 4)) % THREADS == 0;
 
+  // PIPE (the bf16x3 3x3 convolution on the 8-wave shapes, one workgroup per CU): software-pipelined main loop with the halo
+  // tile double-buffered in LDS, see step_pipe below.  The 4-wave shapes keep the plain loop: with 256 threads the staging
+  // registers are twice as many per thread and the second fragment set spills (measured: 2x slower).
+  constexpr bool PIPE = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);
+  constexpr int A_STAGES = PIPE ? 2 : 1;
+
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);         // [HP][LDK]
-  float* Bs0 = As + HP * LDK;                         // [2][BN][LDK]
+  float* As = reinterpret_cast<float*>(smem);         // [A_STAGES][HP][LDK]
+  float* Bs0 = As + A_STAGES * HP * LDK;              // [2][BN][LDK]
   constexpr int SW = PW + 4, SH = PH + 4;             // C1SRC: spectrogram patch with a 2-pixel halo, then the (9, 64) weights
   float* Sp = Bs0 + 2 * BN * LDK;                     // [SH][SW]
   float* W1s = Sp + SH * SW;                          // [9][64]
@@ -124,56 +162,67 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   f32x4 areg[A_F4];
   f32x4 breg[2][B_F4];   // two register sets for the weight tile, always indexed with compile-time constants
 
+  // The halo pixel of each of a thread's A_F4 staging slots never changes (idx = tid + it * THREADS -> pixel idx / 8, channel quad
+  // idx % 8): its image coordinates are computed ONCE, packed (gy << 16 | gx), -1 = outside the image or past the tile.  The
+  // per-chunk loader then needs two integer multiply-adds per load instead of the divisions / 64-bit index chains (~40
+  // instructions per load, the largest block of vector work in the 64-channel layers).
+  static_assert(THREADS % (KC / 4) == 0, "a thread keeps one channel quad for all of its halo pixels");
+  const int aq = tid % (KC / 4);
+  int apix[A_F4];
+#pragma unroll
+  for (int it = 0; it < A_F4; ++it) {
+    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+    apix[it] = (pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy << 16) | gx) : -1;
+  }
+  // 32-bit byte offsets from per-clip scalar bases (the host checks that one clip's input image fits 2 GB)
+  const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * (MODE == 2 ? 4 : 1) * a.H * a.W * a.C0 * sizeof(float);
+  const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
   // load_a only ISSUES the global loads of a halo tile (nothing in it reads a loaded value, so no wait lands between
   // the loads); the on-load affine + ReLU + dropout and the bf16 split happen in store_a, a whole chunk later.
-  static_assert(THREADS % (KC / 4) == 0, "a thread keeps one channel quad for all of its halo pixels");
   auto load_a = [&](int chunk, int tap) __attribute__((always_inline)) {
     if (C1SRC) return;                                 // the tile is computed from the LDS-resident spectrogram patch in store_a
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      const int idx = tid + it * THREADS;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < HP * (KC / 4)) {
-        const int pix = idx / (KC / 4), q = idx % (KC / 4);
-        const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-          if (from0) {
-            if (MODE == 2) {
-              const int sy = 2 * gy + (tap >> 1), sx = 2 * gx + (tap & 1);
-              v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * (2 * a.H) + sy) * (2 * a.W) + sx) * a.C0 + c0 + 4 * q);
-            } else {
-              v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
-            }
-          } else {
-            const int y1 = gy - a.oy1, x1 = gx - a.ox1;
-            if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-              v = *reinterpret_cast<const f32x4*>(a.x1 + (((size_t)b * a.H1 + y1) * a.W1 + x1) * a.C1 + (c0 - a.C0) + 4 * q);
+      if (apix[it] >= 0) {
+        const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
+        if (from0) {
+          unsigned off;
+          if (MODE == 2) off = ((unsigned)((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
+          else off = ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
+          v = *reinterpret_cast<const f32x4*>(xb0 + off);
+        } else {
+          const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+          if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1) {
+            const unsigned off = ((unsigned)(y1 * a.W1 + x1) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
+            v = *reinterpret_cast<const f32x4*>(xb1 + off);
           }
         }
       }
       areg[it] = v;
     }
   };
-  auto store_a = [&](int chunk) __attribute__((always_inline)) {
+  auto store_a = [&](int chunk, float* As) __attribute__((always_inline)) {      // `As`: the halo stage to fill
     const int c0 = chunk * KC;
     const bool affine = a.in_scale0 != nullptr && c0 < a.C0;
     f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};
     if (affine) {
-      a_sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * (tid % (KC / 4)));
-      a_sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * (tid % (KC / 4)));
+      a_sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * aq);
+      a_sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * aq);
     }
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      const int idx = tid + it * THREADS;
-      if (idx < HP * (KC / 4)) {
-        const int pix = idx / (KC / 4), q = idx % (KC / 4);
+      const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4)), q = aq;
+      if (pix < HP) {
         f32x4 v = areg[it];
-        const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+        const bool inside = apix[it] >= 0;
+        const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
         if (C1SRC) {
           v = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {               // conv2's zero padding stays exactly zero
+          if (inside) {                                                    // conv2's zero padding stays exactly zero
             const float* sp = Sp + (pix / HPW) * SW + (pix % HPW);        // 3x3 window of the first layer around (gy, gx)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -187,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           }
         }
-        if (!C1SRC && affine && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {      // padding stays exactly zero
+        if (!C1SRC && affine && inside) {      // padding stays exactly zero
           v = v * a_sc + a_sh;
           v.x = v.x > 0.f ? v.x : 0.f;
           v.y = v.y > 0.f ? v.y : 0.f;
@@ -328,9 +377,110 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     if (!MFPA_EXP_FLAG(a.dbg, 8)) compute(tap, Bs0 + (it & 1) * (BN * LDK));
     if ((chunk_end || A_PER_TAP) && it + 1 < nit) {
       if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();            // every wave is done reading As
-      store_a((it + 1) / TAPS);
+      store_a((it + 1) / TAPS, As);
     }
     if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();
+  };
+
+  // ---- PIPE: the software-pipelined main loop of the bf16x3 3x3 convolution -------------------------------------------------
+  // One (chunk, tap) iteration = two k-substeps of 16 channels, 12 MFMAs each.  The fragments of a substep (8 ds_read_b128 per
+  // wave) are read one substep AHEAD into a second register set while the matrix pipe works on the current one, so no MFMA waits
+  // on an LDS read it has just issued.  The iteration's one barrier sits BETWEEN its two substeps:
+  //     head   : tap 2: split the next chunk's halo (loaded at tap 0, behind the barrier) into the OTHER halo stage
+  //     phase A: read frags(it, s=1) -> F1  ||  MFMA(F0); behind the reads: Bs[nxt] <- B(it+1) registers, global loads of B(it+2)
+  //     barrier  (B(it+1) visible; every fragment read of Bs[cur] has completed: it may be overwritten in the next phase A)
+  //     phase B: read frags(it+1, s=0) -> F0  ||  MFMA(F1)
+  // The weight-tile stores / loads are unconditional (past the end they re-load the last tile into a stage nobody reads), so
+  // each phase is one basic block whose MFMA : LDS : VMEM interleave is pinned with sched_group_barrier.
+  struct Frags { bf16x8 ah[MT], al[MT], bh[NT], bl[NT]; };
+  Frags fr0, fr1;
+  auto read_frags = [&](Frags& f, const float* Asb, const float* Bsb, int tap_off, int sub) __attribute__((always_inline)) {
+    // in the order the MFMAs consume them: (al, bh) terms first, then (ah, bl), then (ah, bh)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      f.al[mt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Asb + a_base[mt] + tap_off) + 32 * sub + 64);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      f.bh[nt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Bsb + b_base[nt]) + 32 * sub);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      f.ah[mt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Asb + a_base[mt] + tap_off) + 32 * sub);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      f.bl[nt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Bsb + b_base[nt]) + 32 * sub + 64);
+  };
+  auto mfma_lo = [&](const Frags& f) __attribute__((always_inline)) {      // the two correction terms: MT*NT*2 MFMAs
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+  };
+  auto mfma_hi = [&](const Frags& f) __attribute__((always_inline)) {      // the main term: MT*NT MFMAs
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+  };
+  constexpr int N_FR = 2 * (MT + NT), N_MFMA = 3 * MT * NT;     // fragment reads / MFMAs of one phase
+  static_assert(N_MFMA >= 3, "a phase needs an MFMA in front of the weight-tile stores and one in front of its loads");
+  // the pinned interleave of a phase: the fragment reads spread evenly behind the first MFMAs; (phase A) the weight-tile LDS
+  // stores behind the next MFMA and its global loads behind the one after; the remaining MFMAs last
+  auto pin_phase = [&](auto WITH_B) __attribute__((always_inline)) {
+    constexpr bool with_b = decltype(WITH_B)::value;
+    constexpr int slots = with_b ? N_MFMA - 2 : N_MFMA;
+    pin_reads<slots, N_FR>();
+    constexpr int used = pin_read_slots(slots, N_FR) + (with_b ? 2 : 0);
+    if constexpr (with_b) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, B_F4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, B_F4, 0);
+    }
+    if constexpr (N_MFMA - used > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - used, 0);
+  };
+  int p_tap = 0, p_chunk = 0;                       // (chunk, tap) of the running iteration
+  auto step_pipe = [&](int it, auto CUR) __attribute__((always_inline)) {
+    constexpr int cur = decltype(CUR)::value;
+    const int chunk = p_chunk, tap = p_tap;
+    const bool last_tap = (tap == TAPS - 1);
+    const int nchunk = last_tap ? chunk + 1 : chunk, ntap = last_tap ? 0 : tap + 1;
+    const float* Asb = As + (chunk & 1) * (HP * LDK);
+    const float* Asn = As + (nchunk & 1) * (HP * LDK);
+    const float* Bsb = Bs0 + (it & 1) * (BN * LDK);
+    float* Bsn = Bs0 + ((it + 1) & 1) * (BN * LDK);
+    const int tap_off = ((tap / 3) * HPW + (tap % 3)) * LDK;
+    const int ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * LDK;
+    // ---- head (own basic blocks, once per chunk each)
+    if (tap == 2 && chunk + 1 < nchunks) {
+      store_a(chunk + 1, As + ((chunk + 1) & 1) * (HP * LDK));
+      // every load of the halo has been consumed or skipped by now: tell the compiler so, or it guards later register reuse
+      // (fragment reads into registers the halo path used) with a wait on the weight loads issued in this iteration
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+    }
+    // ---- phase A
+    read_frags(fr1, Asb, Bsb, tap_off, 1);
+    mfma_lo(fr0);
+    mfma_hi(fr0);
+    store_b(CUR, Bsn);
+    load_b(it + 2 < nit ? it + 2 : nit - 1, std::integral_constant<int, 1 - cur>{});
+    pin_phase(std::true_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B
+    // the next chunk's halo loads go out here, BEHIND this iteration's weight-tile stores: the compiler waits vmcnt(0) in front of
+    // those stores on every path, and must not find loads that were issued a few instructions earlier
+    if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1, 0);
+    read_frags(fr0, Asn, Bsn, ntap_off, 0);          // past the end: a harmless read of valid LDS
+    mfma_lo(fr1);
+    mfma_hi(fr1);
+    pin_phase(std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    p_tap = ntap; p_chunk = nchunk;
   };
 
   if (C1SRC) {
@@ -349,14 +499,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   }
   load_a(0, 0);
   load_b(0, Set0{});
-  store_a(0);
+  store_a(0, As);
   store_b(Set0{}, Bs0);
   if (nit > 1) load_b(1, Set0{});
   __syncthreads();
 
-  for (int it = 0; it < nit; it += 2) {
-    step(it, Set0{});
-    if (it + 1 < nit) step(it + 1, Set1{});
+  if constexpr (PIPE) {
+    read_frags(fr0, As, Bs0, 0, 0);
+    for (int it = 0; it < nit; it += 2) {
+      step_pipe(it, Set0{});
+      if (it + 1 < nit) step_pipe(it + 1, Set1{});
+    }
+  } else {
+    for (int it = 0; it < nit; it += 2) {
+      step(it, Set0{});
+      if (it + 1 < nit) step(it + 1, Set1{});
+    }
   }
 
   // epilogue: out = relu(acc * scale[n] + shift[n]); D[row = pixel][col = channel]
@@ -435,11 +593,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
       }
     }
   }
-  if (MODE == 0 && WN == 1 && a.w1x1 != nullptr) {
-    // OutConv 1x1 to one class: the wave holds all channels of its 64 pixels; reduce over the 32 channel lanes
+  if (MODE == 0 && WN <= 2 && a.w1x1 != nullptr) {
+    // OutConv 1x1 to one class: a wave holds BN / WN channels of its 64 pixels; reduce over the 32 channel lanes, and with
+    // WN == 2 add the two waves' halves through LDS (the staging buffers are free once every wave has left the main loop)
     float wv[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wv[nt] = a.w1x1[n0 + nt * 32 + li];
+    for (int nt = 0; nt < NT; ++nt) wv[nt] = a.w1x1[n0 + wn * (NT * 32) + nt * 32 + li];
+    float* red = As;                                     // [BM] partial sums of the wn == 1 waves
+    if (WN == 2) __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -450,9 +611,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) p += __shfl_xor(p, o);
         const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int gy = y0 + m / PW, gx = x0p + m % PW;
-        if (li == 0 && gy < a.H && gx < a.W) a.y1x1[((size_t)b * a.H + gy) * a.W + gx] = p + a.b1x1;
+        if (WN == 2 && wn == 1 && li == 0) red[m] = p;
+        acc[mt][0][r] = p;                               // kept for the second half below
       }
+    if (WN == 2) __syncthreads();
+    if (wn == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int gy = y0 + m / PW, gx = x0p + m % PW;
+          const float p = acc[mt][0][r] + (WN == 2 ? red[m] : 0.f);
+          if (li == 0 && gy < a.H && gx < a.W) a.y1x1[((size_t)b * a.H + gy) * a.W + gx] = p + a.b1x1;
+        }
+    }
   }
 }
 
@@ -762,7 +935,8 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  const size_t lds = sizeof(float) * ((size_t)HP * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
+  constexpr bool ADB = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);    // PIPE of the kernel: two halo stages
+  const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HP * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(taps_y * (a.Cout / BN)));
   hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC>), grid, dim3(64 * WM * WN), lds, s, a);
   MFPA_CHECK_LAUNCH();
@@ -783,23 +957,30 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   const bool bn128 = (a.Cout % 128 == 0);
   static const int wm_env = MFPA_EXP_ENV("MFPA_CONV_WM", 0);   // experiments
   const int cin = a.C0 + a.C1;
-  const bool big = (wm_env == 4) || (wm_env == 0 && cin >= 256);
+  const bool big = (wm_env == 4) || (wm_env == 0 && cin >= MFPA_CONV_BIG_MIN_CIN);
+  constexpr int WN64 = MFPA_CONV_WN64;   // 2: the pipelined 8-wave shape with waves of 64 px x 32 ch (measured 5-10 % slower than the 4-wave shape)
   if (MODE == 0 && (a.c1_x32 || a.c1_spec64)) {        // checked by the caller: C0 == 64, C1 == 0, Cout == 64, W > 16, H >= 8
-    return launch_conv<64, 8, 32, 4, 1, 0, PREC, true>(a, 1, s);
+    return launch_conv<64, 8, 32, 4, WN64, 0, PREC, true>(a, 1, s);
   }
   if (a.W > 16 && a.H >= 8) {
-    if (!bn128) return launch_conv<64, 8, 32, 4, 1, MODE, PREC>(a, taps_y, s);
+    if (!bn128) return launch_conv<64, 8, 32, 4, WN64, MODE, PREC>(a, taps_y, s);
     if (big) return launch_conv<128, 8, 32, 4, 2, MODE, PREC>(a, taps_y, s);
     return launch_conv<128, 4, 32, 2, 2, MODE, PREC>(a, taps_y, s);
   }
   if (a.W > 16) {
     return bn128 ? launch_conv<128, 4, 32, 2, 2, MODE, PREC>(a, taps_y, s) : launch_conv<64, 4, 32, 2, 1, MODE, PREC>(a, taps_y, s);
   }
+#if MFPA_CONV_BOTTLENECK8
+  if (bn128 && MODE == 0 && PREC == 1 && a.H >= 16) return launch_conv<128, 16, 16, 4, 2, MODE, PREC>(a, taps_y, s);
+#endif
   return bn128 ? launch_conv<128, 8, 16, 2, 2, MODE, PREC>(a, taps_y, s) : launch_conv<64, 8, 16, 2, 1, MODE, PREC>(a, taps_y, s);
 }
 
 template <int MODE>
 int dispatch_conv(ConvArgs& a, hipStream_t s, int precision = 0) {
+  // the halo loader packs pixel coordinates into 16 bits each and addresses one clip's input with 32-bit byte offsets
+  if (a.H > 32767 || a.W > 32767) return MFPA_EINVAL;
+  if ((MODE == 2 ? 4LL : 1LL) * a.H * a.W * a.C0 * 4 > 0xffffffffLL || 1LL * a.H1 * a.W1 * a.C1 * 4 > 0xffffffffLL) return MFPA_EINVAL;
   return precision ? dispatch_conv_p<MODE, 1>(a, s) : dispatch_conv_p<MODE, 0>(a, s);
 }
 

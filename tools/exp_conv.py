@@ -1,21 +1,40 @@
 #!/usr/bin/env python3
-"""Timing experiments on single conv layers (MFPA_CONV_DBG flags): usage exp_conv.py <precision>"""
-import os, sys, time
+"""Per-layer timing of the UNet's 3x3 convolutions (64 clips, random operands, HIP events on the launch stream).
+usage: exp_conv.py [--lib PATH] [--precision 0|1] [--reps N]"""
+import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None)
+ap.add_argument("--precision", type=int, default=1)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--clips", type=int, default=64)
+args = ap.parse_args()
+if args.lib:
+    from musicfpaugment_amd import _lib
+    _lib.set_library_path(args.lib)
 from musicfpaugment_amd import ops_unet as K
-prec = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-layers = [("inc.3 64->64 @257x251", 64, 257, 251, 64, 64), ("d2.3 256->256 @64x62", 64, 64, 62, 256, 256),
-          ("up1.0 1024->512 @32x31", 64, 32, 31, 1024, 512), ("up4.0 128->64 @257x251", 64, 257, 251, 128, 64),
-          ("d1.3 128->128 @128x125", 64, 128, 125, 128, 128), ("d4.3 1024->1024 @16x15", 64, 16, 15, 1024, 1024)]
-for name, B, H, W, Ci, Co in layers:
+prec, B = args.precision, args.clips
+layers = [("inc.3   64->64   @257x251", 257, 251, 64, 64), ("up4.0  128->64   @257x251", 257, 251, 128, 64),
+          ("d1.0    64->128  @128x125", 128, 125, 64, 128), ("d1.3   128->128  @128x125", 128, 125, 128, 128),
+          ("up3.0  256->128  @128x125", 128, 125, 256, 128), ("d2.0   128->256  @64x62", 64, 62, 128, 256),
+          ("d2.3   256->256  @64x62", 64, 62, 256, 256), ("up2.0  512->256  @64x62", 64, 62, 512, 256),
+          ("d3.0   256->512  @32x31", 32, 31, 256, 512), ("d3.3   512->512  @32x31", 32, 31, 512, 512),
+          ("up1.0 1024->512  @32x31", 32, 31, 1024, 512), ("d4.0   512->1024 @16x15", 16, 15, 512, 1024),
+          ("d4.3  1024->1024 @16x15", 16, 15, 1024, 1024)]
+tot = 0.0
+for name, H, W, Ci, Co in layers:
     x = torch.randn(B, H, W, Ci, device="cuda")
     w = torch.randn(9, Co, Ci, device="cuda") * 0.05
     wp = K.split_bf16x3(w) if prec else w
     sc = torch.ones(Co, device="cuda"); sh = torch.zeros(Co, device="cuda")
     K.conv3x3_bn_relu(x, wp, sc, sh, precision=prec); torch.cuda.synchronize()
-    t = time.time()
-    for _ in range(5): K.conv3x3_bn_relu(x, wp, sc, sh, precision=prec)
-    torch.cuda.synchronize(); dt = (time.time() - t) / 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps): K.conv3x3_bn_relu(x, wp, sc, sh, precision=prec)
+    e1.record(); torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) / args.reps * 1e-3
     fl = 2.0 * B * H * W * Ci * Co * 9
-    print(f"{name:28s} {dt*1e6:9.1f} us  {fl/dt/1e12:7.1f} TF/s-eq", flush=True)
+    tot += dt
+    print(f"{name:28s} {dt*1e6:9.1f} us  {fl/dt/1e12:7.1f} TF/s algorithmic", flush=True)
+print(f"sum {tot*1e3:.3f} ms")
