@@ -41,6 +41,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define MFPA_CONV_BOTTLENECK8 1     // the 16x15 level on the 8-wave shape with 16x16-pixel patches (0: round 1's 4-wave 8x16 shape)
 #endif
 
+// PREC 1 weight image ("w3", built by ops_unet.split_bf16x3 / mfpa_pack_conv_weights): [tap][chunk][row][128 B], one row =
+// the 32 channels of a chunk as 8 slots of 16 B, logical slots 0-3 = 32 bf16 hi, 4-7 = 32 bf16 lo, stored at PHYSICAL slot
+// (logical ^ ((row >> 1) & 7)).  A (tap, chunk, 128-row) tile is 16 KB contiguous and is copied verbatim into LDS by LDS-DMA
+// in the pipelined kernels (the XOR keeps a wave's ds_read_b128 fragment reads of 128-byte rows bank-conflict-free); the other
+// kernels undo the XOR while they stage a tile through registers into their padded rows.
+__device__ __forceinline__ int w3_swz(int row) { return (row >> 1) & 7; }
+
 constexpr int KC = 32;        // channels per K chunk
 constexpr int LDK = KC + 4;   // padded LDS row (floats): 144 B -> conflict-free b128 fragment reads
 
@@ -84,7 +91,7 @@ struct ConvArgs {
   const float* w1x1;                 // optional fused OutConv 1x1 to one class (needs the whole Cout in one workgroup):
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
-  int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA
+  int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
   // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
   // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
   const float* c1_x32;               // (B,H,W) float32, or
@@ -134,12 +141,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   // registers are twice as many per thread and the second fragment set spills (measured: 2x slower).
   constexpr bool PIPE = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);
   constexpr int A_STAGES = PIPE ? 2 : 1;
+  // PIPE: a halo stage has a row for every staging slot (A_F4 * THREADS / 8 >= HP), so the split / store pass needs no tail
+  // predicate: every halo load is consumed on every path and hipcc keeps no "maybe pending" state across iterations
+  constexpr int HPS = PIPE ? ((HP * (KC / 4) + THREADS - 1) / THREADS) * (THREADS / (KC / 4)) : HP;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);         // [A_STAGES][HP][LDK]
-  float* Bs0 = As + A_STAGES * HP * LDK;              // [2][BN][LDK]
+  float* As = reinterpret_cast<float*>(smem);         // [A_STAGES][HPS][LDK]
+  constexpr int B_STAGES = 2, B_STAGE = BN * LDK;     // weight-tile stages: [2][BN][LDK] padded rows, written through registers
+  float* Bs0 = As + A_STAGES * HPS * LDK;
   constexpr int SW = PW + 4, SH = PH + 4;             // C1SRC: spectrogram patch with a 2-pixel halo, then the (9, 64) weights
-  float* Sp = Bs0 + 2 * BN * LDK;                     // [SH][SW]
+  float* Sp = Bs0 + B_STAGES * B_STAGE;               // [SH][SW]
   float* W1s = Sp + SH * SW;                          // [9][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   const int nit = nchunks * TAPS;
 
   f32x4 areg[A_F4];
-  f32x4 breg[2][B_F4];   // two register sets for the weight tile, always indexed with compile-time constants
+  f32x4 breg[3][B_F4];   // register sets for the weight tile (the pipelined loop uses three), always indexed with compile-time constants
 
   // The halo pixel of each of a thread's A_F4 staging slots never changes (idx = tid + it * THREADS -> pixel idx / 8, channel quad
   // idx % 8): its image coordinates are computed ONCE, packed (gy << 16 | gx), -1 = outside the image or past the tile.  The
@@ -178,31 +189,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   // 32-bit byte offsets from per-clip scalar bases (the host checks that one clip's input image fits 2 GB)
   const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * (MODE == 2 ? 4 : 1) * a.H * a.W * a.C0 * sizeof(float);
   const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
-  // load_a only ISSUES the global loads of a halo tile (nothing in it reads a loaded value, so no wait lands between
-  // the loads); the on-load affine + ReLU + dropout and the bf16 split happen in store_a, a whole chunk later.
+  // load_a only ISSUES the global loads of a halo tile (nothing in it reads a loaded value, so no wait lands between the
+  // loads); the on-load affine + ReLU + dropout and the bf16 split happen in store_a, a whole chunk later.  Every slot loads
+  // UNCONDITIONALLY -- a pixel outside the image reads offset 0 of the clip and store_a zeroes it: no exec-mask branches, and
+  // a wave issues exactly A_F4 loads per tile, which the pipelined loop's counted vmcnt waits rely on.
+  auto src1_inside = [&](int p) __attribute__((always_inline)) {          // inside the (smaller, zero-padded) second source?
+    const int y1 = (p >> 16) - a.oy1, x1 = (p & 0xffff) - a.ox1;
+    return p >= 0 && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
+  };
   auto load_a = [&](int chunk, int tap) __attribute__((always_inline)) {
     if (C1SRC) return;                                 // the tile is computed from the LDS-resident spectrogram patch in store_a
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (apix[it] >= 0) {
-        const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
-        if (from0) {
-          unsigned off;
-          if (MODE == 2) off = ((unsigned)((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
-          else off = ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
-          v = *reinterpret_cast<const f32x4*>(xb0 + off);
-        } else {
-          const int y1 = gy - a.oy1, x1 = gx - a.ox1;
-          if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1) {
-            const unsigned off = ((unsigned)(y1 * a.W1 + x1) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
-            v = *reinterpret_cast<const f32x4*>(xb1 + off);
-          }
-        }
+      const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
+      if (from0) {
+        unsigned off;
+        if (MODE == 2) off = ((unsigned)((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
+        else off = ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
+        areg[it] = *reinterpret_cast<const f32x4*>(xb0 + (apix[it] >= 0 ? off : 0u));
+      } else {
+        const unsigned off = ((unsigned)(((apix[it] >> 16) - a.oy1) * a.W1 + (gx - a.ox1)) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
+        areg[it] = *reinterpret_cast<const f32x4*>(xb1 + (src1_inside(apix[it]) ? off : 0u));
       }
-      areg[it] = v;
     }
   };
   auto store_a = [&](int chunk, float* As) __attribute__((always_inline)) {      // `As`: the halo stage to fill
@@ -216,9 +226,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
       const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4)), q = aq;
-      if (pix < HP) {
-        f32x4 v = areg[it];
+      if (PIPE || pix < HP) {
         const bool inside = apix[it] >= 0;
+        f32x4 v = areg[it];
+        if (!C1SRC && !(c0 < a.C0 ? inside : src1_inside(apix[it]))) v = f32x4{0.f, 0.f, 0.f, 0.f};      // zero padding
         const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
         if (C1SRC) {
           v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -268,14 +279,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     constexpr int set = decltype(SET)::value;
     const int chunk = it_flat / TAPS, tap = it_flat % TAPS;
     const int wt = (MODE == 1) ? ct_tap : tap;
-    const float* wbase = a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC;
+    // PREC 0: [tap][Cout][Cin] floats; PREC 1: the chunk-major swizzled image (header of this file)
+    const float* wbase = (PREC == 0) ? a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC
+                                     : a.w + (((size_t)wt * nchunks + chunk) * a.Cout + n0) * KC;
 #pragma unroll
     for (int it = 0; it < B_F4; ++it) {
       const int idx = tid + it * THREADS;
       if (B_EXACT || idx < BN * (KC / 4)) {
         const int n = idx / (KC / 4), q = idx % (KC / 4);
-        breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * Cin + 4 * q);
+        if (PREC == 0) breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * Cin + 4 * q);
+        else breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + n * KC + 4 * (q ^ w3_swz(n)));
       }
+    }
+  };
+  auto load_b_ct = [&](int chunk, int tap, auto SET) __attribute__((always_inline)) {     // PREC 1 image, (chunk, tap) given
+    constexpr int set = decltype(SET)::value;
+    const float* wbase = a.w + (((size_t)tap * nchunks + chunk) * a.Cout + n0) * KC;
+#pragma unroll
+    for (int it = 0; it < B_F4; ++it) {
+      const int idx = tid + it * THREADS;
+      const int n = idx / (KC / 4), q = idx % (KC / 4);
+      breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + n * KC + 4 * (q ^ w3_swz(n)));
     }
   };
   auto store_b = [&](auto SET, float* Bs) __attribute__((always_inline)) {
@@ -386,12 +410,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   // One (chunk, tap) iteration = two k-substeps of 16 channels, 12 MFMAs each.  The fragments of a substep (8 ds_read_b128 per
   // wave) are read one substep AHEAD into a second register set while the matrix pipe works on the current one, so no MFMA waits
   // on an LDS read it has just issued.  The iteration's one barrier sits BETWEEN its two substeps:
-  //     head   : tap 2: split the next chunk's halo (loaded at tap 0, behind the barrier) into the OTHER halo stage
-  //     phase A: read frags(it, s=1) -> F1  ||  MFMA(F0); behind the reads: Bs[nxt] <- B(it+1) registers, global loads of B(it+2)
-  //     barrier  (B(it+1) visible; every fragment read of Bs[cur] has completed: it may be overwritten in the next phase A)
-  //     phase B: read frags(it+1, s=0) -> F0  ||  MFMA(F1)
-  // The weight-tile stores / loads are unconditional (past the end they re-load the last tile into a stage nobody reads), so
-  // each phase is one basic block whose MFMA : LDS : VMEM interleave is pinned with sched_group_barrier.
+  //     phase A: read frags(it, s=1) -> F1  ||  MFMA(F0); behind the reads: request weight tile it+3, Bs[(it+1) & 1] <- tile it+1
+  //     barrier  (tile it+1 visible; every fragment read of tile it has completed: its stage is rewritten in the next phase A)
+  //     phase B: (tap 0: issue the loads of the next chunk's halo)  read frags(it+1, s=0) -> F0  ||  MFMA(F1)
+  //              (tap 2: split that halo into the OTHER halo stage)
+  // Each phase is one basic block whose MFMA : LDS : VMEM interleave is pinned with sched_group_barrier.
   struct Frags { bf16x8 ah[MT], al[MT], bh[NT], bl[NT]; };
   Frags fr0, fr1;
   auto read_frags = [&](Frags& f, const float* Asb, const float* Bsb, int tap_off, int sub) __attribute__((always_inline)) {
@@ -426,9 +449,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
   };
   constexpr int N_FR = 2 * (MT + NT), N_MFMA = 3 * MT * NT;     // fragment reads / MFMAs of one phase
-  static_assert(N_MFMA >= 3, "a phase needs an MFMA in front of the weight-tile stores and one in front of its loads");
-  // the pinned interleave of a phase: the fragment reads spread evenly behind the first MFMAs; (phase A) the weight-tile LDS
-  // stores behind the next MFMA and its global loads behind the one after; the remaining MFMAs last
+  static_assert(N_MFMA >= 3, "a phase needs an MFMA in front of the weight-tile loads and one in front of its LDS stores");
+  // the pinned interleave of a phase: the fragment reads spread evenly behind the first MFMAs; (phase A) the loads of the weight
+  // tile three iterations ahead behind the next MFMA, the LDS stores of the next tile behind the one after; the remaining MFMAs last
   auto pin_phase = [&](auto WITH_B) __attribute__((always_inline)) {
     constexpr bool with_b = decltype(WITH_B)::value;
     constexpr int slots = with_b ? N_MFMA - 2 : N_MFMA;
@@ -436,51 +459,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     constexpr int used = pin_read_slots(slots, N_FR) + (with_b ? 2 : 0);
     if constexpr (with_b) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, B_F4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, B_F4, 0);      // the loads of tile it+3 first: they touch no register of the stores
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, B_F4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, B_F4, 0);
     }
     if constexpr (N_MFMA - used > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - used, 0);
   };
-  int p_tap = 0, p_chunk = 0;                       // (chunk, tap) of the running iteration
-  auto step_pipe = [&](int it, auto CUR) __attribute__((always_inline)) {
-    constexpr int cur = decltype(CUR)::value;
-    const int chunk = p_chunk, tap = p_tap;
-    const bool last_tap = (tap == TAPS - 1);
-    const int nchunk = last_tap ? chunk + 1 : chunk, ntap = last_tap ? 0 : tap + 1;
-    const float* Asb = As + (chunk & 1) * (HP * LDK);
-    const float* Asn = As + (nchunk & 1) * (HP * LDK);
-    const float* Bsb = Bs0 + (it & 1) * (BN * LDK);
-    float* Bsn = Bs0 + ((it + 1) & 1) * (BN * LDK);
-    const int tap_off = ((tap / 3) * HPW + (tap % 3)) * LDK;
-    const int ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * LDK;
-    // ---- head (own basic blocks, once per chunk each)
-    if (tap == 2 && chunk + 1 < nchunks) {
-      store_a(chunk + 1, As + ((chunk + 1) & 1) * (HP * LDK));
-      // every load of the halo has been consumed or skipped by now: tell the compiler so, or it guards later register reuse
-      // (fragment reads into registers the halo path used) with a wait on the weight loads issued in this iteration
-      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-    }
-    // ---- phase A
+  // One tap of the pipelined loop; TAP is a compile-time constant (the chunk loop calls it nine times), so every tap-dependent
+  // choice -- LDS offsets of the shifted fragments, which of the three weight register sets is stored / refilled, where the halo
+  // of the next chunk is loaded and split -- is static, a chunk is straight-line code, and hipcc's own s_waitcnt bookkeeping is
+  // EXACT: the LDS stores of tile it+1 wait with vmcnt(B_F4 [+ A_F4]) and leave the loads of tile it+2 in flight.  (With a
+  // runtime tap the conditional halo loads made it merge paths and wait vmcnt(0), i.e. also for the tile requested one
+  // iteration ago: every iteration stalled on an L2 round trip; skipping just those loads returned 11-13 % on the deep layers.
+  // Hiding the loads from hipcc instead -- an inline-asm register ring, and an LDS-DMA ring -- measured 7-15 % SLOWER.)
+  static_assert(!PIPE || (B_EXACT && TAPS == 9), "tile it lives in register set it % 3 = tap % 3");
+  auto tap_body = [&](auto TAP, int chunk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(TAP)::value;
+    constexpr int ntap = (tap + 1) % TAPS;
+    constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * LDK, ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * LDK;
+    const int it = chunk * TAPS + tap;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;             // past the last chunk: the same halo again, into the stage nobody reads
+    const float* Asb = As + (chunk & 1) * (HPS * LDK);
+    const float* Asn = (tap == TAPS - 1) ? As + ((chunk + 1) & 1) * (HPS * LDK) : Asb;
+    const float* Bsb = Bs0 + (it & 1) * B_STAGE;
+    float* Bsn = Bs0 + ((it + 1) & 1) * B_STAGE;
+    // ---- phase A: read frags(it, s=1) -> F1 || MFMA(F0); Bs[(it+1) & 1] <- tile it+1 (set (tap+1) % 3, requested two iterations
+    //      ago; that stage's tile it-1 was last read before the previous barrier); request tile it+3 into set tap % 3
     read_frags(fr1, Asb, Bsb, tap_off, 1);
     mfma_lo(fr0);
     mfma_hi(fr0);
-    store_b(CUR, Bsn);
-    load_b(it + 2 < nit ? it + 2 : nit - 1, std::integral_constant<int, 1 - cur>{});
+    if (!MFPA_EXP_FLAG(a.dbg, 1)) {
+      store_b(std::integral_constant<int, (tap + 1) % 3>{}, Bsn);
+      constexpr int t3 = (tap + 3) % TAPS;
+      const int c3 = (tap + 3 >= TAPS) ? chunk_n : chunk;
+      load_b_ct(c3, t3, std::integral_constant<int, tap % 3>{});
+    }
     pin_phase(std::true_type{});
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- phase B
-    // the next chunk's halo loads go out here, BEHIND this iteration's weight-tile stores: the compiler waits vmcnt(0) in front of
-    // those stores on every path, and must not find loads that were issued a few instructions earlier
-    if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1, 0);
+    // ---- phase B: (tap 0: issue the loads of the next chunk's halo)  read frags(it+1, s=0) -> F0 || MFMA(F1)
+    //      (tap 2: split that halo into the OTHER halo stage)
+    if (tap == 0 && !MFPA_EXP_FLAG(a.dbg, 16)) load_a(chunk_n, 0);
     read_frags(fr0, Asn, Bsn, ntap_off, 0);          // past the end: a harmless read of valid LDS
     mfma_lo(fr1);
     mfma_hi(fr1);
     pin_phase(std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
-    p_tap = ntap; p_chunk = nchunk;
+    if (tap == 2 && !MFPA_EXP_FLAG(a.dbg, 16)) store_a(chunk_n, As + ((chunk + 1) & 1) * (HPS * LDK));
   };
 
   if (C1SRC) {
@@ -498,19 +524,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
     __syncthreads();
   }
   load_a(0, 0);
-  load_b(0, Set0{});
-  store_a(0, As);
-  store_b(Set0{}, Bs0);
-  if (nit > 1) load_b(1, Set0{});
-  __syncthreads();
-
   if constexpr (PIPE) {
+    using Set2 = std::integral_constant<int, 2>;
+    load_b_ct(0, 0, Set0{});
+    store_a(0, As);
+    store_b(Set0{}, Bs0);
+    load_b_ct(0, 1, Set1{});                           // tiles 1 and 2: sets 1 and 2 (tile it lives in set it % 3)
+    load_b_ct(0, 2, Set2{});
+    __syncthreads();
     read_frags(fr0, As, Bs0, 0, 0);
-    for (int it = 0; it < nit; it += 2) {
-      step_pipe(it, Set0{});
-      if (it + 1 < nit) step_pipe(it + 1, Set1{});
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      tap_body(std::integral_constant<int, 0>{}, chunk);
+      tap_body(std::integral_constant<int, 1>{}, chunk);
+      tap_body(std::integral_constant<int, 2>{}, chunk);
+      tap_body(std::integral_constant<int, 3>{}, chunk);
+      tap_body(std::integral_constant<int, 4>{}, chunk);
+      tap_body(std::integral_constant<int, 5>{}, chunk);
+      tap_body(std::integral_constant<int, 6>{}, chunk);
+      tap_body(std::integral_constant<int, 7>{}, chunk);
+      tap_body(std::integral_constant<int, 8>{}, chunk);
     }
   } else {
+    load_b(0, Set0{});
+    store_a(0, As);
+    store_b(Set0{}, Bs0);
+    if (nit > 1) load_b(1, Set0{});
+    __syncthreads();
     for (int it = 0; it < nit; it += 2) {
       step(it, Set0{});
       if (it + 1 < nit) step(it + 1, Set1{});
@@ -671,7 +710,8 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
     for (int it = 0; it < B_F4; ++it) {
       const int row = (tid + it * 256) / (KC / 4);     // tap * 64 + n
       const int tap = row / BN, n = row % BN;
-      breg[it] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.Cout + n0 + n) * a.C0 + c0 + 4 * q);
+      if (PREC == 0) breg[it] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)tap * a.Cout + n0 + n) * a.C0 + c0 + 4 * q);
+      else breg[it] = *reinterpret_cast<const f32x4*>(a.w + (((size_t)tap * nchunks + chunk) * a.Cout + n0 + n) * KC + 4 * (q ^ w3_swz(n)));
     }
   };
   auto store = [&](int chunk) __attribute__((always_inline)) {
@@ -935,8 +975,10 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  constexpr bool ADB = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);    // PIPE of the kernel: two halo stages
-  const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HP * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
+  constexpr bool ADB = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);    // PIPE of the kernel: two padded halo stages
+  constexpr int THREADS = 64 * WM * WN;
+  constexpr int HPS = ADB ? ((HP * (KC / 4) + THREADS - 1) / THREADS) * (THREADS / (KC / 4)) : HP;
+  const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HPS * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(taps_y * (a.Cout / BN)));
   hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC>), grid, dim3(64 * WM * WN), lds, s, a);
   MFPA_CHECK_LAUNCH();

@@ -876,9 +876,9 @@ inline int grid_for(long long work, int per_block = 256, int cap = 256 * 16) {
   return (int)(b < 1 ? 1 : b);
 }
 
-// Convolution weights [tap][Co][Ci] (the master fp32 layout) -> the operand image a conv launch reads: rows n, K-contiguous,
-// every 32-element chunk of K either 32 floats (precision 0) or [32 bf16 hi | 32 bf16 lo] (precision 1: the LDS row format of the
-// bf16x3 kernels).  TR = false: n = co in [row0, row0 + nrows), k = ci (forward).  TR = true: the input-gradient operand --
+// Convolution weights [tap][Co][Ci] (the master fp32 layout) -> the operand image a conv launch reads: precision 0: [tap][row n][K]
+// floats; precision 1: the bf16x3 image of csrc/unet.hip, [tap][chunk of 32 k][row n][128 B = 32 bf16 hi | 32 bf16 lo in 16-byte
+// slots XOR-swizzled by the row] (what ops_unet.split_bf16x3 builds on the host).  TR = false: n = co in [row0, row0 + nrows), k = ci (forward).  TR = true: the input-gradient operand --
 // tap t reads source tap taps-1-t when taps == 9 (the 3x3 kernel flipped; the 2x2 transposed conv keeps its tap), n = ci in
 // [row0, row0 + nrows), k = co.  One workgroup per 32 x 32 (n, k) tile and tap, transposed through LDS so both sides coalesce.
 template <bool TR>
@@ -899,15 +899,16 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const float v = TR ? tile[tx][r] : tile[r][tx];                  // (n = n0 + r, k = k0 + tx)
-    float* orow = out + ((size_t)t * nrows + n0 + r) * K + k0;       // this row's 32-element chunk (128 bytes)
     if (precision == 0) {
-      orow[tx] = v;
+      out[((size_t)t * nrows + n0 + r) * K + k0 + tx] = v;             // [tap][row][K] floats
     } else {
+      // the bf16x3 image of csrc/unet.hip: [tap][chunk][row][8 slots of 16 B], logical slot (hi: 0-3, lo: 4-7) at physical slot ^ swz(row)
+      const int row = n0 + r, swz = (row >> 1) & 7;
+      __bf16* ob = reinterpret_cast<__bf16*>(out + (((size_t)t * (K / 32) + k0 / 32) * nrows + row) * 32);
       const __bf16 hi = (__bf16)v;
       const __bf16 lo = (__bf16)(v - (float)hi);
-      __bf16* ob = reinterpret_cast<__bf16*>(orow);
-      ob[tx] = hi;
-      ob[32 + tx] = lo;
+      ob[(((tx >> 3)) ^ swz) * 8 + (tx & 7)] = hi;
+      ob[((4 + (tx >> 3)) ^ swz) * 8 + (tx & 7)] = lo;
     }
   }
 }

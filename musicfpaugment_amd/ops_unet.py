@@ -38,14 +38,21 @@ def pack_convT2x2(w: torch.Tensor) -> torch.Tensor:
 
 
 def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
-    """Kernel-layout fp32 weights [taps][Cout][Cin] -> the same-shaped float32 container whose every 32-channel
-    chunk (128 bytes) holds [32 bf16 hi | 32 bf16 lo] with w = hi + lo (+ O(2^-17 w)): the LDS row format of the
-    bf16x3 convolution (csrc/unet.hip, PREC 1)."""
+    """Kernel-layout fp32 weights [taps][Cout][Cin] -> the bf16x3 operand image of the convolution kernels (csrc/unet.hip, PREC 1):
+    [tap][chunk = Cin / 32][Cout][128 bytes], a row = the 32 channels of a chunk split w = hi + lo (+ O(2^-17 w)) into 8 slots
+    of 16 bytes, logical slots 0-3 = 32 bf16 hi, 4-7 = 32 bf16 lo, stored at physical slot (logical ^ ((row >> 1) & 7)) -- a
+    (tap, chunk, 128-row) tile is 16 KB contiguous and goes into LDS verbatim by LDS-DMA, the XOR keeps the fragment reads
+    bank-conflict-free.  Returned as an opaque float32 tensor of the input's shape (same byte count)."""
     t, co, ci = w.shape
     w4 = w.reshape(t, co, ci // 32, 32)
     hi = w4.to(torch.bfloat16)
     lo = (w4 - hi.float()).to(torch.bfloat16)
-    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(t, co, ci)
+    rows = torch.cat([hi, lo], dim=-1).reshape(t, co, ci // 32, 8, 8)             # [t][row][chunk][logical slot][8 bf16]
+    swz = (torch.arange(co, device=w.device) >> 1) & 7
+    phys = torch.arange(8, device=w.device)[None, :] ^ swz[:, None]                # physical slot p of row r holds logical p ^ swz(r)
+    idx = phys[None, :, None, :, None].expand(t, co, ci // 32, 8, 8)
+    img = torch.gather(rows, 3, idx).permute(0, 2, 1, 3, 4).contiguous()           # [t][chunk][row][slot][8]
+    return img.view(torch.float32).reshape(t, co, ci)
 
 
 def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[str, torch.Tensor]:
