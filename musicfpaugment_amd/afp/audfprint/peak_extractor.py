@@ -141,7 +141,10 @@ class Audfprint_peaks(object):
         if self.demucs is not None:
             d = self.demucs(d)[:, 0].contiguous()
         uq, n = self.hashes_batch(d)
-        return uq[0, : int(n[0])].cpu().numpy().astype(np.int32)
+        n0 = int(n[0])
+        if n0 < 0:                                           # never a slice bound: hashes_batch raises on overflow, this guards the contract
+            raise ValueError("landmark capacity exceeded")
+        return uq[0, :n0].cpu().numpy().astype(np.int32)
 
     # ------------------------------------------------------------------ landmarks / hashes (next-tier row §8f-1)
     def hashes_batch(self, wav: torch.Tensor, cap: int = 4096, shifts: Optional[int] = None):
@@ -152,17 +155,23 @@ class Audfprint_peaks(object):
         shifts = self.shifts if shifts is None else shifts
         if shifts is None or shifts < 2:
             mask, _, _ = self.find_peaks_batch(wav)
-            _, _, uniq, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf,
-                                                         self.maxpairsperpeak)
-            return uniq, counts[:, 1].contiguous()
+            while True:
+                _, _, uniq, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf,
+                                                             self.maxpairsperpeak)
+                if not bool((counts < 0).any()):            # the kernel flags an overflowing clip with counts [-1, -1]
+                    return uniq, counts[:, 1].contiguous()
+                if cap >= 8192:
+                    raise ValueError("more than 8 peaks in one frame or more than 8192 landmarks in one clip: outside the device "
+                                     "kernel's limits")
+                cap = 8192                                   # retry once with the kernel's largest capacity
         B = wav.shape[0]
         keys = []
         for s in range(shifts):
             shiftsamps = int(s / self.shifts * self.n_hop) if self.shifts and self.shifts > 1 else int(s / shifts * self.n_hop)
             mask, _, _ = self.find_peaks_batch(wav[:, shiftsamps:].contiguous())
             _, hs, _, counts = ops.audfprint_landmarks(mask, cap, self.mindt, self.targetdt, self.targetdf, self.maxpairsperpeak)
-            if bool((counts[:, 0] < 0).any()):
-                raise ValueError("landmark capacity exceeded: raise `cap`")
+            if bool((counts < 0).any()):
+                raise ValueError("landmark capacity exceeded: raise `cap` (the kernel's limit is 8192 landmarks per clip)")
             k = (hs[:, :, 0].to(torch.int64) << 32) + (hs[:, :, 1].to(torch.int64) & 0xFFFFFFFF)     # :447-449
             valid = torch.arange(cap, device=wav.device)[None, :] < counts[:, :1]
             keys.append(torch.where(valid, k, torch.full_like(k, torch.iinfo(torch.int64).max)))

@@ -1,6 +1,7 @@
 """Dejavu peak picking on MI355X -- mirror of afp/dejavu/fingerprint.py:34-171 (up to the peak list).
 
-``get_2D_peaks(arr2D, plot=False, amp_min=50) -> (peak_coordinates, peak_mask)`` keeps the reference
+``fingerprint(channel_samples, Fs, wsize, n_hop, fan_value, amp_min, denoising, denoising_model, get_masks)`` is the reference's
+single-clip entry point with its return forms; ``get_2D_peaks(arr2D, plot=False, amp_min=50) -> (peak_coordinates, peak_mask)`` keeps the reference
 contract (coordinates [(freq, time)] in row-major order, mask float64).  ``fingerprint_peaks_batch``
 is the batched device path: mlab.specgram-style PSD -> /max -> 10 ln -> -mean -> 21x21 local maxima.
 `generate_hashes` / `fingerprint_batch` run the pairing + SHA-1 on the device (mfpa_dejavu_hashes).
@@ -17,6 +18,53 @@ from ...constants import afp_settings
 
 PEAK_NEIGHBORHOOD_SIZE = 10  # afp/dejavu/variables.py:19
 CONNECTIVITY_MASK = 2        # variables.py:18: full square footprint
+
+
+_DENOISERS = {"unet": None, "demucs": None}
+
+
+def set_denoisers(unet=None, demucs=None) -> None:
+    """The reference builds its denoisers at import time from checkpoint files (fingerprint.py:17-31); here the caller hands the
+    modules over once (training.unet.UNet in eval mode on the GPU, training.model.Demucs) and `fingerprint` finds them."""
+    if unet is not None:
+        _DENOISERS["unet"] = unet
+    if demucs is not None:
+        _DENOISERS["demucs"] = demucs
+
+
+def fingerprint(channel_samples, Fs: float = afp_settings["dejavu"]["samplerate"], wsize: int = afp_settings["dejavu"]["n_fft"],
+                n_hop: int = afp_settings["dejavu"]["n_hop"], fan_value: int = afp_settings["dejavu"]["fan_value"],
+                amp_min: int = afp_settings["dejavu"]["amp_min"], denoising: bool = False, denoising_model: str = "unet",
+                get_masks: bool = "False", *, unet=None, device="cuda"):
+    """afp/dejavu/fingerprint.py:34-91 for ONE clip, same signature and return forms: the list [(sha1 hex[:20], t1)] of hashes, or
+    `(hashes, peak_mask (257, nF) float64, specgram (257, nF))` when `get_masks is True` -- the default is the STRING "False" and
+    the test is `is True`, as in the reference (:43,88).  `channel_samples` are the raw (x 32767) samples Dejavu passes in.
+    `denoising=True, denoising_model="unet"`: the spectrogram denoiser on the max-normalised PSD, output squared (:68-75), module
+    from `unet=` or set_denoisers(); with "demucs" nothing happens HERE, as in the reference -- Dejavu denoises the waveform
+    before it calls fingerprint (dejavu.py:85-106).  Everything runs on the device (fingerprint_batch with a batch of one)."""
+    if denoising:
+        assert denoising_model in ["unet", "demucs"]
+    if (int(wsize), int(n_hop)) != (ops.N_FFT, ops.N_HOP):
+        raise NotImplementedError("the device spectrogram is built for NFFT 512 / noverlap 256 (afp/parameters.py)")
+    x = torch.as_tensor(np.asarray(channel_samples, dtype=np.float32) if not isinstance(channel_samples, torch.Tensor) else channel_samples)
+    x = x.to(device, torch.float32).reshape(1, -1)
+    net = None
+    if denoising is True and denoising_model == "unet":
+        net = unet if unet is not None else _DENOISERS["unet"]
+        if net is None:
+            raise ValueError("denoising with the UNet needs the module: pass unet=... or call set_denoisers(unet=...)")
+    n_frames = (x.shape[1] - 256) // 256
+    cap = max(16, (int(fan_value) - 1) * 257 * max(n_frames, 1) // 64)           # a 21 x 21 neighbourhood holds one peak
+    cap = min(cap, 16384)
+    dig, t1, counts, mask, spec = fingerprint_batch(x, amp_min=amp_min, fan_value=fan_value, cap=cap, scale_in=1.0,
+                                                    denoising=net is not None, denoising_model="unet", unet=net)
+    n = int(counts[0])
+    if n < 0:
+        raise ValueError("too many peaks for the device kernel")
+    hashes = _hashes_to_list(dig[0], t1[0], n)
+    if get_masks is True:
+        return hashes, mask[0].to(torch.float64).cpu().numpy(), spec[0].cpu().numpy()
+    return hashes
 
 
 def get_2D_peaks(arr2D, plot: bool = False, amp_min: int = afp_settings["dejavu"]["amp_min"],
@@ -82,10 +130,10 @@ def generate_hashes(peaks: List[Tuple[int, int]], fan_value: int = afp_settings[
 
 
 def fingerprint_batch(wav: torch.Tensor, amp_min: float = afp_settings["dejavu"]["amp_min"],
-                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096, **denoise):
+                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096, scale_in: float = 32767.0, **denoise):
     """fingerprint(...) for a batch (afp/dejavu/fingerprint.py:34-91): (digests (B,cap,10) uint8, t1 (B,cap), counts (B,),
     peak mask, normalised specgram), everything on the device.  ``denoise``: the denoising arguments of
     fingerprint_peaks_batch."""
-    mask, _, spec = fingerprint_peaks_batch(wav, amp_min, **denoise)
+    mask, _, spec = fingerprint_peaks_batch(wav, amp_min, scale_in=scale_in, **denoise)
     dig, t1, counts = ops.dejavu_hashes(mask, cap=cap, peak_cap=cap, fan_value=fan_value)
     return dig, t1, counts, mask, spec

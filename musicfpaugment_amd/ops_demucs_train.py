@@ -161,11 +161,29 @@ class DemucsTrainEngine:
         self.last_losses: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
 
     # ------------------------------------------------------------------ parameters <-> the reference's state_dict
+    def _views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out, off = {}, 0
+        for k, s in self.shapes.items():
+            cnt = int(torch.Size(s).numel())
+            out[k] = flat[off:off + cnt].view(*s)
+            off += cnt
+        return out
+
+    def named_moments(self):
+        """Adam's exp_avg / exp_avg_sq under the reference's parameter names (torch-Adam-compatible checkpoints)."""
+        return self._export(self._views(self.flat_m)), self._export(self._views(self.flat_v))
+
+    def load_named_moments(self, exp_avg: Dict[str, torch.Tensor], exp_avg_sq: Dict[str, torch.Tensor]) -> None:
+        self.load_state_dict(exp_avg, self.flat_m)
+        self.load_state_dict(exp_avg_sq, self.flat_v)
+
     @torch.no_grad()
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], flat: Optional[torch.Tensor] = None) -> None:
+        """Tensors under the reference's state_dict keys -> the kernel layouts of the parameter buffer (default) or of `flat`."""
         f = lambda k: sd[k].detach().to(self.device, torch.float32)
-        P = self.P
-        self.flat_p.zero_()
+        flat = self.flat_p if flat is None else flat
+        P = self.P if flat is self.flat_p else self._views(flat)
+        flat.zero_()
         P["enc0.w"].copy_(f("encoder.0.0.weight")[:, 0, :].t())
         P["enc0.b"].copy_(f("encoder.0.0.bias"))
         for i in range(DEPTH):

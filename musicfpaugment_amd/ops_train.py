@@ -260,24 +260,56 @@ class UNetTrainEngine:
             sd["outc.conv.weight"].copy_(self.P["outc.wb"][:64].view(1, 64, 1, 1))
             sd["outc.conv.bias"].copy_(self.P["outc.wb"][64:])
 
-    def named_grads(self) -> Dict[str, torch.Tensor]:
-        """Gradients re-laid-out under the reference's parameter names (tests / inspection)."""
+    def _named(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One of the flat buffers (gradients, Adam moments, ...) re-laid-out under the reference's parameter names and shapes."""
+        V = {k: flat[o:o + self._n(s)].view(s) for k, (o, s) in self.segs.items()}
         out = {}
         for p in ENC + [d + ".conv.double_conv" for d in DEC]:
-            g0 = self.G[p + ".0.w"]
+            g0 = V[p + ".0.w"]
             out[p + ".0.weight"] = (g0.view(3, 3, 1, -1).permute(3, 2, 0, 1) if g0.dim() == 2
                                     else g0.view(3, 3, g0.shape[1], g0.shape[2]).permute(2, 3, 0, 1)).contiguous()
-            g3 = self.G[p + ".3.w"]
+            g3 = V[p + ".3.w"]
             out[p + ".3.weight"] = g3.view(3, 3, g3.shape[1], g3.shape[2]).permute(2, 3, 0, 1).contiguous()
             for bn, g, b in self._bn_names(p):
-                out[bn + ".weight"] = self.G[g]; out[bn + ".bias"] = self.G[b]
+                out[bn + ".weight"] = V[g]; out[bn + ".bias"] = V[b]
         for d in DEC:
-            gu = self.G[d + ".up.w"]
+            gu = V[d + ".up.w"]
             out[d + ".up.weight"] = gu.view(2, 2, gu.shape[1], gu.shape[2]).permute(3, 2, 0, 1).contiguous()
-            out[d + ".up.bias"] = self.G[d + ".up.b"]
-        out["outc.conv.weight"] = self.G["outc.wb"][:64].view(1, 64, 1, 1)
-        out["outc.conv.bias"] = self.G["outc.wb"][64:]
+            out[d + ".up.bias"] = V[d + ".up.b"]
+        out["outc.conv.weight"] = V["outc.wb"][:64].view(1, 64, 1, 1)
+        out["outc.conv.bias"] = V["outc.wb"][64:]
         return out
+
+    def _load_named(self, flat: torch.Tensor, sd: Dict[str, torch.Tensor]) -> None:
+        """Inverse of _named: tensors under the reference's parameter names -> a flat buffer in the kernel layouts."""
+        V = {k: flat[o:o + self._n(s)].view(s) for k, (o, s) in self.segs.items()}
+        with torch.no_grad():
+            for p in ENC + [d + ".conv.double_conv" for d in DEC]:
+                w0 = sd[p + ".0.weight"].to(flat.device, torch.float32)
+                if w0.shape[1] == 1:
+                    V[p + ".0.w"].copy_(w0.permute(2, 3, 1, 0).reshape(9, w0.shape[0]))
+                else:
+                    V[p + ".0.w"].copy_(K.pack_conv3x3(w0))
+                V[p + ".3.w"].copy_(K.pack_conv3x3(sd[p + ".3.weight"].to(flat.device, torch.float32)))
+                for bn, g, b in self._bn_names(p):
+                    V[g].copy_(sd[bn + ".weight"]); V[b].copy_(sd[bn + ".bias"])
+            for d in DEC:
+                V[d + ".up.w"].copy_(K.pack_convT2x2(sd[d + ".up.weight"].to(flat.device, torch.float32)))
+                V[d + ".up.b"].copy_(sd[d + ".up.bias"])
+            V["outc.wb"][:64].copy_(sd["outc.conv.weight"].reshape(-1))
+            V["outc.wb"][64:].copy_(sd["outc.conv.bias"].reshape(-1))
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        """Gradients re-laid-out under the reference's parameter names (tests / inspection)."""
+        return self._named(self.flat_g)
+
+    def named_moments(self):
+        """Adam's exp_avg / exp_avg_sq under the reference's parameter names (torch-Adam-compatible checkpoints)."""
+        return self._named(self.flat_m), self._named(self.flat_v)
+
+    def load_named_moments(self, exp_avg: Dict[str, torch.Tensor], exp_avg_sq: Dict[str, torch.Tensor]) -> None:
+        self._load_named(self.flat_m, exp_avg)
+        self._load_named(self.flat_v, exp_avg_sq)
 
     # ------------------------------------------------------------------ kernels with engine state
     def _all_reduce_sums(self, sums_and_count: torch.Tensor) -> torch.Tensor:

@@ -7,8 +7,11 @@ ReduceLROnPlateau(min, factor 0.1, patience 10)).
 
 What is kept: constructor argument names, `train_epoch(epoch) -> {"loss": float}`,
 `validation_epoch() -> ({"loss": float}, {"psnr": float})`, the loop quirk (range(1, steps) iterations,
-loss divided by `steps`, train.py:257,341), checkpoint dictionaries with the reference's keys
-(`{"model_state_dict": ...}` for best, + optimizer/epoch for last, train.py:197-221).
+loss divided by `steps`, train.py:257,341), the epoch loop `range(epoch_start, nb_epochs)` with its resume quirk (a resumed run
+starts again AT the saved epoch number, train.py:134-136,174), and checkpoint dictionaries with the reference's keys and
+value formats (train.py:197-221): `best_epoch.pt` = {model_state_dict, best_val_loss}; `last_epoch.pt` = {epoch,
+model_state_dict, optimizer_state_dict (a torch.optim.Adam state_dict over model.parameters()), scheduler_state_dict
+(ReduceLROnPlateau's keys), early_stopping (the object), train_loss, val_losses, best_val_loss} -- either side loads the other's.
 What is different: no tf.data / tensorboard / Progbar; the loaders are plain Python iterators yielding
 `(clean (B,T,1) or (B,T), augmented (B,T,1) or (B,T))` float32 tensors; the step itself runs through
 UNetTrainEngine (HIP kernels, no autograd); one process per GPU with RCCL gradient all-reduce when
@@ -28,21 +31,20 @@ from .unet import UNet
 
 
 class EarlyStopping:
-    """training/train.py:582-612: stop after `patience` epochs without a `min_delta` improvement."""
+    """training/train.py:582-612, branch for branch: an epoch that does not improve the best loss by more than `min_delta`
+    -- an exact plateau and a NaN loss included -- counts; `patience` such epochs in a row stop the run."""
 
-    def __init__(self, patience: int = 20, min_delta: float = 0.0):
+    def __init__(self, patience: int = 5, min_delta: float = 0.0):
         self.patience, self.min_delta = patience, min_delta
         self.counter = 0
-        self.best_loss: Optional[float] = None
+        self.best_loss = float("-inf")
         self.early_stop = False
 
     def __call__(self, val_loss: float) -> None:
-        if self.best_loss is None:
-            self.best_loss = val_loss
-        elif self.best_loss - val_loss > self.min_delta:
+        if self.best_loss == float("-inf") or self.best_loss - val_loss > self.min_delta:
             self.best_loss = val_loss
             self.counter = 0
-        elif self.best_loss - val_loss < self.min_delta:
+        else:
             self.counter += 1
             if self.counter >= self.patience:
                 self.early_stop = True
@@ -56,6 +58,7 @@ class ReduceLROnPlateau:
         self.engine, self.factor, self.patience, self.threshold = engine, factor, patience, threshold
         self.best = float("inf")
         self.num_bad = 0
+        self.last_epoch = 0
 
     def step(self, metric: float) -> None:
         if metric < self.best * (1.0 - self.threshold):
@@ -65,15 +68,36 @@ class ReduceLROnPlateau:
         if self.num_bad > self.patience:
             self.engine.lr *= self.factor
             self.num_bad = 0
+        self.last_epoch += 1
+
+    def state_dict(self) -> Dict[str, Any]:
+        """The keys of torch's ReduceLROnPlateau.state_dict() that carry state (train.py:213), so either side loads the other's."""
+        return {"factor": self.factor, "patience": self.patience, "threshold": self.threshold, "threshold_mode": "rel", "mode": "min",
+                "cooldown": 0, "cooldown_counter": 0, "min_lrs": [0], "eps": 1e-8, "best": self.best, "num_bad_epochs": self.num_bad,
+                "last_epoch": self.last_epoch, "_last_lr": [self.engine.lr]}
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        self.best, self.num_bad = float(sd["best"]), int(sd["num_bad_epochs"])
+        self.last_epoch = int(sd.get("last_epoch", 0))
+        self.factor, self.patience = float(sd.get("factor", self.factor)), int(sd.get("patience", self.patience))
+        self.threshold = float(sd.get("threshold", self.threshold))
 
 
-def _global_max(clip_max: torch.Tensor) -> torch.Tensor:
-    """spectrogram() divides by ONE max over the whole batch (visualisation.py:29); with the batch sharded over
-    ranks that is a scalar MAX all-reduce, so single-device results are reproduced."""
-    m = clip_max.max()
+def _dist_group(group=None):
+    """(torch.distributed, world size, rank) of `group`, or (None, 1, 0) outside a process group."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size(group), dist.get_rank(group)
+    return None, 1, 0
+
+
+def _global_max(clip_max: torch.Tensor, group=None) -> torch.Tensor:
+    """spectrogram() divides by ONE max over the whole batch (visualisation.py:29); with the batch sharded over
+    ranks that is a scalar MAX all-reduce over the engine's process group, so single-device results are reproduced."""
+    m = clip_max.max()
+    dist, world, _ = _dist_group(group)
+    if world > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
     return m
 
 
@@ -84,7 +108,7 @@ class Trainer:
                  scheduler_factor: float = 0.1, scheduler_patience: int = 10, early_stop_patience: int = 20,
                  precision: int = 0, sync_bn: bool = False, factor_sc: float = FACTOR_SC, factor_mag: float = FACTOR_MAG,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, early_stop_min_delta: float = 0.0,
-                 nb_epochs: Optional[int] = None):
+                 nb_epochs: Optional[int] = None, process_group=None):
         """`precision` (not in the reference): 0 = exact fp32 products on the fp32 matrix cores, 1 = bf16x3 (2.4x the
         step rate; gradients deviate ~1e-2 relative from fp32 autograd, see tests/test_gpu_train.py).  `sync_bn` (multi-GPU):
         BatchNorm statistics over the global batch, so that N GPUs x B/N clips reproduce the reference's single-GPU step on
@@ -92,6 +116,7 @@ class Trainer:
         if input_type not in ("spec", "audio"):
             raise ValueError("input_type must be 'spec' (UNet) or 'audio' (Demucs)")
         self.input_type = input_type
+        self.group = process_group                              # the data-parallel ranks (None = the default group)
         self.device = torch.device(device)
         self.model = model.to(self.device)
         if input_type == "audio":
@@ -99,10 +124,10 @@ class Trainer:
             from .loss import MultiResolutionSTFTLoss
             self.mrsl = MultiResolutionSTFTLoss(factor_sc=factor_sc, factor_mag=factor_mag, precision=precision).to(self.device)   # train.py:652-655
             self.engine = DemucsTrainEngine(self.model.state_dict(), self.device, lr=learning_rate, betas=tuple(betas), eps=eps,
-                                            precision=precision, mrstft=self.mrsl, module=self.model)
+                                            precision=precision, mrstft=self.mrsl, module=self.model, dist_group=process_group)
         else:
             self.engine = UNetTrainEngine(self.model, lr=learning_rate, betas=tuple(betas), eps=eps, precision=precision,
-                                          sync_bn=sync_bn)
+                                          sync_bn=sync_bn, process_group=process_group)
         self.scheduler = ReduceLROnPlateau(self.engine, scheduler_factor, scheduler_patience)
         self.early_stopping = EarlyStopping(early_stop_patience, early_stop_min_delta)
         self.nb_epochs = nb_epochs
@@ -110,8 +135,9 @@ class Trainer:
         self.train_loader_iter, self.val_loader_iter = train_loader, val_loader
         self.train_steps, self.val_steps = train_steps, val_steps
         self.ckpt_path = ckpt_path
-        self.epoch = 0
-        self.best_val_loss = float("inf")
+        self.epoch = 0                                          # the last epoch that ran
+        self.epoch_start = 1                                    # train.py:127; a resume sets it to the SAVED epoch number (:134-136)
+        self.best_val_loss = float("inf")                       # the reference's min_valid_loss
         self.losses: Dict[str, list] = {"train": [], "val": []}
 
     @classmethod
@@ -153,8 +179,8 @@ class Trainer:
         cm, cmax = ops.stft_mag(clean.contiguous(), torch.float64)
         am, amax = ops.stft_mag(aug.contiguous(), torch.float64)
         B = cm.shape[0]
-        ops.normalize_(cm, _global_max(cmax).expand(B).contiguous(), per_clip=True)     # clean_specs, float64 target
-        return am, _global_max(amax).expand(B).contiguous(), cm
+        ops.normalize_(cm, _global_max(cmax, self.group).expand(B).contiguous(), per_clip=True)     # clean_specs, float64 target
+        return am, _global_max(amax, self.group).expand(B).contiguous(), cm
 
     def _waves(self, clean_audios: torch.Tensor, augmented_audios: torch.Tensor):
         clean = clean_audios.to(self.device, torch.float32)
@@ -205,10 +231,10 @@ class Trainer:
             mse = torch.mean((pred.double() - clean_spec) ** 2)
             rng = clean_spec.max() - clean_spec.min()
             psnr_total += float(10.0 * torch.log10(rng * rng / mse))
-        val_loss = float(total.item()) / self.val_steps
+        val_loss, psnr = self._mean_over_ranks([float(total.item()) / self.val_steps, psnr_total / self.val_steps])
         self.scheduler.step(val_loss)                           # train.py:462
         self.model.train()
-        return {"loss": val_loss}, {"psnr": psnr_total / self.val_steps}
+        return {"loss": val_loss}, {"psnr": psnr}
 
     def _validation_epoch_audio(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
         """train.py:418-445: predicted = model(augmented); L1 + sc + mag; PSNR on the waveforms."""
@@ -222,11 +248,22 @@ class Trainer:
             mse = torch.mean((pred.double() - clean.double()) ** 2)
             rng = clean.max() - clean.min()
             psnr_total += float(10.0 * torch.log10(rng.double() ** 2 / mse))
-        l1, sc, mag = (parts / self.val_steps).tolist()
+        l1, sc, mag, psnr = self._mean_over_ranks((parts / self.val_steps).tolist() + [psnr_total / self.val_steps])
         val_loss = l1 + sc + mag
         self.scheduler.step(val_loss)
         self.model.train()
-        return ({"loss": val_loss, "l1_loss": l1, "sc_loss": sc, "mag_loss": mag}, {"psnr": psnr_total / self.val_steps})
+        return ({"loss": val_loss, "l1_loss": l1, "sc_loss": sc, "mag_loss": mag}, {"psnr": psnr})
+
+    def _mean_over_ranks(self, values):
+        """Every rank validates its own shard; the numbers that drive the schedule, early stopping and the checkpoints are the
+        MEAN over the ranks of the engine's process group, so all replicas take the same decisions in the same epoch (otherwise
+        Adam would run with per-rank learning rates and one rank could leave the loop while the others wait in an all-reduce)."""
+        dist, world, _ = _dist_group(self.group)
+        if world == 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return (t / world).tolist()
 
     @torch.no_grad()
     def start_epoch(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
@@ -260,47 +297,114 @@ class Trainer:
         return losses, metrics
 
     # ------------------------------------------------------------------ checkpoints (train.py:197-221, :130-161)
-    def save_checkpoint(self, val_loss: float) -> None:
+    def _optimizer_state_dict(self) -> Dict[str, Any]:
+        """The engine's flat Adam state as `torch.optim.Adam(model.parameters()).state_dict()` would hold it (train.py:212)."""
+        names = [n for n, _ in self.model.named_parameters()]
+        m, v = self.engine.named_moments()
+        state = {}
+        if self.engine.step_count > 0:
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(self.engine.step_count)), "exp_avg": m[n].detach().clone(),
+                            "exp_avg_sq": v[n].detach().clone()}
+        group = {"lr": self.engine.lr, "betas": tuple(self.engine.betas), "eps": self.engine.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def _load_optimizer_state_dict(self, opt: Dict[str, Any]) -> None:
+        if "state" not in opt or "param_groups" not in opt:
+            raise ValueError("optimizer_state_dict is not a torch.optim.Adam state_dict ('state' / 'param_groups' missing): "
+                             "checkpoints written by round 1 of this package used a private format and cannot be resumed")
+        names = [n for n, _ in self.model.named_parameters()]
+        g = opt["param_groups"][0]
+        if len(g["params"]) != len(names):
+            raise ValueError(f"optimizer state for {len(g['params'])} parameters, the model has {len(names)}")
+        self.engine.lr = float(g["lr"])
+        st = opt["state"]
+        if len(st) == 0:                                         # saved before the first step
+            self.engine.flat_m.zero_(); self.engine.flat_v.zero_(); self.engine.step_count = 0
+            return
+        zeros = {n: torch.zeros_like(p) for n, p in self.model.named_parameters()}
+        m = {n: st[k]["exp_avg"] if k in st else zeros[n] for n, k in zip(names, g["params"])}
+        v = {n: st[k]["exp_avg_sq"] if k in st else zeros[n] for n, k in zip(names, g["params"])}
+        self.engine.load_named_moments(m, v)
+        self.engine.step_count = int(float(next(iter(st.values()))["step"]))       # an int in torch 1.11, a tensor since 1.12
+
+    def save_checkpoint(self, val_loss: float, train_loss: Optional[Dict[str, Any]] = None,
+                        val_losses: Optional[Dict[str, Any]] = None) -> None:
+        """train.py:188-221: first the best model (updating the running minimum), then `last_epoch.pt` with that minimum.  Rank 0
+        writes; the other ranks only keep the same minimum (they hold the same loss, _mean_over_ranks) and wait at a barrier."""
+        best = val_loss < self.best_val_loss
+        if best:
+            self.best_val_loss = val_loss
         if self.ckpt_path is None or not self.save:
             return
-        os.makedirs(self.ckpt_path, exist_ok=True)
-        self.engine.sync_to_module()
-        sd = self.model.state_dict()
-        torch.save({"epoch": self.epoch, "model_state_dict": sd,
-                    "optimizer_state_dict": {"exp_avg": self.engine.flat_m, "exp_avg_sq": self.engine.flat_v,
-                                             "step": self.engine.step_count, "lr": self.engine.lr},
-                    "losses": self.losses, "best_val_loss": self.best_val_loss},
-                   os.path.join(self.ckpt_path, "last_epoch.pt"))
-        if val_loss < self.best_val_loss:
-            self.best_val_loss = val_loss
-            torch.save({"model_state_dict": sd, "best_val_loss": val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
+        dist, world, rank = _dist_group(self.group)
+        if rank == 0:
+            os.makedirs(self.ckpt_path, exist_ok=True)
+            self.engine.sync_to_module()
+            sd = self.model.state_dict()
+            if best:
+                torch.save({"model_state_dict": sd, "best_val_loss": self.best_val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
+            torch.save({"epoch": self.epoch, "model_state_dict": sd, "optimizer_state_dict": self._optimizer_state_dict(),
+                        "scheduler_state_dict": self.scheduler.state_dict(), "early_stopping": self.early_stopping,
+                        "train_loss": train_loss if train_loss is not None else {"loss": self.losses["train"][-1] if self.losses["train"] else None},
+                        "val_losses": val_losses if val_losses is not None else {"loss": val_loss},
+                        "best_val_loss": self.best_val_loss, "losses": self.losses},
+                       os.path.join(self.ckpt_path, "last_epoch.pt"))
+        if world > 1:
+            dist.barrier(group=self.group)
 
     def load_checkpoint(self) -> bool:
+        """train.py:130-161.  The reference pickles its EarlyStopping OBJECT (class training.train.EarlyStopping): while its file is
+        read that module path resolves to this module, so a checkpoint written by the reference loads here."""
         path = None if self.ckpt_path is None else os.path.join(self.ckpt_path, "last_epoch.pt")
         if path is None or not os.path.exists(path):
             return False
-        ck = torch.load(path, map_location=self.device)
+        import sys
+        import types
+        alias = {}
+        if "training.train" not in sys.modules:
+            alias["training.train"] = sys.modules[__name__]
+            if "training" not in sys.modules:
+                alias["training"] = types.ModuleType("training")
+        sys.modules.update(alias)
+        try:
+            ck = torch.load(path, map_location=self.device, weights_only=False)
+        finally:
+            for k in alias:
+                sys.modules.pop(k, None)
         self.model.load_state_dict(ck["model_state_dict"])
         self.engine.load_from_module()
-        opt = ck["optimizer_state_dict"]
-        self.engine.flat_m.copy_(opt["exp_avg"]); self.engine.flat_v.copy_(opt["exp_avg_sq"])
-        self.engine.step_count, self.engine.lr = opt["step"], opt["lr"]
-        self.epoch, self.losses, self.best_val_loss = ck["epoch"], ck["losses"], ck["best_val_loss"]
+        self._load_optimizer_state_dict(ck["optimizer_state_dict"])
+        self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        es = ck["early_stopping"]
+        get = (lambda k, d: es.get(k, d)) if isinstance(es, dict) else (lambda k, d: getattr(es, k, d))
+        self.early_stopping.counter, self.early_stopping.best_loss = int(get("counter", 0)), float(get("best_loss", float("-inf")))
+        self.early_stopping.early_stop = bool(get("early_stop", False))
+        self.early_stopping.patience, self.early_stopping.min_delta = int(get("patience", self.early_stopping.patience)), float(get("min_delta", self.early_stopping.min_delta))
+        self.epoch_start = int(ck["epoch"])                      # the reference runs the saved epoch number again (train.py:134-136,174)
+        self.epoch = self.epoch_start - 1
+        self.best_val_loss = float(ck["best_val_loss"])
+        self.losses = ck.get("losses", self.losses)
         return True
 
     def training_loop(self, nb_epochs: Optional[int] = None) -> None:
-        """train.py:171-243 without the logging side outputs (`nb_epochs` defaults to the constructor's, as in the reference)."""
+        """train.py:171-243 without the logging side outputs: `for epoch in range(epoch_start, nb_epochs)` -- epochs 1 .. nb_epochs-1,
+        like the reference -- early stopping tested at the top of an epoch, best then last checkpoint after it."""
         nb_epochs = self.nb_epochs if nb_epochs is None else nb_epochs
         if nb_epochs is None:
             raise ValueError("nb_epochs was given neither here nor to the constructor")
         self.load_checkpoint()
-        while self.epoch < nb_epochs:
-            self.epoch += 1
-            self.losses["train"].append(self.train_epoch(self.epoch)["loss"])
-            if self.val_loader_iter is not None:
-                val, _ = self.validation_epoch()
-                self.losses["val"].append(val["loss"])
-                self.early_stopping(val["loss"])
-                self.save_checkpoint(val["loss"])
-                if self.early_stopping.early_stop:
-                    break
+        for epoch in range(self.epoch_start, nb_epochs):
+            if self.early_stopping.early_stop:
+                break
+            self.epoch = epoch
+            train_loss = self.train_epoch(epoch)
+            self.losses["train"].append(train_loss["loss"])
+            if self.val_loader_iter is None:
+                continue
+            val, _ = self.validation_epoch()
+            self.losses["val"].append(val["loss"])
+            self.early_stopping(val["loss"])
+            self.save_checkpoint(val["loss"], train_loss, val)

@@ -177,6 +177,27 @@ def test_two_rank_sync_batchnorm_step_equals_the_single_gpu_step():
     assert float(np.mean(diff > 1e-5)) < 1e-4 and diff.max() <= 2.1e-3
 
 
+def test_two_rank_trainer_loop_keeps_the_replicas_and_their_decisions_in_step():
+    """Trainer.training_loop on two ranks with different training / validation shards: the validation loss that drives the
+    plateau schedule, early stopping and the checkpoints is averaged over the ranks, so both take the same decisions (same lr,
+    same epoch, same best loss), the parameters stay bit-identical, and rank 0 alone writes last_epoch.pt / best_epoch.pt."""
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29539", os.path.join(ROOT, "tests", "_dist_trainer_worker.py"), tmp]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        _check(r)
+        got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]
+        ck = torch.load(os.path.join(tmp, "ckpt", "last_epoch.pt"), weights_only=False)
+        assert os.path.exists(os.path.join(tmp, "ckpt", "best_epoch.pt"))
+    np.testing.assert_array_equal(got[0]["params"], got[1]["params"])
+    np.testing.assert_array_equal(got[0]["val"], got[1]["val"])                  # the rank-averaged losses
+    assert float(got[0]["lr"]) == float(got[1]["lr"]) and int(got[0]["epoch"]) == int(got[1]["epoch"]) == 3
+    assert float(got[0]["best"]) == float(got[1]["best"]) == float(ck["best_val_loss"]) == float(np.min(got[0]["val"]))
+    np.testing.assert_array_equal(got[0]["sched"], got[1]["sched"])
+    assert ck["epoch"] == 3 and len(got[0]["val"]) == 3
+
+
 def test_two_rank_demucs_train_step():
     """Data-parallel Demucs step: the summed (all-reduced) gradients of two ranks and the 1/world scaling in Adam against an
     in-process emulation of the two shards.  Each rank's loss is over its own shard (as under DDP)."""

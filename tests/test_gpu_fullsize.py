@@ -103,6 +103,115 @@ def test_config3_train_step_64_clips_precisions_agree_and_loss_falls():
     assert abs(losses[0][-1] - losses[1][-1]) <= 2e-2 * abs(losses[0][-1]), losses
 
 
+def test_config4_train_step_64_clips_of_8_seconds():
+    """BASELINE configs[3] at the size bench.py --mode train runs: 64 clips x 8 s (257 x 251 spectrograms), Dropout 0.05.  The exact-fp32
+    and the bf16x3 engines see identical weights and dropout masks in step 1: same loss to 1e-4; the loss falls under both."""
+    from musicfpaugment_amd import ops
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    B = 64
+    base = synth.batch(16, seed=5100)
+    noise = synth.batch(16, seed=6100, tonal=False)
+    clean = np.concatenate([base * g for g in (1.0, 0.8, 0.6, 0.4)]).astype(np.float32)
+    aug = np.concatenate([(0.7 * base + 0.3 * noise) * g for g in (1.0, 0.8, 0.6, 0.4)]).astype(np.float32)
+    cm, cmax = ops.stft_mag(torch.from_numpy(clean).cuda(), torch.float64)
+    am, amax = ops.stft_mag(torch.from_numpy(aug).cuda(), torch.float64)
+    assert tuple(cm.shape) == (B, 257, 251)
+    target = ops.normalize_(cm, cmax.max().expand(B).contiguous(), per_clip=True)
+    den = amax.max().expand(B).contiguous()
+    losses = {}
+    for prec in (0, 1):
+        net = UNet(1, 1, rate=0.05)
+        net.load_state_dict(formula_state_dict(0))
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec, wgrad_precision=2 if prec else 0)   # bench.py's arithmetic
+        losses[prec] = [float(eng.train_step(am, den, target)) for _ in range(3)]
+        assert all(np.isfinite(losses[prec])) and losses[prec][-1] < losses[prec][0], losses
+        del eng, net
+        torch.cuda.empty_cache()
+    assert abs(losses[0][0] - losses[1][0]) <= 1e-4 * abs(losses[0][0]), losses
+    assert abs(losses[0][-1] - losses[1][-1]) <= 3e-2 * abs(losses[0][-1]), losses
+
+
+def test_config4_train_step_with_the_augmentation_chain_inside_replayed_on_the_oracle():
+    """BASELINE configs[3] "AugmentFP synthetic noise ... + L1 loss": what bench.py --mode train --augment does in a step --
+    AugmentFP.batch_augment on the device, two spectrograms with their batch-global maxima, UNet train-mode forward, L1 -- against the
+    same step on the CPU oracle with the augmentation DRAWS of that call replayed stage by stage (oracle/augment.py), the
+    spectrograms of oracle/stft.py and torch autograd through oracle/unet.py (Dropout off: its Philox stream cannot be replayed)."""
+    import random
+    from musicfpaugment_amd import ops
+    from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
+    from musicfpaugment_amd.augmentation.constants import DEFAULT_PARAMETERS
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    from oracle import augment as oau
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    irs, noises = synthetic_banks(2, noise_seconds=2.0)
+    torch.manual_seed(11)
+    random.seed(11)
+    par = dict(DEFAULT_PARAMETERS)
+    for k in par:
+        if k.startswith("proba"):
+            par[k] = 0.6
+    af = AugmentFP(None, 8000, parameters=par, ir_bank=irs, noise_bank=noises, device="cuda")
+    B, T = 4, 8000
+    clean_np = synth.batch(B, seed=7300, n=T)
+    clean = torch.from_numpy(clean_np).cuda()
+    # ---- the device step (bench.py bench_train.step)
+    aug = af.batch_augment(clean[:, None, :])[:, 0].contiguous()
+    cm, cmax = ops.stft_mag(clean, torch.float64)
+    am, amax = ops.stft_mag(aug, torch.float64)
+    target = ops.normalize_(cm, cmax.max().expand(B).contiguous(), per_clip=True)
+    net = UNet(1, 1, rate=0.0)
+    sd = formula_state_dict(4)
+    net.load_state_dict(sd)
+    eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=0)
+    loss = float(eng.train_step(am, amax.max().expand(B).contiguous(), target))
+    grads = {k: v.detach().cpu().double() for k, v in eng.named_grads().items()}
+    # ---- replay of the draws on the oracle
+    tr = af.augmentation_pipeline.transforms
+    gates = [t.transform_parameters["should_apply"] for t in tr]
+
+    def gated(x, gate, fn):
+        y = x.clone()
+        for b in range(B):
+            if gate[b]:
+                y[b:b + 1] = fn(x[b:b + 1], b)
+        return y
+
+    x = torch.from_numpy(clean_np)[:, None, :].clone()
+    x = gated(x, gates[0], lambda v, b: oau.highpass(v[:, 0], float(tr[0].draws["cutoff_freq"][b]) / 8000)[:, None])
+    x = gated(x, gates[1], lambda v, b: oau.apply_ir(v, tr[1].draws["ir"][b][None, None, :]))
+    bg = torch.stack([oau.rms_normalize(torch.cat([oau.rms_normalize(noises[sc][k][o:o + n]) for sc, k, o, n in pc]))
+                      for pc in tr[2].draws["pieces"]])
+    x = gated(x, gates[2], lambda v, b: oau.add_background(v, bg[b:b + 1], tr[2].draws["snr_in_db"][b:b + 1]))
+    x = gated(x, gates[3], lambda v, b: oau.gain(v, tr[3].draws["gain_in_db"][b:b + 1]))
+    x = gated(x, gates[4], lambda v, b: oau.clipping(v, tr[4].draws["percentile_threshold"][b:b + 1]))
+    x = gated(x, gates[5], lambda v, b: oau.lowpass(v[:, 0], float(tr[5].draws["cutoff_freq"][b]) / 8000)[:, None])
+    x = gated(x, gates[6], lambda v, b: oau.highpass(v[:, 0], float(tr[6].draws["cutoff_freq"][b]) / 8000)[:, None])
+    x = oau.peak_normalize(x)[:, 0]
+    np.testing.assert_allclose(aug.cpu().numpy(), x.numpy(), rtol=0, atol=5e-5)
+    clean_spec = torch.from_numpy(ostft.spectrogram(clean_np))                      # float64, one max over the batch
+    params = {k: (v.clone().double().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    # (i) the whole chain on the oracle: its own replayed waveform (within 5e-5 of the device's) through STFT, UNet, L1
+    with torch.no_grad():
+        aug_spec_o = torch.from_numpy(ostft.spectrogram(x.numpy().astype(np.float32)))
+        loss_chain = torch.mean(torch.abs(ou.forward(aug_spec_o.float().double()[:, None], params, training=True).squeeze(1) - clean_spec))
+    assert abs(loss - float(loss_chain)) <= 2e-3 * float(loss_chain), (loss, float(loss_chain))
+    # (ii) from the device's augmented waveform on: the step itself, tightly, with autograd for the gradients
+    aug_spec = torch.from_numpy(ostft.spectrogram(aug.cpu().numpy()))
+    pred = ou.forward(aug_spec.float().double()[:, None], params, training=True).squeeze(1)
+    loss_ref = torch.mean(torch.abs(pred - clean_spec))
+    loss_ref.backward()
+    assert abs(loss - float(loss_ref)) <= 2e-5 * float(loss_ref), (loss, float(loss_ref))
+    # the gradients of the big blocks agree with float64 autograd at the level fp32 arithmetic allows through 18 BatchNorms
+    for k in ("outc.conv.weight", "up4.conv.double_conv.3.weight", "down4.maxpool_conv.1.double_conv.0.weight", "inc.double_conv.0.weight"):
+        g_ref = params[k].grad
+        rel = float((grads[k] - g_ref).abs().sum() / g_ref.abs().sum())
+        assert rel < 5e-2, (k, rel)
+
+
 def test_config5_demucs_forward_256_clips_within_tolerance_and_batch_invariant():
     """BASELINE configs[4]: the Demucs waveform denoiser at 256 clips of 8 s.  Two sampled clips go through the oracle; the rest is
     covered by determinism and by invariance to the batch composition -- a 37-clip shard runs other kernel shapes (32-clip LSTM

@@ -213,10 +213,69 @@ def test_trainer_mirror_epoch_and_checkpoint(tmp_path):
     assert (tr3.scheduler.factor, tr3.scheduler.patience) == (0.5, 3)
     assert (tr3.early_stopping.patience, tr3.early_stopping.min_delta) == (7, 0.01)
     tr3.start_epoch()
-    tr3.training_loop()
-    assert tr3.epoch == 2 and len(tr3.losses["train"]) == 2 and not os.path.exists(tmp_path / "none")
+    tr3.training_loop()                                  # nb_epochs = 2: range(1, 2) runs ONE epoch, like the reference (train.py:174)
+    assert tr3.epoch == 1 and len(tr3.losses["train"]) == 1 and not os.path.exists(tmp_path / "none")
     with pytest.raises(ValueError):
         Trainer.from_reference(net3, loader(10), 3, None, 2, {}, torch.optim.SGD(net3.parameters(), lr=0.1), sched, es, 1, "cuda")
+
+
+def test_checkpoint_is_the_reference_format_and_resume_continues_identically(tmp_path):
+    """last_epoch.pt carries the reference's keys in the reference's formats (training/train.py:197-221): the optimizer state loads
+    into torch.optim.Adam(model.parameters()), scheduler / early-stopping state survive, best_val_loss is the value AFTER this
+    epoch's update, and a resumed run starts again at the saved epoch number (:134-136,174) with bit-identical state -- so the
+    continued run equals the uninterrupted one."""
+    from musicfpaugment_amd.training.train import Trainer
+    from musicfpaugment_amd.training.unet import UNet
+
+    def loader(seed):
+        k = 0
+        while True:
+            clean = synth.batch(2, seed=seed + 2 * (k % 3), n=8000)
+            noise = synth.batch(2, seed=seed + 100 + 2 * (k % 3), n=8000, tonal=False)
+            yield torch.from_numpy(clean)[:, :, None], torch.from_numpy((0.7 * clean + 0.3 * noise).astype(np.float32))[:, :, None]
+            k += 1
+
+    def make(path):
+        net = UNet(1, 1, rate=0.0)
+        net.load_state_dict(formula_state_dict(5))
+        return Trainer(net, loader(20), loader(60), learning_rate=1e-3, train_steps=3, val_steps=2, ckpt_path=path,
+                       scheduler_patience=0, early_stop_patience=50)
+
+    a = make(str(tmp_path / "a"))
+    a.training_loop(nb_epochs=3)                          # epochs 1, 2
+    assert a.epoch == 2 and len(a.losses["val"]) == 2
+    ck = torch.load(tmp_path / "a" / "last_epoch.pt", weights_only=False)
+    assert {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "early_stopping", "train_loss", "val_losses",
+            "best_val_loss"} <= set(ck)
+    assert ck["epoch"] == 2 and ck["best_val_loss"] == min(a.losses["val"]) == a.best_val_loss       # updated BEFORE last_epoch.pt
+    assert ck["early_stopping"].best_loss == a.early_stopping.best_loss
+    assert ck["scheduler_state_dict"]["best"] == a.scheduler.best and ck["scheduler_state_dict"]["num_bad_epochs"] == a.scheduler.num_bad
+    # torch's own Adam takes the optimizer state as it is
+    ref_net = UNet(1, 1, rate=0.0)
+    opt = torch.optim.Adam(ref_net.parameters(), lr=1.0)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    assert opt.param_groups[0]["lr"] == a.engine.lr and len(opt.state) == len(list(ref_net.parameters()))
+    name0 = next(n for n, _ in ref_net.named_parameters())
+    assert torch.equal(opt.state[next(iter(ref_net.parameters()))]["exp_avg"].cpu(), a.engine.named_moments()[0][name0].cpu())
+    # resume: a fresh trainer on the same directory continues where `a` would
+    b = make(str(tmp_path / "a"))
+    assert b.load_checkpoint()
+    assert b.epoch_start == 2 and b.engine.step_count == a.engine.step_count and b.engine.lr == a.engine.lr
+    assert torch.equal(b.engine.flat_p, a.engine.flat_p) and torch.equal(b.engine.flat_m, a.engine.flat_m)
+    assert torch.equal(b.engine.flat_v, a.engine.flat_v)
+    assert (b.scheduler.best, b.scheduler.num_bad) == (a.scheduler.best, a.scheduler.num_bad)
+    assert (b.early_stopping.best_loss, b.early_stopping.counter) == (a.early_stopping.best_loss, a.early_stopping.counter)
+    # same batches from here on for both (fresh iterators): one more epoch each
+    a.train_loader_iter, a.val_loader_iter = loader(300), loader(400)
+    b.train_loader_iter, b.val_loader_iter = loader(300), loader(400)
+    la, lb = a.train_epoch(3)["loss"], b.train_epoch(3)["loss"]
+    rel = (a.engine.flat_p - b.engine.flat_p).abs().max().item()
+    assert abs(la - lb) <= 1e-6 * abs(la) and rel <= 2.1e-3         # float-atomic weight gradients: not bit-reproducible run to run
+    # a private-format optimizer state (round 1 of this package) is refused with a clear message
+    ck["optimizer_state_dict"] = {"exp_avg": a.engine.flat_m, "exp_avg_sq": a.engine.flat_v, "step": 1, "lr": 1e-3}
+    torch.save(ck, tmp_path / "a" / "last_epoch.pt")
+    with pytest.raises(ValueError, match="torch.optim.Adam state_dict"):
+        make(str(tmp_path / "a")).load_checkpoint()
 
 
 def _host_keep_mask(seed, thresh, scale, shape_nhwc):
