@@ -34,6 +34,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef MFPA_CONV_BIG_MIN_CIN
 #define MFPA_CONV_BIG_MIN_CIN 64    // 128-channel tiles: the 8-wave 256-pixel shape from this many input channels on (256: round 1's choice)
 #endif
+#ifndef MFPA_CONV_PIPE4
+#define MFPA_CONV_PIPE4 0     // 1: the pipelined loop also for the 4-wave 256 x 64 shape, one wave per SIMD (A/B builds)
+#endif
 #ifndef MFPA_CONV_WN64
 #define MFPA_CONV_WN64 1
 #endif
@@ -70,6 +73,12 @@ constexpr int pin_read_slots(int slots, int left) {      // how many MFMAs pin_r
     ++used;
   }
   return used;
+}
+
+// does this instantiation run the software-pipelined main loop (one workgroup per CU, two halo stages)?
+constexpr bool conv_is_pipe(int BN, int PH, int PW, int WM, int WN, int MODE, int PREC) {
+  return (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 &&
+         (WM * WN == 8 || (MFPA_CONV_PIPE4 != 0 && WM * WN == 4 && BN == 64 && PH * PW == 256));
 }
 
 struct ConvArgs {
@@ -121,7 +130,7 @@ struct ConvArgs {
 //     one barrier                                 (+ barrier, halo store, at a chunk's last tap)
 // so weight loads have two MFMA blocks to land, and the only exposed cost per iteration is the wave skew.
 template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 2 ? 4 : 1);
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
   // PIPE (the bf16x3 3x3 convolution on the 8-wave shapes, one workgroup per CU): software-pipelined main loop with the halo
   // tile double-buffered in LDS, see step_pipe below.  The 4-wave shapes keep the plain loop: with 256 threads the staging
   // registers are twice as many per thread and the second fragment set spills (measured: 2x slower).
-  constexpr bool PIPE = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);
+  constexpr bool PIPE = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC);
   constexpr int A_STAGES = PIPE ? 2 : 1;
   // PIPE: a halo stage has a row for every staging slot (A_F4 * THREADS / 8 >= HP), so the split / store pass needs no tail
   // predicate: every halo load is consumed on every path and hipcc keeps no "maybe pending" state across iterations
@@ -275,32 +284,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_mfm
       }
     }
   };
+  // a thread's (row, quad) inside a weight tile never changes: 32-bit byte offsets computed once, added to a scalar tile base
+  unsigned b_off[B_F4];
+#pragma unroll
+  for (int it = 0; it < B_F4; ++it) {
+    const int idx = tid + it * THREADS;
+    const int n = idx / (KC / 4), q = idx % (KC / 4);
+    b_off[it] = (PREC == 0) ? (unsigned)(n * Cin + 4 * q) * 4u : (unsigned)(n * KC + 4 * (q ^ w3_swz(n))) * 4u;
+  }
   auto load_b = [&](int it_flat, auto SET) __attribute__((always_inline)) {
     constexpr int set = decltype(SET)::value;
     const int chunk = it_flat / TAPS, tap = it_flat % TAPS;
     const int wt = (MODE == 1) ? ct_tap : tap;
     // PREC 0: [tap][Cout][Cin] floats; PREC 1: the chunk-major swizzled image (header of this file)
-    const float* wbase = (PREC == 0) ? a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC
-                                     : a.w + (((size_t)wt * nchunks + chunk) * a.Cout + n0) * KC;
+    const char* wbase = reinterpret_cast<const char*>((PREC == 0) ? a.w + ((size_t)wt * a.Cout + n0) * Cin + chunk * KC
+                                                                 : a.w + (((size_t)wt * nchunks + chunk) * a.Cout + n0) * KC);
 #pragma unroll
-    for (int it = 0; it < B_F4; ++it) {
-      const int idx = tid + it * THREADS;
-      if (B_EXACT || idx < BN * (KC / 4)) {
-        const int n = idx / (KC / 4), q = idx % (KC / 4);
-        if (PREC == 0) breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * Cin + 4 * q);
-        else breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + n * KC + 4 * (q ^ w3_swz(n)));
-      }
-    }
+    for (int it = 0; it < B_F4; ++it)
+      if (B_EXACT || tid + it * THREADS < BN * (KC / 4)) breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + b_off[it]);
   };
   auto load_b_ct = [&](int chunk, int tap, auto SET) __attribute__((always_inline)) {     // PREC 1 image, (chunk, tap) given
     constexpr int set = decltype(SET)::value;
-    const float* wbase = a.w + (((size_t)tap * nchunks + chunk) * a.Cout + n0) * KC;
+    const char* wbase = reinterpret_cast<const char*>(a.w + (((size_t)tap * nchunks + chunk) * a.Cout + n0) * KC);
 #pragma unroll
-    for (int it = 0; it < B_F4; ++it) {
-      const int idx = tid + it * THREADS;
-      const int n = idx / (KC / 4), q = idx % (KC / 4);
-      breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + n * KC + 4 * (q ^ w3_swz(n)));
-    }
+    for (int it = 0; it < B_F4; ++it) breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + b_off[it]);
   };
   auto store_b = [&](auto SET, float* Bs) __attribute__((always_inline)) {
     constexpr int set = decltype(SET)::value;
@@ -975,7 +982,7 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  constexpr bool ADB = (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 && (WM * WN == 8);    // PIPE of the kernel: two padded halo stages
+  constexpr bool ADB = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC);    // PIPE of the kernel: two padded halo stages
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HPS = ADB ? ((HP * (KC / 4) + THREADS - 1) / THREADS) * (THREADS / (KC / 4)) : HP;
   const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HPS * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
