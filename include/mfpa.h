@@ -99,8 +99,11 @@ int mfpa_f64_to_f32(const double* in, float* out, long long n, void* stream);
  *   mean_order 0: numpy sums the spectrogram bin-major (C order: the UNet output),
  *              1: frame-major (the un-denoised |stft| array, which is a transposed view)
  *              -- the pairwise summation tree of np.mean is reproduced in that order
- *   log_input  1: `spec` already holds log(max(s, max/1e6)) computed by the caller
- *              (strict mode: everything downstream is IEEE add/mul/compare -> bit-exact)
+ *   log_input  bit 0: `spec` already holds log(max(s, max/1e6)) computed by the caller
+ *              (strict mode: everything downstream is IEEE add/mul/compare -> bit-exact);
+ *              bit 1 (value 2): denom[b] is the maximum of the float64 spec[b] itself, as
+ *              mfpa_stft_mag returned it with this spectrogram: max(spec / denom) is then 1
+ *              exactly (NaN for an all-zero clip, like numpy) and the max pass is skipped
  *   filtered   (B, T, F-1) float64, FRAME-major workspace consumed by mfpa_audfprint_prune
  *   scratch    (B, F*T) float64 workspace
  */

@@ -64,20 +64,25 @@ class Audfprint_peaks(object):
             self.unet, self.demucs = None, None
 
     # ------------------------------------------------------------------ batched device path
-    def find_peaks_batch(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def find_peaks_batch(self, wav: torch.Tensor, want_spec: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """(B, T) float32 on the GPU -> (mask (B,256,nF) uint8, npeaks (B,) int32, spec (B,257,nF)).
 
         STFT -> per-clip /max -> [UNet] -> log/mean/high-pass -> forward + backward pruning; no host sync.
-        spec is float64 without denoising and float32 with it, like the reference's third return value.
+        spec is float64 without denoising and float32 with it, like the reference's third return value.  `want_spec=False`
+        (peak masks only, no denoiser): the normalised spectrogram is not materialised -- the division by the clip maximum
+        happens inside the log / high-pass kernel, same float64 quotient -- and None is returned in its place.
         """
         mag, cmax = ops.stft_mag(wav, torch.float64)
         a_dec = ops.audfprint_a_dec(self.density, self.n_hop)
         if self.unet is not None:
             spec = self.unet.denoise_spectrogram(mag, cmax, per_clip=True)        # float32 (B,257,nF)
             filtered = ops.audfprint_prepare(spec, None, mean_order=0)            # C-contiguous in the reference
-        else:
+        elif want_spec:
             spec = ops.normalize_(mag, cmax, per_clip=True)
             filtered = ops.audfprint_prepare(spec, None, mean_order=1)            # |stft| is a transposed view there
+        else:
+            spec = None
+            filtered = ops.audfprint_prepare(mag, cmax, mean_order=1, denom_is_clip_max=True)
         mask, npeaks = ops.audfprint_prune(filtered, a_dec, self.maxpksperframe, float(self.f_sd))
         return mask, npeaks, spec
 

@@ -46,7 +46,16 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
 
   bool do_log = false;
   TIn floor_v = 0;
-  if (!log_input) {
+  const bool den_is_max = (log_input & 2) != 0 && has_den && sizeof(TIn) == sizeof(double);
+  log_input &= 1;
+  if (!log_input && den_is_max) {
+    // denom[b] IS the maximum of this float64 clip (the caller says so: it came from mfpa_stft_mag with this spectrogram), so the
+    // maximum of spec / denom is denom / denom = 1 exactly -- or NaN for an all-zero clip, as numpy's 0 / 0 gives -- and the
+    // max pass over the clip is not needed
+    const TIn smax = den > 0.0 ? (TIn)1 : (TIn)NAN;
+    do_log = smax > (TIn)0;
+    floor_v = smax / (TIn)1e6;
+  } else if (!log_input) {
     // pass A: max of the (normalised) spectrogram
     // One workgroup streams its clip: keep 8 independent loads in flight per thread (a single dependent load per
     // iteration leaves the CU waiting on memory latency: 8 waves x 1 load = 4 KB in flight).
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
       } else if (lane == 0) {
         lb[(size_t)c * MAXP + i] = -1;
       }
-      __syncthreads();
+      // (no barrier: the workgroup is ONE wavefront, whose LDS operations complete in program order)
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) th[s] = a_dec * th[s];

@@ -152,8 +152,9 @@ def gauss_table(npoints: int, width: float, device) -> torch.Tensor:
 
 
 def audfprint_prepare(spec: torch.Tensor, denom: Optional[torch.Tensor] = None, mean_order: int = 0,
-                      log_input: bool = False, pole: float = AUDFPRINT_POLE) -> torch.Tensor:
-    """(B, F, T) spectrogram -> frame-major filtered log-spectrogram (B, T, F-1) float64."""
+                      log_input: bool = False, pole: float = AUDFPRINT_POLE, denom_is_clip_max: bool = False) -> torch.Tensor:
+    """(B, F, T) spectrogram -> frame-major filtered log-spectrogram (B, T, F-1) float64.  `denom_is_clip_max`: denom[b] is the
+    maximum of the float64 spec[b] itself (what stft_mag returned with it), so the kernel skips its max pass."""
     require_gpu(spec, "spectrogram")
     if spec.dim() != 3:
         raise ValueError("spectrogram must be (B, F, T)")
@@ -166,7 +167,8 @@ def audfprint_prepare(spec: torch.Tensor, denom: Optional[torch.Tensor] = None, 
     filtered = torch.empty((B, T, F - 1), dtype=torch.float64, device=spec.device)
     scratch = torch.empty((B, F * T), dtype=torch.float64, device=spec.device)
     check(lib().mfpa_audfprint_prepare(ptr(spec), _dtype_code(spec), B, F, T, ptr(denom), int(mean_order),
-                                       int(log_input), float(pole), ptr(filtered), ptr(scratch), stream()),
+                                       int(bool(log_input)) | (2 if (denom_is_clip_max and denom is not None and spec.dtype == torch.float64) else 0),
+                                       float(pole), ptr(filtered), ptr(scratch), stream()),
           "mfpa_audfprint_prepare")
     return filtered
 

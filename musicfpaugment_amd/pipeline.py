@@ -58,7 +58,7 @@ class HotPath:
             from .afp.dejavu.fingerprint import fingerprint_peaks_batch
             mask, npeaks, _ = fingerprint_peaks_batch(wav, denoising=self.unet is not None, denoising_model="unet", unet=self.unet)
             return mask, npeaks
-        mask, npeaks, _ = self.extractor.find_peaks_batch(wav)
+        mask, npeaks, _ = self.extractor.find_peaks_batch(wav, want_spec=False)
         return mask, npeaks
 
 

@@ -366,3 +366,23 @@ def test_file_level_entry_points(tmp_path):
     assert got == want
     with pytest.raises(NotImplementedError):
         ext.wavfile2peaks("x.mp3")
+
+
+def test_masks_only_path_equals_the_full_path_bit_for_bit(ops):
+    """find_peaks_batch(want_spec=False) -- what the bench pipeline runs: the division by the clip maximum inside the log / high-pass
+    kernel and the skipped max pass (the maximum of spec / max is 1, or NaN for a silent clip, without looking) -- gives the masks of the
+    path that materialises the normalised spectrogram, including a silent clip, a one-sample clip and clips of several lengths."""
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+    ext = Audfprint_peaks(None, device="cuda")
+    for n in (64000, 24000, 8000, 2049):
+        wav = synth.batch(6, seed=4100 + n, n=n)
+        wav[2] = 0.0                                           # silent: 0 / 0 = NaN spectrogram, no log step, no peaks
+        wav[4] = 0.0
+        wav[4, n // 2] = 0.75                                  # a single click
+        x = torch.from_numpy(wav).cuda()
+        m0, n0, spec = ext.find_peaks_batch(x)
+        m1, n1, none = ext.find_peaks_batch(x, want_spec=False)
+        assert none is None and spec is not None
+        assert torch.equal(m0, m1) and torch.equal(n0, n1)
+        assert int(n0[2]) == 0

@@ -32,6 +32,7 @@ def timeit(name, fn, ins, reps=20):
 mag, cmax = timeit("stft_mag f64", lambda: ops.stft_mag(wav, torch.float64), (wav,))
 mag32, _ = timeit("stft_mag f32", lambda: ops.stft_mag(wav, torch.float32), (wav,))
 filt = timeit("audfprint_prepare (f64 |stft|)", lambda: ops.audfprint_prepare(mag, denom=cmax, mean_order=1), (mag, cmax))
+filt = timeit("audfprint_prepare (denom = max)", lambda: ops.audfprint_prepare(mag, denom=cmax, mean_order=1, denom_is_clip_max=True), (mag, cmax))
 mask, npk = timeit("audfprint_prune", lambda: ops.audfprint_prune(filt), (filt,))
 psd, pmax = timeit("specgram_psd (dejavu)", lambda: ops.specgram_psd(wav, scale_in=32767.0), (wav,))
 arr = timeit("dejavu_prepare", lambda: ops.dejavu_prepare(psd, pmax, 10.0, mean_order=1), (psd, pmax))
