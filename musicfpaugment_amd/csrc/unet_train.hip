@@ -547,67 +547,85 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
     b = (int)(q / a.tiles_y);
     y0 = ty * WGB_PH; x0p = tx * PW;
   };
+  // A thread's staging slots map to fixed pixels of the patch (pixel = tid / 16 + it * THREADS / 16, channel quad c4): a load is a
+  // per-patch SCALAR base plus an element offset that depends only on the in-patch (row, column) -- two integer multiply-adds and
+  // four compares for the image border, re-derived from compile-time divisors (no register arrays next to the 144 accumulators)
+  // -- instead of a division / 64-bit index chain per load (the loads' address work was the largest single cost of this kernel:
+  // skipping the next patch's loads returned 24 %).  Loads are unconditional: a pixel outside the image reads the element at offset
+  // 0 of its channel quad and is zeroed when it is staged, so there are no exec-mask branches.
+  const int t16 = tid / (WG_T / 4);
+  constexpr int PIX_STEP = WGB_THREADS / (WG_T / 4);
+  auto x_inside = [&](int pix, int y0, int x0p) __attribute__((always_inline)) {            // inside the image (source 0's extent)?
+    const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+    return pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+  };
+  auto x1_inside = [&](int pix, int y0, int x0p) __attribute__((always_inline)) {           // ... and inside the zero-padded second source?
+    const int y1 = y0 + pix / HPW - HALO - a.oy1, x1 = x0p + pix % HPW - HALO - a.ox1;
+    return pix < HP && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
+  };
   auto load_x = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+    if (from0) {
+      const float* base = a.x0 + (size_t)b * a.H * a.W * a.C0 + ci0 + 4 * c4;
 #pragma unroll
-    for (int it = 0; it < X_F4; ++it) {
-      const int pix = (tid + it * WGB_THREADS) / (WG_T / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pix < HP) {
-        const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-          if (from0) {
-            v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4);
-          } else {
-            const int y1 = gy - a.oy1, x1 = gx - a.ox1;
-            if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-              v = *reinterpret_cast<const f32x4*>(a.x1 + (((size_t)b * a.H1 + y1) * a.W1 + x1) * a.C1 + (ci0 - a.C0) + 4 * c4);
-          }
-        }
+      for (int it = 0; it < X_F4; ++it) {
+        const int pix = t16 + it * PIX_STEP;
+        const int off = ((y0 + pix / HPW - HALO) * a.W + (x0p + pix % HPW - HALO)) * a.C0;
+        xr[it] = *reinterpret_cast<const f32x4*>(base + (x_inside(pix, y0, x0p) ? off : 0));
       }
-      xr[it] = v;
+    } else {
+      const float* base = a.x1 + (size_t)b * a.H1 * a.W1 * a.C1 + (ci0 - a.C0) + 4 * c4;
+#pragma unroll
+      for (int it = 0; it < X_F4; ++it) {
+        const int pix = t16 + it * PIX_STEP;
+        const int off = ((y0 + pix / HPW - HALO - a.oy1) * a.W1 + (x0p + pix % HPW - HALO - a.ox1)) * a.C1;
+        xr[it] = *reinterpret_cast<const f32x4*>(base + (x1_inside(pix, y0, x0p) ? off : 0));
+      }
     }
   };
   auto store_x = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < X_F4; ++it) {
-      const int pix = (tid + it * WGB_THREADS) / (WG_T / 4);
+      const int pix = t16 + it * PIX_STEP;
       if (pix < HP) {
+        const bool inside = from0 ? x_inside(pix, y0, x0p) : x1_inside(pix, y0, x0p);
         f32x4 v = xr[it];
-        if (affine) {
-          const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {       // padding stays exactly zero
-            v = v * a_sc + a_sh;
+        if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};               // zero padding
+        if (affine && inside) {                                    // padding stays exactly zero
+          v = v * a_sc + a_sh;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
-            if (a.drop_thresh) {
-              const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4;
+          for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+          if (a.drop_thresh) {
+            const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
+            const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + ci0 + 4 * c4;
 #pragma unroll
-              for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
-            }
+            for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
           }
         }
         wg_store_split<PLAIN>(Xs + pix * ROW, c4, v);
       }
     }
   };
+  // dz tile: zero past the image border is applied when the tile is staged (store_d keeps the patch position for it)
+  int d_y0 = 0, d_x0 = 0;
   auto load_d = [&](int b, int y0, int x0p, int tap) __attribute__((always_inline)) {
+    const float* base = (MODE == 0) ? a.dz + (size_t)b * a.H * a.W * a.Cout + co0 + 4 * c4
+                                    : a.dz + (size_t)b * (2 * a.H) * (2 * a.W) * a.Cout + co0 + 4 * c4;
 #pragma unroll
     for (int it = 0; it < D_F4; ++it) {
-      const int pix = (tid + it * WGB_THREADS) / (WG_T / 4);
+      const int pix = t16 + it * PIX_STEP;
       const int gy = y0 + pix / PW, gx = x0p + pix % PW;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < a.H && gx < a.W) {
-        if (MODE == 0)
-          v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)b * a.H + gy) * a.W + gx) * a.Cout + co0 + 4 * c4);
-        else
-          v = *reinterpret_cast<const f32x4*>(a.dz + (((size_t)b * (2 * a.H) + 2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout + co0 + 4 * c4);
-      }
-      dr[it] = v;
+      const int off = (MODE == 0) ? (gy * a.W + gx) * a.Cout : ((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout;
+      dr[it] = *reinterpret_cast<const f32x4*>(base + ((gy < a.H && gx < a.W) ? off : 0));
     }
+    d_y0 = y0; d_x0 = x0p;
   };
   auto store_d = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int it = 0; it < D_F4; ++it) wg_store_split<PLAIN>(Ds + ((tid + it * WGB_THREADS) / (WG_T / 4)) * ROW, c4, dr[it]);
+    for (int it = 0; it < D_F4; ++it) {
+      const int pix = t16 + it * PIX_STEP;
+      const bool in = d_y0 + pix / PW < a.H && d_x0 + pix % PW < a.W;
+      wg_store_split<PLAIN>(Ds + pix * ROW, c4, in ? dr[it] : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
   };
   auto mfma3 = [&](floatx16& c, wg_bf16x8 ah, wg_bf16x8 al, wg_bf16x8 bh, wg_bf16x8 bl) __attribute__((always_inline)) {
     if (!PLAIN) {
