@@ -37,6 +37,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef MFPA_CONV_PIPE4
 #define MFPA_CONV_PIPE4 0     // 1: the pipelined loop also for the 4-wave 256 x 64 shape, one wave per SIMD (A/B builds)
 #endif
+#ifndef MFPA_CONV_PIPE_COND_A
+#define MFPA_CONV_PIPE_COND_A 0   // 1: the pipelined loop skips halo slots outside the image too (A/B builds)
+#endif
 #ifndef MFPA_CONV_WN64
 #define MFPA_CONV_WN64 1
 #endif
@@ -188,22 +191,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   // instructions per load, the largest block of vector work in the 64-channel layers).
   static_assert(THREADS % (KC / 4) == 0, "a thread keeps one channel quad for all of its halo pixels");
   const int aq = tid % (KC / 4);
+  // packed as: bit 31 = outside the image (or past the tile), bits 30..16 / 15..0 = row / column CLAMPED into the image -- a slot
+  // outside still loads (unconditionally, see load_a), from its nearest image pixel: a line its neighbours fetch anyway (every
+  // outside slot reading ONE fixed address made that line a hot spot: +4-8 % on the 8-wave fp32 kernel)
   int apix[A_F4];
 #pragma unroll
   for (int it = 0; it < A_F4; ++it) {
     const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
     const int gy = y0 + pix / HPW - HALO, gx = x0p + pix % HPW - HALO;
-    apix[it] = (pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy << 16) | gx) : -1;
+    const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+    apix[it] = (in ? 0 : (int)0x80000000) | (cy << 16) | cx;
   }
   // 32-bit byte offsets from per-clip scalar bases (the host checks that one clip's input image fits 2 GB)
   const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * (MODE == 2 ? 4 : 1) * a.H * a.W * a.C0 * sizeof(float);
   const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
   // load_a only ISSUES the global loads of a halo tile (nothing in it reads a loaded value, so no wait lands between the
   // loads); the on-load affine + ReLU + dropout and the bf16 split happen in store_a, a whole chunk later.  Every slot loads
-  // UNCONDITIONALLY -- a pixel outside the image reads offset 0 of the clip and store_a zeroes it: no exec-mask branches, and
+  // UNCONDITIONALLY -- a pixel outside the image reads its nearest image pixel and store_a zeroes it: no exec-mask branches, and
   // a wave issues exactly A_F4 loads per tile, which the pipelined loop's counted vmcnt waits rely on.
   auto src1_inside = [&](int p) __attribute__((always_inline)) {          // inside the (smaller, zero-padded) second source?
-    const int y1 = (p >> 16) - a.oy1, x1 = (p & 0xffff) - a.ox1;
+    const int y1 = ((p >> 16) & 0x7fff) - a.oy1, x1 = (p & 0xffff) - a.ox1;
     return p >= 0 && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
   };
   auto load_a = [&](int chunk, int tap) __attribute__((always_inline)) {
@@ -212,16 +220,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     const bool from0 = c0 < a.C0;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
+      const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;           // clamped into the image
+      // PIPE: every slot loads, so that a wave issues exactly A_F4 loads per tile and hipcc's vmcnt bookkeeping stays exact; the
+      // plain loop skips slots outside the image (measured: unconditional loads cost its fp32 8-wave form 4-8 %)
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (from0) {
         unsigned off;
         if (MODE == 2) off = ((unsigned)((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
         else off = ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
-        areg[it] = *reinterpret_cast<const f32x4*>(xb0 + (apix[it] >= 0 ? off : 0u));
+        if ((PIPE && !MFPA_CONV_PIPE_COND_A) || apix[it] >= 0) v = *reinterpret_cast<const f32x4*>(xb0 + off);
       } else {
-        const unsigned off = ((unsigned)(((apix[it] >> 16) - a.oy1) * a.W1 + (gx - a.ox1)) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
-        areg[it] = *reinterpret_cast<const f32x4*>(xb1 + (src1_inside(apix[it]) ? off : 0u));
+        const int y1 = min(max(gy - a.oy1, 0), a.H1 - 1), x1 = min(max(gx - a.ox1, 0), a.W1 - 1);
+        const unsigned off = ((unsigned)(y1 * a.W1 + x1) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
+        if ((PIPE && !MFPA_CONV_PIPE_COND_A) || src1_inside(apix[it])) v = *reinterpret_cast<const f32x4*>(xb1 + off);
       }
+      areg[it] = v;
     }
   };
   auto store_a = [&](int chunk, float* As) __attribute__((always_inline)) {      // `As`: the halo stage to fill
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
         const bool inside = apix[it] >= 0;
         f32x4 v = areg[it];
         if (!C1SRC && !(c0 < a.C0 ? inside : src1_inside(apix[it]))) v = f32x4{0.f, 0.f, 0.f, 0.f};      // zero padding
-        const int gy = apix[it] >> 16, gx = apix[it] & 0xffff;
+        const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;
         if (C1SRC) {
           v = f32x4{0.f, 0.f, 0.f, 0.f};
           if (inside) {                                                    // conv2's zero padding stays exactly zero
@@ -1006,7 +1019,7 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   const bool bn128 = (a.Cout % 128 == 0);
   static const int wm_env = MFPA_EXP_ENV("MFPA_CONV_WM", 0);   // experiments
   const int cin = a.C0 + a.C1;
-  const bool big = (wm_env == 4) || (wm_env == 0 && cin >= MFPA_CONV_BIG_MIN_CIN);
+  const bool big = (wm_env == 4) || (wm_env == 0 && cin >= ((PREC == 1 && MODE == 0) ? MFPA_CONV_BIG_MIN_CIN : 256));   // the plain loop keeps round 1's measured threshold
   constexpr int WN64 = MFPA_CONV_WN64;   // 2: the pipelined 8-wave shape with waves of 64 px x 32 ch (measured 5-10 % slower than the 4-wave shape)
   if (MODE == 0 && (a.c1_x32 || a.c1_spec64)) {        // checked by the caller: C0 == 64, C1 == 0, Cout == 64, W > 16, H >= 8
     return launch_conv<64, 8, 32, 4, WN64, 0, PREC, true>(a, 1, s);

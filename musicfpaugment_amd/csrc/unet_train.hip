@@ -564,21 +564,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
     return pix < HP && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
   };
   auto load_x = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+    // a slot outside the image loads its nearest image pixel (a line its neighbours fetch anyway; one fixed address for all of them
+    // would be a hot spot) and is zeroed when it is staged
     if (from0) {
       const float* base = a.x0 + (size_t)b * a.H * a.W * a.C0 + ci0 + 4 * c4;
 #pragma unroll
       for (int it = 0; it < X_F4; ++it) {
         const int pix = t16 + it * PIX_STEP;
-        const int off = ((y0 + pix / HPW - HALO) * a.W + (x0p + pix % HPW - HALO)) * a.C0;
-        xr[it] = *reinterpret_cast<const f32x4*>(base + (x_inside(pix, y0, x0p) ? off : 0));
+        const int gy = min(max(y0 + pix / HPW - HALO, 0), a.H - 1), gx = min(max(x0p + pix % HPW - HALO, 0), a.W - 1);
+        xr[it] = *reinterpret_cast<const f32x4*>(base + (gy * a.W + gx) * a.C0);
       }
     } else {
       const float* base = a.x1 + (size_t)b * a.H1 * a.W1 * a.C1 + (ci0 - a.C0) + 4 * c4;
 #pragma unroll
       for (int it = 0; it < X_F4; ++it) {
         const int pix = t16 + it * PIX_STEP;
-        const int off = ((y0 + pix / HPW - HALO - a.oy1) * a.W1 + (x0p + pix % HPW - HALO - a.ox1)) * a.C1;
-        xr[it] = *reinterpret_cast<const f32x4*>(base + (x1_inside(pix, y0, x0p) ? off : 0));
+        const int y1 = min(max(y0 + pix / HPW - HALO - a.oy1, 0), a.H1 - 1), x1 = min(max(x0p + pix % HPW - HALO - a.ox1, 0), a.W1 - 1);
+        xr[it] = *reinterpret_cast<const f32x4*>(base + (y1 * a.W1 + x1) * a.C1);
       }
     }
   };
@@ -613,9 +615,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
 #pragma unroll
     for (int it = 0; it < D_F4; ++it) {
       const int pix = t16 + it * PIX_STEP;
-      const int gy = y0 + pix / PW, gx = x0p + pix % PW;
+      const int gy = min(y0 + pix / PW, a.H - 1), gx = min(x0p + pix % PW, a.W - 1);       // clamped; zeroed in store_d when outside
       const int off = (MODE == 0) ? (gy * a.W + gx) * a.Cout : ((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout;
-      dr[it] = *reinterpret_cast<const f32x4*>(base + ((gy < a.H && gx < a.W) ? off : 0));
+      dr[it] = *reinterpret_cast<const f32x4*>(base + off);
     }
     d_y0 = y0; d_x0 = x0p;
   };
