@@ -714,6 +714,7 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
   const int nchunks = a.C0 / KC;
   const int q = tid % (KC / 4);
   const bool affine = a.in_scale0 != nullptr;
+  const char* xb = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * sizeof(float);   // 32-bit offsets from the clip's base
 
   f32x4 areg[A_F4], breg[B_F4];
   auto load = [&](int chunk) __attribute__((always_inline)) {
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
       const int pix = (tid + it * 256) / (KC / 4);
       const int gy = y0 + pix / PW, gx = x0p + pix % PW;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < a.H && gx < a.W) v = *reinterpret_cast<const f32x4*>(a.x0 + (((size_t)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * q);
+      if (gy < a.H && gx < a.W) v = *reinterpret_cast<const f32x4*>(xb + ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * q)) * 4u);
       areg[it] = v;
     }
 #pragma unroll
@@ -829,24 +830,34 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
       }
     }
   }
-  // epilogue: D[row = pixel][col = channel]; tap t writes output pixel (2 gy + (t >> 1), 2 gx + (t & 1))
+  // epilogue: D[row = pixel][col = channel]; tap t writes output pixel (2 gy + (t >> 1), 2 gx + (t & 1)).  32-bit byte offsets from
+  // a scalar per-clip base (the host checks that one clip's output fits 4 GB): one offset per pixel, the four taps and the two
+  // channel tiles are wave-uniform displacements of it (the first form computed a 64-bit index per stored element: 128 of them
+  // against 48 MFMAs per 32-channel chunk, the largest block of vector work in this kernel)
+  float sc[NT], sh[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + nt * 32 + li;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
+    sc[nt] = a.scale ? a.scale[n] : 1.f;
+    sh[nt] = a.shift ? a.shift[n] : 0.f;
+  }
+  char* yb = reinterpret_cast<char*>(a.y + (size_t)b * (2 * a.H) * (2 * a.W) * a.Cout);
+  const unsigned cout4 = (unsigned)a.Cout * 4u, row4 = 2u * (unsigned)a.W * cout4;
+  const unsigned nb = (unsigned)(n0 + li) * 4u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int gy = y0 + m / PW, gx = x0p + m % PW;
-      if (gy < a.H && gx < a.W) {
+  for (int r = 0; r < 16; ++r) {
+    const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int gy = y0 + m / PW, gx = x0p + m % PW;
+    if (gy < a.H && gx < a.W) {
+      char* yp = yb + ((unsigned)(2 * gy) * row4 + (unsigned)(2 * gx) * cout4 + nb);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float v = acc[t][nt][r] * sc + sh;
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v = acc[t][nt][r] * sc[nt] + sh[nt];
           if (a.relu) v = v > 0.f ? v : 0.f;
-          a.y[(((size_t)b * (2 * a.H) + 2 * gy + (t >> 1)) * (2 * a.W) + 2 * gx + (t & 1)) * a.Cout + n] = v;
+          *reinterpret_cast<float*>(yp + ((t >> 1) * row4 + (t & 1) * cout4 + nt * 128u)) = v;
         }
-      }
     }
   }
 }
@@ -1072,6 +1083,7 @@ int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, 
   if (B == 0) return MFPA_OK;
   if (!x || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
   if (Cin < KC || Cin % KC || Cout < 64 || Cout % 64 || (precision != 0 && precision != 1)) return MFPA_EINVAL;
+  if (4LL * H * W * Cout * 4 > 0xffffffffLL || 1LL * H * W * Cin * 4 > 0xffffffffLL) return MFPA_EINVAL;   // 32-bit byte offsets inside one clip
   ConvArgs a{};
   a.x0 = x; a.w = w; a.scale = nullptr; a.shift = bias; a.y = y;
   a.C0 = Cin; a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 0; a.yH = H; a.yW = W;
