@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
-PMC_TRAFFIC_BF16X3 = "r01d_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
+PMC_TRAFFIC_BF16X3 = "r02_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
 
 
 def _oracle_chain():
