@@ -320,6 +320,13 @@ typedef struct mfpa_wgrad_desc {
 } mfpa_wgrad_desc;
 int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream);
 
+/* precision 3 of mfpa_wgrad_mfma: dz / x0 / x1 are bfloat16 tensors of the same shapes holding the ACTIVATED operands (in_scale0 /
+ * in_shift0 / dropout must be off), one bf16 MFMA per product like precision 2.  mfpa_act_to_bf16 makes such a copy: out[e] =
+ * bf16(z[e]) (scale == NULL), or bf16(dropout_e(relu(z[e] * scale[c] + shift[c]))) -- the on-load transform the fp32 kernels apply
+ * (the previous layer's BatchNorm + ReLU + Dropout, training/unet.py:8-25,99-103).  z (n) float32, n a multiple of C, C % 4 == 0. */
+int mfpa_act_to_bf16(const float* z, long long n, int C, const float* scale, const float* shift, unsigned drop_seed,
+                     unsigned drop_thresh, float drop_scale, void* out_bf16, void* stream);
+
 /* First layer (1 input channel): dw[tap][co] += sum_p dz[p][co] * x[p + tap]; x as in
  * mfpa_conv3x3_c1_bn_relu (per-clip denominators). */
 int mfpa_wgrad_c1(const float* dz, const float* x32, const double* spec64, const double* denom, int B, int H,
@@ -338,8 +345,9 @@ int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dp
                  double* workspace, void* stream);
 
 /* Operand image of a convolution's weights, rebuilt from the master fp32 parameters after every optimiser step (replaces the
- * host-side flip / transpose / bf16 split of the packing code).  w: [taps][Co][Ci] fp32.  out: [taps][nrows][K] rows, K-contiguous,
- * 32-element chunks as 32 floats (precision 0) or [32 bf16 hi | 32 bf16 lo] (precision 1).  flip_transpose = 0: rows = output
+ * host-side flip / transpose / bf16 split of the packing code).  w: [taps][Co][Ci] fp32.  out, precision 0: [taps][nrows][K] float rows;
+ * precision 1: the bf16x3 image [taps][K / 32][nrows][128 B], a row = 32 bf16 hi | 32 bf16 lo in eight 16-byte slots stored at slot
+ * index (logical ^ ((row >> 1) & 7)) -- a (tap, chunk, 128-row) tile is 16 KB contiguous (csrc/unet.hip).  flip_transpose = 0: rows = output
  * channels row0 .. row0+nrows-1, K = Ci (forward operand).  flip_transpose = 1: rows = input channels row0 .. row0+nrows-1,
  * K = Co, and for taps == 9 the kernel is flipped (tap t <- 8 - t): the input-gradient operand (training/unet.py's Conv2d /
  * ConvTranspose2d backward).  Co, Ci, row0, nrows multiples of 32. */

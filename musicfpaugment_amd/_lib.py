@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class MfpaError(RuntimeError):
@@ -127,6 +127,7 @@ _SIGNATURES = {
     "mfpa_outconv_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p], c_int),
     "mfpa_l1_loss": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_act_to_bf16": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
     "mfpa_pack_conv_weights": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_adam_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int,
                         c_float, c_void_p], c_int),

@@ -484,8 +484,13 @@ __device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
 // the four rows of a transposing block on bank offsets 0 / 192 / 128 / 64).  A weight gradient sums over every pixel of the
 // batch, so the 2^-9 rounding of the products averages out (relative L1 2e-3 vs fp32 on one layer, the level of fp32
 // autograd's own noise through the BatchNorm backward) and nothing downstream consumes it except the optimiser.
-template <int MODE, int PW, int NW, bool PLAIN>
+// BF16IN (with PLAIN): dz / x0 / x1 are bf16 tensors that already hold the ACTIVATED values (mfpa_act_to_bf16: the previous layer's
+// BatchNorm + ReLU + dropout applied, or a plain cast) -- every (co, ci) tile re-reads the patches of both operands, so for layers
+// with many tiles halving the bytes per re-read pays for one cast pass (the kernel was bound by what it pulls from L2: skipping its
+// loads returned 24 %); staging is then a 16-byte copy, no split.
+template <int MODE, int PW, int NW, bool PLAIN, bool BF16IN = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(WgradArgs a) {
+  static_assert(!BF16IN || PLAIN, "bf16 operands carry only the hi halves");
   constexpr int ROW = PLAIN ? 192 : WGB_ROW;
   constexpr int WGB_THREADS = 64 * NW, WGB_PIX = 16 * NW;
   constexpr int WGB_PH = WGB_PIX / PW;
@@ -629,6 +634,67 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
       wg_store_split<PLAIN>(Ds + pix * ROW, c4, in ? dr[it] : f32x4{0.f, 0.f, 0.f, 0.f});
     }
   };
+  // ---- BF16IN staging: 8 threads per pixel, one 16-byte piece (8 channels) each
+  typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int X_L = BF16IN ? (HP * 8 + WGB_THREADS - 1) / WGB_THREADS : 1;
+  constexpr int D_L = BF16IN ? WGB_PIX * 8 / WGB_THREADS : 1;
+  constexpr int PIX_STEP8 = WGB_THREADS / 8;
+  const int c8 = tid % 8, t8 = tid / 8;
+  wg_u32x4 xr16[X_L], dr16[D_L];
+  auto load_x16 = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+    if (from0) {
+      const char* base = reinterpret_cast<const char*>(a.x0) + ((size_t)b * a.H * a.W * a.C0 + ci0 + 8 * c8) * 2;
+#pragma unroll
+      for (int it = 0; it < X_L; ++it) {
+        const int pix = t8 + it * PIX_STEP8;
+        const int gy = min(max(y0 + pix / HPW - HALO, 0), a.H - 1), gx = min(max(x0p + pix % HPW - HALO, 0), a.W - 1);
+        xr16[it] = *reinterpret_cast<const wg_u32x4*>(base + (size_t)((gy * a.W + gx) * a.C0) * 2);
+      }
+    } else {
+      const char* base = reinterpret_cast<const char*>(a.x1) + ((size_t)b * a.H1 * a.W1 * a.C1 + (ci0 - a.C0) + 8 * c8) * 2;
+#pragma unroll
+      for (int it = 0; it < X_L; ++it) {
+        const int pix = t8 + it * PIX_STEP8;
+        const int y1 = min(max(y0 + pix / HPW - HALO - a.oy1, 0), a.H1 - 1), x1 = min(max(x0p + pix % HPW - HALO - a.ox1, 0), a.W1 - 1);
+        xr16[it] = *reinterpret_cast<const wg_u32x4*>(base + (size_t)((y1 * a.W1 + x1) * a.C1) * 2);
+      }
+    }
+  };
+  auto store_x16 = [&](int y0, int x0p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < X_L; ++it) {
+      const int pix = t8 + it * PIX_STEP8;
+      if (pix < HP) {
+        const bool inside = from0 ? x_inside(pix, y0, x0p) : x1_inside(pix, y0, x0p);
+        *reinterpret_cast<wg_u32x4*>(Xs + pix * ROW + 16 * c8) = inside ? xr16[it] : wg_u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto load_d16 = [&](int b, int y0, int x0p, int tap) __attribute__((always_inline)) {
+    const char* base = reinterpret_cast<const char*>(a.dz) +
+                       ((size_t)b * (MODE == 0 ? 1 : 4) * a.H * a.W * a.Cout + co0 + 8 * c8) * 2;
+#pragma unroll
+    for (int it = 0; it < D_L; ++it) {
+      const int pix = t8 + it * PIX_STEP8;
+      const int gy = min(y0 + pix / PW, a.H - 1), gx = min(x0p + pix % PW, a.W - 1);
+      const int off = (MODE == 0) ? (gy * a.W + gx) * a.Cout : ((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout;
+      dr16[it] = *reinterpret_cast<const wg_u32x4*>(base + (size_t)off * 2);
+    }
+    d_y0 = y0; d_x0 = x0p;
+  };
+  auto store_d16 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < D_L; ++it) {
+      const int pix = t8 + it * PIX_STEP8;
+      const bool in = d_y0 + pix / PW < a.H && d_x0 + pix % PW < a.W;
+      *reinterpret_cast<wg_u32x4*>(Ds + pix * ROW + 16 * c8) = in ? dr16[it] : wg_u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  // one set of names for the patch loop below
+  auto LOAD_X = [&](int b, int y0, int x0p) __attribute__((always_inline)) { if constexpr (BF16IN) load_x16(b, y0, x0p); else load_x(b, y0, x0p); };
+  auto STORE_X = [&](int b, int y0, int x0p) __attribute__((always_inline)) { if constexpr (BF16IN) store_x16(y0, x0p); else store_x(b, y0, x0p); };
+  auto LOAD_D = [&](int b, int y0, int x0p, int tap) __attribute__((always_inline)) { if constexpr (BF16IN) load_d16(b, y0, x0p, tap); else load_d(b, y0, x0p, tap); };
+  auto STORE_D = [&]() __attribute__((always_inline)) { if constexpr (BF16IN) store_d16(); else store_d(); };
   auto mfma3 = [&](floatx16& c, wg_bf16x8 ah, wg_bf16x8 al, wg_bf16x8 bh, wg_bf16x8 bl) __attribute__((always_inline)) {
     if (!PLAIN) {
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
@@ -641,26 +707,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   long long patch = bzi;
   if (patch < npatch) {
     decode(patch, b, y0, x0p);
-    load_x(b, y0, x0p);
-    load_d(b, y0, x0p, 0);
+    LOAD_X(b, y0, x0p);
+    LOAD_D(b, y0, x0p, 0);
   }
   for (; patch < npatch; patch += gridDim.z) {
     __syncthreads();                       // the previous patch's fragment reads are done
-    store_x(b, y0, x0p);
-    store_d();
+    STORE_X(b, y0, x0p);
+    STORE_D();
     __syncthreads();
     const long long next = patch + gridDim.z;
     int nb = 0, ny0 = 0, nx0 = 0;
     if (MODE == 0 && next < npatch) {      // prefetch the next patch; the loads land during the MFMA block below
       decode(next, nb, ny0, nx0);
-      load_x(nb, ny0, nx0);
-      load_d(nb, ny0, nx0, 0);
+      LOAD_X(nb, ny0, nx0);
+      LOAD_D(nb, ny0, nx0, 0);
     }
     for (int tap = 0; tap < (MODE == 0 ? 1 : TAPS); ++tap) {
       if (MODE == 1 && tap > 0) {          // transposed conv: the tap's strided view of dz replaces the dz tile
         __syncthreads();
-        load_d(b, y0, x0p, tap);
-        store_d();
+        LOAD_D(b, y0, x0p, tap);
+        STORE_D();
         __syncthreads();
       }
 #pragma unroll 1   // one k-step's 9 taps in flight at a time: bounds the live fragment registers next to 144 accumulators
@@ -689,8 +755,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
     }
     if (MODE == 1 && next < npatch) {
       decode(next, nb, ny0, nx0);
-      load_x(nb, ny0, nx0);
-      load_d(nb, ny0, nx0, 0);
+      LOAD_X(nb, ny0, nx0);
+      LOAD_D(nb, ny0, nx0, 0);
     }
     b = nb; y0 = ny0; x0p = nx0;
   }
@@ -933,6 +999,33 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
   }
 }
 
+
+// Activation -> bf16 copy for the bf16-operand weight-gradient kernel: out[e] = bf16(act(z[e])), act = the consumer's on-load
+// transform (relu(z * scale[c] + shift[c]), then the stateless dropout mask of element e) or the identity (scale == NULL).
+__global__ __launch_bounds__(256) void act_to_bf16_kernel(const float* __restrict__ z, long long n4, int C, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, unsigned drop_seed, unsigned drop_thresh,
+                                                          float drop_scale, __bf16* __restrict__ out) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + 4 * i);
+    if (scale) {
+      const int c = (int)((4 * i) % C);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+      v = v * sc + sh;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      if (drop_thresh) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)(4 * i + k)) ? v[k] * drop_scale : 0.f;
+      }
+    }
+    bf16x4_t o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (__bf16)v[k];
+    *reinterpret_cast<bf16x4_t*>(out + 4 * i) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1106,11 +1199,12 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
   if (split > 65535) split = 65535;
   dim3 grid(d->Cout / WG_T, (d->C0 + d->C1) / WG_T, (unsigned)split);
   hipStream_t s = mfpa_stream(stream);
-  if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
+  if (d->precision < 0 || d->precision > 3) return MFPA_EINVAL;
+  if (d->precision == 3 && (d->in_scale0 || d->drop_thresh)) return MFPA_EINVAL;      // bf16 operands are already activated
   if (d->precision >= 1) {
     // transposing LDS reads need every lane live (512-thread workgroups, no early exits) -- guaranteed by the kernel shape
     static const int nw_env = MFPA_EXP_ENV("MFPA_WGRAD_NW", 0);   // experiments: 4 or 8 waves
-    const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : 8;
+    const int nw = (d->precision != 3 && (nw_env == 4 || nw_env == 8)) ? nw_env : 8;
     const int pix = 16 * nw;
     const int pw = d->W <= 16 ? 16 : 32, phh = pix / pw;
     a.tiles_x = (d->W + pw - 1) / pw;
@@ -1123,7 +1217,7 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
     grid.z = (unsigned)split_b;
     static const int xcd_env = MFPA_EXP_ENV("MFPA_GEMM_XCD", 1);   // 0: plain order (experiments)
     a.xcd = xcd_env;
-    const bool plain = d->precision == 2;
+    const bool plain = d->precision >= 2;
     const size_t lds = (size_t)(plain ? 192 : WGB_ROW) * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
     const dim3 blk(64 * nw);
 #define MFPA_WG_LAUNCH(M, P, N, Q) hipLaunchKernelGGL((wgrad_bf16x3_kernel<M, P, N, Q>), grid, blk, lds, s, a)
@@ -1134,7 +1228,13 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
       else if (pw == 32) MFPA_WG_LAUNCH(1, 32, N, Q);       \
       else MFPA_WG_LAUNCH(1, 16, N, Q);                     \
     } while (0)
-    if (nw == 8 && plain) MFPA_WG_PICK(8, true);
+    if (d->precision == 3) {
+      if (d->mode == 0 && pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 32, 8, true, true>), grid, dim3(512), lds, s, a);
+      else if (d->mode == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 16, 8, true, true>), grid, dim3(512), lds, s, a);
+      else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32, 8, true, true>), grid, dim3(512), lds, s, a);
+      else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 16, 8, true, true>), grid, dim3(512), lds, s, a);
+    }
+    else if (nw == 8 && plain) MFPA_WG_PICK(8, true);
     else if (nw == 8) MFPA_WG_PICK(8, false);
     else if (plain) MFPA_WG_PICK(4, true);
     else MFPA_WG_PICK(4, false);
@@ -1147,6 +1247,17 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
     const size_t lds = sizeof(float) * ((size_t)WG_PIX * WG_T + (size_t)WG_PH * WG_PW * WG_T);
     hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
   }
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_act_to_bf16(const float* z, long long n, int C, const float* scale, const float* shift, unsigned drop_seed,
+                     unsigned drop_thresh, float drop_scale, void* out_bf16, void* stream) {
+  if (n == 0) return MFPA_OK;
+  if (!z || !out_bf16 || n < 0 || C < 4 || C % 4 || n % C) return MFPA_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr) || (drop_thresh && !scale)) return MFPA_EINVAL;
+  hipLaunchKernelGGL(act_to_bf16_kernel, dim3(grid_for(n / 4, 256, 256 * 32)), dim3(256), 0, mfpa_stream(stream), z, n / 4, C, scale, shift,
+                     drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(out_bf16));
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

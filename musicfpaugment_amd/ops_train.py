@@ -105,8 +105,27 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
+BF16_WGRAD_MIN_CH = 256     # plain-bf16 weight gradients: layers with at least this many channels on both sides read bf16 copies
+
+
+def act_to_bf16(z: torch.Tensor, in_affine: Optional[Stats] = None) -> torch.Tensor:
+    """bf16 copy of an NHWC float32 tensor with the consumer's on-load transform applied (mfpa_act_to_bf16)."""
+    out = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
+    check(lib().mfpa_act_to_bf16(ptr(z), z.numel(), z.shape[-1], ptr(in_affine.scale) if in_affine else 0,
+                                 ptr(in_affine.shift) if in_affine else 0, _drop(in_affine)[0], _drop(in_affine)[1],
+                                 _drop(in_affine)[2], ptr(out), stream()), "mfpa_act_to_bf16")
+    return out
+
+
 def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0):
     B, H, W, C0 = x0.shape
+    cin = C0 + (0 if x1 is None else x1.shape[3])
+    if precision == 2 and min(Cout, cin) >= BF16_WGRAD_MIN_CH:
+        # every (co, ci) tile re-reads both operands: with >= 4 tiles per side one cast pass to bf16 (activation applied) halves what
+        # the tiles pull through L2; same products as precision 2 (one bf16 MFMA each, fp32 accumulate)
+        dz, x0, in_affine = act_to_bf16(dz), act_to_bf16(x0, in_affine), None
+        x1 = None if x1 is None else act_to_bf16(x1)
+        precision = 3
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
                   in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), dw=ptr(dw), C0=C0,
                   C1=0 if x1 is None else x1.shape[3], H1=0 if x1 is None else x1.shape[1],
