@@ -378,7 +378,9 @@ typedef struct mfpa_gemm_desc {
   const float* addend; long long ldadd, strideAdd;
   float* C; long long ldc, strideC;
   int batch, M, N, K, npad, mode, relu;
-  int precision;   /* 0: fp32 MFMA (K multiple of 16); 1: bf16x3 where K >= 128 is a multiple of 32 or K is 48 / 96 (fp32 MFMA otherwise) */
+  int precision;   /* 0: fp32 MFMA (K multiple of 16); 1: bf16x3 where K >= 128 is a multiple of 32 or K is 48 / 96 (fp32 MFMA otherwise);
+                    * 2: bf16x3 with W ALREADY split -- every 32-element chunk of a row as [32 bf16 hi | 32 bf16 lo], w = hi + lo -- for
+                    * weights that do not change between calls (K >= 128 a multiple of 32, npad a multiple of 128, no c1_x) */
   /* optional (K <= 256, fp32 kernel): A is COMPUTED while it is staged as the first encoder layer of
    * mfpa_conv1d_c1_relu -- A[b][m][c] = relu(c1_b[c] + sum_j c1_w[j][c] * c1_x[b][4m + j]), c1_x (batch, c1_lin), c1_w (8, K) --
    * so its (B, L, K) output never exists in HBM (model.py:231-238); A may then be NULL. */
@@ -478,6 +480,19 @@ int mfpa_lstm_layer_range(const float* whh_grouped, float* xp, float* hseq, floa
                           float* xsum, const float* skip, int train, int t0, int t1, void* stream);
 int mfpa_lstm_layer_bwd_range(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn,
                               int H, int t0, int t1, void* stream);
+
+/* mfpa_lstm_layer_range as ONE persistent launch (lstm_seq_kernel, csrc/demucs.hip): a workgroup keeps the W_hh slice of its 16
+ * hidden units in registers for all steps, the workgroups of a 64-clip slab exchange h[t] through `work` (already split into
+ * bf16 hi / lo) and meet at a device-memory counter after every step.  Same arguments and results as mfpa_lstm_layer_range
+ * (model.py:91-110, torch.nn.LSTM's recurrence); `work` = device scratch of the size mfpa_lstm_seq_work_bytes reports, owned by this
+ * layer while the call runs, zeroed once before its first use.  Every wait in the kernel is bounded: if one ever gives up the
+ * kernel raises the 32-bit word at byte mfpa_lstm_seq_error_offset() of `work` (and finishes with undefined results); callers
+ * read that word at their next synchronisation point.  Shapes outside the persistent kernel's range (H / 128 not in {2,4,6,8},
+ * ceil(B / 64) * H / 16 workgroups > CUs) take the per-step path inside the same call. */
+int mfpa_lstm_seq_work_bytes(int B, int H, long long* bytes);   /* HOST function: *bytes = size of `work` */
+int mfpa_lstm_seq_error_offset(void);
+int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
+                        const float* skip, int train, int t0, int t1, void* work, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Waveform-domain spectral losses of the Demucs branch, training/loss.py:10-186 (MultiResolutionSTFTLoss; forward).

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class MfpaError(RuntimeError):
@@ -95,6 +95,10 @@ _SIGNATURES = {
     "mfpa_lstm_layer_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "mfpa_lstm_layer_range": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                c_int, c_void_p], c_int),
+    "mfpa_lstm_layer_seq": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                             c_int, c_void_p, c_void_p], c_int),
+    "mfpa_lstm_seq_work_bytes": ([c_int, c_int, c_void_p], c_int),
+    "mfpa_lstm_seq_error_offset": ([], c_int),
     "mfpa_lstm_layer_bwd_range": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
                                   c_int),
     "mfpa_gemm_tn": ([c_void_p, c_void_p], c_int),

@@ -425,6 +425,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
 // per CU.
 constexpr int WBN = 128;
 
+// WSPLIT: W arrives already split -- every 32-element chunk of a row as [32 bf16 hi | 32 bf16 lo] (ops_demucs.split_rows, for weights
+// that do not change between calls): staging it is a 16-byte copy instead of 12 vector instructions per quad in every workgroup.
+template <bool WSPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];
   char* As = wsm;                                    // [2][GBM][HROW]
@@ -466,7 +469,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) split_store(As + (buf * GBM + r0 + 32 * i) * HROW, ar[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store(Bs + (buf * WBN + r0 + 32 * i) * HROW, br[i]);
+    for (int i = 0; i < 4; ++i) {
+      if (WSPLIT) *reinterpret_cast<f32x4*>(Bs + (buf * WBN + r0 + 32 * i) * HROW + 16 * q) = br[i];
+      else split_store(Bs + (buf * WBN + r0 + 32 * i) * HROW, br[i]);
+    }
   };
 
   floatx16 acc[2][2];
@@ -996,6 +1002,251 @@ static int lstm_launch(const float* hprev, long long ldhp, const float* whh_grou
   return MFPA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------- persistent LSTM layer
+// The whole time range of one layer in ONE launch.  The per-step kernel above re-reads its W_hh slice (and splits it into
+// bf16 hi / lo) in every one of the 248 steps and pays a launch per step; here
+//   * a workgroup owns 64 clips x 16 hidden units (64 gate columns) for all steps.  Its W_hh slice lives in REGISTERS, already
+//     split: wave w holds the MFMA B-fragments of K range [w H/8, (w+1) H/8) (H = 768: 2 column tiles x 6 k-steps x (hi, lo)
+//     = 96 VGPRs), so W_hh is read from memory once per launch;
+//   * h[t-1] is exchanged between workgroups through a ping-pong buffer that already holds the split form
+//     ([32 bf16 hi | 32 bf16 lo] per 32 units, written once by the cell that produced it, not by each of its 48 readers);
+//     a wave reads its A-fragments of it straight from global memory (L2) in MFMA layout: no LDS staging of operands;
+//   * the 8 partial 64 x 64 gate tiles (one per K range) are summed through LDS by the cell threads, which keep c in registers;
+//   * the workgroups of one 64-clip slab meet at a counter in device memory after every step (release / acquire at agent
+//     scope: the other XCDs' L2s see the new h).  Every wait is BOUNDED: after LSTM_SPIN_LIMIT polls a workgroup raises the
+//     error word and from then on nobody waits, so the grid always drains; the host reads the word later (mfpa_lstm_seq_error).
+// The grid must be co-resident (one workgroup per CU: 136 KB of LDS): the host checks slabs x groups <= CUs, else the
+// per-step kernels run.
+constexpr int QW = 8;                        // waves = K ranges
+constexpr int QGLD = 68;                     // floats per clip row of a partial gate slab (64 + pad)
+constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22;
+constexpr int LSTM_SYNC_WORDS = 1024;        // head of the work buffer: counter of slab s at word 16 s, error word at 512
+constexpr int LSTM_ERR_WORD = 512;
+
+struct LstmSeqArgs {
+  const float* whh;       // grouped W_hh (4H, H)
+  float* xp;              // (B, Tn, 4H) projections (+ biases); training: overwritten with the gate activations
+  float* hseq;            // (B, Tn, H)
+  float* cseq;            // training: (B, Tn, H)
+  float* cstate;          // inference: (B, H), read at t0 > 0, written at the end
+  float* xsum;            // optional (B, Tn, H): h + skip
+  const float* skip;
+  unsigned* sync;         // LSTM_SYNC_WORDS words
+  char* hsplit;           // [2][B][H * 4 bytes]
+  int B, Tn, H, t0, t1, train, nslab, ngroups;
+};
+
+// COH 0: the waiting thread invalidates L1 / L2 once per step and h is read with ordinary (cached) loads; 1: no invalidate, h is read
+// with agent-scope (sc1) buffer loads that do not trust the local caches.
+template <int KS, int COH>          // k-steps of 16 per wave: H = 128 KS
+__global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  float* G = reinterpret_cast<float*>(lsm);                 // [QW][64][QGLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = a.H;
+  int slab, grp;
+  {
+    const int id = blockIdx.x, total = a.nslab * a.ngroups;
+    const int per_xcd = (total + 7) / 8;
+    const int lin = (id % 8) * per_xcd + id / 8;            // slab-major: the workgroups of a slab sit in as few XCDs as possible
+    if (lin >= total) return;                               // padding workgroups: they are not counted at the barrier
+    slab = lin / a.ngroups; grp = lin % a.ngroups;
+  }
+  const int m0 = slab * 64;
+  unsigned* cnt = a.sync + 16 * slab;
+  unsigned* err = a.sync + LSTM_ERR_WORD;
+  const unsigned members = (unsigned)a.ngroups;
+  const size_t rowb = (size_t)H * 4;                        // bytes per clip row of the split exchange buffer
+  const size_t bufb = (size_t)a.B * rowb;
+
+  // ---- W_hh fragments, split once
+  l_bf16x8 wh[2][KS], wl[2][KS];
+  {
+    const float* Wg = a.whh + (size_t)grp * 64 * H;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float* p = Wg + (size_t)(nt * 32 + li) * H + (wave * KS + s) * 16 + 8 * lh;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const __bf16 h0 = (__bf16)v0[k], h1 = (__bf16)v1[k];
+          wh[nt][s][k] = h0; wh[nt][s][4 + k] = h1;
+          wl[nt][s][k] = (__bf16)(v0[k] - (float)h0); wl[nt][s][4 + k] = (__bf16)(v1[k] - (float)h1);
+        }
+      }
+  }
+  // ---- cell threads: clip tid / 8, hidden units u0, u0 + 1
+  const int clip = tid >> 3, up = tid & 7;
+  const int m = m0 + clip;
+  const bool live = m < a.B;
+  const int u0 = grp * LU + 2 * up;
+  const size_t ldh = (size_t)a.Tn * H, ldx = (size_t)a.Tn * 4 * H;
+  const size_t split_off = (size_t)(live ? m : 0) * rowb + (size_t)(u0 >> 5) * 128 + (size_t)(u0 & 31) * 2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 l_bf16x2 __attribute__((ext_vector_type(2)));
+  auto put_split = [&](char* buf, f32x2 h) __attribute__((always_inline)) {
+    l_bf16x2 hi, lo;
+    hi[0] = (__bf16)h[0]; hi[1] = (__bf16)h[1];
+    lo[0] = (__bf16)(h[0] - (float)hi[0]); lo[1] = (__bf16)(h[1] - (float)hi[1]);
+    // agent-scope stores (sc1: written through to memory), so the release below needs no L2 write-back
+    __hip_atomic_store(reinterpret_cast<unsigned*>(buf + split_off), __builtin_bit_cast(unsigned, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(buf + split_off + 64), __builtin_bit_cast(unsigned, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  f32x2 c = {0.f, 0.f};
+  if (live) {
+    f32x2 hp = {0.f, 0.f};
+    if (a.t0 > 0) {
+      hp = *reinterpret_cast<const f32x2*>(a.hseq + (size_t)m * ldh + (size_t)(a.t0 - 1) * H + u0);
+      c = a.train ? *reinterpret_cast<const f32x2*>(a.cseq + (size_t)m * ldh + (size_t)(a.t0 - 1) * H + u0)
+                  : *reinterpret_cast<const f32x2*>(a.cstate + (size_t)m * H + u0);
+    }
+    put_split(a.hsplit + (size_t)((a.t0 + 1) & 1) * bufb, hp);          // h[t] lives in buffer t & 1
+  }
+  // ---- slab barrier: arrive after the stores above, wait until all `members` workgroups of the slab have arrived `round` times
+  bool dead = false;
+  auto arrive = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores of h have been acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto wait = [&](unsigned round) __attribute__((always_inline)) {
+    if (tid == 0) {
+      if (!dead) {
+        const unsigned target = round * members;
+        unsigned n = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if ((++n & 63u) == 0u &&
+              (n > LSTM_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (!COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one invalidate per step: the loads of h below go through L1 / L2
+    }
+    __syncthreads();
+  };
+  arrive();
+
+  // A-fragment rows of this lane (clamped: rows past B compute garbage that is never stored)
+  size_t arow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int r = m0 + mt * 32 + li;
+    r = r < a.B ? r : a.B - 1;
+    arow[mt] = (size_t)r * rowb + (size_t)wave * KS * 64 + 16 * lh;      // k = (wave KS + s) 16 + 8 lh -> chunk k / 32, 2 (k % 32)
+  }
+  constexpr int PF = KS < 3 ? KS : 3;                      // k-steps of A loads in flight
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(a.hsplit, 0, (int)(2 * bufb), 0x00020000);
+  for (int t = a.t0; t < a.t1; ++t) {
+    // the projections do not depend on h: fetch them before the wait
+    f32x2 xg[4];
+    f32x2 ad = {0.f, 0.f};
+    if (live) {
+      const float* xr = a.xp + (size_t)m * ldx + (size_t)t * 4 * H + u0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xg[g] = *reinterpret_cast<const f32x2*>(xr + g * H);
+      if (a.xsum) ad = *reinterpret_cast<const f32x2*>(a.skip + (size_t)m * ldh + (size_t)t * H + u0);
+    }
+    wait((unsigned)(t - a.t0 + 1));
+    const char* hp = a.hsplit + (size_t)((t + 1) & 1) * bufb;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][r] = 0.f;
+    l_bf16x8 fa[PF][2][2];
+    auto issue = [&](int s, l_bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const size_t off = arow[mt] + (size_t)(s >> 1) * 128 + (size_t)(s & 1) * 32;
+        if (COH) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const unsigned o = (unsigned)(((t + 1) & 1) * bufb + off);
+          f[mt][0] = __builtin_bit_cast(l_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, o, 0, 16));
+          f[mt][1] = __builtin_bit_cast(l_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, o + 64, 0, 16));
+        } else {
+          f[mt][0] = *reinterpret_cast<const l_bf16x8*>(hp + off);
+          f[mt][1] = *reinterpret_cast<const l_bf16x8*>(hp + off + 64);
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) issue(s, fa[s]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % PF][mt][1], wh[nt][s], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % PF][mt][0], wl[nt][s], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % PF][mt][0], wh[nt][s], acc[mt][nt], 0, 0, 0);
+        }
+      if (s + PF < KS) issue(s + PF, fa[s % PF]);
+    }
+    // partial gate tiles -> LDS
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          G[(wave * 64 + row) * QGLD + nt * 32 + li] = acc[mt][nt][r];
+        }
+    __syncthreads();
+    if (live) {
+      f32x2 gs[4] = {xg[0], xg[1], xg[2], xg[3]};
+#pragma unroll
+      for (int w = 0; w < QW; ++w) {
+        const float* g = G + (w * 64 + clip) * QGLD + 2 * up;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gs[q] += *reinterpret_cast<const f32x2*>(g + 16 * q);
+      }
+      f32x2 hn, vi, vf, vg, vo;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float si = 1.f / (1.f + expf(-gs[0][k])), sf = 1.f / (1.f + expf(-gs[1][k])), so = 1.f / (1.f + expf(-gs[3][k]));
+        const float tg = tanhf(gs[2][k]);
+        c[k] = sf * c[k] + si * tg;
+        hn[k] = so * tanhf(c[k]);
+        vi[k] = si; vf[k] = sf; vg[k] = tg; vo[k] = so;
+      }
+      put_split(a.hsplit + (size_t)(t & 1) * bufb, hn);
+      const size_t o = (size_t)m * ldh + (size_t)t * H + u0;
+      *reinterpret_cast<f32x2*>(a.hseq + o) = hn;
+      if (a.xsum) *reinterpret_cast<f32x2*>(a.xsum + o) = hn + ad;
+      if (a.train) {
+        float* gr = a.xp + (size_t)m * ldx + (size_t)t * 4 * H + u0;
+        *reinterpret_cast<f32x2*>(gr) = vi;
+        *reinterpret_cast<f32x2*>(gr + H) = vf;
+        *reinterpret_cast<f32x2*>(gr + 2 * H) = vg;
+        *reinterpret_cast<f32x2*>(gr + 3 * H) = vo;
+        *reinterpret_cast<f32x2*>(a.cseq + o) = c;
+      }
+    }
+    if (t + 1 < a.t1) arrive();                            // (its __syncthreads also frees the gate slabs for the next step)
+  }
+  if (live && !a.train) *reinterpret_cast<f32x2*>(a.cstate + (size_t)m * H + u0) = c;
+}
+
+static int lstm_seq_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  return cus;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1027,16 +1278,20 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if ((long long)a.nx * a.ny * a.nz > 0x3fffffffLL) return MFPA_EINVAL;
   auto grid1d = [&](int nx) { a.nx = nx; return dim3((unsigned)((((long long)nx * a.ny * a.nz + 7) / 8) * 8)); };
   dim3 grid = grid1d(d->npad / GBN);
-  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
+  if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
+  if (d->precision == 2 && !(d->K % HKC == 0 && d->K >= 128 && d->npad % WBN == 0 && !d->c1_x)) return MFPA_EINVAL;   // pre-split W: the wide kernel only
   // K >= 128: the chunked bf16x3 kernel.  (At first the K = 128 / 192 levels ran faster on the fp32 kernel; that was the
   // epilogue's serialised addend loads and 64-bit addressing, not the arithmetic: with those fixed the fp32 MFMA rate is what
   // bounds them -- PMC: 2.2 of 4.0 ms MFMA-busy on the K = 192 transposed convolution -- and bf16x3 is 10 % faster end to end.)
   static const int shortk = MFPA_EXP_ENV("MFPA_SHORTK", 1);   // 0: the fp32-MFMA kernels for K < 256 (experiments)
   hipStream_t st = mfpa_stream(stream);
   static const int wide = MFPA_EXP_ENV("MFPA_GEMM_WIDE", 1);   // 0: always the 128 x 64 tile (experiments)
-  if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128 && wide && d->npad % WBN == 0) {
+  if (d->precision == 2) {
     dim3 gw = grid1d(d->npad / WBN);
-    hipLaunchKernelGGL(gemm_bf16x3_wide_kernel, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);
+    hipLaunchKernelGGL(gemm_bf16x3_wide_kernel<true>, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);
+  } else if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128 && wide && d->npad % WBN == 0) {
+    dim3 gw = grid1d(d->npad / WBN);
+    hipLaunchKernelGGL(gemm_bf16x3_wide_kernel<false>, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);
   } else if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128) {
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, mfpa_stream(stream), a);
   } else if (d->precision == 1 && shortk && d->K == 48 && d->c1_x) {
@@ -1169,6 +1424,51 @@ int mfpa_lstm_layer_range(const float* whh_grouped, float* xp, float* hseq, floa
 int mfpa_lstm_layer(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
                     const float* skip, int train, void* stream) {
   return mfpa_lstm_layer_range(whh_grouped, xp, hseq, cseq, cstate, B, Tn, H, xsum, skip, train, 0, Tn, stream);
+}
+
+/* The persistent form of mfpa_lstm_layer_range (lstm_seq_kernel): one launch for steps [t0, t1).  `work` = device scratch of
+ * mfpa_lstm_seq_work_bytes(B, H) bytes, private to this layer while the call is in flight; its error word (mfpa_lstm_seq_error)
+ * must be zero before the first use (hipMemset the buffer once).  Shapes the persistent kernel does not take (H not 128 KS for
+ * KS in {2, 4, 6, 8}, more 64-clip slabs x H / 16 groups than CUs) run the per-step kernels: the result is the same either way. */
+int mfpa_lstm_seq_work_bytes(int B, int H, long long* bytes) {
+  if (!bytes || B < 0 || H < 0) return MFPA_EINVAL;
+  *bytes = (long long)LSTM_SYNC_WORDS * 4 + 2LL * B * H * 4;
+  return MFPA_OK;
+}
+
+int mfpa_lstm_seq_error_offset(void) { return LSTM_ERR_WORD * 4; }
+
+int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
+                        const float* skip, int train, int t0, int t1, void* work, void* stream) {
+  if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
+  if (!whh_grouped || !xp || !hseq || !work || B < 0 || Tn < 0 || H < LKC || H % LKC || (xsum && !skip) || t0 < 0 || t1 > Tn) return MFPA_EINVAL;
+  if (train ? !cseq : !cstate) return MFPA_EINVAL;
+  const int ks = H / 128, nslab = (B + 63) / 64, ngroups = H / LU;
+  static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_SEQ", 1);
+  if (!persistent || !(ks == 2 || ks == 4 || ks == 6 || ks == 8) || nslab > 32 || (long long)B * H * 8 > 0x7fffffffLL || (long long)nslab * ngroups > lstm_seq_cus())
+    return mfpa_lstm_layer_range(whh_grouped, xp, hseq, cseq, cstate, B, Tn, H, xsum, skip, train, t0, t1, stream);
+  LstmSeqArgs a;
+  a.whh = whh_grouped; a.xp = xp; a.hseq = hseq; a.cseq = cseq; a.cstate = cstate; a.xsum = xsum; a.skip = skip;
+  a.sync = reinterpret_cast<unsigned*>(work);
+  a.hsplit = reinterpret_cast<char*>(work) + (size_t)LSTM_SYNC_WORDS * 4;
+  a.B = B; a.Tn = Tn; a.H = H; a.t0 = t0; a.t1 = t1; a.train = train; a.nslab = nslab; a.ngroups = ngroups;
+  hipStream_t st = mfpa_stream(stream);
+  MFPA_HIP(hipMemsetAsync(work, 0, (size_t)LSTM_ERR_WORD * 4, st));          // the slab counters; the error word stays
+  const unsigned grid = (unsigned)(((nslab * ngroups + 7) / 8) * 8);
+  const size_t lds = (size_t)QW * 64 * QGLD * sizeof(float);
+  static const int coh = MFPA_EXP_ENV("MFPA_LSTM_COH", 1);   // 0: one L1 / L2 invalidate per step + cached loads (7.83 vs 7.58 ms for both layers of 256 clips)
+#define SEQ_LAUNCH(KS_)                                                                                             \
+  if (coh) hipLaunchKernelGGL((lstm_seq_kernel<KS_, 1>), dim3(grid), dim3(64 * QW), lds, st, a);                    \
+  else hipLaunchKernelGGL((lstm_seq_kernel<KS_, 0>), dim3(grid), dim3(64 * QW), lds, st, a)
+  switch (ks) {
+    case 2: SEQ_LAUNCH(2); break;
+    case 4: SEQ_LAUNCH(4); break;
+    case 6: SEQ_LAUNCH(6); break;
+    default: SEQ_LAUNCH(8); break;
+  }
+#undef SEQ_LAUNCH
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
 }
 
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,

@@ -98,6 +98,10 @@ def pack_demucs_weights(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.
         H = whh.shape[1]                                         # rows regrouped [H/16][i16|f16|g16|o16] for mfpa_lstm_step
         pw[f"lstm{layer}.whh_grouped"] = whh.reshape(4, H // 16, 16, H).permute(1, 0, 2, 3).reshape(4 * H, H).contiguous()
         pw[f"lstm{layer}.b"] = (f(f"lstm.lstm.bias_ih_l{layer}") + f(f"lstm.lstm.bias_hh_l{layer}")).contiguous()
+    if PRESPLIT_WEIGHTS:
+        for k, w in pw.items():
+            if k.endswith((".w", ".gw", ".wih")):
+                attach_split(w)
     return pw
 
 
@@ -109,15 +113,41 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
 FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
 _PAD_ROWS_ONLY = True   # zero only the two padding rows of the GLU output (0: memset the whole buffer)
 LAST_LAYER_GEMM = True    # False: the stand-alone VALU kernel mfpa_convT1d_c1 for the last ConvTranspose1d
+PRESPLIT_WEIGHTS = True   # False: the GEMMs split the fp32 weights on the fly (the only form the training engine uses)
+SPLIT_MIN_ROWS = 1        # rows of A from which the pre-split operand (the 128 x 128 kernel) is used
 PRECISION = 1     # 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 (3 bf16 MFMAs per product, fp32 accumulate)
+
+
+def split_rows(W: torch.Tensor) -> torch.Tensor:
+    """[Npad][K] float32 (K a multiple of 32) -> the same-shaped float32 container whose every 32-element chunk of a row holds
+    [32 bf16 hi | 32 bf16 lo], w = hi + lo (+ O(2^-17 w)): the pre-split weight operand of mfpa_gemm_mfma precision 2."""
+    n, k = W.shape
+    w4 = W.reshape(n, k // 32, 32)
+    hi = w4.to(torch.bfloat16)
+    lo = (w4 - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(n, k)
+
+
+def attach_split(W: torch.Tensor) -> torch.Tensor:
+    """A packed inference weight does not change between calls: hang a pre-split copy on it for the wide bf16x3 GEMM (the split
+    otherwise runs in every workgroup for every K chunk).  An in-place update of W is noticed through its version counter."""
+    if W.dim() == 2 and W.shape[1] % 32 == 0 and W.shape[1] >= 128 and W.shape[0] % 128 == 0 and W.is_cuda:
+        W._mfpa_split = (W._version, split_rows(W))
+    return W
 
 
 def gemm(A: int, lda, strideA, batch, M, W, bias, N, C: int, ldc, strideC, *, mode=0, relu=0, addend: int = 0, ldadd=0,
          strideAdd=0, precision=None, c1=None, C2: int = 0, ldc2=0, strideC2=0):
     """C[b][m][:N] = epi(A-window[b][m] @ W^T + bias); A, C, addend, C2 are device addresses, strides in floats."""
-    d = GemmDesc(A=A, lda=lda, strideA=strideA, W=ptr(W), bias=ptr(bias), addend=addend, ldadd=ldadd,
+    precision = PRECISION if precision is None else precision
+    wptr = ptr(W)
+    if precision == 1 and c1 is None:
+        ent = getattr(W, "_mfpa_split", None)
+        if ent is not None and ent[0] == W._version and M >= SPLIT_MIN_ROWS:
+            wptr, precision = ptr(ent[1]), 2
+    d = GemmDesc(A=A, lda=lda, strideA=strideA, W=wptr, bias=ptr(bias), addend=addend, ldadd=ldadd,
                  strideAdd=strideAdd, C=C, ldc=ldc, strideC=strideC, batch=batch, M=M, N=N, K=W.shape[1], npad=W.shape[0],
-                 mode=mode, relu=int(relu), precision=PRECISION if precision is None else precision,
+                 mode=mode, relu=int(relu), precision=precision,
                  C2=C2, ldc2=ldc2, strideC2=strideC2)
     if c1 is not None:                 # (x (B, Lin), w (8, K), b (K)): A is the first encoder layer, computed in the loader
         d.c1_x, d.c1_lin, d.c1_w, d.c1_b = ptr(c1[0]), c1[0].shape[1], ptr(c1[1]), ptr(c1[2])
@@ -141,6 +171,42 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
+PERSISTENT_LSTM = True    # False: one launch per time step (mfpa_lstm_layer_range)
+_LSTM_WORK: Dict[tuple, list] = {}
+
+
+def _lstm_work(dev, layer: int, B: int, H: int) -> torch.Tensor:
+    """Scratch of the persistent LSTM kernel for one layer (mfpa_lstm_layer_seq): the exchange buffers of h and the slab counters.
+    Kept per (device, stream, layer, shape); whenever it is handed out again the error word of its PREVIOUS use is looked at through
+    a pinned host copy made then (no synchronisation on the way): a wait that gave up inside the kernel surfaces here as MfpaError."""
+    from ._lib import MfpaError
+    L = lib()
+    st = torch.cuda.current_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream, layer, B, H)
+    ent = _LSTM_WORK.get(key)
+    off = L.mfpa_lstm_seq_error_offset() // 4
+    if ent is None:
+        nbytes = ctypes.c_longlong(0)
+        check(L.mfpa_lstm_seq_work_bytes(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
+        buf = torch.zeros(nbytes.value // 4, dtype=torch.int32, device=dev)
+        ent = _LSTM_WORK[key] = [buf, torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    buf, host, ev = ent
+    if ev is not None and ev.query() and int(host[0]) != 0:
+        raise MfpaError("mfpa_lstm_layer_seq: a workgroup gave up waiting for its slab (the grid was not co-resident?); "
+                        "set ops_demucs.PERSISTENT_LSTM = False")
+    host.copy_(buf[off:off + 1], non_blocking=True)           # stream-ordered: the state all earlier uses left
+    ent[2] = torch.cuda.Event()
+    ent[2].record(st)
+    return buf
+
+
+def lstm_seq_error() -> bool:
+    """Synchronise and report whether any persistent LSTM launch so far gave up a wait (tests)."""
+    torch.cuda.synchronize()
+    off = lib().mfpa_lstm_seq_error_offset() // 4
+    return any(int(ent[0][off]) != 0 for ent in _LSTM_WORK.values())
+
+
 def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped, precision: int, train: bool):
     """Both LSTM layers (model.py:91-110) on x (B, Tn, H): returns (xsum = h1 + skip, saved) with saved = per layer
     (input, gates-or-projections, hseq, cseq-or-None).
@@ -162,7 +228,14 @@ def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped,
     try:
         gemm(_p(x), H, 0, 1, B * Tn, wih[0], bias[0], 4 * H, _p(xp[0]), 4 * H, 0, precision=precision)
 
+        work = [_lstm_work(dev, k, B, H) for k in range(2)] if PERSISTENT_LSTM else None
+
         def layer(k, a, b):
+            if work is not None:
+                check(L.mfpa_lstm_layer_seq(ptr(whh_grouped[k]), ptr(xp[k]), ptr(hs[k]), ptr(cs[k]) if train else 0,
+                                            0 if train else ptr(cstate[k]), B, Tn, H, ptr(xsum) if k == 1 else 0,
+                                            ptr(skip) if k == 1 else 0, int(train), a, b, ptr(work[k]), stream()), "mfpa_lstm_layer_seq")
+                return
             check(L.mfpa_lstm_layer_range(ptr(whh_grouped[k]), ptr(xp[k]), ptr(hs[k]), ptr(cs[k]) if train else 0,
                                           0 if train else ptr(cstate[k]), B, Tn, H, ptr(xsum) if k == 1 else 0,
                                           ptr(skip) if k == 1 else 0, int(train), a, b, stream()), "mfpa_lstm_layer_range")

@@ -88,3 +88,91 @@ def test_errors(net):
         net(torch.zeros(1, 8000))
     with pytest.raises(ValueError):
         net(torch.zeros(1, 2, 8000, device="cuda"))
+
+
+def test_presplit_weights_give_the_same_bits(net):
+    """mfpa_gemm_mfma precision 2 (W split once on the host, ops_demucs.split_rows) = precision 1 (split in every workgroup):
+    the same bf16 hi / lo values reach the same MFMAs, so the outputs are identical, GEMM by GEMM and for the whole network."""
+    from musicfpaugment_amd import ops_demucs as D
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K) in [(1000, 384, 768), (257, 128, 128), (64, 1536, 3072)]:
+        A = torch.randn(M, K, generator=g).cuda()
+        W = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        c1, c2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        D.gemm(D._p(A), K, 0, 1, M, W, bias, N, D._p(c1), N, 0, precision=1)
+        D.attach_split(W)
+        assert W._mfpa_split[1].shape == W.shape
+        D.gemm(D._p(A), K, 0, 1, M, W, bias, N, D._p(c2), N, 0, precision=1)
+        assert torch.equal(c1, c2)
+        assert (c1 - (A.double() @ W.double().t() + bias.double()).float()).abs().max() < 1e-4
+        W.mul_(2.0)                                        # an in-place update retires the split copy
+        D.gemm(D._p(A), K, 0, 1, M, W, bias, N, D._p(c2), N, 0, precision=1)
+        torch.testing.assert_close(c2 - bias, 2 * (c1 - bias), rtol=1e-5, atol=1e-5)
+    wav = torch.from_numpy(synth.noise_batch(2, 16000, seed=5)).cuda() if hasattr(synth, "noise_batch") else torch.randn(2, 16000, generator=g).cuda()
+    y_split = net(wav)
+    old = D.PRESPLIT_WEIGHTS
+    try:
+        D.PRESPLIT_WEIGHTS = False
+        net._packed = None
+        y_fly = net(wav)
+    finally:
+        D.PRESPLIT_WEIGHTS = old
+        net._packed = None
+    assert torch.equal(y_split, y_fly)
+
+
+def _lstm_reference(x, skip, wih, bias, whh):
+    """torch.nn.LSTM's recurrence (model.py:91-110) in float64 on the CPU: two layers, then + skip."""
+    B, Tn, H = x.shape
+    inp = x.double()
+    for k in range(2):
+        h = torch.zeros(B, H, dtype=torch.float64)
+        c = torch.zeros(B, H, dtype=torch.float64)
+        out = []
+        for t in range(Tn):
+            g = inp[:, t] @ wih[k].double().t() + bias[k].double() + h @ whh[k].double().t()
+            i, f, gg, o = g.split(H, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            out.append(h)
+        inp = torch.stack(out, dim=1)
+    return inp + skip.double()
+
+
+@pytest.mark.parametrize("B,Tn,H,train", [(70, 9, 256, False), (256, 7, 768, False), (33, 6, 768, True), (130, 20, 512, False)])
+def test_persistent_lstm_layer(B, Tn, H, train):
+    """mfpa_lstm_layer_seq (one persistent launch per layer: W_hh in registers, h exchanged in split form, slab barriers in
+    device memory) against the float64 recurrence and against the per-step kernels; ragged slabs, both chunked (two streams) and
+    whole-sequence forms, the training form's saved gates and cell states; no wait may have given up."""
+    from musicfpaugment_amd import ops_demucs as D
+    g = torch.Generator().manual_seed(B + Tn)
+    x = torch.randn(B, Tn, H, generator=g) * 0.5
+    skip = torch.randn(B, Tn, H, generator=g)
+    wih = [torch.randn(4 * H, H, generator=g) / np.sqrt(H) for _ in range(2)]
+    whh = [torch.randn(4 * H, H, generator=g) / np.sqrt(H) for _ in range(2)]
+    bias = [torch.randn(4 * H, generator=g) * 0.1 for _ in range(2)]
+    grouped = [w.reshape(4, H // 16, 16, H).permute(1, 0, 2, 3).reshape(4 * H, H).contiguous().cuda() for w in whh]
+    want = _lstm_reference(x, skip, wih, bias, whh)
+    dev = lambda ts: [t.cuda() for t in ts]
+    runs = {}
+    old = (D.PERSISTENT_LSTM, D.LSTM_CHUNK)
+    try:
+        for name, pers, chunk in [("seq", True, old[1]), ("seq-chunked", True, 4), ("steps", False, old[1])]:
+            D.PERSISTENT_LSTM, D.LSTM_CHUNK = pers, chunk
+            xsum, saved = D.lstm_two_layers(x.cuda(), skip.cuda(), dev(wih), dev(bias), grouped, 1, train)
+            torch.cuda.synchronize()
+            runs[name] = (xsum.cpu(), [tuple(None if s is None else s.cpu() for s in lay) for lay in saved])
+    finally:
+        D.PERSISTENT_LSTM, D.LSTM_CHUNK = old
+    assert not D.lstm_seq_error()
+    for name, (xsum, saved) in runs.items():
+        err = (xsum.double() - want).abs().max().item()
+        assert err < 2e-4, (name, err)
+    for name in ("seq-chunked", "steps"):
+        assert (runs[name][0] - runs["seq"][0]).abs().max() < 1e-4
+        for la, lb in zip(runs[name][1], runs["seq"][1]):
+            for ta, tb in zip(la, lb):
+                assert (ta is None) == (tb is None)
+                if ta is not None:
+                    assert (ta - tb).abs().max() < 1e-4           # hseq, saved gates, cell states

@@ -151,11 +151,49 @@ def test_lstm_train_step_pair():
     assert _rel(dg @ wih.detach().double(), x.grad) < 1e-4
 
 
-def _oracle_step(sd, clean, aug):
+class _ReluWithMasks:
+    """Stands in for torch.nn.functional inside oracle.demucs while one forward runs: the k-th ReLU multiplies by the k-th given
+    mask instead of by (x > 0), and notes where the two disagree and how far from zero the pre-activation is there."""
+
+    def __init__(self, F, masks):
+        self._F, self.masks, self.k, self.disagree = F, masks, 0, []
+
+    def __getattr__(self, name):
+        return getattr(self._F, name)
+
+    def relu(self, x):
+        m = self.masks[self.k]
+        self.k += 1
+        dis = (x.detach() > 0) != m
+        self.disagree.append((int(dis.sum()), float(x.detach().abs()[dis].max()) if bool(dis.any()) else 0.0))
+        return x * m.to(x.dtype)
+
+
+def _relu_masks(eng):
+    """The ReLU decisions the device forward took (5 encoder convolutions, 4 transposed convolutions), as (B, C, L) masks."""
+    return [(t > 0).permute(0, 2, 1).cpu() for t in list(eng.S["a"]) + list(eng.S["r"])]
+
+
+def _oracle_step(sd, clean, aug, masks=None):
+    """One float64 autograd step through the oracle.  The gradient of a ReLU network jumps where a pre-activation crosses zero,
+    and among ~7e5 ReLU sites a few sit within float32 rounding of it: with `masks` (the device's decisions) those ties are taken
+    the device's way -- after checking that they ARE ties (|pre-activation| < 2e-6, at most a handful) -- so the comparison is
+    about the arithmetic, not about which side of zero a 2e-8 landed."""
     from oracle import demucs as od
     from oracle import loss as ol
     params = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
-    pred = od.forward(aug.double(), params)[:, 0]
+    shim = None
+    if masks is not None:
+        shim = _ReluWithMasks(od.F, masks)
+        od.F = shim
+    try:
+        pred = od.forward(aug.double(), params)[:, 0]
+    finally:
+        if shim is not None:
+            od.F = shim._F
+    if shim is not None:
+        assert shim.k == len(masks)
+        assert sum(n for n, _ in shim.disagree) <= 16 and max(v for _, v in shim.disagree) < 2e-6, shim.disagree
     l1 = torch.nn.functional.l1_loss(pred, clean.double())
     sc, mag, _ = ol.multi_resolution_stft_loss(pred, clean.double())
     (l1 + sc + mag).backward()
@@ -175,11 +213,11 @@ def test_train_step_gradients_vs_autograd():
     from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
     sd = formula_state_dict(0)
     clean, aug = _inputs()
-    pred_w, (l1_w, sc_w, mag_w), grads = _oracle_step(sd, clean, aug)
     eng = DemucsTrainEngine(sd, "cuda", precision=0)
     back = eng.state_dict()                                              # the reference layout round-trips
     assert all(torch.equal(back[k].cpu(), sd[k]) for k in sd)
     pred = eng.forward(aug.cuda())
+    pred_w, (l1_w, sc_w, mag_w), grads = _oracle_step(sd, clean, aug, _relu_masks(eng))
     assert _rel(pred.cpu(), pred_w) < 1e-5
     l1, sc, mag, dpred = eng.loss_and_grad(pred, clean.cuda())
     np.testing.assert_allclose([float(l1), float(sc), float(mag)], [l1_w, sc_w, mag_w], rtol=1e-3)
@@ -206,9 +244,9 @@ def test_ragged_lengths_gradients_vs_autograd(B, n):
     sd = formula_state_dict(0)
     clean = torch.from_numpy(synth.batch(B, seed=41, n=n))
     aug = (clean + 0.05 * torch.from_numpy(synth.batch(B, seed=87, n=n))).float()
-    pred_w, _, grads = _oracle_step(sd, clean, aug)
     eng = DemucsTrainEngine(sd, "cuda", precision=0)
     pred = eng.forward(aug.cuda())
+    pred_w, _, grads = _oracle_step(sd, clean, aug, _relu_masks(eng))
     assert pred.shape == (B, n) and _rel(pred.cpu(), pred_w) < 1e-5
     _, _, _, dpred = eng.loss_and_grad(pred, clean.cuda())
     eng.backward(dpred)
