@@ -14,6 +14,7 @@
 // The 1-channel ends (first Conv1d, last ConvTranspose1d), the sinc x2 resamplers and the std normalisation are
 // small VALU kernels.
 #include "mfpa_common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -31,6 +32,7 @@ struct GemmArgs {
   const float* bias;                           // [Npad] or null
   const float* addend; long long ldadd, strideAdd;   // mode 2: y += addend[b*strideAdd + m*ldadd + n]
   float* C; long long ldc, strideC;
+  int exp;                                     // experiments only (MFPA_EXP_FLAG): bit 0 / 1 = every K chunk re-reads chunk 0 of A / W
   int nx, ny, nz, xcd;                         // tile grid (n tiles, m tiles, clips) of the 1-D launch; xcd = 1: XCD-aware tile order
   float* C2; long long ldc2, strideC2;         // training: second output (mode 1: the packed GLU pre-activations; relu 2: relu(y) before the addition)
   int M, N, K, mode, relu;                     // mode 0: bias(+relu); 1: GLU (N = output columns = Npad_total/2 pairs); 2: + addend;
@@ -517,6 +519,175 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(GemmArgs a) {
   // the shared epilogue takes a 32-row x 64-column wave tile at row (wave index) * 32: two calls per wave
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) gemm_epilogue(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+}
+
+// The software-pipelined form of the wide kernel (the schedule of conv_mfma_kernel<PREC 1>'s tap body, unet.hip): 8 waves own a
+// 256 x 128 tile (4 x 2 waves of 64 x 64), one workgroup per CU.  A K chunk of 32 is two k-steps; the fragments of a k-step are
+// read from LDS one step AHEAD of the MFMAs that use them (two register sets of fragments), the barrier sits between the two
+// k-steps of a chunk, and the global loads run two chunks ahead of their LDS stores through two register sets (straight-line
+// code per chunk parity, so hipcc's vmcnt bookkeeping is exact: no s_waitcnt vmcnt(0) in the steady state).  Rows past M are
+// clamped to row M - 1 when loaded (never stored), so every load is unconditional.  K must be a multiple of 64, at least 128.
+constexpr int PBM = 256;
+template <int SLOTS, int LEFT, int I = 0>
+__device__ __forceinline__ void g_pin_reads() {          // "one MFMA, then k LDS reads", LEFT reads spread over SLOTS MFMAs
+  if constexpr (I < SLOTS && LEFT > 0) {
+    constexpr int k = (LEFT + (SLOTS - I) - 1) / (SLOTS - I);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, k, 0);
+    g_pin_reads<SLOTS, LEFT - k, I + 1>();
+  }
+}
+
+template <bool WSPLIT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char psm[];
+  constexpr int ASZ = PBM * HROW, BSZ = WBN * HROW;
+  char* As = psm;                                    // [2][PBM][HROW]
+  char* Bs = psm + 2 * ASZ;                          // [2][WBN][HROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  int bx, by, b;
+  if (!gemm_tile(a, bx, by, b)) return;
+  const int n0 = bx * WBN, m0 = by * PBM;
+  const int nk = a.K / HKC;
+  const int q = tid & 7, r0 = tid >> 3;              // staging: column quad, rows r0 + 64 i
+  const float* ap[4];
+  const float* bp[2];
+  {
+    const float* Ab = a.A + (size_t)b * a.strideA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + r0 + 64 * i;
+      m = m < a.M ? m : a.M - 1;
+      ap[i] = Ab + (size_t)m * a.lda + 4 * q;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bp[i] = a.W + (size_t)(n0 + r0 + 64 * i) * a.K + 4 * q;
+  }
+  struct Stage { f32x4 a[4], b[2]; };
+  Stage st0, st1;
+  auto load = [&](int kc, Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.a[i] = *reinterpret_cast<const f32x4*>(ap[i] + (MFPA_EXP_FLAG(a.exp, 1) ? 0 : kc) * HKC);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st.b[i] = *reinterpret_cast<const f32x4*>(bp[i] + (MFPA_EXP_FLAG(a.exp, 2) ? 0 : kc) * HKC);
+  };
+  auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
+    g_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
+    *reinterpret_cast<g_bf16x4*>(row + 64 + 8 * q) = lo;
+  };
+  auto store = [&](int buf, const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store(As + buf * ASZ + (r0 + 64 * i) * HROW, st.a[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (WSPLIT) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (r0 + 64 * i) * HROW + 16 * q) = st.b[i];
+      else split_store(Bs + buf * BSZ + (r0 + 64 * i) * HROW, st.b[i]);
+    }
+  };
+  struct Frags { g_bf16x8 ah[2], al[2], bh[2], bl[2]; };
+  Frags fr0, fr1;
+  const char* Ap = As + (wm * 64 + li) * HROW + 16 * lh;
+  const char* Bp = Bs + (wn * 64 + li) * HROW + 16 * lh;
+  auto read_frags = [&](Frags& f, int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f.ah[t] = *reinterpret_cast<const g_bf16x8*>(Ap + buf * ASZ + t * 32 * HROW + 32 * s);
+      f.al[t] = *reinterpret_cast<const g_bf16x8*>(Ap + buf * ASZ + t * 32 * HROW + 64 + 32 * s);
+      f.bh[t] = *reinterpret_cast<const g_bf16x8*>(Bp + buf * BSZ + t * 32 * HROW + 32 * s);
+      f.bl[t] = *reinterpret_cast<const g_bf16x8*>(Bp + buf * BSZ + t * 32 * HROW + 64 + 32 * s);
+    }
+  };
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  auto mfma12 = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+  };
+  constexpr int N_DSW = WSPLIT ? 10 : 12;            // LDS stores of one chunk per thread
+  // one K chunk; SET = chunk parity = LDS buffer it is computed from; STORE: chunk kc + 1 (register set SET ^ 1) goes to the other
+  // buffer; LOAD: that register set is refilled with chunk kc + 3
+  auto body = [&](auto SET_, auto STORE_, auto LOAD_, int kc) __attribute__((always_inline)) {
+    constexpr int SET = decltype(SET_)::value;
+    constexpr bool STORE = decltype(STORE_)::value, LOAD = decltype(LOAD_)::value;
+    Stage& other = SET ? st0 : st1;
+    read_frags(fr1, SET, 1);
+    mfma12(fr0);
+    if constexpr (STORE) store(SET ^ 1, other);
+    if constexpr (LOAD) load(kc + 3, other);
+    g_pin_reads<8, 8>();
+    if constexpr (STORE) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, N_DSW / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, N_DSW - N_DSW / 2, 0);
+      if constexpr (LOAD) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STORE) read_frags(fr0, SET ^ 1, 0);
+    mfma12(fr1);
+    if constexpr (STORE) g_pin_reads<12, 8>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // (the scheduling barriers keep the prologue's loads in the order the loop issues them, so the vmcnt state merged at the loop
+  // header is the steady state's and the first stores of a trip do not wait for the newest loads)
+  load(0, st0);
+  __builtin_amdgcn_sched_barrier(0);
+  load(1, st1);
+  __builtin_amdgcn_sched_barrier(0);
+  store(0, st0);
+  __builtin_amdgcn_sched_barrier(0);
+  load(2, st0);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  read_frags(fr0, 0, 0);
+  int kc = 0;
+  for (; kc < nk - 4; kc += 2) {
+    body(S0{}, T{}, T{}, kc);
+    body(S1{}, T{}, T{}, kc + 1);
+  }
+  body(S0{}, T{}, T{}, kc);                               // kc = nk - 4: chunk nk - 1 is the last load
+  body(S1{}, T{}, F{}, kc + 1);
+  body(S0{}, T{}, F{}, kc + 2);
+  body(S1{}, F{}, F{}, kc + 3);
+  const bool full = m0 + PBM <= a.M;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    if (full) gemm_epilogue_t<true>(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+    else gemm_epilogue_t<false>(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+  }
 }
 
 // Short-K layers with bf16x3 products (K = 48 and 96: the full-rate outer levels of the network; measured on 256 clips: forward
@@ -1275,6 +1446,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   a.c1_x = d->c1_x; a.c1_lin = d->c1_lin; a.c1_w = d->c1_w; a.c1_b = d->c1_b;
   static const int xcd_env = MFPA_EXP_ENV("MFPA_GEMM_XCD", 1);   // 0: plain tile order (experiments)
   a.ny = (d->M + GBM - 1) / GBM; a.nz = d->batch; a.nx = d->npad / GBN; a.xcd = xcd_env;
+  a.exp = MFPA_EXP_ENV("MFPA_GEMM_EXP", 0);
   if ((long long)a.nx * a.ny * a.nz > 0x3fffffffLL) return MFPA_EINVAL;
   auto grid1d = [&](int nx) { a.nx = nx; return dim3((unsigned)((((long long)nx * a.ny * a.nz + 7) / 8) * 8)); };
   dim3 grid = grid1d(d->npad / GBN);
@@ -1286,7 +1458,15 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   static const int shortk = MFPA_EXP_ENV("MFPA_SHORTK", 1);   // 0: the fp32-MFMA kernels for K < 256 (experiments)
   hipStream_t st = mfpa_stream(stream);
   static const int wide = MFPA_EXP_ENV("MFPA_GEMM_WIDE", 1);   // 0: always the 128 x 64 tile (experiments)
-  if (d->precision == 2) {
+  static const int pipe = MFPA_EXP_ENV("MFPA_GEMM_PIPE", 1);   // 0: the 128 x 128 kernel without the software pipeline (experiments)
+  const bool wide_ok = d->K % HKC == 0 && d->K >= 128 && d->npad % WBN == 0 && (d->precision == 2 || (d->precision == 1 && wide));
+  if (wide_ok && pipe && d->K % (2 * HKC) == 0 && d->M >= PBM) {
+    a.ny = (d->M + PBM - 1) / PBM;
+    dim3 gw = grid1d(d->npad / WBN);
+    const size_t lds = (size_t)2 * (PBM + WBN) * HROW;
+    if (d->precision == 2) hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel<true>, gw, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel<false>, gw, dim3(512), lds, st, a);
+  } else if (d->precision == 2) {
     dim3 gw = grid1d(d->npad / WBN);
     hipLaunchKernelGGL(gemm_bf16x3_wide_kernel<true>, gw, dim3(256), (size_t)2 * (GBM + WBN) * HROW, mfpa_stream(stream), a);
   } else if (d->precision == 1 && d->K % HKC == 0 && d->K >= 128 && wide && d->npad % WBN == 0) {
