@@ -406,6 +406,12 @@ int mfpa_conv1d_c1(const float* x, int B, int Lin, int Lout, int C, const float*
                    void* stream);
 /* Last decoder layer ConvTranspose1d(C->1, k8, s4): P (B,L+2,C) with zero first/last rows -> y (B, 4(L+1)), w (8,C). */
 int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float bias, float* y, void* stream);
+/* The whole last decoder level in one launch (model.py:80-88,316-318: Conv1d(C, 2C, 1) + GLU + ConvTranspose1d(C, 1, 8, 4)):
+ * x (B, L, C) -> y (B, 4 (L + 1)) without the (B, L, C) GLU output in memory.  gw (128, C) / gb (128) = the 1x1 weights and bias
+ * in the packed GLU tile order of mfpa_gemm_mfma mode 1, wl (8, C) tap-major as for mfpa_convT1d_c1.  C must be 48 (MFPA_EINVAL
+ * otherwise: callers then run mfpa_gemm_mfma mode 1 + mfpa_convT1d_c1). */
+int mfpa_glu_convT1d_c1(const float* x, int B, int L, int C, const float* gw, const float* gb, const float* wl, float bias, float* y,
+                        void* stream);
 /* The same with the bias read from device memory (training: the optimiser updates it there). */
 int mfpa_convT1d_c1_dev(const float* P, int B, int L, int C, const float* w, const float* bias_dev, float* y, void* stream);
 /* LSTM cell (gate order i,f,g,o; model.py:91-110 via nn.LSTM): gates (B,4H) rows ldg apart, c (B,H) in/out,

@@ -809,6 +809,139 @@ __global__ __launch_bounds__(256, 2) void gemm_shortk_bf16x3_kernel(GemmArgs a) 
   gemm_epilogue(a, acc, m0, n0, b, wave, li, lh);
 }
 
+// ---------------------------------------------------------------------------------- last decoder level in one launch
+// Conv1d(1x1, C -> 2C) + GLU + ConvTranspose1d(C -> 1, k8, s4) of the last decoder level (model.py:80-88,316-318) without the
+// (B, L, C) intermediate: as two launches that tensor (3.15 GB per 256 clips at C = 48) is written once and read twice.
+// A workgroup owns 127 output groups of a clip (group t = samples 4t .. 4t+3 = taps 0..3 of g[t] + taps 4..7 of g[t-1]) and
+// computes the 128 GLU rows g[127 by - 1 .. 127 by + 126] they need (one row of overlap instead of an exchange):
+//   * the 1x1 + GLU is the short-K bf16x3 MFMA GEMM of gemm_shortk_bf16x3_kernel (K = C = 48 in one chunk, all 128 packed columns
+//     in one workgroup, so a row's 48 GLU outputs meet in one place); W is staged once per workgroup and reused for TPW tiles;
+//   * g goes to LDS in fp32 (over the A rows of the same wave: no extra barrier), a thread pair per row forms the 8 tap sums
+//     p[t][j] = sum_c g[t][c] w[j][c] with fp32 FMAs, and y[4t + j] = bias + p[t][j] + p[t-1][j+4] is written coalesced.
+constexpr int TT_K = 48, TT_ROW = 4 * TT_K + 16, TT_OUT = 127, TT_TPW = 8;
+
+__global__ __launch_bounds__(256, 2) void glu_convT_c1_kernel(const float* __restrict__ x, int L, const float* __restrict__ gw,
+                                                              const float* __restrict__ gb, const float* __restrict__ wl, float bias,
+                                                              float* __restrict__ y, int tiles_per_clip, int groups) {
+  constexpr int K = TT_K, ROW = TT_ROW, QPR = K / 4, NQ = 128 * QPR / 256;      // 12 quads per row, 6 per thread
+  __shared__ __attribute__((aligned(16))) char As[128 * ROW];                   // A rows (bf16 hi | lo), then g rows (fp32) of the same wave
+  __shared__ __attribute__((aligned(16))) char Ws[128 * ROW];
+  __shared__ __attribute__((aligned(16))) float wls[8 * K];
+  __shared__ __attribute__((aligned(16))) float Ps[128 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int tile0 = blockIdx.x * TT_TPW;
+  const float* xb = x + (size_t)b * L * K;
+  float* yb = y + (size_t)b * 4 * (L + 1);
+  auto split_store = [&](char* row, int q, f32x4 v) __attribute__((always_inline)) {
+    g_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
+    *reinterpret_cast<g_bf16x4*>(row + 2 * K + 8 * q) = lo;
+  };
+  f32x4 ar[NQ];
+  auto load_a = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int idx = tid + 256 * i;
+      int t = tile * TT_OUT - 1 + idx / QPR;               // rows outside [0, L) are masked when g is written
+      t = t < 0 ? 0 : (t < L ? t : L - 1);
+      ar[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)t * K + 4 * (idx % QPR));
+    }
+  };
+  load_a(tile0);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int idx = tid + 256 * i;
+    split_store(Ws + (idx / QPR) * ROW, idx % QPR, *reinterpret_cast<const f32x4*>(gw + (size_t)(idx / QPR) * K + 4 * (idx % QPR)));
+  }
+  for (int i = tid; i < 8 * K; i += 256) wls[i] = wl[i];
+  float gbias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) gbias[nt] = gb[nt * 32 + li];
+  const char* Ap = As + (wave * 32 + li) * ROW + 16 * lh;
+  const char* Bp = Ws + li * ROW + 16 * lh;
+  const int ntile = tiles_per_clip - tile0 < TT_TPW ? tiles_per_clip - tile0 : TT_TPW;
+  for (int it = 0; it < ntile; ++it) {
+    const int tile = tile0 + it;
+    const int tbase = tile * TT_OUT - 1;                   // clip row of tile row 0
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int idx = tid + 256 * i;
+      split_store(As + (idx / QPR) * ROW, idx % QPR, ar[i]);
+    }
+    if (it + 1 < ntile) load_a(tile + 1);
+    __syncthreads();                                       // A (and, the first time, W / wl) staged
+    floatx16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(Ap + 32 * s);
+      const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(Ap + 2 * K + 32 * s);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * ROW + 32 * s);
+        const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * ROW + 2 * K + 32 * s);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+      }
+    }
+    // GLU -> g rows in LDS (fp32, same 208-byte rows; this wave's own 32 rows, whose fragments it has just read)
+    float* Gs = reinterpret_cast<float*>(As);
+    constexpr int GLDF = ROW / 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int t = tbase + row;
+      const bool in = t >= 0 && t < L;
+      const float g0 = (acc[0][r] + gbias[0]) * gemm_sigmoid(acc[1][r] + gbias[1]);
+      Gs[row * GLDF + li] = in ? g0 : 0.f;
+      if (li < K - 32) {
+        const float g1 = (acc[2][r] + gbias[2]) * gemm_sigmoid(acc[3][r] + gbias[3]);
+        Gs[row * GLDF + 32 + li] = in ? g1 : 0.f;
+      }
+    }
+    // (rows tid / 2 of a wave's 64 threads are that wave's own 32 rows: only the wave's own LDS stores are needed here)
+    {
+      const int row = tid >> 1, half = tid & 1;
+      const float* g = Gs + row * GLDF;
+      const float* w = wls + half * 4 * K;
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int c = 0; c < K; c += 4) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j * K + c);
+          p[j] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(Ps + row * 8 + 4 * half) = p;
+    }
+    __syncthreads();                                       // p of all 128 rows
+    if (tid < 2 * TT_OUT) {
+      const int i = 1 + (tid >> 1), j = (tid & 1) * 2;     // tile row of the group, first of its two samples
+      const int t = tbase + i;                             // group index: 127 tile .. 127 tile + 126
+      if (t < groups) {
+        float2 o;
+        o.x = bias + Ps[i * 8 + j] + Ps[(i - 1) * 8 + 4 + j];
+        o.y = bias + Ps[i * 8 + j + 1] + Ps[(i - 1) * 8 + 5 + j];
+        *reinterpret_cast<float2*>(yb + 4 * (size_t)t + j) = o;
+      }
+    }
+    __syncthreads();                                       // p and g are free: the next tile's A may be staged
+  }
+}
+
 // ---------------------------------------------------------------------------------- small kernels
 // mix / (floor + std), zero-padded to VL samples; std = unbiased std over time (model.py:293-301).
 __global__ __launch_bounds__(256) void demucs_prep_kernel(const float* __restrict__ wav, int T, int VL, float floor_,
@@ -1647,6 +1780,21 @@ int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float*
     default: SEQ_LAUNCH(8); break;
   }
 #undef SEQ_LAUNCH
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+/* Last decoder level of Demucs in one launch (model.py:80-88: Conv1d(C, 2C, 1) + GLU + ConvTranspose1d(C, 1, 8, 4), no ReLU):
+ * x (B, L, C) -> y (B, 4 (L + 1)).  gw / gb = the 1x1 weights and bias in the packed GLU tile order of mfpa_gemm_mfma mode 1
+ * (128 rows x C for C = 48), wl (8, C) tap-major = weight[c][0][j], bias = the ConvTranspose1d bias.  C must be 48. */
+int mfpa_glu_convT1d_c1(const float* x, int B, int L, int C, const float* gw, const float* gb, const float* wl, float bias, float* y,
+                        void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !gw || !gb || !wl || !y || B < 0 || L < 1 || C != TT_K || B > 65535) return MFPA_EINVAL;
+  const int groups = L + 1;
+  const int tiles = (groups + TT_OUT - 1) / TT_OUT;
+  hipLaunchKernelGGL(glu_convT_c1_kernel, dim3((tiles + TT_TPW - 1) / TT_TPW, B), dim3(256), 0, mfpa_stream(stream), x, L, gw, gb, wl, bias, y,
+                     tiles, groups);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -112,6 +112,7 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
 
 FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
 _PAD_ROWS_ONLY = True   # zero only the two padding rows of the GLU output (0: memset the whole buffer)
+FUSE_LAST_LEVEL = True    # False: the last decoder level as two launches (1x1 + GLU, then the transposed convolution)
 LAST_LAYER_GEMM = True    # False: the stand-alone VALU kernel mfpa_convT1d_c1 for the last ConvTranspose1d
 PRESPLIT_WEIGHTS = True   # False: the GEMMs split the fp32 weights on the fly (the only form the training engine uses)
 SPLIT_MIN_ROWS = 1        # rows of A from which the pre-split operand (the 128 x 128 kernel) is used
@@ -318,6 +319,12 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
     Lcur = Tn
     for d in range(DEPTH):
         C = chans[DEPTH - 1 - d]
+        if d == DEPTH - 1 and FUSE_LAST_LEVEL and precision == 1 and C == 48:
+            y = new(B, 4 * (Lcur + 1))                           # 1x1 + GLU + ConvTranspose1d(48 -> 1) without the GLU output in memory
+            check(L.mfpa_glu_convT1d_c1(ptr(x), B, Lcur, C, ptr(pw[f"dec{d}.gw"]), ptr(pw[f"dec{d}.gb"]), ptr(pw["decL.w"]), pw["decL.b"],
+                                        ptr(y), stream()), "mfpa_glu_convT1d_c1")
+            x, Lcur = y, 4 * (Lcur + 1)
+            break
         if _PAD_ROWS_ONLY:
             P = new(B, Lcur + 2, C)                                                # rows 0 and L+1 are the zero padding
             P[:, 0].zero_()

@@ -176,3 +176,30 @@ def test_persistent_lstm_layer(B, Tn, H, train):
                 assert (ta is None) == (tb is None)
                 if ta is not None:
                     assert (ta - tb).abs().max() < 1e-4           # hseq, saved gates, cell states
+
+
+@pytest.mark.parametrize("B,L", [(3, 1000), (2, 127), (1, 126), (2, 128), (1, 1), (2, 5 * 127 * 8 + 3)])
+def test_last_decoder_level_in_one_launch(B, L):
+    """mfpa_glu_convT1d_c1 = Conv1d(48, 96, 1) + GLU + ConvTranspose1d(48, 1, 8, 4) (model.py:80-88) against torch in float64;
+    tile edges (127 output groups per tile, 8 tiles per workgroup) and one-row inputs."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    C = 48
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, L, C, generator=g)
+    w1 = torch.randn(2 * C, C, generator=g) / np.sqrt(C)
+    b1 = torch.randn(2 * C, generator=g) * 0.3
+    wt = torch.randn(C, 1, 8, generator=g) / np.sqrt(C)
+    bt = 0.123
+    want = F.conv_transpose1d(F.glu(F.conv1d(x.double().permute(0, 2, 1), w1.double()[:, :, None], b1.double()), dim=1),
+                              wt.double(), torch.tensor([bt], dtype=torch.float64), stride=4)[:, 0]
+    gw, gb = D._pack_glu(w1, b1)
+    wl = wt[:, 0, :].t().contiguous()
+    y = torch.full((B, 4 * (L + 1)), float("nan"), device="cuda")
+    xd, gwd, gbd, wld = x.cuda(), gw.cuda(), gb.cuda(), wl.cuda()
+    check(lib().mfpa_glu_convT1d_c1(ptr(xd), B, L, C, ptr(gwd), ptr(gbd), ptr(wld), bt, ptr(y), stream()), "tail")
+    assert want.shape == y.shape
+    err = (y.cpu().double() - want).abs().max().item()
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+    assert lib().mfpa_glu_convT1d_c1(ptr(xd), B, L, 32, ptr(gwd), ptr(gbd), ptr(wld), bt, ptr(y), stream()) == -22
