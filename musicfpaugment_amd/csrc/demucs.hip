@@ -942,6 +942,127 @@ __global__ __launch_bounds__(256, 2) void glu_convT_c1_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------- first encoder level in one launch
+// Conv1d(1 -> C, k8, s4) + ReLU + Conv1d(C -> 2C, 1) + GLU of the first encoder level (model.py:66-75,303-307): x (B, Lin) -> h
+// (B, Lout, C).  gemm_shortk_bf16x3_kernel<true, 48, 48> does the same with 128 x 64 tiles, i.e. TWO workgroups (the value /
+// gate column pairs 0..31 and 32..47) each evaluate the first convolution for the same 128 rows; here a workgroup owns all 128
+// packed columns: the first convolution (fp32 FMAs, bias then taps 0..7 -- conv1d_c1_kernel's order) and the bf16 split run once
+// per row, W is staged once per workgroup and reused for TT_TPW tiles.
+__global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict__ x, int Lin, int Lout, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ gw,
+                                                        const float* __restrict__ gb, float* __restrict__ y, int tiles_per_clip) {
+  constexpr int K = TT_K, ROW = TT_ROW, QPR = K / 4, NQ = 128 * QPR / 256;
+  __shared__ __attribute__((aligned(16))) char As[128 * ROW];
+  __shared__ __attribute__((aligned(16))) char Ws[128 * ROW];
+  __shared__ __attribute__((aligned(16))) float xs[2][128 * 4 + 8];             // the samples under a tile's 128 rows, double-buffered
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int tile0 = blockIdx.x * TT_TPW;
+  const float* xb = x + (size_t)b * Lin;
+  char* yb = reinterpret_cast<char*>(y + (size_t)b * Lout * K);
+  auto split_store = [&](char* row, int q, f32x4 v) __attribute__((always_inline)) {
+    g_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
+    *reinterpret_cast<g_bf16x4*>(row + 2 * K + 8 * q) = lo;
+  };
+  // samples 512 tile .. 512 tile + 519 (rows past Lout read clamped samples; those rows are never stored)
+  float xr[3];
+  auto load_x = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i;
+      long long sidx = 512LL * tile + idx;
+      sidx = sidx < Lin ? sidx : Lin - 1;
+      xr[i] = idx < 520 ? xb[sidx] : 0.f;
+    }
+  };
+  auto store_x = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 520) xs[buf][idx] = xr[i];
+    }
+  };
+  load_x(tile0);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int idx = tid + 256 * i;
+    split_store(Ws + (idx / QPR) * ROW, idx % QPR, *reinterpret_cast<const f32x4*>(gw + (size_t)(idx / QPR) * K + 4 * (idx % QPR)));
+  }
+  const int cq = tid % QPR, cr = tid / QPR;                 // first-convolution slot: channel quad, first row
+  f32x4 wq[9];                                               // its 8 taps and bias
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wq[j] = *reinterpret_cast<const f32x4*>(w1 + j * K + 4 * cq);
+  wq[8] = *reinterpret_cast<const f32x4*>(b1 + 4 * cq);
+  float gbias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) gbias[nt] = gb[nt * 32 + li];
+  store_x(0);
+  const char* Ap = As + (wave * 32 + li) * ROW + 16 * lh;
+  const char* Bp = Ws + li * ROW + 16 * lh;
+  const int ntile = tiles_per_clip - tile0 < TT_TPW ? tiles_per_clip - tile0 : TT_TPW;
+  __syncthreads();
+  for (int it = 0; it < ntile; ++it) {
+    const int tile = tile0 + it;
+    if (it + 1 < ntile) load_x(tile + 1);
+    // A = relu(b1 + sum_j w1[j] * x[4 row + j]): thread (quad cq, row group cr) keeps its quad's 8 taps + bias in registers and
+    // walks rows cr, cr + 21, ... (252 of the 256 threads; 7 slots each)
+    const float* xt = xs[it & 1];
+    if (tid < 252) {
+#pragma unroll
+      for (int p = 0; p < 7; ++p) {
+        const int row = cr + 21 * p;
+        if (row < 128) {
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(xt + 4 * row), s1 = *reinterpret_cast<const f32x4*>(xt + 4 * row + 4);
+          f32x4 v = wq[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v += (j < 4 ? s0[j & 3] : s1[j & 3]) * wq[j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+          split_store(As + row * ROW, cq, v);
+        }
+      }
+    }
+    if (it + 1 < ntile) store_x((it + 1) & 1);
+    __syncthreads();
+    floatx16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(Ap + 32 * s);
+      const g_bf16x8 al = *reinterpret_cast<const g_bf16x8*>(Ap + 2 * K + 32 * s);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * ROW + 32 * s);
+        const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(Bp + nt * 32 * ROW + 2 * K + 32 * s);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+      }
+    }
+    const int mbase = tile * 128 + wave * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + (r & 3) + 8 * (r >> 2);
+      if (m < Lout) {
+        const unsigned o = ((unsigned)m * K + (unsigned)li) * 4u;
+        st_f32(yb, o, (acc[0][r] + gbias[0]) * gemm_sigmoid(acc[1][r] + gbias[1]));
+        if (li < K - 32) st_f32(yb, o + 128u, (acc[2][r] + gbias[2]) * gemm_sigmoid(acc[3][r] + gbias[3]));
+      }
+    }
+    __syncthreads();                                       // every wave has read its A fragments: the next tile may be staged
+  }
+}
+
 // ---------------------------------------------------------------------------------- small kernels
 // mix / (floor + std), zero-padded to VL samples; std = unbiased std over time (model.py:293-301).
 __global__ __launch_bounds__(256) void demucs_prep_kernel(const float* __restrict__ wav, int T, int VL, float floor_,
@@ -1795,6 +1916,22 @@ int mfpa_glu_convT1d_c1(const float* x, int B, int L, int C, const float* gw, co
   const int tiles = (groups + TT_OUT - 1) / TT_OUT;
   hipLaunchKernelGGL(glu_convT_c1_kernel, dim3((tiles + TT_TPW - 1) / TT_TPW, B), dim3(256), 0, mfpa_stream(stream), x, L, gw, gb, wl, bias, y,
                      tiles, groups);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+/* First encoder level of Demucs in one launch (model.py:66-75: Conv1d(1, C, 8, 4) + ReLU + Conv1d(C, 2C, 1) + GLU):
+ * x (B, Lin) -> y (B, Lout, C), Lout = (Lin - 8) / 4 + 1.  w1 (8, C) tap-major and b1 (C) as for mfpa_conv1d_c1; gw (128, C) / gb
+ * (128) in the packed GLU tile order of mfpa_gemm_mfma mode 1.  C must be 48. */
+int mfpa_conv1d_c1_glu(const float* x, int B, int Lin, int Lout, int C, const float* w1, const float* b1, const float* gw,
+                       const float* gb, float* y, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!x || !w1 || !b1 || !gw || !gb || !y || B < 0 || B > 65535 || C != TT_K || Lout < 1 || Lin < 4 * ((long long)Lout - 1) + 8 ||
+      (long long)Lout * C * 4 > 0xffffffffLL)
+    return MFPA_EINVAL;
+  const int tiles = (Lout + 127) / 128;
+  hipLaunchKernelGGL(c1_glu_kernel, dim3((tiles + TT_TPW - 1) / TT_TPW, B), dim3(256), 0, mfpa_stream(stream), x, Lin, Lout, w1, b1, gw, gb, y,
+                     tiles);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

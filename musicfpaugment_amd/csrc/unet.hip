@@ -43,6 +43,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef MFPA_CONV_WN64
 #define MFPA_CONV_WN64 1
 #endif
+#ifndef MFPA_CONV_MT4
+#define MFPA_CONV_MT4 0             // 1: the 256 x 128 tile on FOUR waves of 128 px x 64 ch (8 x 32 patches); 2: also the 16 x 16 patches of the bottleneck
+                                    // (measured per layer: 3-17 % SLOWER than the 8-wave shape -- a quarter less LDS traffic does not pay for one wave per SIMD)
+#endif
 #ifndef MFPA_CONV_BOTTLENECK8
 #define MFPA_CONV_BOTTLENECK8 1     // the 16x15 level on the 8-wave shape with 16x16-pixel patches (0: round 1's 4-wave 8x16 shape)
 #endif
@@ -79,9 +83,9 @@ constexpr int pin_read_slots(int slots, int left) {      // how many MFMAs pin_r
 }
 
 // does this instantiation run the software-pipelined main loop (one workgroup per CU, two halo stages)?
-constexpr bool conv_is_pipe(int BN, int PH, int PW, int WM, int WN, int MODE, int PREC) {
+constexpr bool conv_is_pipe(int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, int MT = 2) {
   return (MFPA_CONV_PIPE != 0) && MODE == 0 && PREC == 1 &&
-         (WM * WN == 8 || (MFPA_CONV_PIPE4 != 0 && WM * WN == 4 && BN == 64 && PH * PW == 256));
+         (WM * WN * MT == 16 || (MFPA_CONV_PIPE4 != 0 && WM * WN == 4 && BN == 64 && PH * PW == 256));
 }
 
 struct ConvArgs {
@@ -132,8 +136,11 @@ struct ConvArgs {
 //     MFMA block of iteration it from As / Bs[it&1]
 //     one barrier                                 (+ barrier, halo store, at a chunk's last tap)
 // so weight loads have two MFMA blocks to land, and the only exposed cost per iteration is the wave skew.
-template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
+// MT_ = 32-pixel MFMA tiles per wave: 2 (a wave owns 64 pixels), or 4 -- 128 pixels x (BN / WN) channels per wave, FOUR waves for the
+// 256 x 128 tile, one per SIMD with the whole register file (256 VGPRs + 206 AGPRs, no scratch): 12 fragment reads per 24 MFMAs
+// instead of 16, a quarter less LDS traffic.  Measured 3-17 % slower per layer than two 64-pixel waves per SIMD (MFPA_CONV_MT4).
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false, int MT_ = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT_)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int TAPS = (MODE == 0) ? 9 : (MODE == 2 ? 4 : 1);
@@ -141,9 +148,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   constexpr int HPW = PW + 2 * HALO, HPH = PH + 2 * HALO;
   constexpr int HP = HPW * HPH;                       // halo-tile pixels
   constexpr int BM = PH * PW;
-  static_assert(BM == 64 * WM, "workgroup tile is 64*WM pixels");
+  constexpr int MT = MT_;
+  constexpr int WPX = 32 * MT;                        // pixels per wave
+  static_assert(BM == WPX * WM, "workgroup tile is 32*MT*WM pixels");
   constexpr int NT = BN / (32 * WN);                  // 32-wide n tiles per wave
-  constexpr int MT = 2;
   constexpr int A_F4 = (HP * (KC / 4) + THREADS - 1) / THREADS;
   constexpr int B_F4 = (BN * (KC / 4) + THREADS - 1) / THREADS;
   constexpr bool B_EXACT = (BN * (KC / 4)) % THREADS == 0;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   // PIPE (the bf16x3 3x3 convolution on the 8-wave shapes, one workgroup per CU): software-pipelined main loop with the halo
   // tile double-buffered in LDS, see step_pipe below.  The 4-wave shapes keep the plain loop: with 256 threads the staging
   // registers are twice as many per thread and the second fragment set spills (measured: 2x slower).
-  constexpr bool PIPE = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC);
+  constexpr bool PIPE = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);
   constexpr int A_STAGES = PIPE ? 2 : 1;
   // PIPE: a halo stage has a row for every staging slot (A_F4 * THREADS / 8 >= HP), so the split / store pass needs no tail
   // predicate: every halo load is consumed on every path and hipcc keeps no "maybe pending" state across iterations
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   int a_base[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = wm * 64 + mt * 32 + li;
+    const int m = wm * WPX + mt * 32 + li;
     a_base[mt] = ((m / PW) * HPW + (m % PW)) * LDK + 4 * lh;
   }
   int b_base[NT];
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = wm * WPX + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gy = y0 + m / PW, gx = x0p + m % PW;
         if (interior || (gy < a.yH && gx < a.yW)) {
           unsigned pix;
@@ -629,21 +637,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
       const int n = n0 + wn * (NT * 32) + nt * 32 + li;
       if (PW == 32) {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int py = (y0 + (wm * 2)) / 2, px = (x0p + col) / 2;
-          if (py < Ho && px < Wo) {
-            const float v = fmaxf(fmaxf(acc[0][nt][r], acc[0][nt][r + 1]), fmaxf(acc[1][nt][r], acc[1][nt][r + 1]));
-            a.y_pool[(((size_t)b * Ho + py) * Wo + px) * a.Cout + n] = v;
+        for (int mp = 0; mp < MT; mp += 2)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int py = (y0 + wm * MT + mp) / 2, px = (x0p + col) / 2;
+            if (py < Ho && px < Wo) {
+              const float v = fmaxf(fmaxf(acc[mp][nt][r], acc[mp][nt][r + 1]), fmaxf(acc[mp + 1][nt][r], acc[mp + 1][nt][r + 1]));
+              a.y_pool[(((size_t)b * Ho + py) * Wo + px) * a.Cout + n] = v;
+            }
           }
-        }
       } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 8; r += 2) {
             const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;       // pixel in the 2x16 tile, row 0
-            const int py = (y0 + 2 * (wm * 2 + mt)) / 2, px = (x0p + (q % 16)) / 2;
+            const int py = (y0 + 2 * (wm * MT + mt)) / 2, px = (x0p + (q % 16)) / 2;
             if (py < Ho && px < Wo) {
               const float v = fmaxf(fmaxf(acc[mt][nt][r], acc[mt][nt][r + 1]), fmaxf(acc[mt][nt][r + 8], acc[mt][nt][r + 9]));
               a.y_pool[(((size_t)b * Ho + py) * Wo + px) * a.Cout + n] = v;
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
         for (int nt = 0; nt < NT; ++nt) p += acc[mt][nt][r] * wv[nt];
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) p += __shfl_xor(p, o);
-        const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = wm * WPX + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (WN == 2 && wn == 1 && li == 0) red[m] = p;
         acc[mt][0][r] = p;                               // kept for the second half below
       }
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = wm * WPX + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int gy = y0 + m / PW, gx = x0p + m % PW;
           const float p = acc[mt][0][r] + (WN == 2 ? red[m] : 0.f);
           if (li == 0 && gy < a.H && gx < a.W) a.y1x1[((size_t)b * a.H + gy) * a.W + gx] = p + a.b1x1;
@@ -997,7 +1007,7 @@ __global__ __launch_bounds__(256) void conv1x1_out_kernel(const float* __restric
   }
 }
 
-template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false>
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false, int MT = 2>
 int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
@@ -1006,12 +1016,12 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  constexpr bool ADB = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC);    // PIPE of the kernel: two padded halo stages
+  constexpr bool ADB = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);    // PIPE of the kernel: two padded halo stages
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HPS = ADB ? ((HP * (KC / 4) + THREADS - 1) / THREADS) * (THREADS / (KC / 4)) : HP;
   const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HPS * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(taps_y * (a.Cout / BN)));
-  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC, MT>), grid, dim3(64 * WM * WN), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1037,6 +1047,12 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   }
   if (a.W > 16 && a.H >= 8) {
     if (!bn128) return launch_conv<64, 8, 32, 4, WN64, MODE, PREC>(a, taps_y, s);
+#if MFPA_CONV_MT4 || defined(MFPA_EXPERIMENTS)
+    if constexpr (MODE == 0 && PREC == 1) {
+      static const int mt4 = MFPA_EXP_ENV("MFPA_CONV_MT4", MFPA_CONV_MT4);
+      if (big && mt4) return launch_conv<128, 8, 32, 2, 2, MODE, PREC, false, 4>(a, taps_y, s);
+    }
+#endif
     if (big) return launch_conv<128, 8, 32, 4, 2, MODE, PREC>(a, taps_y, s);
     return launch_conv<128, 4, 32, 2, 2, MODE, PREC>(a, taps_y, s);
   }
@@ -1044,6 +1060,12 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
     return bn128 ? launch_conv<128, 4, 32, 2, 2, MODE, PREC>(a, taps_y, s) : launch_conv<64, 4, 32, 2, 1, MODE, PREC>(a, taps_y, s);
   }
 #if MFPA_CONV_BOTTLENECK8
+#if MFPA_CONV_MT4 || defined(MFPA_EXPERIMENTS)
+  if constexpr (MODE == 0 && PREC == 1) {
+    static const int mt4b = MFPA_EXP_ENV("MFPA_CONV_MT4", MFPA_CONV_MT4);
+    if (bn128 && a.H >= 16 && mt4b >= 2) return launch_conv<128, 16, 16, 2, 2, MODE, PREC, false, 4>(a, taps_y, s);
+  }
+#endif
   if (bn128 && MODE == 0 && PREC == 1 && a.H >= 16) return launch_conv<128, 16, 16, 4, 2, MODE, PREC>(a, taps_y, s);
 #endif
   return bn128 ? launch_conv<128, 8, 16, 2, 2, MODE, PREC>(a, taps_y, s) : launch_conv<64, 8, 16, 2, 1, MODE, PREC>(a, taps_y, s);
