@@ -39,6 +39,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
 PMC_TRAFFIC_BF16X3 = "r02_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
+PMC_TRAFFIC_DEMUCS = "r02_pmc_traffic_demucs.json"   # the same for the Demucs forward (GEMM family + LSTM launches)
 
 
 def _oracle_chain():
@@ -178,7 +179,7 @@ def cpu_baseline(budget_s: float, seed: int):
 
 def _demucs_traffic(B):
     """HBM bytes per step of the Demucs forward's GEMM family from the committed rocprofv3 --pmc passes, scaled to B clips."""
-    pmc = os.path.join(ROOT, "profiles", "r01e_pmc_traffic_demucs.json")
+    pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_DEMUCS)
     if not os.path.exists(pmc):
         return None
     with open(pmc) as fh:
@@ -235,21 +236,21 @@ def bench_demucs(args, rank, world, dev, dist):
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3 GEMMs and LSTM steps (fp32 operands split into bf16 hi+lo, fp32 accumulate)"
-            if args.precision == "bf16x3" else "f32 GEMMs (the fused LSTM step is bf16x3)", "data": "synthetic",
+            if args.precision == "bf16x3" else "f32 GEMMs (the LSTM recurrence is bf16x3)", "data": "synthetic",
             "config": {"workload": f"Demucs() causal denoiser forward ({args.precision} MFMA GEMMs, formula weights) -> STFT -> "
                                    "Audfprint peak-pick, 8 s clips", "clips_per_gpu_per_step": B, "peaks_last_step_rank0": int(npeaks.sum()),
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": _demucs_traffic(B),
-                          "traffic_source": "profiles/r01e_pmc_traffic_demucs.json (offline PMC passes, FETCH_SIZE x2 + WRITE_SIZE of the GEMM and LSTM-step launches, scaled to the batch)",
+                          "traffic_source": f"profiles/{PMC_TRAFFIC_DEMUCS} (offline PMC passes, FETCH_SIZE x2 + WRITE_SIZE of the GEMM-family and LSTM launches, scaled to the batch)",
                           "mfma_flops_issued_per_algorithmic_flop": 3,
                           "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                          "kernel": "gemm_bf16x3(_wide)_kernel + gemm_shortk_bf16x3_kernel + lstm_step_kernel (the recurrence timed as one group)",
+                          "kernel": "gemm_bf16x3_pipe/_wide/_kernel + gemm_shortk_bf16x3_kernel + c1_glu_kernel + glu_convT_c1_kernel + lstm_seq_kernel (the recurrence timed as one group)",
                           "launches": timer.launches(), "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}
                          if args.precision == "bf16x3" else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                          "kernel": "gemm_mfma_kernel + lstm_step_kernel (bf16x3)", "launches": timer.launches(),
+                          "kernel": "gemm_mfma_kernel + lstm_seq_kernel (bf16x3)", "launches": timer.launches(),
                           "kernel_ms_per_step": round(gemm_ms / args.steps, 3)})})
     return result
 

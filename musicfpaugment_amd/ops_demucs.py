@@ -297,8 +297,11 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
             # (12 MB per clip) is never written
             h = new(B, Lout, C)
             if FUSE_FIRST_LEVEL and precision == 1 and C == 48:          # one workgroup per 128 rows owns all packed GLU columns
+                t0 = _K._TIMER.start() if _K._TIMER is not None else None      # counted with the GEMM family (bench.py's roofline block)
                 check(L.mfpa_conv1d_c1_glu(ptr(x), B, Lin, Lout, C, ptr(pw["enc0.w"]), ptr(pw["enc0.b"]), ptr(pw["enc0.gw"]),
                                            ptr(pw["enc0.gb"]), ptr(h), stream()), "mfpa_conv1d_c1_glu")
+                if t0 is not None:
+                    _K._TIMER.stop(t0)
             else:
                 gemm_p(0, C, Lout * C, B, Lout, pw["enc0.gw"], pw["enc0.gb"], C, _p(h), C, Lout * C, mode=1,
                        c1=(x, pw["enc0.w"], pw["enc0.b"]))
@@ -326,8 +329,11 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
         C = chans[DEPTH - 1 - d]
         if d == DEPTH - 1 and FUSE_LAST_LEVEL and precision == 1 and C == 48:
             y = new(B, 4 * (Lcur + 1))                           # 1x1 + GLU + ConvTranspose1d(48 -> 1) without the GLU output in memory
+            t0 = _K._TIMER.start() if _K._TIMER is not None else None
             check(L.mfpa_glu_convT1d_c1(ptr(x), B, Lcur, C, ptr(pw[f"dec{d}.gw"]), ptr(pw[f"dec{d}.gb"]), ptr(pw["decL.w"]), pw["decL.b"],
                                         ptr(y), stream()), "mfpa_glu_convT1d_c1")
+            if t0 is not None:
+                _K._TIMER.stop(t0)
             x, Lcur = y, 4 * (Lcur + 1)
             break
         if _PAD_ROWS_ONLY:
