@@ -942,7 +942,15 @@ __global__ __launch_bounds__(256, 2) void glu_convT_c1_kernel(const float* __res
   }
 }
 
-// ---------------------------------------------------------------------------------- first encoder level in one launch
+// ---------------------------------------------------------------------------------- first encoder level in one launch (EXPERIMENT)
+// NOT in the product build.  Measured +1.7 % on the Demucs forward and bit-identical to the 128 x 64-tile form while ONE workgroup
+// runs per CU (any size); with TWO per CU (its natural occupancy) sporadic rows of the first convolution come out wrong in the
+// low half of packed-fp32 pairs, for the same lanes of every wave, differently from run to run.  Extra barriers at every phase
+// boundary, s_nop after the LDS stores, vmcnt(0) before the first use of the prefetched samples, samples via LDS or straight
+// from memory, and removing the exec-mask region did not change it; forcing one workgroup per CU (extra dynamic LDS) did, at which
+// point it is slower than the form it replaces.  Cause not found: tools/probes/head_kernel_two_wg_per_cu.py reproduces it against
+// libmfpa_exp.so.  Kept for that investigation only.
+#ifdef MFPA_EXPERIMENTS
 // Conv1d(1 -> C, k8, s4) + ReLU + Conv1d(C -> 2C, 1) + GLU of the first encoder level (model.py:66-75,303-307): x (B, Lin) -> h
 // (B, Lout, C).  gemm_shortk_bf16x3_kernel<true, 48, 48> does the same with 128 x 64 tiles, i.e. TWO workgroups (the value /
 // gate column pairs 0..31 and 32..47) each evaluate the first convolution for the same 128 rows; here a workgroup owns all 128
@@ -952,9 +960,10 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
                                                         const float* __restrict__ b1, const float* __restrict__ gw,
                                                         const float* __restrict__ gb, float* __restrict__ y, int tiles_per_clip) {
   constexpr int K = TT_K, ROW = TT_ROW, QPR = K / 4, NQ = 128 * QPR / 256;
+  constexpr int NSLOT = 7;                                                      // rows per first-convolution thread: cr + 21 p
+  constexpr bool ALLT = true;   // threads 252..255 (cr = 21) recompute rows 21, 42, .. of quads 0..3: the same values, no exec-mask region
   __shared__ __attribute__((aligned(16))) char As[128 * ROW];
   __shared__ __attribute__((aligned(16))) char Ws[128 * ROW];
-  __shared__ __attribute__((aligned(16))) float xs[2][128 * 4 + 8];             // the samples under a tile's 128 rows, double-buffered
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y;
@@ -971,66 +980,55 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
     *reinterpret_cast<g_bf16x4*>(row + 8 * q) = hi;
     *reinterpret_cast<g_bf16x4*>(row + 2 * K + 8 * q) = lo;
   };
-  // samples 512 tile .. 512 tile + 519 (rows past Lout read clamped samples; those rows are never stored)
-  float xr[3];
+  // first-convolution slot of a thread: channel quad cq, rows cr + 21 p of every tile (252 of the 256 threads); the 8 samples under
+  // a row come straight from memory (two aligned float4, L1 hits for the 11 other quads of the row), one tile ahead
+  const int cq = tid % QPR, cr = tid / QPR;
+  f32x4 xr[NSLOT][2];
   auto load_x = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i;
-      long long sidx = 512LL * tile + idx;
-      sidx = sidx < Lin ? sidx : Lin - 1;
-      xr[i] = idx < 520 ? xb[sidx] : 0.f;
+    for (int p = 0; p < NSLOT; ++p) {
+      int m = tile * 128 + cr + 21 * p;
+      m = m < Lout ? m : Lout - 1;                         // rows past Lout (and slots past row 127) are never used
+      const float* px = xb + 4 * (size_t)m;
+      xr[p][0] = *reinterpret_cast<const f32x4*>(px);
+      xr[p][1] = *reinterpret_cast<const f32x4*>(px + 4);
     }
   };
-  auto store_x = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < 520) xs[buf][idx] = xr[i];
-    }
-  };
-  load_x(tile0);
+  if (ALLT || tid < 252) load_x(tile0);
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int idx = tid + 256 * i;
     split_store(Ws + (idx / QPR) * ROW, idx % QPR, *reinterpret_cast<const f32x4*>(gw + (size_t)(idx / QPR) * K + 4 * (idx % QPR)));
   }
-  const int cq = tid % QPR, cr = tid / QPR;                 // first-convolution slot: channel quad, first row
-  f32x4 wq[9];                                               // its 8 taps and bias
+  f32x4 wq[9];                                               // the quad's 8 taps and bias
 #pragma unroll
   for (int j = 0; j < 8; ++j) wq[j] = *reinterpret_cast<const f32x4*>(w1 + j * K + 4 * cq);
   wq[8] = *reinterpret_cast<const f32x4*>(b1 + 4 * cq);
   float gbias[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) gbias[nt] = gb[nt * 32 + li];
-  store_x(0);
   const char* Ap = As + (wave * 32 + li) * ROW + 16 * lh;
   const char* Bp = Ws + li * ROW + 16 * lh;
   const int ntile = tiles_per_clip - tile0 < TT_TPW ? tiles_per_clip - tile0 : TT_TPW;
-  __syncthreads();
   for (int it = 0; it < ntile; ++it) {
     const int tile = tile0 + it;
-    if (it + 1 < ntile) load_x(tile + 1);
-    // A = relu(b1 + sum_j w1[j] * x[4 row + j]): thread (quad cq, row group cr) keeps its quad's 8 taps + bias in registers and
-    // walks rows cr, cr + 21, ... (252 of the 256 threads; 7 slots each)
-    const float* xt = xs[it & 1];
-    if (tid < 252) {
+    // A = relu(b1 + sum_j w1[j] * x[4 row + j]), bias then taps 0..7 (conv1d_c1_kernel's order), split into LDS
+    if (ALLT || tid < 252) {
 #pragma unroll
-      for (int p = 0; p < 7; ++p) {
+      for (int p = 0; p < NSLOT; ++p) {
         const int row = cr + 21 * p;
         if (row < 128) {
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(xt + 4 * row), s1 = *reinterpret_cast<const f32x4*>(xt + 4 * row + 4);
           f32x4 v = wq[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v += (j < 4 ? s0[j & 3] : s1[j & 3]) * wq[j];
+          for (int j = 0; j < 8; ++j) v += xr[p][j >> 2][j & 3] * wq[j];
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
           split_store(As + row * ROW, cq, v);
         }
       }
+      if (it + 1 < ntile) load_x(tile + 1);
     }
-    if (it + 1 < ntile) store_x((it + 1) & 1);
-    __syncthreads();
+    __syncthreads();                                       // A (and, the first time, W) staged
     floatx16 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -1062,6 +1060,7 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
     __syncthreads();                                       // every wave has read its A fragments: the next tile may be staged
   }
 }
+#endif  // MFPA_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------- small kernels
 // mix / (floor + std), zero-padded to VL samples; std = unbiased std over time (model.py:293-301).
@@ -1920,6 +1919,7 @@ int mfpa_glu_convT1d_c1(const float* x, int B, int L, int C, const float* gw, co
   return MFPA_OK;
 }
 
+#ifdef MFPA_EXPERIMENTS
 /* First encoder level of Demucs in one launch (model.py:66-75: Conv1d(1, C, 8, 4) + ReLU + Conv1d(C, 2C, 1) + GLU):
  * x (B, Lin) -> y (B, Lout, C), Lout = (Lin - 8) / 4 + 1.  w1 (8, C) tap-major and b1 (C) as for mfpa_conv1d_c1; gw (128, C) / gb
  * (128) in the packed GLU tile order of mfpa_gemm_mfma mode 1.  C must be 48. */
@@ -1927,14 +1927,15 @@ int mfpa_conv1d_c1_glu(const float* x, int B, int Lin, int Lout, int C, const fl
                        const float* gb, float* y, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!x || !w1 || !b1 || !gw || !gb || !y || B < 0 || B > 65535 || C != TT_K || Lout < 1 || Lin < 4 * ((long long)Lout - 1) + 8 ||
-      (long long)Lout * C * 4 > 0xffffffffLL)
+      (long long)Lout * C * 4 > 0xffffffffLL || Lin % 4 != 0 || ((size_t)x & 15) != 0)        // the rows' samples are read as aligned float4
     return MFPA_EINVAL;
   const int tiles = (Lout + 127) / 128;
-  hipLaunchKernelGGL(c1_glu_kernel, dim3((tiles + TT_TPW - 1) / TT_TPW, B), dim3(256), 0, mfpa_stream(stream), x, Lin, Lout, w1, b1, gw, gb, y,
+  hipLaunchKernelGGL(c1_glu_kernel, dim3((tiles + TT_TPW - 1) / TT_TPW, B), dim3(256), (size_t)MFPA_EXP_ENV("MFPA_HEAD_LDS", 0), mfpa_stream(stream), x, Lin, Lout, w1, b1, gw, gb, y,
                      tiles);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
+#endif
 
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
                    const float* addend, long long ldadd, void* stream) {
