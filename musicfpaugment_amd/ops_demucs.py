@@ -182,6 +182,12 @@ def _lstm_work(dev, layer: int, B: int, H: int) -> torch.Tensor:
     a pinned host copy made then (no synchronisation on the way): a wait that gave up inside the kernel surfaces here as MfpaError."""
     from ._lib import MfpaError
     L = lib()
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP graph capture: scratch from the graph's own pool, zeroed by a captured fill on every replay; no host-side
+        # look at the error word (nothing may synchronise or query here) -- a replayed graph reports through its results only
+        nbytes = ctypes.c_longlong(0)
+        check(L.mfpa_lstm_seq_work_bytes(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
+        return torch.zeros(nbytes.value // 4, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream, layer, B, H)
     ent = _LSTM_WORK.get(key)
