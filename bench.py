@@ -245,7 +245,7 @@ def bench_demucs(args, rank, world, dev, dist):
                           "traffic_source": f"profiles/{PMC_TRAFFIC_DEMUCS} (offline PMC passes, FETCH_SIZE x2 + WRITE_SIZE of the GEMM-family and LSTM launches, scaled to the batch)",
                           "mfma_flops_issued_per_algorithmic_flop": 3,
                           "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                          "kernel": "gemm_bf16x3_pipe/_wide/_kernel + gemm_shortk_bf16x3_kernel + glu_convT_c1_kernel + lstm_seq_kernel (the recurrence timed as one group)",
+                          "kernel": "gemm_bf16x3_pipe/_wide/_kernel + gemm_shortk_bf16x3_kernel + c1_glu_kernel + glu_convT_c1_kernel + lstm_seq_kernel (the recurrence timed as one group)",
                           "launches": timer.launches(), "kernel_ms_per_step": round(gemm_ms / args.steps, 3)}
                          if args.precision == "bf16x3" else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -406,6 +406,13 @@ int mfpa_conv1d_c1(const float* x, int B, int Lin, int Lout, int C, const float*
                    void* stream);
 /* Last decoder layer ConvTranspose1d(C->1, k8, s4): P (B,L+2,C) with zero first/last rows -> y (B, 4(L+1)), w (8,C). */
 int mfpa_convT1d_c1(const float* P, int B, int L, int C, const float* w, float bias, float* y, void* stream);
+/* The whole first encoder level in one launch (model.py:66-75,303-307: Conv1d(1, C, 8, 4) + ReLU + Conv1d(C, 2C, 1) + GLU):
+ * x (B, Lin) -> y (B, Lout, C), Lout = (Lin - 8) / 4 + 1; the (B, Lout, C) output of the first convolution never exists in
+ * memory and, unlike mfpa_gemm_mfma with c1_x set, is evaluated once per row (one workgroup owns all packed GLU columns); the
+ * result has the same bits as that form.  w1 (8, C) tap-major, b1 (C) as for mfpa_conv1d_c1; gw (128, C) / gb (128) in the
+ * packed GLU tile order.  C must be 48, Lin a multiple of 4 and x 16-byte aligned (a row's 8 samples are read as two float4). */
+int mfpa_conv1d_c1_glu(const float* x, int B, int Lin, int Lout, int C, const float* w1, const float* b1, const float* gw,
+                       const float* gb, float* y, void* stream);
 /* The whole last decoder level in one launch (model.py:80-88,316-318: Conv1d(C, 2C, 1) + GLU + ConvTranspose1d(C, 1, 8, 4)):
  * x (B, L, C) -> y (B, 4 (L + 1)) without the (B, L, C) GLU output in memory.  gw (128, C) / gb (128) = the 1x1 weights and bias
  * in the packed GLU tile order of mfpa_gemm_mfma mode 1, wl (8, C) tap-major as for mfpa_convT1d_c1.  C must be 48 (MFPA_EINVAL

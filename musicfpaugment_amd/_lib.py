@@ -95,6 +95,7 @@ _SIGNATURES = {
     "mfpa_lstm_layer_bwd": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "mfpa_lstm_layer_range": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                c_int, c_void_p], c_int),
+    "mfpa_conv1d_c1_glu": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_glu_convT1d_c1": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "mfpa_lstm_layer_seq": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                              c_int, c_void_p, c_void_p], c_int),

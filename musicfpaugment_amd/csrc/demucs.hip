@@ -942,15 +942,7 @@ __global__ __launch_bounds__(256, 2) void glu_convT_c1_kernel(const float* __res
   }
 }
 
-// ---------------------------------------------------------------------------------- first encoder level in one launch (EXPERIMENT)
-// NOT in the product build.  Measured +1.7 % on the Demucs forward and bit-identical to the 128 x 64-tile form while ONE workgroup
-// runs per CU (any size); with TWO per CU (its natural occupancy) sporadic rows of the first convolution come out wrong in the
-// low half of packed-fp32 pairs, for the same lanes of every wave, differently from run to run.  Extra barriers at every phase
-// boundary, s_nop after the LDS stores, vmcnt(0) before the first use of the prefetched samples, samples via LDS or straight
-// from memory, and removing the exec-mask region did not change it; forcing one workgroup per CU (extra dynamic LDS) did, at which
-// point it is slower than the form it replaces.  Cause not found: tools/probes/head_kernel_two_wg_per_cu.py reproduces it against
-// libmfpa_exp.so.  Kept for that investigation only.
-#ifdef MFPA_EXPERIMENTS
+// ---------------------------------------------------------------------------------- first encoder level in one launch
 // Conv1d(1 -> C, k8, s4) + ReLU + Conv1d(C -> 2C, 1) + GLU of the first encoder level (model.py:66-75,303-307): x (B, Lin) -> h
 // (B, Lout, C).  gemm_shortk_bf16x3_kernel<true, 48, 48> does the same with 128 x 64 tiles, i.e. TWO workgroups (the value /
 // gate column pairs 0..31 and 32..47) each evaluate the first convolution for the same 128 rows; here a workgroup owns all 128
@@ -961,7 +953,7 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
                                                         const float* __restrict__ gb, float* __restrict__ y, int tiles_per_clip) {
   constexpr int K = TT_K, ROW = TT_ROW, QPR = K / 4, NQ = 128 * QPR / 256;
   constexpr int NSLOT = 7;                                                      // rows per first-convolution thread: cr + 21 p
-  constexpr bool ALLT = true;   // threads 252..255 (cr = 21) recompute rows 21, 42, .. of quads 0..3: the same values, no exec-mask region
+  constexpr bool ALLT = false;
   __shared__ __attribute__((aligned(16))) char As[128 * ROW];
   __shared__ __attribute__((aligned(16))) char Ws[128 * ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1019,8 +1011,25 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
         const int row = cr + 21 * p;
         if (row < 128) {
           f32x4 v = wq[8];
+#ifndef MFPA_HEAD_PACKED_FMA
+          // One v_fma_f32 per element, kept from being paired (the empty asm).  Written as `v += x * wq[j]` hipcc emits
+          // v_pk_fma_f32 with op_sel:[0,1,0] (the LOW lane takes the HIGH half of the sample pair) for the odd samples, and with
+          // TWO workgroups per CU -- i.e. while the SIMD's other wave runs MFMAs -- the low lane of those instructions sporadically
+          // came out wrong: wrong rows of A, different from run to run, only at > 256 workgroups; bit-exact with one workgroup per
+          // CU, with this form, and in the 128 x 64-tile GEMM form, whose loader only uses the op_sel_hi:[1,0,1] broadcast
+          // (profiles/r02_pk_fma_op_sel.md; -DMFPA_HEAD_PACKED_FMA + tools/probes/head_kernel_two_wg_per_cu.py reproduce it).
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float t = __builtin_fmaf(xr[p][j >> 2][j & 3], wq[j][k], v[k]);
+              asm volatile("" : "+v"(t));
+              v[k] = t;
+            }
+#else
 #pragma unroll
           for (int j = 0; j < 8; ++j) v += xr[p][j >> 2][j & 3] * wq[j];
+#endif
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
           split_store(As + row * ROW, cq, v);
@@ -1060,8 +1069,6 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
     __syncthreads();                                       // every wave has read its A fragments: the next tile may be staged
   }
 }
-#endif  // MFPA_EXPERIMENTS
-
 // ---------------------------------------------------------------------------------- small kernels
 // mix / (floor + std), zero-padded to VL samples; std = unbiased std over time (model.py:293-301).
 __global__ __launch_bounds__(256) void demucs_prep_kernel(const float* __restrict__ wav, int T, int VL, float floor_,
@@ -1919,7 +1926,6 @@ int mfpa_glu_convT1d_c1(const float* x, int B, int L, int C, const float* gw, co
   return MFPA_OK;
 }
 
-#ifdef MFPA_EXPERIMENTS
 /* First encoder level of Demucs in one launch (model.py:66-75: Conv1d(1, C, 8, 4) + ReLU + Conv1d(C, 2C, 1) + GLU):
  * x (B, Lin) -> y (B, Lout, C), Lout = (Lin - 8) / 4 + 1.  w1 (8, C) tap-major and b1 (C) as for mfpa_conv1d_c1; gw (128, C) / gb
  * (128) in the packed GLU tile order of mfpa_gemm_mfma mode 1.  C must be 48. */
@@ -1935,8 +1941,6 @@ int mfpa_conv1d_c1_glu(const float* x, int B, int Lin, int Lout, int C, const fl
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
-#endif
-
 int mfpa_lstm_cell(const float* gates, long long ldg, float* c, int B, int H, float* hout, long long ldh, float* hsum,
                    const float* addend, long long ldadd, void* stream) {
   if (B == 0) return MFPA_OK;

@@ -111,6 +111,7 @@ def _p(t: torch.Tensor, off_floats: int = 0) -> int:
 
 
 FUSE_FIRST_LAYER = True   # False: run mfpa_conv1d_c1_relu as its own launch
+FUSE_FIRST_LEVEL = True   # False: the first convolution inside the loader of the 128 x 64-tile GLU GEMM (evaluated twice per row)
 _PAD_ROWS_ONLY = True   # zero only the two padding rows of the GLU output (0: memset the whole buffer)
 FUSE_LAST_LEVEL = True    # False: the last decoder level as two launches (1x1 + GLU, then the transposed convolution)
 LAST_LAYER_GEMM = True    # False: the stand-alone VALU kernel mfpa_convT1d_c1 for the last ConvTranspose1d
@@ -301,8 +302,15 @@ def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: in
             # Conv1d(1 -> 48, k8, s4) + ReLU is evaluated inside the loader of the 1x1 + GLU GEMM: its (B, L, 48) output
             # (12 MB per clip) is never written
             h = new(B, Lout, C)
-            gemm_p(0, C, Lout * C, B, Lout, pw["enc0.gw"], pw["enc0.gb"], C, _p(h), C, Lout * C, mode=1,
-                   c1=(x, pw["enc0.w"], pw["enc0.b"]))
+            if FUSE_FIRST_LEVEL and precision == 1 and C == 48 and Lin % 4 == 0:   # one workgroup per 128 rows owns all packed GLU columns
+                t0 = _K._TIMER.start() if _K._TIMER is not None else None      # counted with the GEMM family (bench.py's roofline block)
+                check(L.mfpa_conv1d_c1_glu(ptr(x), B, Lin, Lout, C, ptr(pw["enc0.w"]), ptr(pw["enc0.b"]), ptr(pw["enc0.gw"]),
+                                           ptr(pw["enc0.gb"]), ptr(h), stream()), "mfpa_conv1d_c1_glu")
+                if t0 is not None:
+                    _K._TIMER.stop(t0)
+            else:
+                gemm_p(0, C, Lout * C, B, Lout, pw["enc0.gw"], pw["enc0.gb"], C, _p(h), C, Lout * C, mode=1,
+                       c1=(x, pw["enc0.w"], pw["enc0.b"]))
         else:
             a = new(B, Lout, C)
             if i == 0:

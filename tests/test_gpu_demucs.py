@@ -203,3 +203,54 @@ def test_last_decoder_level_in_one_launch(B, L):
     err = (y.cpu().double() - want).abs().max().item()
     assert err < 2e-5 * max(1.0, want.abs().max().item()), err
     assert lib().mfpa_glu_convT1d_c1(ptr(xd), B, L, 32, ptr(gwd), ptr(gbd), ptr(wld), bt, ptr(y), stream()) == -22
+
+
+@pytest.mark.parametrize("B,Lout", [(3, 1000), (2, 128), (1, 129), (2, 1), (2, 8 * 128 * 3 + 5)])
+def test_first_encoder_level_in_one_launch(B, Lout):
+    """mfpa_conv1d_c1_glu = Conv1d(1, 48, 8, 4) + ReLU + Conv1d(48, 96, 1) + GLU (model.py:66-75) against torch in float64; tile
+    edges (128 rows per tile, 8 tiles per workgroup), inputs longer than the last window needs."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    C = 48
+    Lin = 4 * (Lout - 1) + 8 + 4 * (Lout % 3)                       # a multiple of 4: the rows' samples are read as aligned float4
+    g = torch.Generator().manual_seed(Lout)
+    x = torch.randn(B, Lin, generator=g)
+    w0 = torch.randn(C, 1, 8, generator=g) / np.sqrt(8)
+    b0 = torch.randn(C, generator=g) * 0.3
+    w1 = torch.randn(2 * C, C, generator=g) / np.sqrt(C)
+    b1 = torch.randn(2 * C, generator=g) * 0.3
+    a = F.relu(F.conv1d(x.double()[:, None, :4 * (Lout - 1) + 8], w0.double(), b0.double(), stride=4))     # the first Lout windows
+    want = F.glu(F.conv1d(a, w1.double()[:, :, None], b1.double()), dim=1).permute(0, 2, 1)
+    assert want.shape == (B, Lout, C)
+    gw, gb = D._pack_glu(w1, b1)
+    xd, w0d, b0d, gwd, gbd = x.cuda(), w0[:, 0, :].t().contiguous().cuda(), b0.cuda(), gw.cuda(), gb.cuda()
+    y = torch.full((B, Lout, C), float("nan"), device="cuda")
+    check(lib().mfpa_conv1d_c1_glu(ptr(xd), B, Lin, Lout, C, ptr(w0d), ptr(b0d), ptr(gwd), ptr(gbd), ptr(y), stream()), "head")
+    err = (y.cpu().double() - want).abs().max().item()
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+    assert lib().mfpa_conv1d_c1_glu(ptr(xd), B, 4 * (Lout - 1) + 4, Lout, C, ptr(w0d), ptr(b0d), ptr(gwd), ptr(gbd), ptr(y), stream()) == -22
+    assert lib().mfpa_conv1d_c1_glu(ptr(xd), B, Lin - 1, Lout, C, ptr(w0d), ptr(b0d), ptr(gwd), ptr(gbd), ptr(y), stream()) == -22
+
+
+def test_first_encoder_level_with_two_workgroups_per_cu_is_bit_exact():
+    """More workgroups than CUs (two share a CU, i.e. a SIMD runs this kernel's first-convolution FMAs next to another wave's
+    MFMAs): every run must give the bits of the 128 x 64-tile GEMM form, which evaluates the same arithmetic in the same order.
+    This is the case in which the packed-fp32 form of the convolution (v_pk_fma_f32 op_sel:[0,1,0]) returned sporadically wrong
+    rows -- small shapes and one-workgroup-per-CU launches never showed it (profiles/r02_pk_fma_op_sel.md)."""
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    C, B, Lout = 48, 48, 64084
+    Lin = 4 * (Lout - 1) + 8
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Lin, generator=g).cuda()
+    w0 = (torch.randn(8, C, generator=g) / np.sqrt(8)).cuda()
+    b0 = (torch.randn(C, generator=g) * 0.3).cuda()
+    gw, gb = D._pack_glu(torch.randn(2 * C, C, generator=g) / np.sqrt(C), torch.randn(2 * C, generator=g) * 0.3)
+    gw, gb = gw.cuda(), gb.cuda()
+    ref = torch.empty(B, Lout, C, device="cuda")
+    D.gemm(0, C, Lout * C, B, Lout, gw, gb, C, D._p(ref), C, Lout * C, mode=1, c1=(x, w0, b0))
+    for _ in range(4):
+        y = torch.full((B, Lout, C), float("nan"), device="cuda")
+        check(lib().mfpa_conv1d_c1_glu(ptr(x), B, Lin, Lout, C, ptr(w0), ptr(b0), ptr(gw), ptr(gb), ptr(y), stream()), "head")
+        assert torch.equal(y, ref)

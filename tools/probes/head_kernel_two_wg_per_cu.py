@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Reproduces the unexplained corruption of the experimental c1_glu_kernel (csrc/demucs.hip, -DMFPA_EXPERIMENTS builds only):
-bit-identical to the 128 x 64-tile GEMM form while one workgroup runs per CU, sporadically wrong rows with two.
-usage: head_kernel_two_wg_per_cu.py            (needs musicfpaugment_amd/libmfpa_exp.so: python -m musicfpaugment_amd.csrc.build --experiments)
+"""Reproduces what profiles/r02_pk_fma_op_sel.md describes: c1_glu_kernel (csrc/demucs.hip) with its first convolution written as
+`v += x * w` -- hipcc then emits v_pk_fma_f32 ... op_sel:[0,1,0] -- returns sporadically wrong rows once two workgroups share a CU.
+Builds musicfpaugment_amd/libmfpa_exp.so with -DMFPA_HEAD_PACKED_FMA unless --product is given (the shipped scalar-FMA form).
+usage: head_kernel_two_wg_per_cu.py [--product]
        MFPA_HEAD_LDS=40000 head_kernel_two_wg_per_cu.py      (extra dynamic LDS -> one workgroup per CU -> no differences)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from musicfpaugment_amd import _lib
+if "--build" in sys.argv:                                  # (run once where hipcc is: the GPU boxes use the prebuilt file)
+    from musicfpaugment_amd.csrc import build
+    build.build(verbose=False, experiments=True, extra_flags=[] if "--product" in sys.argv else ["-DMFPA_HEAD_PACKED_FMA"], force=True)
+    sys.exit(0)
 exp = os.path.join(os.path.dirname(_lib.__file__), "libmfpa_exp.so")
 _lib.set_library_path(exp)
 from musicfpaugment_amd import ops_demucs as D
