@@ -1466,6 +1466,7 @@ struct LstmSeqArgs {
   unsigned* sync;         // LSTM_SYNC_WORDS words
   char* hsplit;           // [2][B][H * 4 bytes]
   int B, Tn, H, t0, t1, train, nslab, ngroups;
+  int dbg;                // -DMFPA_EXPERIMENTS builds only (MFPA_LSTM_DBG, timing experiments: results are wrong): 1 no MFMAs, 2 no loads of h, 4 no waits, 8 no s_sleep in the poll
 };
 
 // COH 0: the waiting thread invalidates L1 / L2 once per step and h is read with ordinary (cached) loads; 1: no invalidate, h is read
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
             dead = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          if (!MFPA_EXP_FLAG(a.dbg, 8)) __builtin_amdgcn_s_sleep(1);
         }
       }
       if (!COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one invalidate per step: the loads of h below go through L1 / L2
@@ -1585,7 +1586,7 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
       for (int g = 0; g < 4; ++g) xg[g] = *reinterpret_cast<const f32x2*>(xr + g * H);
       if (a.xsum) ad = *reinterpret_cast<const f32x2*>(a.skip + (size_t)m * ldh + (size_t)t * H + u0);
     }
-    wait((unsigned)(t - a.t0 + 1));
+    if (!MFPA_EXP_FLAG(a.dbg, 4)) wait((unsigned)(t - a.t0 + 1));
     const char* hp = a.hsplit + (size_t)((t + 1) & 1) * bufb;
     floatx16 acc[2][2];
 #pragma unroll
@@ -1597,7 +1598,9 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const size_t off = arow[mt] + (size_t)(s >> 1) * 128 + (size_t)(s & 1) * 32;
-        if (COH) {
+        if (MFPA_EXP_FLAG(a.dbg, 2)) {
+          f[mt][0] = wh[0][0]; f[mt][1] = wl[0][0];
+        } else if (COH) {
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           const unsigned o = (unsigned)(((t + 1) & 1) * bufb + off);
           f[mt][0] = __builtin_bit_cast(l_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, o, 0, 16));
@@ -1616,6 +1619,7 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+          if (MFPA_EXP_FLAG(a.dbg, 1)) { acc[mt][nt][0] += (float)fa[s % PF][mt][0][0] + (float)fa[s % PF][mt][1][0]; continue; }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % PF][mt][1], wh[nt][s], acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % PF][mt][0], wl[nt][s], acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s % PF][mt][0], wh[nt][s], acc[mt][nt], 0, 0, 0);
@@ -1892,6 +1896,7 @@ int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float*
   a.sync = reinterpret_cast<unsigned*>(work);
   a.hsplit = reinterpret_cast<char*>(work) + (size_t)LSTM_SYNC_WORDS * 4;
   a.B = B; a.Tn = Tn; a.H = H; a.t0 = t0; a.t1 = t1; a.train = train; a.nslab = nslab; a.ngroups = ngroups;
+  a.dbg = MFPA_EXP_ENV("MFPA_LSTM_DBG", 0);
   hipStream_t st = mfpa_stream(stream);
   MFPA_HIP(hipMemsetAsync(work, 0, (size_t)LSTM_ERR_WORD * 4, st));          // the slab counters; the error word stays
   const unsigned grid = (unsigned)(((nslab * ngroups + 7) / 8) * 8);
