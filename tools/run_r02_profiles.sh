@@ -8,7 +8,7 @@ rm -rf $O/kt
 # HBM traffic of the conv family: one 64-clip forward (bench.py --clips 64 --steps 1 --warmup 0), FETCH_SIZE and WRITE_SIZE in separate passes
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o p --output-format csv -- python3 bench.py --clips 64 --steps 1 --warmup 0 --cpu-seconds 0 --no-configs > $O/pmc_f.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o p --output-format csv -- python3 bench.py --clips 64 --steps 1 --warmup 0 --cpu-seconds 0 --no-configs > $O/pmc_w.log 2>&1
-python tools/summarize_pmc.py $O/pmc_f $O/pmc_w $O/pmc_traffic_bf16x3.json 64 conv_mfma_kernel,convT_mfma_kernel "the MFMA convolution launches of ONE {clips}-clip UNet eval forward (bf16x3)" ', 1(, (false|true))?>$' > $O/pmc_traffic.log 2>&1
+python tools/summarize_pmc.py $O/pmc_f $O/pmc_w $O/pmc_traffic_bf16x3.json 64 conv_mfma_kernel,convT_mfma_kernel "the MFMA convolution launches of ONE {clips}-clip UNet eval forward (bf16x3)" ', 1(, (false|true)(, [0-9]+)?)?>$' > $O/pmc_traffic.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/pmc_s1 -o p --output-format csv -- python3 bench.py --clips 64 --steps 1 --warmup 0 --cpu-seconds 0 --no-configs > $O/pmc_s1.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU -d $O/pmc_s2 -o p --output-format csv -- python3 bench.py --clips 64 --steps 1 --warmup 0 --cpu-seconds 0 --no-configs > $O/pmc_s2.log 2>&1
 python tools/summarize_sq.py $O/pmc_s1 conv_mfma_kernel,convT_mfma_kernel $O/pmc_sq1.json > $O/pmc_sq1.txt 2>&1
