@@ -43,6 +43,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef MFPA_CONV_WN64
 #define MFPA_CONV_WN64 1
 #endif
+#ifndef MFPA_CONV_STATIC_TAPS
+#define MFPA_CONV_STATIC_TAPS 1     // 3x3 plain loop with compile-time taps (0: one runtime (chunk, tap) iteration, round 1's form)
+#endif
 #ifndef MFPA_CONV_MT4
 #define MFPA_CONV_MT4 0             // 1: the 256 x 128 tile on FOUR waves of 128 px x 64 ch (8 x 32 patches); 2: also the 16 x 16 patches of the bottleneck
                                     // (measured per layer: 3-17 % SLOWER than the 8-wave shape -- a quarter less LDS traffic does not pay for one wave per SIMD)
@@ -324,6 +327,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     for (int it = 0; it < B_F4; ++it)
       if (B_EXACT || tid + it * THREADS < BN * (KC / 4)) breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + b_off[it]);
   };
+  auto load_b_at = [&](int chunk, int tap, auto SET) __attribute__((always_inline)) {     // load_b with (chunk, tap) given: no division
+    constexpr int set = decltype(SET)::value;
+    const char* wbase = reinterpret_cast<const char*>((PREC == 0) ? a.w + ((size_t)tap * a.Cout + n0) * Cin + chunk * KC
+                                                                 : a.w + (((size_t)tap * nchunks + chunk) * a.Cout + n0) * KC);
+#pragma unroll
+    for (int it = 0; it < B_F4; ++it)
+      if (B_EXACT || tid + it * THREADS < BN * (KC / 4)) breg[set][it] = *reinterpret_cast<const f32x4*>(wbase + b_off[it]);
+  };
   auto load_b_ct = [&](int chunk, int tap, auto SET) __attribute__((always_inline)) {     // PREC 1 image, (chunk, tap) given
     constexpr int set = decltype(SET)::value;
     const char* wbase = reinterpret_cast<const char*>(a.w + (((size_t)tap * nchunks + chunk) * a.Cout + n0) * KC);
@@ -360,8 +371,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) b_base[nt] = (wn * (NT * 32) + nt * 32 + li) * LDK + 4 * lh;
 
-  auto compute = [&](int tap, const float* Bs) __attribute__((always_inline)) {
-    const int tap_off = (MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0;
+  auto compute = [&](int tap_off, const float* Bs) __attribute__((always_inline)) {       // tap_off: LDS offset (floats) of the tap's shifted A fragments
     if (PREC == 1) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -426,12 +436,46 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     }
     if (!A_PER_TAP && tap == 0 && it + TAPS < nit) load_a(it / TAPS + 1, 0);   // next chunk's halo, a whole chunk ahead
     if (A_PER_TAP && it + 1 < nit) load_a((it + 1) / TAPS, (it + 1) % TAPS);
-    if (!MFPA_EXP_FLAG(a.dbg, 8)) compute(tap, Bs0 + (it & 1) * (BN * LDK));
+    if (!MFPA_EXP_FLAG(a.dbg, 8)) compute((MODE == 0) ? ((tap / 3) * HPW + (tap % 3)) * LDK : 0, Bs0 + (it & 1) * (BN * LDK));
     if ((chunk_end || A_PER_TAP) && it + 1 < nit) {
       if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();            // every wave is done reading As
       store_a((it + 1) / TAPS, As);
     }
     if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();
+  };
+
+  // The same iteration with the tap (and the parity of `it`, i.e. the weight register set and LDS stage) as compile-time constants:
+  // the 3x3 convolution's plain loop then runs a chunk as nine straight-line taps -- no it / 9 and it % 9, no runtime tap offset
+  // added to every fragment address (PMC on the 64-channel layers: 3.8 scalar and 4.8 vector instructions per MFMA with the
+  // runtime form, their K is only 18 .. 36 iterations long)
+  auto step_s = [&](auto TAP_, auto PAR_, int chunk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(TAP_)::value, par = decltype(PAR_)::value;
+    constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * LDK;
+    const bool more = chunk + 1 < nchunks;                               // a chunk follows this one
+    if (!MFPA_EXP_FLAG(a.dbg, 1)) {
+      if (tap + 1 < TAPS || more) store_b(std::integral_constant<int, par>{}, Bs0 + (par ^ 1) * (BN * LDK));
+      if (tap + 2 < TAPS) load_b_at(chunk, tap + 2, std::integral_constant<int, 1 - par>{});
+      else if (more) load_b_at(chunk + 1, tap + 2 - TAPS, std::integral_constant<int, 1 - par>{});
+    }
+    if (tap == 0 && more) load_a(chunk + 1, 0);
+    if (!MFPA_EXP_FLAG(a.dbg, 8)) compute(tap_off, Bs0 + par * (BN * LDK));
+    if (tap == TAPS - 1 && more) {
+      if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();
+      store_a(chunk + 1, As);
+    }
+    if (!MFPA_EXP_FLAG(a.dbg, 2)) __syncthreads();
+  };
+  auto chunk_s = [&](auto PAR0_, int chunk) __attribute__((always_inline)) {      // nine taps; PAR0 = parity of the chunk's first iteration
+    constexpr int p0 = decltype(PAR0_)::value;
+    step_s(std::integral_constant<int, 0>{}, std::integral_constant<int, p0>{}, chunk);
+    step_s(std::integral_constant<int, 1>{}, std::integral_constant<int, p0 ^ 1>{}, chunk);
+    step_s(std::integral_constant<int, 2>{}, std::integral_constant<int, p0>{}, chunk);
+    step_s(std::integral_constant<int, 3>{}, std::integral_constant<int, p0 ^ 1>{}, chunk);
+    step_s(std::integral_constant<int, 4>{}, std::integral_constant<int, p0>{}, chunk);
+    step_s(std::integral_constant<int, 5>{}, std::integral_constant<int, p0 ^ 1>{}, chunk);
+    step_s(std::integral_constant<int, 6>{}, std::integral_constant<int, p0>{}, chunk);
+    step_s(std::integral_constant<int, 7>{}, std::integral_constant<int, p0 ^ 1>{}, chunk);
+    step_s(std::integral_constant<int, 8>{}, std::integral_constant<int, p0>{}, chunk);
   };
 
   // ---- PIPE: the software-pipelined main loop of the bf16x3 3x3 convolution -------------------------------------------------
@@ -578,9 +622,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     store_b(Set0{}, Bs0);
     if (nit > 1) load_b(1, Set0{});
     __syncthreads();
-    for (int it = 0; it < nit; it += 2) {
-      step(it, Set0{});
-      if (it + 1 < nit) step(it + 1, Set1{});
+    if constexpr (MODE == 0 && MFPA_CONV_STATIC_TAPS != 0) {
+      // nine is odd: the parity of a chunk's first iteration alternates from chunk to chunk
+      int chunk = 0;
+      for (; chunk + 1 < nchunks; chunk += 2) {
+        chunk_s(Set0{}, chunk);
+        chunk_s(Set1{}, chunk + 1);
+      }
+      if (chunk < nchunks) chunk_s(Set0{}, chunk);
+    } else {
+      for (int it = 0; it < nit; it += 2) {
+        step(it, Set0{});
+        if (it + 1 < nit) step(it + 1, Set1{});
+      }
     }
   }
 
