@@ -52,3 +52,21 @@ def test_unet_flop_count_matches_the_survey_figure():
     assert abs(unet_mfma_gflop(257, 251) - UNET_MFMA_GFLOP_PER_CLIP) < 1e-3
     assert abs(unet_mfma_gflop(257, 94) - (34.177 - 0.027 - 0.003)) < 5e-3       # the reference's 3 s training length
     assert unet_mfma_gflop(257, 249) < unet_mfma_gflop(257, 251)
+
+
+def test_presplit_weight_image_layout_and_accuracy():
+    """ops_demucs.split_rows (the weight operand of mfpa_gemm_mfma precision 2): every 32-element chunk of a row becomes
+    [32 bf16 hi | 32 bf16 lo] in the same float32 container, hi = bf16(w), lo = bf16(w - hi), and hi + lo reproduces w to 2^-16."""
+    from musicfpaugment_amd import ops_demucs as D
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(128, 96, generator=g)
+    S = D.split_rows(W)
+    assert S.shape == W.shape and S.dtype == torch.float32
+    halves = S.view(torch.bfloat16).reshape(128, 3, 2, 32)                    # (row, chunk, hi | lo, 32)
+    hi, lo = halves[:, :, 0].float(), halves[:, :, 1].float()
+    w3 = W.reshape(128, 3, 32)
+    assert torch.equal(hi, w3.to(torch.bfloat16).float())
+    assert torch.equal(lo, (w3 - hi).to(torch.bfloat16).float())
+    assert float(((hi + lo) - w3).abs().max()) <= 2.0 ** -16 * float(w3.abs().max())
+    # CPU tensors and shapes the pre-split kernel does not take get no copy attached
+    assert not hasattr(D.attach_split(W), "_mfpa_split")
