@@ -140,7 +140,7 @@ def _lstm_reference(x, skip, wih, bias, whh):
     return inp + skip.double()
 
 
-@pytest.mark.parametrize("B,Tn,H,train", [(70, 9, 256, False), (256, 7, 768, False), (33, 6, 768, True), (130, 20, 512, False)])
+@pytest.mark.parametrize("B,Tn,H,train", [(70, 9, 256, False), (256, 7, 768, False), (33, 6, 768, True), (130, 20, 512, False), (65, 5, 1024, True)])
 def test_persistent_lstm_layer(B, Tn, H, train):
     """mfpa_lstm_layer_seq (one persistent launch per layer: W_hh in registers, h exchanged in split form, slab barriers in
     device memory) against the float64 recurrence and against the per-step kernels; ragged slabs, both chunked (two streams) and
