@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Timing of the weight-gradient kernel per layer shape, fp32 MFMA vs bf16x3: python tools/exp_wgrad.py"""
+"""Timing of the weight-gradient kernel per layer shape, fp32 MFMA vs bf16x3 vs bf16: python tools/exp_wgrad.py [--lib PATH]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":
+    from musicfpaugment_amd import _lib
+    _lib.set_library_path(sys.argv[2])
 from musicfpaugment_amd import ops_train as T
 layers = [("inc.3 64->64 @257x251", 64, 257, 251, 64, 64), ("d1.3 128->128 @128x125", 64, 128, 125, 128, 128),
           ("d2.3 256->256 @64x62", 64, 64, 62, 256, 256), ("d3.3 512->512 @32x31", 64, 32, 31, 512, 512),
