@@ -500,7 +500,9 @@ int mfpa_lstm_layer_bwd_range(const float* whhT, float* gates, const float* cseq
  * (model.py:91-110, torch.nn.LSTM's recurrence); `work` = device scratch of the size mfpa_lstm_seq_work_bytes reports, owned by this
  * layer while the call runs, zeroed once before its first use.  Every wait in the kernel is bounded: if one ever gives up the
  * kernel raises the 32-bit word at byte mfpa_lstm_seq_error_offset() of `work` (and finishes with undefined results); callers
- * read that word at their next synchronisation point.  Shapes outside the persistent kernel's range (H / 128 not in {2,4,6,8},
+ * read that word at their next synchronisation point.  The grid must be co-resident: the call checks its own workgroups against the
+ * CU count, but it cannot see other work -- a second process (or another persistent launch) occupying the same GPU at that moment
+ * is exactly the case the bounded waits and the error word exist for; one process per GPU is the intended deployment.  Shapes outside the persistent kernel's range (H / 128 not in {2,4,6,8},
  * ceil(B / 64) * H / 16 workgroups > CUs) take the per-step path inside the same call. */
 int mfpa_lstm_seq_work_bytes(int B, int H, long long* bytes);   /* HOST function: *bytes = size of `work` */
 int mfpa_lstm_seq_error_offset(void);
