@@ -509,6 +509,19 @@ int mfpa_lstm_seq_error_offset(void);
 int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
                         const float* skip, int train, int t0, int t1, void* work, void* stream);
 
+/* mfpa_lstm_layer_bwd_range as ONE persistent launch (lstm_bwd_seq_kernel, csrc/demucs_train.hip): the backward recurrence of a layer for
+ * steps t1-1 .. t0 (torch.nn.LSTM's backward through time, training/train.py:275-312 via autograd in the reference).  A workgroup keeps
+ * the W_hh^T rows of its 16 hidden units in registers (16 x 16 x 32 MFMAs, K = 4H), the workgroups of a 64-clip slab exchange dgates[t]
+ * through `work` (already split into bf16 hi / lo) and meet at a device-memory counter after every step.  Same arguments and results as
+ * mfpa_lstm_layer_bwd_range; `work`, the bounded waits and the error word as for mfpa_lstm_layer_seq (size: mfpa_lstm_bwd_seq_work_bytes,
+ * error word at byte mfpa_lstm_seq_error_offset()).  A workgroup reads its slab's whole dgates[t+1] (K = 4H) every step, so the slab is
+ * the smallest of 16 / 32 / 64 clips whose workgroups (slabs x H / 16) fit `wg_budget` (0 = one per CU; a caller that runs two such launches
+ * concurrently, like the chunked two-stream pipeline, passes half the CU count: every workgroup of a launch must be resident at once).
+ * H / 64 outside {4, 8, 12} or too many workgroups even with 64-clip slabs: the per-step path. */
+int mfpa_lstm_bwd_seq_work_bytes(int B, int H, long long* bytes);   /* HOST function */
+int mfpa_lstm_layer_bwd_seq(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
+                            int t0, int t1, int wg_budget, void* work, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Waveform-domain spectral losses of the Demucs branch, training/loss.py:10-186 (MultiResolutionSTFTLoss; forward).
  * The STFT of a resolution is mfpa_reflect_pad + mfpa_gemm_mfma (precision 0) with a windowed DFT matrix

@@ -643,6 +643,246 @@ __global__ __launch_bounds__(BTHREADS, 1) void lstm_step_bwd_kernel(const float*
   }
 }
 
+
+// ---------------------------------------------------------------------------------- persistent LSTM backward layer
+// The backward recurrence of a layer for steps t1-1 .. t0 in ONE launch: lstm_seq_kernel's scheme (demucs.hip) turned round.
+//   dh[t] = dhout[t] + dgates[t+1] W_hh  is K = 4H long and 16 hidden units wide per workgroup, so the weights only fit the
+//   registers with the 16 x 16 x 32 MFMA: wave w of 8 holds the B-fragments of W_hh^T rows u0 .. u0+15, K range [w 4H/8, ..):
+//   KS = H / 64 k-steps x (hi, lo) x 4 VGPRs (96 at H = 768), read once per launch instead of once per step;
+//   dgates[t+1] (64 clips x 4H, already split [32 hi | 32 lo] by the cells that produced it) is exchanged through a ping-pong
+//   buffer with agent-scope stores / buffer loads, A-fragments read straight from it; the 8 partial 64 x 16 tiles meet in LDS;
+//   a cell thread owns (clip, 2 units): dc lives in its registers, the saved gate activations / cell states / dhout of step t are
+//   fetched before the wait; it writes dgates[t] over the activations (the weight-gradient GEMMs read them later) and into the
+//   exchange buffer.  Slab counter, bounded waits and the error word as in lstm_seq_kernel.
+constexpr int QB_W = 8;
+constexpr int QB_GLD = 17;
+constexpr unsigned QB_SPIN_LIMIT = 1u << 22;
+constexpr int QB_SYNC_WORDS = 1024, QB_ERR_WORD = 512;
+
+struct LstmBwdSeqArgs {
+  const float* whhT;      // (H, 4H)
+  float* gates;           // (B, Tn, 4H): activations [i | f | g | o] in, pre-activation gradients out
+  const float* cseq;      // (B, Tn, H)
+  const float* dhout;     // (B, Tn, H)
+  float* dcstate;         // (B, H): read when t1 < Tn, written at the end
+  unsigned* sync;
+  char* gsplit;           // [2][B][4H * 4 bytes]
+  int B, Tn, H, t0, t1, nslab, ngroups;
+};
+
+// MTB = 16-clip MFMA row tiles per workgroup (slab = 16 MTB clips).  A workgroup reads its slab's WHOLE dgates[t+1] row block every
+// step (K = 4H: 12 KB per clip), four times the forward's bytes, and a CU pulls ~60 GB/s of such loads: small batches therefore use
+// small slabs, so that more CUs share the reading (64 clips: 192 workgroups of 16 clips instead of 48 of 64).
+template <int KS, int MTB>          // k-steps of 32 per wave: 4H = 256 KS
+__global__ __launch_bounds__(64 * QB_W, 1) void lstm_bwd_seq_kernel(LstmBwdSeqArgs a) {
+  constexpr int SLAB = 16 * MTB;
+  constexpr int UPT = MTB == 4 ? 2 : 1;                     // hidden units per cell thread
+  constexpr int TPC = 16 / UPT;                             // cell threads per clip
+  __shared__ __attribute__((aligned(16))) float G[QB_W * SLAB * QB_GLD];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, kg = lane >> 4;
+  const int H = a.H, K = 4 * a.H;
+  int slab, grp;
+  {
+    const int id = blockIdx.x, total = a.nslab * a.ngroups;
+    const int per_xcd = (total + 7) / 8;
+    const int lin = (id % 8) * per_xcd + id / 8;
+    if (lin >= total) return;                               // padding workgroups are not counted at the barrier
+    slab = lin / a.ngroups; grp = lin % a.ngroups;
+  }
+  const int m0 = slab * SLAB, u0 = grp * 16;
+  unsigned* cnt = a.sync + 16 * slab;
+  unsigned* err = a.sync + QB_ERR_WORD;
+  const unsigned members = (unsigned)a.ngroups;
+  const size_t rowb = (size_t)K * 4, bufb = (size_t)a.B * rowb;
+
+  // ---- W_hh^T fragments of this workgroup's 16 units, split once
+  t_bf16x8 wh[KS], wl[KS];
+  {
+    const float* Wr = a.whhT + (size_t)(u0 + ln) * K + (size_t)wave * KS * 32 + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(Wr + 32 * s), v1 = *reinterpret_cast<const f32x4*>(Wr + 32 * s + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const __bf16 h0 = (__bf16)v0[k], h1 = (__bf16)v1[k];
+        wh[s][k] = h0; wh[s][4 + k] = h1;
+        wl[s][k] = (__bf16)(v0[k] - (float)h0); wl[s][4 + k] = (__bf16)(v1[k] - (float)h1);
+      }
+    }
+  }
+  // ---- cell threads: clip tid / TPC, hidden units u .. u + UPT - 1
+  const int clip = tid / TPC, ui = tid % TPC;
+  const int m = m0 + clip;
+  const bool live = clip < SLAB && m < a.B;
+  const int u = u0 + UPT * ui;
+  const size_t ldg = (size_t)a.Tn * K, ldh = (size_t)a.Tn * H;
+  auto put_split = [&](char* buf, int q, const float (&v)[UPT]) __attribute__((always_inline)) {   // gate q of this thread's units -> the exchange rows
+    const int col = q * H + u;
+    char* p = buf + (size_t)(live ? m : 0) * rowb + (size_t)(col >> 5) * 128 + (size_t)(col & 31) * 2;
+    if (UPT == 2) {
+      const __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[UPT - 1];
+      const __bf16 l0 = (__bf16)(v[0] - (float)h0), l1 = (__bf16)(v[UPT - 1] - (float)h1);
+      const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+      const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+      __hip_atomic_store(reinterpret_cast<unsigned*>(p), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned*>(p + 64), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const __bf16 h0 = (__bf16)v[0];
+      const __bf16 l0 = (__bf16)(v[0] - (float)h0);
+      __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned short*>(p + 64), __builtin_bit_cast(unsigned short, l0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  float dc[UPT];
+#pragma unroll
+  for (int k = 0; k < UPT; ++k) dc[k] = 0.f;
+  if (live) {
+    char* buf = a.gsplit + (size_t)(a.t1 & 1) * bufb;                // dgates[t] live in buffer t & 1
+    if (a.t1 < a.Tn) {                                               // a later range has run: its dgates[t1] and dc
+      const float* gr = a.gates + (size_t)m * ldg + (size_t)a.t1 * K + u;
+#pragma unroll
+      for (int k = 0; k < UPT; ++k) dc[k] = a.dcstate[(size_t)m * H + u + k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[UPT];
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) v[k] = gr[q * H + k];
+        put_split(buf, q, v);
+      }
+    } else {
+      float z[UPT];
+#pragma unroll
+      for (int k = 0; k < UPT; ++k) z[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) put_split(buf, q, z);
+    }
+  }
+  bool dead = false;
+  auto arrive = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto wait = [&](unsigned round) __attribute__((always_inline)) {
+    if (tid == 0 && !dead) {
+      const unsigned target = round * members;
+      unsigned n = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if ((++n & 63u) == 0u && (n > QB_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  };
+  arrive();
+
+  unsigned arow[MTB];
+#pragma unroll
+  for (int mt = 0; mt < MTB; ++mt) {
+    int r = m0 + mt * 16 + ln;
+    r = r < a.B ? r : a.B - 1;
+    arow[mt] = (unsigned)((size_t)r * rowb + (size_t)wave * KS * 128 + 16 * kg);          // k-step s = chunk wave KS + s of the row
+  }
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(a.gsplit, 0, (int)(2 * bufb), 0x00020000);
+  constexpr int PF = (MTB == 4) ? 2 : (KS < 4 ? KS : 4);    // k-steps of A loads in flight (8 MTB VGPRs each)
+  for (int t = a.t1 - 1; t >= a.t0; --t) {
+    // what the cell needs of step t does not depend on the recurrence: fetch it before the wait
+    float gv[4][UPT], ct[UPT], cp[UPT], dho[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) { gv[0][k] = gv[1][k] = gv[2][k] = gv[3][k] = 0.f; ct[k] = cp[k] = dho[k] = 0.f; }
+    if (live) {
+      const float* gr = a.gates + (size_t)m * ldg + (size_t)t * K + u;
+      const size_t o = (size_t)m * ldh + (size_t)t * H + u;
+#pragma unroll
+      for (int k = 0; k < UPT; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q][k] = gr[q * H + k];
+        ct[k] = a.cseq[o + k];
+        if (t > 0) cp[k] = a.cseq[o + k - H];
+        dho[k] = a.dhout[o + k];
+      }
+    }
+    wait((unsigned)(a.t1 - t));
+    const unsigned pb = (unsigned)(((t + 1) & 1) * bufb);
+    f32x4 acc[MTB];
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    t_bf16x8 fa[PF][MTB][2];
+    auto issue = [&](int s, t_bf16x8 (&f)[MTB][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < MTB; ++mt) {
+        const unsigned o = pb + arow[mt] + (unsigned)s * 128u;
+        f[mt][0] = __builtin_bit_cast(t_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(grsrc, o, 0, 16));
+        f[mt][1] = __builtin_bit_cast(t_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(grsrc, o + 64, 0, 16));
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) issue(s, fa[s]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < MTB; ++mt) {
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s % PF][mt][1], wh[s], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s % PF][mt][0], wl[s], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s % PF][mt][0], wh[s], acc[mt], 0, 0, 0);
+      }
+      if (s + PF < KS) issue(s + PF, fa[s % PF]);
+    }
+    // partial tiles -> LDS: D[row = 4 kg + j][col = ln] of m-tile mt
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) G[(wave * SLAB + mt * 16 + 4 * kg + j) * QB_GLD + ln] = acc[mt][j];
+    __syncthreads();
+    if (live) {
+      float dg_[4][UPT];
+#pragma unroll
+      for (int k = 0; k < UPT; ++k) {
+        float dh = dho[k];
+#pragma unroll
+        for (int w = 0; w < QB_W; ++w) dh += G[(w * SLAB + clip) * QB_GLD + UPT * ui + k];
+        const float vi = gv[0][k], vf = gv[1][k], vg = gv[2][k], vo = gv[3][k];
+        const float tc = tanhf(ct[k]);
+        dg_[3][k] = dh * tc * vo * (1.f - vo);
+        const float dcv = dc[k] + dh * vo * (1.f - tc * tc);
+        dg_[0][k] = dcv * vg * vi * (1.f - vi);
+        dg_[1][k] = dcv * cp[k] * vf * (1.f - vf);
+        dg_[2][k] = dcv * vi * (1.f - vg * vg);
+        dc[k] = dcv * vf;
+      }
+      char* buf = a.gsplit + (size_t)(t & 1) * bufb;
+      float* gr = a.gates + (size_t)m * ldg + (size_t)t * K + u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        put_split(buf, q, dg_[q]);
+#pragma unroll
+        for (int k = 0; k < UPT; ++k) gr[q * H + k] = dg_[q][k];
+      }
+    }
+    if (t > a.t0) arrive();                                  // (its __syncthreads also frees the partial-tile slabs)
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) a.dcstate[(size_t)m * H + u + k] = dc[k];
+  }
+}
+
+static int lstm_bwd_seq_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  return cus;
+}
+
 }  // namespace
 
 extern "C" {
@@ -787,6 +1027,58 @@ int mfpa_lstm_layer_bwd_range(const float* whhT, float* gates, const float* cseq
 int mfpa_lstm_layer_bwd(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
                         void* stream) {
   return mfpa_lstm_layer_bwd_range(whhT, gates, cseq, dhout, dcstate, B, Tn, H, 0, Tn, stream);
+}
+
+/* mfpa_lstm_layer_bwd_range as ONE persistent launch (lstm_bwd_seq_kernel): same arguments and results; `work` = device scratch of the
+ * size mfpa_lstm_bwd_seq_work_bytes reports, owned by this layer while the call runs, zeroed once before its first use; the error
+ * word (bounded waits, as for mfpa_lstm_layer_seq) sits at the same byte offset.  Shapes outside the persistent kernel's range
+ * (H / 64 not in {4, 8, 12}, more workgroups than `wg_budget` even with 64-clip slabs) take the per-step path inside the same call.
+ * wg_budget: how many workgroups this launch may keep resident (0 = one per CU); a caller running two such launches at once passes half. */
+int mfpa_lstm_bwd_seq_work_bytes(int B, int H, long long* bytes) {
+  if (!bytes || B < 0 || H < 0) return MFPA_EINVAL;
+  *bytes = (long long)QB_SYNC_WORDS * 4 + 2LL * B * 4 * H * 4;
+  return MFPA_OK;
+}
+
+int mfpa_lstm_layer_bwd_seq(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
+                            int t0, int t1, int wg_budget, void* work, void* stream) {
+  if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
+  if (!whhT || !gates || !cseq || !dhout || !dcstate || !work || B < 0 || Tn < 0 || t0 < 0 || t1 > Tn || H < 64) return MFPA_EINVAL;
+  const int ks = (H % 64 == 0) ? H / 64 : 0, ngroups = H / 16;
+  static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_BWD_SEQ", 1);
+  static const int force_mtb = MFPA_EXP_ENV("MFPA_LSTM_BWD_MTB", 0);
+  // the smallest slab (16, 32 or 64 clips) whose workgroups still fit the chip: more CUs share the reading of dgates[t+1]
+  // (every workgroup of a launch must be resident at once; a caller that runs two such launches side by side -- the chunked
+  // two-stream pipeline -- passes half the CUs as wg_budget, 0 = all of them)
+  const int budget = (wg_budget > 0 && wg_budget < lstm_bwd_seq_cus()) ? wg_budget : lstm_bwd_seq_cus();
+  int mtb = 0;
+  for (int c = 1; c <= 4 && !mtb; c *= 2)
+    if ((long long)((B + 16 * c - 1) / (16 * c)) * ngroups <= budget) mtb = c;
+  if (force_mtb == 1 || force_mtb == 2 || force_mtb == 4) mtb = force_mtb;
+  const int nslab = mtb ? (B + 16 * mtb - 1) / (16 * mtb) : 0;
+  if (!persistent || !mtb || !(ks == 4 || ks == 8 || ks == 12) || nslab > 32 || (long long)B * H * 32 > 0x7fffffffLL ||
+      (long long)nslab * ngroups > budget)
+    return mfpa_lstm_layer_bwd_range(whhT, gates, cseq, dhout, dcstate, B, Tn, H, t0, t1, stream);
+  LstmBwdSeqArgs a;
+  a.whhT = whhT; a.gates = gates; a.cseq = cseq; a.dhout = dhout; a.dcstate = dcstate;
+  a.sync = reinterpret_cast<unsigned*>(work);
+  a.gsplit = reinterpret_cast<char*>(work) + (size_t)QB_SYNC_WORDS * 4;
+  a.B = B; a.Tn = Tn; a.H = H; a.t0 = t0; a.t1 = t1; a.nslab = nslab; a.ngroups = ngroups;
+  hipStream_t st = mfpa_stream(stream);
+  MFPA_HIP(hipMemsetAsync(work, 0, (size_t)QB_ERR_WORD * 4, st));           // the slab counters; the error word stays
+  const unsigned grid = (unsigned)(((nslab * ngroups + 7) / 8) * 8);
+#define QB_LAUNCH(KS_)                                                                                         \
+  if (mtb == 1) hipLaunchKernelGGL((lstm_bwd_seq_kernel<KS_, 1>), dim3(grid), dim3(64 * QB_W), 0, st, a);      \
+  else if (mtb == 2) hipLaunchKernelGGL((lstm_bwd_seq_kernel<KS_, 2>), dim3(grid), dim3(64 * QB_W), 0, st, a); \
+  else hipLaunchKernelGGL((lstm_bwd_seq_kernel<KS_, 4>), dim3(grid), dim3(64 * QB_W), 0, st, a)
+  switch (ks) {
+    case 4: QB_LAUNCH(4); break;
+    case 8: QB_LAUNCH(8); break;
+    default: QB_LAUNCH(12); break;
+  }
+#undef QB_LAUNCH
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
 }
 
 }  // extern "C"

@@ -174,28 +174,33 @@ def _side_stream(dev) -> "torch.cuda.Stream":
 
 
 PERSISTENT_LSTM = True    # False: one launch per time step (mfpa_lstm_layer_range)
+PERSISTENT_LSTM_BWD = True   # training: the backward recurrence as one launch per range too (mfpa_lstm_layer_bwd_seq)
+PIPELINE_LSTM_BWD = False    # training: the two layers' backward recurrences as a chunk pipeline on two streams, like the forward (measured at 64 clips,
+                             # ms per step, three runs each: persistent + one layer after the other 41.1 / 41.7 / 42.8; per-step launches + pipeline
+                             # 42.3 / 42.6 / 42.7; persistent + pipeline 43.2 / 43.5 / 45.6; per-step, no pipeline 44.1 / 44.3 / 45.4)
 _LSTM_WORK: Dict[tuple, list] = {}
 
 
-def _lstm_work(dev, layer: int, B: int, H: int) -> torch.Tensor:
+def _lstm_work(dev, layer: int, B: int, H: int, backward: bool = False) -> torch.Tensor:
     """Scratch of the persistent LSTM kernel for one layer (mfpa_lstm_layer_seq): the exchange buffers of h and the slab counters.
     Kept per (device, stream, layer, shape); whenever it is handed out again the error word of its PREVIOUS use is looked at through
     a pinned host copy made then (no synchronisation on the way): a wait that gave up inside the kernel surfaces here as MfpaError."""
     from ._lib import MfpaError
     L = lib()
+    size_fn = L.mfpa_lstm_bwd_seq_work_bytes if backward else L.mfpa_lstm_seq_work_bytes      # the backward form exchanges 4H columns
     if torch.cuda.is_current_stream_capturing():
         # inside a HIP graph capture: scratch from the graph's own pool, zeroed by a captured fill on every replay; no host-side
         # look at the error word (nothing may synchronise or query here) -- a replayed graph reports through its results only
         nbytes = ctypes.c_longlong(0)
-        check(L.mfpa_lstm_seq_work_bytes(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
+        check(size_fn(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
         return torch.zeros(nbytes.value // 4, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream(dev)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream, layer, B, H)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream, layer, B, H, backward)
     ent = _LSTM_WORK.get(key)
     off = L.mfpa_lstm_seq_error_offset() // 4
     if ent is None:
         nbytes = ctypes.c_longlong(0)
-        check(L.mfpa_lstm_seq_work_bytes(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
+        check(size_fn(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
         buf = torch.zeros(nbytes.value // 4, dtype=torch.int32, device=dev)
         ent = _LSTM_WORK[key] = [buf, torch.zeros(1, dtype=torch.int32).pin_memory(), None]
     buf, host, ev = ent

@@ -445,7 +445,16 @@ class DemucsTrainEngine:
         t0 = _K._TIMER.start() if _K._TIMER is not None else None
         timer, _K._TIMER = _K._TIMER, None
 
+        pipelined = D.PIPELINE_LSTM and D.PIPELINE_LSTM_BWD and Tn > D.LSTM_CHUNK and B <= D.PIPELINE_MAX_CLIPS
+        # two persistent launches run side by side in the chunked pipeline: each may keep half the CUs' worth of workgroups resident
+        wg_budget = torch.cuda.get_device_properties(dev).multi_processor_count // 2 if pipelined else 0
+        bwork = {id(g1): D._lstm_work(dev, 1, B, H, backward=True), id(g0): D._lstm_work(dev, 0, B, H, backward=True)} if D.PERSISTENT_LSTM_BWD else None
+
         def bwd(whhT, gates, cseq, dhout, dc, a, b):
+            if bwork is not None:            # one persistent launch for the range (csrc/demucs_train.hip: lstm_bwd_seq_kernel)
+                check(L.mfpa_lstm_layer_bwd_seq(ptr(whhT), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, a, b, wg_budget,
+                                                ptr(bwork[id(gates)]), stream()), "mfpa_lstm_layer_bwd_seq")
+                return
             check(L.mfpa_lstm_layer_bwd_range(ptr(whhT), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, a, b, stream()),
                   "mfpa_lstm_layer_bwd_range")
 
@@ -453,7 +462,7 @@ class DemucsTrainEngine:
             D.gemm(_p(g1, a * 4 * H), 4 * H, Tn * 4 * H, B, b - a, W["lstm1.wihT"], None, H, _p(dx1, a * H), H, Tn * H, precision=prec)
 
         try:
-            if not D.PIPELINE_LSTM or Tn <= D.LSTM_CHUNK or B > D.PIPELINE_MAX_CLIPS:
+            if not pipelined:
                 bwd(W["lstm1.whhT"], g1, cseq1, dxsum, dc1, 0, Tn)
                 dx_chunk(0, Tn)
                 bwd(W["lstm0.whhT"], g0, cseq0, dx1, dc0, 0, Tn)

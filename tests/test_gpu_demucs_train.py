@@ -388,3 +388,63 @@ def test_trainer_audio_branch():
         assert tr2.load_checkpoint()
         assert torch.equal(tr2.engine.flat_p, tr.engine.flat_p) and torch.equal(tr2.engine.flat_m, tr.engine.flat_m)
         assert tr2.engine.step_count == tr.engine.step_count
+
+
+@pytest.mark.parametrize("B,Tn,H", [(70, 9, 256), (64, 12, 768), (33, 7, 512), (130, 6, 768)])
+def test_persistent_lstm_backward_layer(B, Tn, H):
+    """mfpa_lstm_layer_bwd_seq (one persistent launch: W_hh^T rows in registers on 16 x 16 x 32 MFMAs, dgates exchanged in split form,
+    slab barriers in device memory) against the per-step kernels on the same saved state, whole range and two chained ranges
+    (the chunked pipeline's use), ragged slabs; and against the float64 recurrence of the same backward."""
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    from musicfpaugment_amd import ops_demucs as D
+    L = lib()
+    g = torch.Generator().manual_seed(B * Tn)
+    gates0 = torch.cat([torch.rand(B, Tn, H, generator=g), torch.rand(B, Tn, H, generator=g), torch.rand(B, Tn, H, generator=g) * 2 - 1,
+                        torch.rand(B, Tn, H, generator=g)], dim=2).contiguous()                 # [sig i | sig f | tanh g | sig o]
+    cseq = (torch.randn(B, Tn, H, generator=g) * 0.7).contiguous()
+    dhout = (torch.randn(B, Tn, H, generator=g) * 0.1).contiguous()
+    whh = torch.randn(4 * H, H, generator=g) / np.sqrt(H)
+    whhT = whh.t().contiguous()                                                                # (H, 4H)
+    # float64 recurrence
+    W = whh.double()
+    dgn = torch.zeros(B, 4 * H, dtype=torch.float64)
+    dc = torch.zeros(B, H, dtype=torch.float64)
+    want = torch.zeros(B, Tn, 4 * H, dtype=torch.float64)
+    for t in range(Tn - 1, -1, -1):
+        vi, vf, vg, vo = [x.double() for x in gates0[:, t].split(H, dim=1)]
+        ct = cseq[:, t].double()
+        cp = cseq[:, t - 1].double() if t else torch.zeros_like(ct)
+        dh = dhout[:, t].double() + dgn @ W
+        tc = torch.tanh(ct)
+        dO = dh * tc * vo * (1 - vo)
+        dcv = dc + dh * vo * (1 - tc * tc)
+        di = dcv * vg * vi * (1 - vi)
+        df = dcv * cp * vf * (1 - vf)
+        dg = dcv * vi * (1 - vg * vg)
+        dc = dcv * vf
+        dgn = torch.cat([di, df, dg, dO], dim=1)
+        want[:, t] = dgn
+    dev = lambda t: t.clone().cuda()
+    whhT_d, cseq_d, dhout_d = dev(whhT), dev(cseq), dev(dhout)
+    outs = {}
+    nbytes = __import__("ctypes").c_longlong(0)
+    check(L.mfpa_lstm_bwd_seq_work_bytes(B, H, __import__("ctypes").addressof(nbytes)), "bytes")
+    for name, ranges, seq, budget in [("steps", [(0, Tn)], False, 0), ("seq", [(0, Tn)], True, 0), ("seq-two-ranges", [(Tn // 2, Tn), (0, Tn // 2)], True, 0),
+                                      ("seq-half-the-chip", [(0, Tn)], True, 128), ("seq-64-clip-slabs", [(0, Tn)], True, 48 * ((B + 63) // 64))]:
+        gd, dcs = dev(gates0), torch.full((B, H), float("nan"), device="cuda")
+        work = torch.zeros(nbytes.value // 4, dtype=torch.int32, device="cuda")
+        for (a, b) in ranges:
+            if seq:
+                check(L.mfpa_lstm_layer_bwd_seq(ptr(whhT_d), ptr(gd), ptr(cseq_d), ptr(dhout_d), ptr(dcs), B, Tn, H, a, b, budget, ptr(work), stream()), "seq")
+            else:
+                check(L.mfpa_lstm_layer_bwd_range(ptr(whhT_d), ptr(gd), ptr(cseq_d), ptr(dhout_d), ptr(dcs), B, Tn, H, a, b, stream()), "range")
+        torch.cuda.synchronize()
+        assert int(work[L.mfpa_lstm_seq_error_offset() // 4]) == 0
+        outs[name] = (gd.cpu(), dcs.cpu())
+    scale = float(want.abs().max())
+    for name, (gd, dcs) in outs.items():
+        err = float((gd.double() - want).abs().max())
+        assert err < 2e-4 * scale, (name, err, scale)
+        assert float((dcs.double() - dc).abs().max()) < 2e-4 * max(1.0, float(dc.abs().max())), name
+    for name in ("seq", "seq-two-ranges", "seq-half-the-chip", "seq-64-clip-slabs"):
+        assert float((outs[name][0] - outs["steps"][0]).abs().max()) < 1e-4 * scale
