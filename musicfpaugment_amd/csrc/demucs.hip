@@ -1471,10 +1471,23 @@ struct LstmSeqArgs {
 
 // COH 0: the waiting thread invalidates L1 / L2 once per step and h is read with ordinary (cached) loads; 1: no invalidate, h is read
 // with agent-scope (sc1) buffer loads that do not trust the local caches.
-template <int KS, int COH>          // k-steps of 16 per wave: H = 128 KS
+// MS = 32-clip MFMA row tiles per workgroup (slab = 32 MS clips): 2 for large batches; 1 while that still leaves half the chip free --
+// twice the workgroups, each reading half as much of h per step (the step is bound by what a CU can pull, see the timing experiments).
+template <int N> struct LFV { float v[N]; __device__ __forceinline__ float& operator[](int i) { return v[i]; } __device__ __forceinline__ const float& operator[](int i) const { return v[i]; } };
+template <int N> __device__ __forceinline__ LFV<N> lfv_load(const float* p) { LFV<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = p[i];
+  return r; }
+template <int N> __device__ __forceinline__ void lfv_store(float* p, const LFV<N>& x) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) p[i] = x.v[i]; }
+
+template <int KS, int COH, int MS>          // k-steps of 16 per wave: H = 128 KS
 __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
+  constexpr int SLAB = 32 * MS, UPT = MS, TPC = 16 / UPT;   // clips per workgroup; hidden units per cell thread; cell threads per clip
+  typedef LFV<UPT> fv;
   extern __shared__ __attribute__((aligned(16))) char lsm[];
-  float* G = reinterpret_cast<float*>(lsm);                 // [QW][64][QGLD]
+  float* G = reinterpret_cast<float*>(lsm);                 // [QW][SLAB][QGLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int H = a.H;
@@ -1486,7 +1499,7 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
     if (lin >= total) return;                               // padding workgroups: they are not counted at the barrier
     slab = lin / a.ngroups; grp = lin % a.ngroups;
   }
-  const int m0 = slab * 64;
+  const int m0 = slab * SLAB;
   unsigned* cnt = a.sync + 16 * slab;
   unsigned* err = a.sync + LSTM_ERR_WORD;
   const unsigned members = (unsigned)a.ngroups;
@@ -1511,30 +1524,39 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
         }
       }
   }
-  // ---- cell threads: clip tid / 8, hidden units u0, u0 + 1
-  const int clip = tid >> 3, up = tid & 7;
+  // ---- cell threads: clip tid / TPC, hidden units u0 .. u0 + UPT - 1
+  const int clip = tid / TPC, up = tid % TPC;
   const int m = m0 + clip;
   const bool live = m < a.B;
-  const int u0 = grp * LU + 2 * up;
+  const int u0 = grp * LU + UPT * up;
   const size_t ldh = (size_t)a.Tn * H, ldx = (size_t)a.Tn * 4 * H;
   const size_t split_off = (size_t)(live ? m : 0) * rowb + (size_t)(u0 >> 5) * 128 + (size_t)(u0 & 31) * 2;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 l_bf16x2 __attribute__((ext_vector_type(2)));
-  auto put_split = [&](char* buf, f32x2 h) __attribute__((always_inline)) {
-    l_bf16x2 hi, lo;
-    hi[0] = (__bf16)h[0]; hi[1] = (__bf16)h[1];
-    lo[0] = (__bf16)(h[0] - (float)hi[0]); lo[1] = (__bf16)(h[1] - (float)hi[1]);
+  auto put_split = [&](char* buf, const fv& h) __attribute__((always_inline)) {
     // agent-scope stores (sc1: written through to memory), so the release below needs no L2 write-back
-    __hip_atomic_store(reinterpret_cast<unsigned*>(buf + split_off), __builtin_bit_cast(unsigned, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned*>(buf + split_off + 64), __builtin_bit_cast(unsigned, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (UPT == 2) {
+      const __bf16 h0 = (__bf16)h[0], h1 = (__bf16)h[UPT - 1];
+      const __bf16 l0 = (__bf16)(h[0] - (float)h0), l1 = (__bf16)(h[UPT - 1] - (float)h1);
+      const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+      const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+      __hip_atomic_store(reinterpret_cast<unsigned*>(buf + split_off), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned*>(buf + split_off + 64), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const __bf16 h0 = (__bf16)h[0];
+      const __bf16 l0 = (__bf16)(h[0] - (float)h0);
+      __hip_atomic_store(reinterpret_cast<unsigned short*>(buf + split_off), __builtin_bit_cast(unsigned short, h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned short*>(buf + split_off + 64), __builtin_bit_cast(unsigned short, l0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   };
-  f32x2 c = {0.f, 0.f};
+  fv c;
+#pragma unroll
+  for (int k = 0; k < UPT; ++k) c[k] = 0.f;
   if (live) {
-    f32x2 hp = {0.f, 0.f};
+    fv hp;
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) hp[k] = 0.f;
     if (a.t0 > 0) {
-      hp = *reinterpret_cast<const f32x2*>(a.hseq + (size_t)m * ldh + (size_t)(a.t0 - 1) * H + u0);
-      c = a.train ? *reinterpret_cast<const f32x2*>(a.cseq + (size_t)m * ldh + (size_t)(a.t0 - 1) * H + u0)
-                  : *reinterpret_cast<const f32x2*>(a.cstate + (size_t)m * H + u0);
+      hp = lfv_load<UPT>(a.hseq + (size_t)m * ldh + (size_t)(a.t0 - 1) * H + u0);
+      c = a.train ? lfv_load<UPT>(a.cseq + (size_t)m * ldh + (size_t)(a.t0 - 1) * H + u0) : lfv_load<UPT>(a.cstate + (size_t)m * H + u0);
     }
     put_split(a.hsplit + (size_t)((a.t0 + 1) & 1) * bufb, hp);          // h[t] lives in buffer t & 1
   }
@@ -1567,9 +1589,9 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
   arrive();
 
   // A-fragment rows of this lane (clamped: rows past B compute garbage that is never stored)
-  size_t arow[2];
+  size_t arow[MS];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MS; ++mt) {
     int r = m0 + mt * 32 + li;
     r = r < a.B ? r : a.B - 1;
     arow[mt] = (size_t)r * rowb + (size_t)wave * KS * 64 + 16 * lh;      // k = (wave KS + s) 16 + 8 lh -> chunk k / 32, 2 (k % 32)
@@ -1578,25 +1600,26 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
   const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(a.hsplit, 0, (int)(2 * bufb), 0x00020000);
   for (int t = a.t0; t < a.t1; ++t) {
     // the projections do not depend on h: fetch them before the wait
-    f32x2 xg[4];
-    f32x2 ad = {0.f, 0.f};
+    fv xg[4], ad;
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) { xg[0][k] = xg[1][k] = xg[2][k] = xg[3][k] = 0.f; ad[k] = 0.f; }
     if (live) {
       const float* xr = a.xp + (size_t)m * ldx + (size_t)t * 4 * H + u0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xg[g] = *reinterpret_cast<const f32x2*>(xr + g * H);
-      if (a.xsum) ad = *reinterpret_cast<const f32x2*>(a.skip + (size_t)m * ldh + (size_t)t * H + u0);
+      for (int g = 0; g < 4; ++g) xg[g] = lfv_load<UPT>(xr + g * H);
+      if (a.xsum) ad = lfv_load<UPT>(a.skip + (size_t)m * ldh + (size_t)t * H + u0);
     }
     if (!MFPA_EXP_FLAG(a.dbg, 4)) wait((unsigned)(t - a.t0 + 1));
     const char* hp = a.hsplit + (size_t)((t + 1) & 1) * bufb;
-    floatx16 acc[2][2];
+    floatx16 acc[MS][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * MS; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i >> 1][i & 1][r] = 0.f;
-    l_bf16x8 fa[PF][2][2];
-    auto issue = [&](int s, l_bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+    l_bf16x8 fa[PF][MS][2];
+    auto issue = [&](int s, l_bf16x8 (&f)[MS][2]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MS; ++mt) {
         const size_t off = arow[mt] + (size_t)(s >> 1) * 128 + (size_t)(s & 1) * 32;
         if (MFPA_EXP_FLAG(a.dbg, 2)) {
           f[mt][0] = wh[0][0]; f[mt][1] = wl[0][0];
@@ -1616,7 +1639,7 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MS; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           if (MFPA_EXP_FLAG(a.dbg, 1)) { acc[mt][nt][0] += (float)fa[s % PF][mt][0][0] + (float)fa[s % PF][mt][1][0]; continue; }
@@ -1628,48 +1651,51 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
     }
     // partial gate tiles -> LDS
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MS; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          G[(wave * 64 + row) * QGLD + nt * 32 + li] = acc[mt][nt][r];
+          G[(wave * SLAB + row) * QGLD + nt * 32 + li] = acc[mt][nt][r];
         }
     __syncthreads();
     if (live) {
-      f32x2 gs[4] = {xg[0], xg[1], xg[2], xg[3]};
+      fv gs[4] = {xg[0], xg[1], xg[2], xg[3]};
 #pragma unroll
       for (int w = 0; w < QW; ++w) {
-        const float* g = G + (w * 64 + clip) * QGLD + 2 * up;
+        const float* g = G + (w * SLAB + clip) * QGLD + UPT * up;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gs[q] += *reinterpret_cast<const f32x2*>(g + 16 * q);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int k = 0; k < UPT; ++k) gs[q][k] += g[16 * q + k];
       }
-      f32x2 hn, vi, vf, vg, vo;
+      fv hn, vi, vf, vg, vo, hs;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < UPT; ++k) {
         const float si = 1.f / (1.f + expf(-gs[0][k])), sf = 1.f / (1.f + expf(-gs[1][k])), so = 1.f / (1.f + expf(-gs[3][k]));
         const float tg = tanhf(gs[2][k]);
         c[k] = sf * c[k] + si * tg;
         hn[k] = so * tanhf(c[k]);
+        hs[k] = hn[k] + ad[k];
         vi[k] = si; vf[k] = sf; vg[k] = tg; vo[k] = so;
       }
       put_split(a.hsplit + (size_t)(t & 1) * bufb, hn);
       const size_t o = (size_t)m * ldh + (size_t)t * H + u0;
-      *reinterpret_cast<f32x2*>(a.hseq + o) = hn;
-      if (a.xsum) *reinterpret_cast<f32x2*>(a.xsum + o) = hn + ad;
+      lfv_store<UPT>(a.hseq + o, hn);
+      if (a.xsum) lfv_store<UPT>(a.xsum + o, hs);
       if (a.train) {
         float* gr = a.xp + (size_t)m * ldx + (size_t)t * 4 * H + u0;
-        *reinterpret_cast<f32x2*>(gr) = vi;
-        *reinterpret_cast<f32x2*>(gr + H) = vf;
-        *reinterpret_cast<f32x2*>(gr + 2 * H) = vg;
-        *reinterpret_cast<f32x2*>(gr + 3 * H) = vo;
-        *reinterpret_cast<f32x2*>(a.cseq + o) = c;
+        lfv_store<UPT>(gr, vi);
+        lfv_store<UPT>(gr + H, vf);
+        lfv_store<UPT>(gr + 2 * H, vg);
+        lfv_store<UPT>(gr + 3 * H, vo);
+        lfv_store<UPT>(a.cseq + o, c);
       }
     }
     if (t + 1 < a.t1) arrive();                            // (its __syncthreads also frees the gate slabs for the next step)
   }
-  if (live && !a.train) *reinterpret_cast<f32x2*>(a.cstate + (size_t)m * H + u0) = c;
+  if (live && !a.train) lfv_store<UPT>(a.cstate + (size_t)m * H + u0, c);
 }
 
 static int lstm_seq_cus() {
@@ -1887,9 +1913,16 @@ int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float*
   if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
   if (!whh_grouped || !xp || !hseq || !work || B < 0 || Tn < 0 || H < LKC || H % LKC || (xsum && !skip) || t0 < 0 || t1 > Tn) return MFPA_EINVAL;
   if (train ? !cseq : !cstate) return MFPA_EINVAL;
-  const int ks = H / 128, nslab = (B + 63) / 64, ngroups = H / LU;
+  const int ks = H / 128, ngroups = H / LU;
   static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_SEQ", 1);
-  if (!persistent || !(ks == 2 || ks == 4 || ks == 6 || ks == 8) || nslab > 32 || (long long)B * H * 8 > 0x7fffffffLL || (long long)nslab * ngroups > lstm_seq_cus())
+  static const int force_ms = MFPA_EXP_ENV("MFPA_LSTM_MS", 0);
+  // 32-clip slabs while their workgroups leave half the chip free (two such launches may run side by side in the chunked pipeline),
+  // else 64-clip slabs
+  int ms = ((long long)((B + 31) / 32) * ngroups <= lstm_seq_cus() / 2) ? 1 : 2;
+  if (force_ms == 1 || force_ms == 2) ms = force_ms;
+  const int nslab = (B + 32 * ms - 1) / (32 * ms);
+  if (!persistent || !(ks == 2 || ks == 4 || ks == 6 || ks == 8) || nslab > 32 || (long long)B * H * 8 > 0x7fffffffLL ||
+      (long long)nslab * ngroups > lstm_seq_cus())
     return mfpa_lstm_layer_range(whh_grouped, xp, hseq, cseq, cstate, B, Tn, H, xsum, skip, train, t0, t1, stream);
   LstmSeqArgs a;
   a.whh = whh_grouped; a.xp = xp; a.hseq = hseq; a.cseq = cseq; a.cstate = cstate; a.xsum = xsum; a.skip = skip;
@@ -1900,11 +1933,12 @@ int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float*
   hipStream_t st = mfpa_stream(stream);
   MFPA_HIP(hipMemsetAsync(work, 0, (size_t)LSTM_ERR_WORD * 4, st));          // the slab counters; the error word stays
   const unsigned grid = (unsigned)(((nslab * ngroups + 7) / 8) * 8);
-  const size_t lds = (size_t)QW * 64 * QGLD * sizeof(float);
+  const size_t lds = (size_t)QW * 32 * ms * QGLD * sizeof(float);
   static const int coh = MFPA_EXP_ENV("MFPA_LSTM_COH", 1);   // 0: one L1 / L2 invalidate per step + cached loads (7.83 vs 7.58 ms for both layers of 256 clips)
-#define SEQ_LAUNCH(KS_)                                                                                             \
-  if (coh) hipLaunchKernelGGL((lstm_seq_kernel<KS_, 1>), dim3(grid), dim3(64 * QW), lds, st, a);                    \
-  else hipLaunchKernelGGL((lstm_seq_kernel<KS_, 0>), dim3(grid), dim3(64 * QW), lds, st, a)
+#define SEQ_LAUNCH(KS_)                                                                                                   \
+  if (ms == 1) hipLaunchKernelGGL((lstm_seq_kernel<KS_, 1, 1>), dim3(grid), dim3(64 * QW), lds, st, a);                   \
+  else if (coh) hipLaunchKernelGGL((lstm_seq_kernel<KS_, 1, 2>), dim3(grid), dim3(64 * QW), lds, st, a);                  \
+  else hipLaunchKernelGGL((lstm_seq_kernel<KS_, 0, 2>), dim3(grid), dim3(64 * QW), lds, st, a)
   switch (ks) {
     case 2: SEQ_LAUNCH(2); break;
     case 4: SEQ_LAUNCH(4); break;
