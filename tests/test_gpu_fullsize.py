@@ -267,6 +267,38 @@ def test_demucs_train_step_64_clips_precisions_agree_and_loss_falls():
             np.testing.assert_allclose([float(v) for v in eng2.last_losses], first[0], rtol=2e-4)
 
 
+def test_demucs_train_step_lstm_schedules_agree():
+    """One backward pass at the bench shape with every schedule of the two LSTM layers: persistent launches layer after layer (the
+    default), persistent launches as a chunk pipeline on two streams (two grids resident at once: the workgroup budget), and the
+    per-step kernels -- the same gradients to rounding (248 steps, 8 chunks of 31)."""
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd.ops_demucs_train import DemucsTrainEngine
+    from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
+    B = 64
+    base = synth.batch(16, seed=6200)
+    noise = synth.batch(16, seed=6300, tonal=False)
+    clean = torch.from_numpy(np.concatenate([base] * 4)[:B].copy()).cuda()
+    aug = torch.from_numpy(np.concatenate([(0.7 * base + 0.3 * noise).astype(np.float32)] * 4)[:B].copy()).cuda()
+    old = (D.PERSISTENT_LSTM, D.PERSISTENT_LSTM_BWD, D.PIPELINE_LSTM_BWD)
+    grads = {}
+    try:
+        for name, flags in [("default", old), ("pipelined", (True, True, True)), ("per-step", (False, False, True))]:
+            D.PERSISTENT_LSTM, D.PERSISTENT_LSTM_BWD, D.PIPELINE_LSTM_BWD = flags
+            eng = DemucsTrainEngine(demucs_formula(0), "cuda", precision=1)
+            pred = eng.forward(aug)
+            _, _, _, dpred = eng.loss_and_grad(pred, clean)
+            eng.backward(dpred)
+            torch.cuda.synchronize()
+            grads[name] = eng.flat_g.clone()
+    finally:
+        D.PERSISTENT_LSTM, D.PERSISTENT_LSTM_BWD, D.PIPELINE_LSTM_BWD = old
+    assert not D.lstm_seq_error()
+    ref = grads["per-step"]
+    for name in ("default", "pipelined"):
+        rel = float((grads[name] - ref).abs().sum() / ref.abs().sum())
+        assert rel < 2e-4, (name, rel)
+
+
 def test_config1_dejavu_picker_256_clips_bit_exact_and_batch_invariant(net):
     """configs[1] with the second picker: mlab.specgram PSD -> /max -> 10 ln -> -mean -> 21x21 local
     maxima on 256 clips; sampled clips through the oracle, the rest through batch-composition properties.  Then the denoised
