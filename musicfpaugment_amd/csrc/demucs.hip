@@ -1750,7 +1750,7 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   static const int wide = MFPA_EXP_ENV("MFPA_GEMM_WIDE", 1);   // 0: always the 128 x 64 tile (experiments)
   static const int pipe = MFPA_EXP_ENV("MFPA_GEMM_PIPE", 1);   // 0: the 128 x 128 kernel without the software pipeline (experiments)
   const bool wide_ok = d->K % HKC == 0 && d->K >= 128 && d->npad % WBN == 0 && (d->precision == 2 || (d->precision == 1 && wide));
-  if (wide_ok && pipe && d->K % (2 * HKC) == 0 && d->M >= PBM) {
+  if (wide_ok && pipe && d->K % (2 * HKC) == 0 && d->M >= MFPA_EXP_ENV("MFPA_GEMM_PIPE_MINM", 192)) {   // (rows past M are clamped when loaded: a 249-row clip fills 97 % of a 256-row tile)
     a.ny = (d->M + PBM - 1) / PBM;
     dim3 gw = grid1d(d->npad / WBN);
     const size_t lds = (size_t)2 * (PBM + WBN) * HROW;
