@@ -1026,6 +1026,20 @@ __global__ __launch_bounds__(256, 2) void c1_glu_kernel(const float* __restrict_
               asm volatile("" : "+v"(t));
               v[k] = t;
             }
+#elif MFPA_HEAD_PACKED_FMA == 2
+          // packed FMAs WITHOUT operand selection: every sample is first materialised as an {x, x} pair (experiment)
+          {
+            typedef float hf2 __attribute__((ext_vector_type(2)));
+            hf2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              hf2 xx = {xr[p][j >> 2][j & 3], xr[p][j >> 2][j & 3]};
+              asm volatile("" : "+v"(xx));
+              v01 += xx * hf2{wq[j][0], wq[j][1]};
+              v23 += xx * hf2{wq[j][2], wq[j][3]};
+            }
+            v = f32x4{v01[0], v01[1], v23[0], v23[1]};
+          }
 #else
 #pragma unroll
           for (int j = 0; j < 8; ++j) v += xr[p][j >> 2][j & 3] * wq[j];
