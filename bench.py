@@ -177,6 +177,20 @@ def cpu_baseline(budget_s: float, seed: int):
     return out
 
 
+def _rank_report(dist, dev, world, units, dt):
+    """N > 1 lines verify themselves: `ranks_seen` = a SUM all-reduce of 1 over the process group on the device (RCCL under the
+    driver's launch) -- it must equal n_gpus --, and every rank's own units/s (all-gathered), so that a rank that did no work, a
+    group that silently shrank, or one slow GPU shows in the line itself.  None at N = 1 without a process group."""
+    if dist is None:
+        return None
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([units / dt], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return {"ranks_seen": int(round(one.item())), "per_rank_value": [round(float(v.item()), 3) for v in allr]}
+
+
 def _demucs_traffic(B):
     """HBM bytes per step of the Demucs forward's GEMM family from the committed rocprofv3 --pmc passes, scaled to B clips."""
     pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_DEMUCS)
@@ -227,11 +241,12 @@ def bench_demucs(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    rep = _rank_report(dist, dev, world, B * args.steps, dt)
     result = None
     if rank == 0:
         gemm_ms = timer.total_ms()
         achieved = 20.13e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12
-        result = ({
+        result = ({**(rep or {}),
             "metric": "8s/8kHz clips/sec (Demucs forward + STFT + peak-pick)", "value": round(world * B * args.steps / dt_max, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -255,18 +270,33 @@ def bench_demucs(args, rank, world, dev, dist):
     return result
 
 
+def metric_queries(N, dev, T=64000):
+    """The peak-metrics experiment's synthetic queries, resident in HBM: 64 generated base clips, rolled by a per-query offset, and
+    their AugmentFP versions (device chain, fixed seeds: every rank -- and tests/test_gpu_fullsize.py -- builds the same N pairs)."""
+    import random
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
+    base = torch.from_numpy(synth.batch(64, seed=synth.BASE_SEED)).to(dev)
+    idx = torch.arange(N, device=dev)
+    shift = (idx // 64 * 977) % T
+    cols = (torch.arange(T, device=dev)[None, :] + shift[:, None]) % T
+    clean = torch.gather(base[idx % 64], 1, cols)
+    random.seed(7); torch.manual_seed(7)
+    irs, noises = synthetic_banks(0)
+    af = AugmentFP(None, 8000, ir_bank=irs, noise_bank=noises, device=dev)
+    aug = torch.cat([af.batch_augment(clean[s:s + 256][:, None, :])[:, 0] for s in range(0, N, 256)])
+    return clean, aug
+
+
 def bench_metrics(args, rank, world, dev, dist):
     """BASELINE config 5, second half: the end-to-end peak-metrics experiment (testing/audfprint_exps.py:86-157) over
     --queries synthetic queries: clean clip -> AugmentFP query (device) -> peaks of clean / query / denoised query
     (Demucs on the waveform, or the UNet on the spectrogram) -> per-query precision / recall / F1 / PSNR -> means.
     The queries are a FIXED total split over the ranks (strong scaling); the only collective is the all-gather of the
     per-query result rows."""
-    import random
-    from musicfpaugment_amd import synth
     from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
-    from musicfpaugment_amd.augmentation import AugmentFP, synthetic_banks
     from musicfpaugment_amd.testing.audfprint_exps import compute_peaks_metrics
-    N, T = args.queries, 64000
+    N = args.queries
     if args.denoiser == "demucs":
         from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
         from musicfpaugment_amd.training.model import Demucs
@@ -282,16 +312,7 @@ def bench_metrics(args, rank, world, dev, dist):
         net.precision = 1 if args.precision == "bf16x3" else 0
         an_den = Audfprint_peaks(None, denoising=True, denoising_model="unet", unet=net, device=dev)
     an_no = Audfprint_peaks(None, device=dev)
-    # every rank builds the same N queries (identical seeds), resident in HBM: 64 base clips, rolled and re-augmented
-    base = torch.from_numpy(synth.batch(64, seed=synth.BASE_SEED)).to(dev)
-    idx = torch.arange(N, device=dev)
-    shift = (idx // 64 * 977) % T
-    cols = (torch.arange(T, device=dev)[None, :] + shift[:, None]) % T
-    clean = torch.gather(base[idx % 64], 1, cols)
-    random.seed(7); torch.manual_seed(7)
-    irs, noises = synthetic_banks(0)
-    af = AugmentFP(None, 8000, ir_bank=irs, noise_bank=noises, device=dev)
-    aug = torch.cat([af.batch_augment(clean[s:s + 256][:, None, :])[:, 0] for s in range(0, N, 256)])
+    clean, aug = metric_queries(N, dev)
 
     def barrier():
         if dist is not None:
@@ -310,9 +331,10 @@ def bench_metrics(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    rep = _rank_report(dist, dev, world, (N // world) * args.steps, dt)
     result = None
     if rank == 0:
-        result = ({
+        result = ({**(rep or {}),
             "metric": "queries/sec (peak-metrics experiment: 3 peak extractions + denoiser + P/R/F1/PSNR per query)",
             "value": round(N * args.steps / dt_max, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
@@ -379,13 +401,14 @@ def bench_demucs_train(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    rep = _rank_report(dist, dev, world, B * args.steps, dt)
     result = None
     if rank == 0:
         gemm_ms = timer.total_ms()
         gflop = 3 * 20.13 * n / 64000.0                  # forward + input gradients + weight gradients, per clip
         achieved = gflop * 1e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12
         phases = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in eng.phases.items()}
-        result = ({
+        result = ({**(rep or {}),
             "metric": f"{args.seconds:g}s/8kHz clips/sec (Demucs train step: fwd + L1 + MRSTFT loss + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True,
@@ -460,6 +483,7 @@ def bench_train(args, rank, world, dev, dist):
     timer = ops_unet.KernelTimer()
     ops_unet.set_timer(timer)
     comm0 = (eng.comm_calls, eng.comm_bytes)
+    eng.comm_wait_events = [] if dist is not None else None      # events around the gradient-bucket waits -> exposed all-reduce time
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -473,13 +497,19 @@ def bench_train(args, rank, world, dev, dist):
     # collectives per step: the engine's gradient buckets (+ SyncBN sums) and the two scalar MAX all-reduces of the spectrogram maxima
     ar_calls = (eng.comm_calls - comm0[0]) // args.steps + (2 if dist is not None else 0)
     ar_bytes = (eng.comm_bytes - comm0[1]) // args.steps + (16 if dist is not None else 0)
+    # what the step WAITED for its gradient buckets (they are launched asynchronously during backward and waited on once, in front
+    # of Adam): HIP events on the compute stream around those waits, mean per step on this rank
+    ar_wait_ms = (round(sum(a.elapsed_time(b) for a, b in eng.comm_wait_events) / args.steps, 3)
+                  if eng.comm_wait_events else None)
+    eng.comm_wait_events = None
+    rep = _rank_report(dist, dev, world, B * args.steps, dt)
     result = None
     if rank == 0:
         mfma_gflop = (280.1 - 3 * 0.082) * (1 + nsamp // 256) / 251.0   # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU); scales with the frames
         conv_ms = timer.total_ms()
         achieved = mfma_gflop * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12
         issue_x = 2.0 + {"bf16x3": 3, "bf16": 1, "fp32": 0}[args.wgrad] / 3.0      # fp32 weight gradients run on the fp32 cores
-        result = ({
+        result = ({**(rep or {}),
             "metric": f"{args.seconds:g}s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
@@ -491,6 +521,7 @@ def bench_train(args, rank, world, dev, dist):
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "loss_last": float(loss),
                        "allreduce_calls_per_step": ar_calls, "allreduce_bytes_per_step": ar_bytes,
+                       "allreduce_exposed_wait_ms_per_step": ar_wait_ms,
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
                                       + ("synchronised (global-batch)" if eng.sync_bn else "per-GPU")
                                       + " BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
@@ -567,12 +598,13 @@ def bench_infer(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    rep = _rank_report(dist, dev, world, B * args.steps, dt)
     total_peaks = int(npeaks.sum().item())
 
     if rank != 0:
         return None
     clips = world * B * args.steps
-    out = {
+    out = {**(rep or {}),
         "metric": ("8s/8kHz clips/sec (STFT+UNet+peak-pick)" if net is not None else "8s/8kHz clips/sec (STFT+peak-pick, no UNet)")
                   + (" [Dejavu picker]" if args.picker == "dejavu" else ""),
         "value": round(clips / dt_max, 3),
@@ -647,12 +679,14 @@ def bench_launch_check(args, rank, world, dist):
     relay, with NO kernel launched -- it measures nothing and says so.  It lets the `python bench.py --gpus N` self-launch
     path run where there is no GPU (the hot path itself has no CPU fallback)."""
     t = torch.tensor([float(rank)], dtype=torch.float64)
+    rep = None
     if dist is not None:
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rep = _rank_report(dist, torch.device("cpu"), world, 1.0 + rank, 1.0)
     if rank != 0:
         return None
-    return {"metric": "launch-check (launcher / rendezvous / JSON relay only; no kernel ran, nothing was measured)", "value": None,
+    return {**(rep or {}), "metric": "launch-check (launcher / rendezvous / JSON relay only; no kernel ran, nothing was measured)", "value": None,
             "unit": "clips/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
             "config": {"workload": "none", "max_rank_seen": int(t.item())}}
@@ -674,9 +708,13 @@ def other_configs(args, dev):
     plan = [
         ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
         ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
-        ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=1, warmup=1, clips=512)),
+        ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
         ("config4_unet_train_step", bench_train, dict(mode="train", steps=3, warmup=1, clips=64, seconds=8.0)),
         ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=3, warmup=1, clips=256)),
+        # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
+        # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
+        ("config5_peak_metrics", bench_metrics, dict(mode="metrics", queries=10000, denoiser="demucs", steps=1, warmup=1, clips=256)),
+        ("config5_peak_metrics_unet", bench_metrics, dict(mode="metrics", queries=2000, denoiser="unet", steps=1, warmup=1, clips=256)),
     ]
     for name, fn, kw in plan:
         t0 = time.perf_counter()
@@ -698,16 +736,15 @@ def other_configs(args, dev):
 def _self_launch(n: int, argv) -> int:
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a CHILD process tree -- this process has
     not touched the GPU and never execs -- relay rank 0's JSON line on stdout, everything else on stderr, and return the child's code."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT", "RANK", "LOCAL_RANK")}
+    env["MASTER_ADDR"] = "127.0.0.1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    # --standalone: torch.distributed.run's own c10d rendezvous on a port IT binds (rdzv endpoint 127.0.0.1:0 -> a free port, held
+    # from the moment it is chosen; a bind-then-close probe here could lose the port to another process before the ranks start)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__), *argv]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in proc.stdout.splitlines():

@@ -500,14 +500,18 @@ int mfpa_lstm_layer_bwd_range(const float* whhT, float* gates, const float* cseq
  * (model.py:91-110, torch.nn.LSTM's recurrence); `work` = device scratch of the size mfpa_lstm_seq_work_bytes reports, owned by this
  * layer while the call runs, zeroed once before its first use.  Every wait in the kernel is bounded: if one ever gives up the
  * kernel raises the 32-bit word at byte mfpa_lstm_seq_error_offset() of `work` (and finishes with undefined results); callers
- * read that word at their next synchronisation point.  The grid must be co-resident: the call checks its own workgroups against the
- * CU count, but it cannot see other work -- a second process (or another persistent launch) occupying the same GPU at that moment
- * is exactly the case the bounded waits and the error word exist for; one process per GPU is the intended deployment.  Shapes outside the persistent kernel's range (H / 128 not in {2,4,6,8},
- * ceil(B / 64) * H / 16 workgroups > CUs) take the per-step path inside the same call. */
+ * read that word before the results leave their operator (the Python host does: ops_demucs.lstm_results_ok).  The grid must be
+ * co-resident: the call keeps its own workgroups within `wg_budget` (0 = one per CU of the current device; a caller that runs two
+ * such launches side by side, like the chunked two-stream pipeline, passes half the CU count), but it cannot see other work --
+ * mfpa_lstm_seq_workgroups reports how many workgroups a launch keeps resident so that a host can account for launches in flight on
+ * other streams (ops_demucs._ResidentGuard); a second PROCESS occupying the same GPU is the case the bounded waits and the error word
+ * exist for; one process per GPU is the intended deployment.  Shapes outside the persistent kernel's range (H / 128 not in
+ * {2,4,6,8}, more workgroups than the budget even with 64-clip slabs) take the per-step path inside the same call. */
 int mfpa_lstm_seq_work_bytes(int B, int H, long long* bytes);   /* HOST function: *bytes = size of `work` */
 int mfpa_lstm_seq_error_offset(void);
+int mfpa_lstm_seq_workgroups(int B, int H, int wg_budget, int* workgroups);   /* HOST function: resident workgroups of the launch, 0 = per-step path */
 int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
-                        const float* skip, int train, int t0, int t1, void* work, void* stream);
+                        const float* skip, int train, int t0, int t1, int wg_budget, void* work, void* stream);
 
 /* mfpa_lstm_layer_bwd_range as ONE persistent launch (lstm_bwd_seq_kernel, csrc/demucs_train.hip): the backward recurrence of a layer for
  * steps t1-1 .. t0 (torch.nn.LSTM's backward through time, training/train.py:275-312 via autograd in the reference).  A workgroup keeps
@@ -519,6 +523,7 @@ int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float*
  * concurrently, like the chunked two-stream pipeline, passes half the CU count: every workgroup of a launch must be resident at once).
  * H / 64 outside {4, 8, 12} or too many workgroups even with 64-clip slabs: the per-step path. */
 int mfpa_lstm_bwd_seq_work_bytes(int B, int H, long long* bytes);   /* HOST function */
+int mfpa_lstm_bwd_seq_workgroups(int B, int H, int wg_budget, int* workgroups);   /* HOST function, as mfpa_lstm_seq_workgroups */
 int mfpa_lstm_layer_bwd_seq(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
                             int t0, int t1, int wg_budget, void* work, void* stream);
 

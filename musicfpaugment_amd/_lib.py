@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class MfpaError(RuntimeError):
@@ -98,7 +98,9 @@ _SIGNATURES = {
     "mfpa_conv1d_c1_glu": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_glu_convT1d_c1": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "mfpa_lstm_layer_seq": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
-                             c_int, c_void_p, c_void_p], c_int),
+                             c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_lstm_seq_workgroups": ([c_int, c_int, c_int, c_void_p], c_int),
+    "mfpa_lstm_bwd_seq_workgroups": ([c_int, c_int, c_int, c_void_p], c_int),
     "mfpa_lstm_layer_bwd_seq": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
                                  c_int),
     "mfpa_lstm_bwd_seq_work_bytes": ([c_int, c_int, c_void_p], c_int),

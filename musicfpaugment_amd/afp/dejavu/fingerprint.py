@@ -54,13 +54,17 @@ def fingerprint(channel_samples, Fs: float = afp_settings["dejavu"]["samplerate"
         if net is None:
             raise ValueError("denoising with the UNet needs the module: pass unet=... or call set_denoisers(unet=...)")
     n_frames = (x.shape[1] - 256) // 256
-    cap = max(16, (int(fan_value) - 1) * 257 * max(n_frames, 1) // 64)           # a 21 x 21 neighbourhood holds one peak
-    cap = min(cap, 16384)
+    # at most one peak per 21 x 21 neighbourhood (it would need ~64 cells per peak to pack them), each paired with fan_value - 1
+    # later peaks: `peaks` bounds the peak list (the kernel's limit is 16384 per call), `cap` only sizes the hash output -- a full
+    # song has more than 16384 hashes long before it has 16384 peaks
+    peaks = max(16, 257 * max(n_frames, 1) // 64)
+    cap = max(16, peaks * max(int(fan_value) - 1, 1))
     dig, t1, counts, mask, spec = fingerprint_batch(x, amp_min=amp_min, fan_value=fan_value, cap=cap, scale_in=1.0,
+                                                    peak_cap=min(peaks, 16384),
                                                     denoising=net is not None, denoising_model="unet", unet=net)
     n = int(counts[0])
     if n < 0:
-        raise ValueError("too many peaks for the device kernel")
+        raise ValueError("more than 16384 peaks in one recording: outside the device kernel's limit (split the recording)")
     hashes = _hashes_to_list(dig[0], t1[0], n)
     if get_masks is True:
         return hashes, mask[0].to(torch.float64).cpu().numpy(), spec[0].cpu().numpy()
@@ -130,10 +134,12 @@ def generate_hashes(peaks: List[Tuple[int, int]], fan_value: int = afp_settings[
 
 
 def fingerprint_batch(wav: torch.Tensor, amp_min: float = afp_settings["dejavu"]["amp_min"],
-                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096, scale_in: float = 32767.0, **denoise):
+                      fan_value: int = afp_settings["dejavu"]["fan_value"], cap: int = 4096, scale_in: float = 32767.0,
+                      peak_cap: int = None, **denoise):
     """fingerprint(...) for a batch (afp/dejavu/fingerprint.py:34-91): (digests (B,cap,10) uint8, t1 (B,cap), counts (B,),
     peak mask, normalised specgram), everything on the device.  ``denoise``: the denoising arguments of
     fingerprint_peaks_batch."""
     mask, _, spec = fingerprint_peaks_batch(wav, amp_min, scale_in=scale_in, **denoise)
-    dig, t1, counts = ops.dejavu_hashes(mask, cap=cap, peak_cap=cap, fan_value=fan_value)
+    # only the PEAK list is bounded by the kernel (<= 16384 peaks per clip, sorted in LDS); the hash capacity is just output memory
+    dig, t1, counts = ops.dejavu_hashes(mask, cap=cap, peak_cap=min(cap, 16384) if peak_cap is None else peak_cap, fan_value=fan_value)
     return dig, t1, counts, mask, spec

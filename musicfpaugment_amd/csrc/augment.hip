@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void lowpass_taps_kernel(const float* __restri
 // A filter may be far longer than the clip (a 0.5 Hz high-pass at 8 kHz has 128 001 taps): a workgroup only multiplies the
 // taps that meet a real sample for at least one of its outputs, [klo, khi); the taps before / after that range see only
 // the replicated first / last sample (or zeros), so they enter as two tap sums.  Work per clip <= T * (T + 1023) MACs.
-__global__ __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, int T, int Tout, const float* __restrict__ taps,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void fir_kernel(const float* __restrict__ x, int T, int Tout, const float* __restrict__ taps,
                                                   const long long* __restrict__ tap_off, const int* __restrict__ ntaps,
                                                   const int* __restrict__ off, const uint8_t* __restrict__ apply, int pad_mode,
                                                   int out_mode, float* __restrict__ y, float* __restrict__ peak) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void gather_background_kernel(const float* __
 
 // AddBackgroundNoise.apply_transform (background_noise.py:183-215): y = x + rms(x) / 10^(snr/20) * noise; y /= max|y|.
 // PeakNormalization (peak_normalization.py:38-67) is the same kernel with noise == nullptr: y = x / max|x| when max > 0.
-__global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ x, int T, const float* __restrict__ noise,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(1024) void mix_kernel(const float* __restrict__ x, int T, const float* __restrict__ noise,
                                                    const float* __restrict__ snr_db, const uint8_t* __restrict__ apply,
                                                    float* __restrict__ y) {
   __shared__ float sh[16];

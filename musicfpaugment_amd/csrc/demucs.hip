@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void gemm_shortk_bf16x3_kernel(GemmArgs a) 
 //     p[t][j] = sum_c g[t][c] w[j][c] with fp32 FMAs, and y[4t + j] = bias + p[t][j] + p[t-1][j+4] is written coalesced.
 constexpr int TT_K = 48, TT_ROW = 4 * TT_K + 16, TT_OUT = 127, TT_TPW = 8;
 
-__global__ __launch_bounds__(256, 2) void glu_convT_c1_kernel(const float* __restrict__ x, int L, const float* __restrict__ gw,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(256, 2) void glu_convT_c1_kernel(const float* __restrict__ x, int L, const float* __restrict__ gw,
                                                               const float* __restrict__ gb, const float* __restrict__ wl, float bias,
                                                               float* __restrict__ y, int tiles_per_clip, int groups) {
   constexpr int K = TT_K, ROW = TT_ROW, QPR = K / 4, NQ = 128 * QPR / 256;      // 12 quads per row, 6 per thread
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ void rs_fir4(const float* __restrict__ w, const float
 }
 
 // upsample2 (model.py:41-53): y[2i] = x[i], y[2i+1] = sum_k x[i + k - 55] ker[k], k < 112 (zero beyond the ends).
-__global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, int T, const float* __restrict__ ker,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, int T, const float* __restrict__ ker,
                                                         float* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) float win[RS_OUT + RS_TAPS + 8];
   __shared__ __attribute__((aligned(16))) float kk[RS_TAPS];
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict_
 }
 
 // downsample2 (model.py:69-88): out[i] = 0.5 * (x[2i] + sum_k xodd[i + k - 56] ker[k]), xodd[j] = x[2j+1] (0 beyond the end).
-__global__ __launch_bounds__(256) void downsample2_kernel(const float* __restrict__ x, int T, const float* __restrict__ ker,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void downsample2_kernel(const float* __restrict__ x, int T, const float* __restrict__ ker,
                                                           float* __restrict__ y, int To, const float* __restrict__ scale,
                                                           int Tkeep) {
   __shared__ __attribute__((aligned(16))) float wodd[RS_OUT + RS_TAPS + 8];
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void downsample2_kernel(const float* __restric
 }
 
 // First encoder conv: Conv1d(1 -> C, k=8, s=4) + ReLU on (B, Lin) -> (B, Lout, C).  w [8][C] (tap-major), bias [C].
-__global__ __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict__ x, int Lin, int Lout, int C,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict__ x, int Lin, int Lout, int C,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         float* __restrict__ y, int relu) {
   const int b = blockIdx.y, C4 = C / 4;
@@ -1712,14 +1712,23 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
   if (live && !a.train) lfv_store<UPT>(a.cstate + (size_t)m * H + u0, c);
 }
 
-static int lstm_seq_cus() {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    cus = n;
-  }
-  return cus;
+static int lstm_seq_cus() { return mfpa_current_device_cus(); }
+
+// Slab size (ms x 32 clips) and resident workgroups of the persistent forward launch for (B, H) under `wg_budget` (0 = one per CU):
+// 32-clip slabs while their workgroups leave half the chip free, else 64-clip slabs; 0 workgroups = the per-step path.
+static int lstm_seq_plan(int B, int H, int wg_budget, int* ms_out) {
+  const int cus = lstm_seq_cus();
+  const int budget = (wg_budget > 0 && wg_budget < cus) ? wg_budget : cus;
+  const int ks = H / 128, ngroups = H / LU;
+  static const int force_ms = MFPA_EXP_ENV("MFPA_LSTM_MS", 0);
+  int ms = ((long long)((B + 31) / 32) * ngroups <= (budget < cus / 2 ? budget : cus / 2)) ? 1 : 2;
+  if (force_ms == 1 || force_ms == 2) ms = force_ms;
+  const int nslab = (B + 32 * ms - 1) / (32 * ms);
+  if (ms_out) *ms_out = ms;
+  if (H % 128 || !(ks == 2 || ks == 4 || ks == 6 || ks == 8) || nslab > 32 || (long long)B * H * 8 > 0x7fffffffLL ||
+      (long long)nslab * ngroups > budget)
+    return 0;
+  return nslab * ngroups;
 }
 
 }  // namespace
@@ -1922,22 +1931,27 @@ int mfpa_lstm_seq_work_bytes(int B, int H, long long* bytes) {
 
 int mfpa_lstm_seq_error_offset(void) { return LSTM_ERR_WORD * 4; }
 
+int mfpa_lstm_seq_workgroups(int B, int H, int wg_budget, int* workgroups) {
+  if (!workgroups || B < 0 || H < LKC || H % LKC) return MFPA_EINVAL;
+  static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_SEQ", 1);
+  *workgroups = (persistent && B > 0) ? lstm_seq_plan(B, H, wg_budget, nullptr) : 0;
+  return MFPA_OK;
+}
+
 int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float* cseq, float* cstate, int B, int Tn, int H, float* xsum,
-                        const float* skip, int train, int t0, int t1, void* work, void* stream) {
+                        const float* skip, int train, int t0, int t1, int wg_budget, void* work, void* stream) {
   if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
   if (!whh_grouped || !xp || !hseq || !work || B < 0 || Tn < 0 || H < LKC || H % LKC || (xsum && !skip) || t0 < 0 || t1 > Tn) return MFPA_EINVAL;
   if (train ? !cseq : !cstate) return MFPA_EINVAL;
   const int ks = H / 128, ngroups = H / LU;
   static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_SEQ", 1);
-  static const int force_ms = MFPA_EXP_ENV("MFPA_LSTM_MS", 0);
-  // 32-clip slabs while their workgroups leave half the chip free (two such launches may run side by side in the chunked pipeline),
-  // else 64-clip slabs
-  int ms = ((long long)((B + 31) / 32) * ngroups <= lstm_seq_cus() / 2) ? 1 : 2;
-  if (force_ms == 1 || force_ms == 2) ms = force_ms;
-  const int nslab = (B + 32 * ms - 1) / (32 * ms);
-  if (!persistent || !(ks == 2 || ks == 4 || ks == 6 || ks == 8) || nslab > 32 || (long long)B * H * 8 > 0x7fffffffLL ||
-      (long long)nslab * ngroups > lstm_seq_cus())
+  // every workgroup of the launch must be resident at once: the plan keeps them within `wg_budget` (0 = one per CU of the current
+  // device; a caller running two such launches side by side -- the chunked two-stream pipeline -- passes half the CU count)
+  int ms = 2;
+  const int wgs = persistent ? lstm_seq_plan(B, H, wg_budget, &ms) : 0;
+  if (wgs == 0)
     return mfpa_lstm_layer_range(whh_grouped, xp, hseq, cseq, cstate, B, Tn, H, xsum, skip, train, t0, t1, stream);
+  const int nslab = (B + 32 * ms - 1) / (32 * ms);
   LstmSeqArgs a;
   a.whh = whh_grouped; a.xp = xp; a.hseq = hseq; a.cseq = cseq; a.cstate = cstate; a.xsum = xsum; a.skip = skip;
   a.sync = reinterpret_cast<unsigned*>(work);

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void colsum_any_kernel(const float* __restrict
 // dw[j][c] += sum_{b,t} x[b*ldx + 4t + j] * g[b*strideG + t*ldg + c],  j < 8, t < L   (w (8, C) tap-major)
 // serves encoder.0.0 (x = the upsampled input, g = the masked gradient of its ReLU output) and the last
 // ConvTranspose1d (x = the gradient of its output, g = the GLU output it consumed).
-__global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g,
+__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g,
                                                        long long ldg, long long strideG, int L, int C, float* __restrict__ dw,
                                                        int rows_per_block) {
   __shared__ float accs[8 * 256];                        // C <= 256
@@ -873,14 +873,23 @@ __global__ __launch_bounds__(64 * QB_W, 1) void lstm_bwd_seq_kernel(LstmBwdSeqAr
   }
 }
 
-static int lstm_bwd_seq_cus() {
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    cus = n;
-  }
-  return cus;
+static int lstm_bwd_seq_cus() { return mfpa_current_device_cus(); }
+
+// slab size (mtb x 16 clips) and resident workgroups of the persistent backward launch; 0 = the per-step path
+static int lstm_bwd_seq_plan(int B, int H, int wg_budget, int* mtb_out) {
+  const int ks = (H % 64 == 0) ? H / 64 : 0, ngroups = H / 16;
+  static const int force_mtb = MFPA_EXP_ENV("MFPA_LSTM_BWD_MTB", 0);
+  const int cus = lstm_bwd_seq_cus();
+  const int budget = (wg_budget > 0 && wg_budget < cus) ? wg_budget : cus;
+  int mtb = 0;
+  for (int c = 1; c <= 4 && !mtb; c *= 2)
+    if ((long long)((B + 16 * c - 1) / (16 * c)) * ngroups <= budget) mtb = c;
+  if (force_mtb == 1 || force_mtb == 2 || force_mtb == 4) mtb = force_mtb;
+  const int nslab = mtb ? (B + 16 * mtb - 1) / (16 * mtb) : 0;
+  if (mtb_out) *mtb_out = mtb;
+  if (!mtb || !(ks == 4 || ks == 8 || ks == 12) || nslab > 32 || (long long)B * H * 32 > 0x7fffffffLL || (long long)nslab * ngroups > budget)
+    return 0;
+  return nslab * ngroups;
 }
 
 }  // namespace
@@ -1040,25 +1049,27 @@ int mfpa_lstm_bwd_seq_work_bytes(int B, int H, long long* bytes) {
   return MFPA_OK;
 }
 
+int mfpa_lstm_bwd_seq_workgroups(int B, int H, int wg_budget, int* workgroups) {
+  if (!workgroups || B < 0 || H < 64) return MFPA_EINVAL;
+  static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_BWD_SEQ", 1);
+  *workgroups = (persistent && B > 0) ? lstm_bwd_seq_plan(B, H, wg_budget, nullptr) : 0;
+  return MFPA_OK;
+}
+
 int mfpa_lstm_layer_bwd_seq(const float* whhT, float* gates, const float* cseq, const float* dhout, float* dcstate, int B, int Tn, int H,
                             int t0, int t1, int wg_budget, void* work, void* stream) {
   if (B == 0 || Tn == 0 || t1 <= t0) return MFPA_OK;
   if (!whhT || !gates || !cseq || !dhout || !dcstate || !work || B < 0 || Tn < 0 || t0 < 0 || t1 > Tn || H < 64) return MFPA_EINVAL;
   const int ks = (H % 64 == 0) ? H / 64 : 0, ngroups = H / 16;
   static const int persistent = MFPA_EXP_ENV("MFPA_LSTM_BWD_SEQ", 1);
-  static const int force_mtb = MFPA_EXP_ENV("MFPA_LSTM_BWD_MTB", 0);
   // the smallest slab (16, 32 or 64 clips) whose workgroups still fit the chip: more CUs share the reading of dgates[t+1]
   // (every workgroup of a launch must be resident at once; a caller that runs two such launches side by side -- the chunked
   // two-stream pipeline -- passes half the CUs as wg_budget, 0 = all of them)
-  const int budget = (wg_budget > 0 && wg_budget < lstm_bwd_seq_cus()) ? wg_budget : lstm_bwd_seq_cus();
   int mtb = 0;
-  for (int c = 1; c <= 4 && !mtb; c *= 2)
-    if ((long long)((B + 16 * c - 1) / (16 * c)) * ngroups <= budget) mtb = c;
-  if (force_mtb == 1 || force_mtb == 2 || force_mtb == 4) mtb = force_mtb;
-  const int nslab = mtb ? (B + 16 * mtb - 1) / (16 * mtb) : 0;
-  if (!persistent || !mtb || !(ks == 4 || ks == 8 || ks == 12) || nslab > 32 || (long long)B * H * 32 > 0x7fffffffLL ||
-      (long long)nslab * ngroups > budget)
+  const int wgs = persistent ? lstm_bwd_seq_plan(B, H, wg_budget, &mtb) : 0;
+  if (wgs == 0)
     return mfpa_lstm_layer_bwd_range(whhT, gates, cseq, dhout, dcstate, B, Tn, H, t0, t1, stream);
+  const int nslab = (B + 16 * mtb - 1) / (16 * mtb);
   LstmBwdSeqArgs a;
   a.whhT = whhT; a.gates = gates; a.cseq = cseq; a.dhout = dhout; a.dcstate = dcstate;
   a.sync = reinterpret_cast<unsigned*>(work);

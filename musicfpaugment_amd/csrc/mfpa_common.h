@@ -31,6 +31,40 @@
     if (e__ != hipSuccess) return MFPA_EHIP - (int)e__;       \
   } while (0)
 
+// Kernels carrying this attribute are compiled without packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+// hipcc pairs scalar float expressions into those freely and, when one operand sits in the high half of a register pair, selects it
+// with op_sel:[..1..] (the LOW lane reads a HIGH half).  That encoding returned sporadically wrong low lanes next to MFMA waves on
+// this toolchain (profiles/r02_pk_fma_op_sel.md), so the product library contains none: every kernel in which hipcc chose it carries
+// this attribute (same IEEE results: a packed FMA is two scalar FMAs), and tests/test_isa_scan.py disassembles the shipped
+// libmfpa.so and fails on any packed-fp32 instruction with an op_sel:[...] operand selection.
+#define MFPA_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+
+// One scalar v_fma_f32, kept from being paired into v_pk_fma_f32 (the empty asm): for a few FMAs inside a large templated kernel
+// whose other packed arithmetic should stay packed.
+__device__ __forceinline__ float mfpa_fma1(float a, float b, float c) {
+  float t = __builtin_fmaf(a, b, c);
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+// CU count of the CURRENT device (cached per device id: a process may drive several GPUs).  The persistent LSTM kernels size their
+// grids against it -- one workgroup per CU is the residency they rely on (their LDS / register footprint allows no second one).
+static inline int mfpa_current_device_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev >= 64) {
+    int n = 0;
+    return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess ? n : 0;
+  }
+  if (cus[dev] <= 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 static inline hipStream_t mfpa_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 __device__ __forceinline__ double mfpa_wave_max(double v) {

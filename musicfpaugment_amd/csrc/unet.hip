@@ -272,7 +272,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
             for (int t = 0; t < 9; ++t) {
               const float sv = sp[(t / 3) * SW + (t % 3)];
               const f32x4 wv = *reinterpret_cast<const f32x4*>(W1s + t * 64 + c0 + 4 * q);
-              v.x += sv * wv.x; v.y += sv * wv.y; v.z += sv * wv.z; v.w += sv * wv.w;
+              // scalar FMAs on purpose: as `v += sv * wv` hipcc emits v_pk_fma_f32 ... op_sel:[1,0,0] for the odd samples of a pair (mfpa_common.h)
+              v.x = mfpa_fma1(sv, wv.x, v.x); v.y = mfpa_fma1(sv, wv.y, v.y); v.z = mfpa_fma1(sv, wv.z, v.z); v.w = mfpa_fma1(sv, wv.w, v.w);
             }
             const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.c1_scale + c0 + 4 * q);
             const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.c1_shift + c0 + 4 * q);

@@ -179,13 +179,17 @@ PIPELINE_LSTM_BWD = False    # training: the two layers' backward recurrences as
                              # ms per step, three runs each: persistent + one layer after the other 41.1 / 41.7 / 42.8; per-step launches + pipeline
                              # 42.3 / 42.6 / 42.7; persistent + pipeline 43.2 / 43.5 / 45.6; per-step, no pipeline 44.1 / 44.3 / 45.4)
 _LSTM_WORK: Dict[tuple, list] = {}
+_LSTM_TOUCHED: Dict[int, list] = {}      # device index -> work-buffer entries used since the last lstm_results_ok()
+
+
+def _dev_index(dev) -> int:
+    return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
 def _lstm_work(dev, layer: int, B: int, H: int, backward: bool = False) -> torch.Tensor:
     """Scratch of the persistent LSTM kernel for one layer (mfpa_lstm_layer_seq): the exchange buffers of h and the slab counters.
-    Kept per (device, stream, layer, shape); whenever it is handed out again the error word of its PREVIOUS use is looked at through
-    a pinned host copy made then (no synchronisation on the way): a wait that gave up inside the kernel surfaces here as MfpaError."""
-    from ._lib import MfpaError
+    Kept per (device, stream, layer, shape).  Every entry handed out is remembered until lstm_results_ok() has looked at its error
+    word -- the operators call that before their results leave them (demucs_forward, DemucsTrainEngine.train_step)."""
     L = lib()
     size_fn = L.mfpa_lstm_bwd_seq_work_bytes if backward else L.mfpa_lstm_seq_work_bytes      # the backward form exchanges 4H columns
     if torch.cuda.is_current_stream_capturing():
@@ -195,22 +199,104 @@ def _lstm_work(dev, layer: int, B: int, H: int, backward: bool = False) -> torch
         check(size_fn(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
         return torch.zeros(nbytes.value // 4, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream(dev)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st.cuda_stream, layer, B, H, backward)
+    key = (_dev_index(dev), st.cuda_stream, layer, B, H, backward)
     ent = _LSTM_WORK.get(key)
-    off = L.mfpa_lstm_seq_error_offset() // 4
     if ent is None:
         nbytes = ctypes.c_longlong(0)
         check(size_fn(B, H, ctypes.addressof(nbytes)), "mfpa_lstm_seq_work_bytes")
         buf = torch.zeros(nbytes.value // 4, dtype=torch.int32, device=dev)
-        ent = _LSTM_WORK[key] = [buf, torch.zeros(1, dtype=torch.int32).pin_memory(), None]
-    buf, host, ev = ent
-    if ev is not None and ev.query() and int(host[0]) != 0:
-        raise MfpaError("mfpa_lstm_layer_seq: a workgroup gave up waiting for its slab (the grid was not co-resident?); "
-                        "set ops_demucs.PERSISTENT_LSTM = False")
-    host.copy_(buf[off:off + 1], non_blocking=True)           # stream-ordered: the state all earlier uses left
-    ent[2] = torch.cuda.Event()
-    ent[2].record(st)
-    return buf
+        ent = _LSTM_WORK[key] = [buf, torch.zeros(1, dtype=torch.int32).pin_memory()]
+    touched = _LSTM_TOUCHED.setdefault(key[0], [])
+    if not any(e is ent for e in touched):
+        touched.append(ent)
+    return ent[0]
+
+
+def lstm_results_ok(dev) -> bool:
+    """Did every persistent LSTM launch issued on `dev` since the last call finish its waits?  Called where results leave an operator.
+
+    The kernels spin on inter-workgroup counters and need their whole grid co-resident; a wait that gives up (another process on the
+    GPU, a grid that could not become resident) raises an error word in the launch's scratch and the kernel finishes with garbage.
+    The word of every scratch buffer used since the last call is copied to pinned host memory behind the launches (stream order) and
+    read after ONE event synchronisation per stream: the host waits until the GPU has passed the recurrence -- everything the operator
+    queued behind it (the decoder, the peak picker) is still in the queue, so the GPU does not idle.
+    On error: the words are cleared, the persistent path is switched OFF for the process (PERSISTENT_LSTM / _BWD = False: the
+    per-step kernels need no co-residency) and False is returned -- the caller re-runs its launches.  Under HIP-graph capture nothing
+    can be checked (no host access): returns True, and the capture's scratch lives in the graph's pool."""
+    global PERSISTENT_LSTM, PERSISTENT_LSTM_BWD
+    idx = _dev_index(dev)
+    touched = _LSTM_TOUCHED.get(idx)
+    if not touched or torch.cuda.is_current_stream_capturing():
+        return True
+    off = lib().mfpa_lstm_seq_error_offset() // 4
+    # the buffers were used on the current stream and the side stream: the copy is ordered behind BOTH through an event
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(idx)
+    if side is not None and side is not cur:
+        cur.wait_stream(side)
+    for buf, host in touched:
+        host.copy_(buf[off:off + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    ev.synchronize()
+    bad = [e for e in touched if int(e[1][0]) != 0]
+    _LSTM_TOUCHED[idx] = []
+    if not bad:
+        return True
+    for buf, host in bad:
+        buf[off:off + 1].zero_()
+    PERSISTENT_LSTM = False
+    PERSISTENT_LSTM_BWD = False
+    import warnings
+    warnings.warn("a persistent LSTM launch gave up waiting for its slab (its grid was not co-resident: another process or kernel held "
+                  "the CUs); the per-step LSTM kernels are used from now on and the affected call is re-run", RuntimeWarning)
+    return False
+
+
+class _ResidentGuard:
+    """Accounting of persistent LSTM grids in flight on one device, so that launches issued from different streams (or host threads)
+    of this process never need more resident workgroups than the device has CUs: a grid whose workgroups cannot all become resident
+    next to another resident persistent grid would spin forever (until its bounded waits give up).  Before a launch of `wgs`
+    workgroups on stream s, launches still in flight on OTHER streams are summed; while they and the new one exceed the CU count,
+    s is made to wait (device-side, stream.wait_event -- the host never blocks) for the oldest of them."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.inflight: Dict[int, list] = {}          # device index -> [(event, stream id, workgroups)]
+
+    def admit(self, dev, wgs: int):
+        """Call right before the launch; returns a callable to call right after it (records the launch's completion event)."""
+        if wgs <= 0 or torch.cuda.is_current_stream_capturing():
+            return lambda: None
+        idx = _dev_index(dev)
+        cus = torch.cuda.get_device_properties(idx).multi_processor_count
+        st = torch.cuda.current_stream(dev)
+        with self.lock:
+            live = [e for e in self.inflight.get(idx, []) if not e[0].query()]
+            others = [e for e in live if e[1] != st.cuda_stream]
+            while others and sum(e[2] for e in others) + wgs > cus:
+                oldest = others.pop(0)
+                st.wait_event(oldest[0])
+                live.remove(oldest)
+            self.inflight[idx] = live
+
+        def done():
+            ev = torch.cuda.Event()
+            ev.record(st)
+            with self.lock:
+                self.inflight.setdefault(idx, []).append((ev, st.cuda_stream, wgs))
+        return done
+
+
+_GUARD = _ResidentGuard()
+
+
+def lstm_seq_workgroups(B: int, H: int, wg_budget: int = 0, backward: bool = False) -> int:
+    n = ctypes.c_int(0)
+    fn = lib().mfpa_lstm_bwd_seq_workgroups if backward else lib().mfpa_lstm_seq_workgroups
+    check(fn(B, H, wg_budget, ctypes.addressof(n)), "mfpa_lstm_seq_workgroups")
+    return n.value
 
 
 def lstm_seq_error() -> bool:
@@ -242,12 +328,19 @@ def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped,
         gemm(_p(x), H, 0, 1, B * Tn, wih[0], bias[0], 4 * H, _p(xp[0]), 4 * H, 0, precision=precision)
 
         work = [_lstm_work(dev, k, B, H) for k in range(2)] if PERSISTENT_LSTM else None
+        pipelined = PIPELINE_LSTM and Tn > LSTM_CHUNK and B <= PIPELINE_MAX_CLIPS
+        # two persistent launches run side by side in the chunked pipeline: each may keep half the CUs' worth of workgroups resident
+        wg_budget = torch.cuda.get_device_properties(dev).multi_processor_count // 2 if pipelined else 0
+        wgs = lstm_seq_workgroups(B, H, wg_budget) if work is not None else 0
 
         def layer(k, a, b):
             if work is not None:
+                done = _GUARD.admit(dev, wgs)
                 check(L.mfpa_lstm_layer_seq(ptr(whh_grouped[k]), ptr(xp[k]), ptr(hs[k]), ptr(cs[k]) if train else 0,
                                             0 if train else ptr(cstate[k]), B, Tn, H, ptr(xsum) if k == 1 else 0,
-                                            ptr(skip) if k == 1 else 0, int(train), a, b, ptr(work[k]), stream()), "mfpa_lstm_layer_seq")
+                                            ptr(skip) if k == 1 else 0, int(train), a, b, wg_budget, ptr(work[k]), stream()),
+                      "mfpa_lstm_layer_seq")
+                done()
                 return
             check(L.mfpa_lstm_layer_range(ptr(whh_grouped[k]), ptr(xp[k]), ptr(hs[k]), ptr(cs[k]) if train else 0,
                                           0 if train else ptr(cstate[k]), B, Tn, H, ptr(xsum) if k == 1 else 0,
@@ -257,7 +350,7 @@ def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped,
             gemm(_p(hs[0], a * H), H, Tn * H, B, b - a, wih[1], bias[1], 4 * H, _p(xp[1], a * 4 * H), 4 * H, Tn * 4 * H,
                  precision=precision)
 
-        if not PIPELINE_LSTM or Tn <= LSTM_CHUNK or B > PIPELINE_MAX_CLIPS:
+        if not pipelined:
             layer(0, 0, Tn)
             gemm(_p(hs[0]), H, 0, 1, B * Tn, wih[1], bias[1], 4 * H, _p(xp[1]), 4 * H, 0, precision=precision)
             layer(1, 0, Tn)
@@ -283,7 +376,16 @@ def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped,
 
 def demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: int = PRECISION) -> torch.Tensor:
     """(B, T) float32 on the GPU -> (B, T) denoised waveform.  model.py:290-326.  `precision` selects the GEMM arithmetic
-    (the fused LSTM step is always bf16x3)."""
+    (the fused LSTM step is always bf16x3).  Before the result is returned the persistent LSTM launches' error words are read
+    (lstm_results_ok: one event wait, the decoder stays queued behind it); a launch that gave up is re-run on the per-step kernels."""
+    out = _demucs_forward(pw, wav, precision)
+    if not lstm_results_ok(wav.device):
+        out = _demucs_forward(pw, wav, precision)               # PERSISTENT_LSTM is off now: no co-residency needed
+        lstm_results_ok(wav.device)
+    return out
+
+
+def _demucs_forward(pw: Dict[str, torch.Tensor], wav: torch.Tensor, precision: int = PRECISION) -> torch.Tensor:
     import functools
     gemm_p = functools.partial(gemm, precision=precision)
     B, T = wav.shape

@@ -450,10 +450,14 @@ class DemucsTrainEngine:
         wg_budget = torch.cuda.get_device_properties(dev).multi_processor_count // 2 if pipelined else 0
         bwork = {id(g1): D._lstm_work(dev, 1, B, H, backward=True), id(g0): D._lstm_work(dev, 0, B, H, backward=True)} if D.PERSISTENT_LSTM_BWD else None
 
+        bwgs = D.lstm_seq_workgroups(B, H, wg_budget, backward=True) if bwork is not None else 0
+
         def bwd(whhT, gates, cseq, dhout, dc, a, b):
             if bwork is not None:            # one persistent launch for the range (csrc/demucs_train.hip: lstm_bwd_seq_kernel)
+                done = D._GUARD.admit(dev, bwgs)
                 check(L.mfpa_lstm_layer_bwd_seq(ptr(whhT), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, a, b, wg_budget,
                                                 ptr(bwork[id(gates)]), stream()), "mfpa_lstm_layer_bwd_seq")
+                done()
                 return
             check(L.mfpa_lstm_layer_bwd_range(ptr(whhT), ptr(gates), ptr(cseq), ptr(dhout), ptr(dc), B, Tn, H, a, b, stream()),
                   "mfpa_lstm_layer_bwd_range")
@@ -586,6 +590,14 @@ class DemucsTrainEngine:
             l1, sc, mag, dpred = self.loss_and_grad(pred, clean, Cys)
         with _Phase(self, "backward"):
             self.backward(dpred)
+        # the persistent LSTM launches' error words, read BEFORE the parameters are touched (one event wait: the host catches up with
+        # the GPU at the end of the backward recurrence, the encoder's backward launches stay queued behind it).  A launch that gave
+        # up (its grid was not co-resident) leaves garbage gradients: the step is repeated on the per-step kernels.
+        if not D.lstm_results_ok(clean.device):
+            pred = self.forward(augmented.contiguous())
+            l1, sc, mag, dpred = self.loss_and_grad(pred, clean, Cys)
+            self.backward(dpred)
+            D.lstm_results_ok(clean.device)
         with _Phase(self, "adam"):
             self.adam_step()
         self.last_losses = (l1, sc, mag)

@@ -186,6 +186,9 @@ class UNetTrainEngine:
         # RCCL path of a one-GPU box: tests/test_gpu_dist.py, `torchrun --nproc-per-node 1 bench.py --mode train`)
         self.collectives_at_world_one = bool(collectives_at_world_one)
         self.comm_calls, self.comm_bytes = 0, 0            # collectives issued by this engine / their payload bytes
+        # set to a list (bench.py): a pair of events on the compute stream around the gradient-bucket waits of every step, i.e. the
+        # all-reduce time that backward did NOT hide
+        self.comm_wait_events = None
         # arithmetic of the convolutions: 0 = fp32 MFMA, 1 = bf16x3 (3 bf16 MFMAs per fp32 product); `wgrad_precision`
         # overrides it for the weight-gradient kernel, which also offers 2 = plain bf16 products (a weight gradient sums over
         # every pixel of the batch: relative L1 ~2e-3).  Reductions, BatchNorm statistics, the loss and Adam are fp32/fp64.
@@ -498,9 +501,17 @@ class UNetTrainEngine:
                 check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
                                                   st.drop[0], st.drop[1], st.drop[2], stream()), "mfpa_maxpool2_bwd_add")
             handles.append(self._reduce_bucket(name))
+        ev = None
+        if self.comm_wait_events is not None and any(h is not None for h in handles):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
         for h in handles:
             if h is not None:
                 h.wait()
+        if ev is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.comm_wait_events.append((ev, ev1))
         self._recs = None
 
     def _reduce_bucket(self, name):

@@ -40,8 +40,9 @@ def _psnr(pred: torch.Tensor, target64: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def compute_peaks_metrics(clean_wav: torch.Tensor, augmented_wav: torch.Tensor, analyzer_no_den: Audfprint_peaks,
-                          analyzer_den: Audfprint_peaks, batch: int = 256) -> Dict[str, float]:
-    """clean_wav, augmented_wav: (N, T) float32 (any device).  Returns the reference's result dictionary."""
+                          analyzer_den: Audfprint_peaks, batch: int = 256, per_query: bool = False):
+    """clean_wav, augmented_wav: (N, T) float32 (any device).  Returns the reference's result dictionary; with
+    `per_query=True` also the (N, 8) float64 tensor of per-query values behind the means (columns in the dictionary's key order)."""
     import torch.distributed as dist
     N = clean_wav.shape[0]
     ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -73,7 +74,7 @@ def compute_peaks_metrics(clean_wav: torch.Tensor, augmented_wav: torch.Tensor, 
     mean = (local.sum(dim=0) / max(N, 1)).cpu().tolist()             # sums in query order: identical on every rank
     keys = ["precision_no_den", "recall_no_den", "f1_score_no_den", "psnr_no_den_spec", "prec_den", "rec_den", "f1_den",
             "psnr_den_spec"]
-    return dict(zip(keys, mean))
+    return (dict(zip(keys, mean)), local) if per_query else dict(zip(keys, mean))
 
 
 def compute_peaks_metrics_files(queries_augmented, clean_dir: str, analyzer_no_den: Audfprint_peaks, analyzer_den: Audfprint_peaks,

@@ -50,6 +50,44 @@ class EarlyStopping:
                 self.early_stop = True
 
 
+class _RefEarlyStopping(EarlyStopping):
+    """EarlyStopping under the reference's pickle name (training.train.EarlyStopping, train.py:582-612, same attributes): what
+    `last_epoch.pt` holds under "early_stopping", so that the reference unpickles this package's checkpoints into ITS class and
+    this package reads the reference's with `torch.load(weights_only=True)` plus this one allow-listed name."""
+
+
+_RefEarlyStopping.__module__ = "training.train"
+_RefEarlyStopping.__qualname__ = _RefEarlyStopping.__name__ = "EarlyStopping"
+
+
+class _MainEarlyStopping(EarlyStopping):
+    """The same class as pickled by a reference run started with `python -m training.train` (train.py:697): there the defining
+    module is `__main__`.  Allow-listed for loading only."""
+
+
+_MainEarlyStopping.__module__ = "__main__"
+_MainEarlyStopping.__qualname__ = _MainEarlyStopping.__name__ = "EarlyStopping"
+
+
+def _early_stopping_for_pickle(es: EarlyStopping):
+    """(object to pickle, sys.modules entries to hold while pickling).  pickle resolves `training.train.EarlyStopping` when it
+    WRITES too: inside a process that has the reference imported that is the reference's own class, otherwise a stub module."""
+    import sys
+    import types
+    ref = sys.modules.get("training.train")
+    if ref is not None and hasattr(ref, "EarlyStopping"):
+        cls, alias = ref.EarlyStopping, {}
+    else:
+        stub = types.ModuleType("training.train")
+        stub.EarlyStopping = _RefEarlyStopping
+        cls, alias = _RefEarlyStopping, {"training.train": stub}
+        if "training" not in sys.modules:
+            alias["training"] = types.ModuleType("training")
+    obj = cls.__new__(cls)
+    obj.__dict__.update(patience=es.patience, min_delta=es.min_delta, counter=es.counter, best_loss=es.best_loss, early_stop=es.early_stop)
+    return obj, alias
+
+
 class ReduceLROnPlateau:
     """torch.optim.lr_scheduler.ReduceLROnPlateau(mode="min", factor, patience) on the engine's lr
     (default relative threshold 1e-4, cooldown 0), as wired at train.py:662-666."""
@@ -340,40 +378,48 @@ class Trainer:
         if self.ckpt_path is None or not self.save:
             return
         dist, world, rank = _dist_group(self.group)
+        self.engine.sync_to_module()          # every rank: whoever reads trainer.model afterwards sees the trained weights
+        err = None
         if rank == 0:
-            os.makedirs(self.ckpt_path, exist_ok=True)
-            self.engine.sync_to_module()
-            sd = self.model.state_dict()
-            if best:
-                torch.save({"model_state_dict": sd, "best_val_loss": self.best_val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
-            torch.save({"epoch": self.epoch, "model_state_dict": sd, "optimizer_state_dict": self._optimizer_state_dict(),
-                        "scheduler_state_dict": self.scheduler.state_dict(), "early_stopping": self.early_stopping,
-                        "train_loss": train_loss if train_loss is not None else {"loss": self.losses["train"][-1] if self.losses["train"] else None},
-                        "val_losses": val_losses if val_losses is not None else {"loss": val_loss},
-                        "best_val_loss": self.best_val_loss, "losses": self.losses},
-                       os.path.join(self.ckpt_path, "last_epoch.pt"))
+            try:
+                os.makedirs(self.ckpt_path, exist_ok=True)
+                sd = self.model.state_dict()
+                if best:
+                    torch.save({"model_state_dict": sd, "best_val_loss": self.best_val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
+                import sys
+                es_obj, alias = _early_stopping_for_pickle(self.early_stopping)
+                sys.modules.update(alias)
+                try:
+                    torch.save({"epoch": self.epoch, "model_state_dict": sd, "optimizer_state_dict": self._optimizer_state_dict(),
+                                "scheduler_state_dict": self.scheduler.state_dict(), "early_stopping": es_obj,
+                                "train_loss": train_loss if train_loss is not None else {"loss": self.losses["train"][-1] if self.losses["train"] else None},
+                                "val_losses": val_losses if val_losses is not None else {"loss": val_loss},
+                                "best_val_loss": self.best_val_loss, "losses": self.losses},
+                               os.path.join(self.ckpt_path, "last_epoch.pt"))
+                finally:
+                    for k in alias:
+                        sys.modules.pop(k, None)
+            except Exception as e:            # the other ranks are waiting: tell them before raising
+                err = e
         if world > 1:
-            dist.barrier(group=self.group)
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.device)
+            dist.broadcast(flag, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            if err is None and int(flag.item()):
+                raise RuntimeError("rank 0 failed to write the checkpoint")
+        if err is not None:
+            raise err
 
     def load_checkpoint(self) -> bool:
-        """train.py:130-161.  The reference pickles its EarlyStopping OBJECT (class training.train.EarlyStopping): while its file is
-        read that module path resolves to this module, so a checkpoint written by the reference loads here."""
+        """train.py:130-161.  Read with `torch.load(weights_only=True)`: tensors and plain containers, plus ONE allow-listed class
+        name -- training.train.EarlyStopping (`__main__.EarlyStopping` when the reference ran as `python -m training.train`), the object
+        the reference pickles under "early_stopping" (train.py:215) and this
+        package writes under the same name (_RefEarlyStopping) -- so nothing in a `last_epoch.pt` can run code here, and the file
+        goes both ways: the reference's loader unpickles this package's checkpoint into its own EarlyStopping class."""
         path = None if self.ckpt_path is None else os.path.join(self.ckpt_path, "last_epoch.pt")
         if path is None or not os.path.exists(path):
             return False
-        import sys
-        import types
-        alias = {}
-        if "training.train" not in sys.modules:
-            alias["training.train"] = sys.modules[__name__]
-            if "training" not in sys.modules:
-                alias["training"] = types.ModuleType("training")
-        sys.modules.update(alias)
-        try:
-            ck = torch.load(path, map_location=self.device, weights_only=False)
-        finally:
-            for k in alias:
-                sys.modules.pop(k, None)
+        with torch.serialization.safe_globals([_RefEarlyStopping, _MainEarlyStopping]):
+            ck = torch.load(path, map_location=self.device, weights_only=True)
         self.model.load_state_dict(ck["model_state_dict"])
         self.engine.load_from_module()
         self._load_optimizer_state_dict(ck["optimizer_state_dict"])

@@ -43,6 +43,12 @@ def test_host_only_entry_points(lib):
     np.testing.assert_allclose(out[512:1024:2], np.cos(2 * np.pi * m / 256), atol=3e-16)
     np.testing.assert_allclose(out[513:1024:2], -np.sin(2 * np.pi * m / 256), atol=3e-16)
     assert h.mfpa_stft_tables(None, None) == lib.EINVAL
+    # resident workgroups of a persistent LSTM launch: host arithmetic against the current device's CU count (none here -> 0,
+    # i.e. the per-step path); bad arguments are rejected
+    n = ctypes.c_int(-1)
+    assert h.mfpa_lstm_seq_workgroups(64, 768, 0, ctypes.addressof(n)) == 0 and n.value >= 0
+    assert h.mfpa_lstm_bwd_seq_workgroups(64, 768, 0, ctypes.addressof(n)) == 0 and n.value >= 0
+    assert h.mfpa_lstm_seq_workgroups(64, 768, 0, None) == lib.EINVAL and h.mfpa_lstm_seq_workgroups(64, 100, 0, ctypes.addressof(n)) == lib.EINVAL
 
 
 def test_argument_errors_do_not_touch_the_gpu(lib):

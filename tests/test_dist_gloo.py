@@ -100,3 +100,22 @@ def test_bench_self_launches_its_ranks_when_called_with_gpus_2():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["max_rank_seen"] == 1 and out["value"] is None
+
+
+def test_bench_line_verifies_itself_with_eight_ranks():
+    """The driver's 8-GPU launch, rehearsed on CPU ranks over gloo (--mode launch-check: no kernel): `ranks_seen` -- a SUM
+    all-reduce of 1 over the process group -- equals the world size and every rank's own figure arrives by all-gather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--mode", "launch-check"], env=env,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["config"]["max_rank_seen"] == 7
+    assert out["per_rank_value"] == [float(k + 1) for k in range(8)]

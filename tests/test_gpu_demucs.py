@@ -254,3 +254,119 @@ def test_first_encoder_level_with_two_workgroups_per_cu_is_bit_exact():
         y = torch.full((B, Lout, C), float("nan"), device="cuda")
         check(lib().mfpa_conv1d_c1_glu(ptr(x), B, Lin, Lout, C, ptr(w0), ptr(b0), ptr(gw), ptr(gb), ptr(y), stream()), "head")
         assert torch.equal(y, ref)
+
+
+def test_one_channel_kernels_beside_an_mfma_gemm_on_a_second_stream_are_bit_exact():
+    """mfpa_conv1d_c1 and mfpa_c1_wgrad (the two one-channel ends of the Demucs training step) at > 256 workgroups on a side
+    stream while a bf16x3 MFMA GEMM keeps the main stream busy -- DemucsTrainEngine.train_step overlaps exactly these
+    (ops_demucs_train.py: the clean signal's STFT GEMMs run on a side stream while forward() starts with mfpa_conv1d_c1).  Both
+    kernels contained `v_pk_fma_f32 ... op_sel:[0,1,0]`, the form that returned wrong low lanes next to MFMA waves
+    (profiles/r02_pk_fma_op_sel.md); they are now compiled without packed fp32 (MFPA_NO_PK_F32, tests/test_isa_scan.py).
+    Four overlapped runs must reproduce the bits of a run with the GPU to itself."""
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd._lib import check, lib, ptr, stream
+    C, B, Lout = 48, 16, 64084                                      # 16 x 64084 x 12 quads / 256 threads = 48 063 workgroups' worth
+    Lin = 4 * (Lout - 1) + 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Lin, generator=g).cuda()
+    w0 = (torch.randn(8, C, generator=g) / np.sqrt(8)).cuda()
+    b0 = (torch.randn(C, generator=g) * 0.3).cuda()
+    gr = torch.randn(B, Lout, C, generator=g).cuda()
+    # the MFMA work: a K = 768, N = 768 GEMM over 64 x 2048 rows (about 1 ms per launch), bf16x3
+    M, K, N = 2048, 768, 768
+    A = torch.randn(64, M, K, generator=g).cuda()
+    Wg = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    bg = torch.zeros(N, device="cuda")
+    Cg = torch.empty(64, M, N, device="cuda")
+
+    def head(y):
+        check(lib().mfpa_conv1d_c1(ptr(x), B, Lin, Lout, C, ptr(w0), ptr(b0), 1, ptr(y), stream()), "conv1d_c1")
+
+    def wgrad(dw):
+        dw.zero_()
+        check(lib().mfpa_c1_wgrad(ptr(x), Lin, ptr(gr), C, Lout * C, B, Lout, C, ptr(dw), stream()), "c1_wgrad")
+
+    y_ref = torch.empty(B, Lout, C, device="cuda")
+    head(y_ref)
+    want = torch.relu(torch.nn.functional.conv1d(x[:, None, :], w0.t()[:, None, :], b0, stride=4)).permute(0, 2, 1)
+    assert (y_ref - want).abs().max().item() < 1e-5
+    dw_runs = []
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(4):
+        y = torch.full((B, Lout, C), float("nan"), device="cuda")
+        dw = torch.empty(8, C, device="cuda")
+        side.wait_stream(torch.cuda.current_stream())
+        for _ in range(3):                                           # main stream: MFMA waves on every CU for ~3 ms
+            D.gemm(D._p(A), K, M * K, 64, M, Wg, bg, N, D._p(Cg), N, M * N, precision=1)
+        with torch.cuda.stream(side):
+            head(y)
+            wgrad(dw)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref)
+        dw_runs.append(dw.clone())
+    # the weight gradient adds partial sums with float atomics (order varies): equal to rounding, and right against torch
+    want_dw = torch.einsum("btj,btc->jc", x.double().unfold(1, 8, 4)[:, :Lout].cpu(), gr.double().cpu())
+    for dw in dw_runs:
+        assert (dw.double().cpu() - want_dw).abs().max().item() < 2e-3 * want_dw.abs().max().item()
+
+
+def test_persistent_lstm_failure_is_caught_before_the_result_leaves_and_the_call_is_rerun(net):
+    """A persistent LSTM launch whose waits gave up (grid not co-resident: another process on the GPU) returns garbage and raises the
+    error word of its scratch.  Simulated by raising the word by hand -- the kernel then skips every wait, exactly the state after a
+    give-up.  demucs_forward must notice BEFORE returning (ops_demucs.lstm_results_ok), clear the word, switch the persistent path
+    off for the process, re-run on the per-step kernels and return the right audio -- also for the only / last call of a run."""
+    from musicfpaugment_amd import ops_demucs as D
+    from musicfpaugment_amd._lib import lib
+    from oracle.unet import relative_l1
+    x = torch.from_numpy(synth.batch(3, seed=77, n=16000)).cuda()
+    old = (D.PERSISTENT_LSTM, D.PERSISTENT_LSTM_BWD)
+    try:
+        D.PERSISTENT_LSTM = True
+        want = net(x)                                                 # healthy run (creates the scratch buffers of this shape)
+        assert D.PERSISTENT_LSTM and not D.lstm_seq_error()
+        off = lib().mfpa_lstm_seq_error_offset() // 4
+        for ent in D._LSTM_WORK.values():
+            ent[0][off] = 1
+        with pytest.warns(RuntimeWarning, match="persistent LSTM"):
+            got = net(x)
+        assert not D.PERSISTENT_LSTM and not D.PERSISTENT_LSTM_BWD    # off for the rest of the process
+        assert not D.lstm_seq_error()                                 # words cleared
+        assert relative_l1(got.cpu(), want.cpu()) <= 1e-5             # the per-step kernels' result (same arithmetic, other schedule)
+        assert relative_l1(net(x).cpu(), want.cpu()) <= 1e-5          # and later calls stay right
+    finally:
+        D.PERSISTENT_LSTM, D.PERSISTENT_LSTM_BWD = old
+
+
+def test_resident_guard_orders_persistent_grids_that_do_not_fit_side_by_side():
+    """ops_demucs._ResidentGuard: persistent grids in flight on OTHER streams of this process are accounted for; a new one that
+    would push the resident workgroups past the CU count makes its stream wait (device-side) for the oldest of them, one that fits
+    does not wait.  Checked with events around a long-running kernel standing in for the first grid."""
+    from musicfpaugment_amd import ops_demucs as D
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    guard = D._ResidentGuard()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(first_wgs, second_wgs):
+        with torch.cuda.stream(a):
+            done = guard.admit(dev, first_wgs)
+            for _ in range(6):
+                big @ big                                              # tens of milliseconds on stream a
+            done()
+            end_a = torch.cuda.Event(enable_timing=True)
+            end_a.record(a)
+        with torch.cuda.stream(b):
+            guard.admit(dev, second_wgs)()
+            at_b = torch.cuda.Event(enable_timing=True)
+            at_b.record(b)
+        torch.cuda.synchronize()
+        return end_a.elapsed_time(at_b)                                # > 0: stream b got past its admit only after a's work ended
+
+    assert run(cus - 64, 128) >= 0.0                                   # 192 + 128 > 256 CUs: b waits for a
+    assert run(64, 64) < 0.0                                           # fits side by side: b does not wait
+    assert D.lstm_seq_workgroups(256, 768) == 4 * 48 and D.lstm_seq_workgroups(64, 768, cus // 2) == 2 * 48
+    assert D.lstm_seq_workgroups(96, 768, cus // 2) == 2 * 48 and D.lstm_seq_workgroups(4096, 768) == 0      # too many slabs: per-step path

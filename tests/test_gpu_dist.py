@@ -17,15 +17,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# torch.distributed.run binds its own rendezvous port (c10d endpoint 127.0.0.1:0 under --standalone): no fixed port to clash on a
+# shared box.  Workers still find MASTER_ADDR / MASTER_PORT in their environment.
+RDZV = ("--standalone", "--local-addr", "127.0.0.1")
+
+
 def _check(r):
-    """Fail on a real error of the workers; skip when the two-process rendezvous itself cannot be set up on this host."""
+    """A failed launch is an ERROR, also when it is the rendezvous that failed: these tests are the only multi-process (and the only
+    RCCL) evidence a one-GPU box can give, so they must not turn into skips silently.  MFPA_REQUIRE_DIST=0 restores the skip for
+    hosts where a second process cannot be started at all."""
     if r.returncode == 0:
         return
     tail = r.stdout[-2000:] + r.stderr[-4000:]
-    for marker in ("RendezvousError", "RendezvousConnectionError", "Address already in use", "EADDRINUSE",
-                   "failed to connect", "Connection refused", "DistNetworkError"):
-        if marker in tail:
-            pytest.skip("two-process rendezvous unavailable here: " + marker)
+    if os.environ.get("MFPA_REQUIRE_DIST", "1") == "0":
+        for marker in ("RendezvousError", "RendezvousConnectionError", "Address already in use", "EADDRINUSE",
+                       "failed to connect", "Connection refused", "DistNetworkError"):
+            if marker in tail:
+                pytest.skip("two-process rendezvous unavailable here: " + marker)
     raise AssertionError(tail)
 
 
@@ -35,8 +43,7 @@ def test_two_rank_train_step_matches_the_emulated_data_parallel_step():
     from musicfpaugment_amd.training.unet import UNet
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29533", os.path.join(ROOT, "tests", "_dist_train_worker.py"), tmp]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "tests", "_dist_train_worker.py"), tmp]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         _check(r)
         got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]
@@ -81,8 +88,7 @@ def test_two_rank_peak_metrics_experiment_equals_single_process():
     want = worker.run()                                                          # world size 1: no collective
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29534", os.path.join(ROOT, "tests", "_dist_metrics_worker.py"), tmp]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "tests", "_dist_metrics_worker.py"), tmp]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         _check(r)
         got = json.load(open(os.path.join(tmp, "metrics.json")))
@@ -97,8 +103,7 @@ def test_bench_runs_under_torchrun_with_two_ranks(mode):
     bucketed gradient all-reduce in train mode) with two ranks sharing cuda:0 over gloo (MFPA_DIST_BACKEND; the driver uses RCCL)."""
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MFPA_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8",
            "--mode", mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     _check(r)
@@ -109,6 +114,11 @@ def test_bench_runs_under_torchrun_with_two_ranks(mode):
     assert out["scaling"] == "weak" and out["unit"] == "clips/s" and "roofline" in out
     assert "cpu_baseline" not in out                                             # N = 1 only
     assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 0.01 * out["value"]   # whole-job aggregate
+    # the line verifies itself: a SUM all-reduce of 1 over the group saw both ranks, and each rank's own rate is there
+    assert out["ranks_seen"] == 2 and len(out["per_rank_value"]) == 2 and min(out["per_rank_value"]) > 0
+    assert sum(out["per_rank_value"]) >= 0.99 * out["value"]                     # value uses the MAX time over ranks
+    if mode == "train":
+        assert out["config"]["allreduce_exposed_wait_ms_per_step"] is not None and out["config"]["allreduce_exposed_wait_ms_per_step"] >= 0
 
 
 @pytest.mark.parametrize("mode", ["infer", "train"])
@@ -139,8 +149,7 @@ def test_bench_on_rccl_at_world_size_one(mode):
     import json
     env = {k: v for k, v in os.environ.items() if k != "MFPA_DIST_BACKEND"}
     env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29538", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips", "8",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", *RDZV, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--clips", "8",
            "--mode", mode, "--cpu-seconds", "0", "--no-configs"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     _check(r)
@@ -148,6 +157,7 @@ def test_bench_on_rccl_at_world_size_one(mode):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["dist_backend"].startswith("rccl")
+    assert out["ranks_seen"] == 1 and len(out["per_rank_value"]) == 1           # all-reduce / all-gather on the device through RCCL
     if mode == "train":
         assert out["config"]["allreduce_calls_per_step"] == 11 and out["config"]["allreduce_bytes_per_step"] == 31_036_481 * 4 + 16 and np.isfinite(out["config"]["loss_last"])
 
@@ -163,8 +173,7 @@ def test_two_rank_sync_batchnorm_step_equals_the_single_gpu_step():
     want = eng.flat_p.cpu().numpy()
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29536", os.path.join(ROOT, "tests", "_dist_syncbn_worker.py"), tmp]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "tests", "_dist_syncbn_worker.py"), tmp]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         _check(r)
         got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]
@@ -183,12 +192,13 @@ def test_two_rank_trainer_loop_keeps_the_replicas_and_their_decisions_in_step():
     same epoch, same best loss), the parameters stay bit-identical, and rank 0 alone writes last_epoch.pt / best_epoch.pt."""
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29539", os.path.join(ROOT, "tests", "_dist_trainer_worker.py"), tmp]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "tests", "_dist_trainer_worker.py"), tmp]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         _check(r)
         got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]
-        ck = torch.load(os.path.join(tmp, "ckpt", "last_epoch.pt"), weights_only=False)
+        from musicfpaugment_amd.training.train import _RefEarlyStopping
+        with torch.serialization.safe_globals([_RefEarlyStopping]):
+            ck = torch.load(os.path.join(tmp, "ckpt", "last_epoch.pt"), weights_only=True)
         assert os.path.exists(os.path.join(tmp, "ckpt", "best_epoch.pt"))
     np.testing.assert_array_equal(got[0]["params"], got[1]["params"])
     np.testing.assert_array_equal(got[0]["val"], got[1]["val"])                  # the rank-averaged losses
@@ -205,8 +215,7 @@ def test_two_rank_demucs_train_step():
     from musicfpaugment_amd.training.demucs_weights import formula_state_dict as demucs_formula
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29537", os.path.join(ROOT, "tests", "_dist_demucs_worker.py"), tmp]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "tests", "_dist_demucs_worker.py"), tmp]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         _check(r)
         got = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(2)]

@@ -244,7 +244,10 @@ def test_checkpoint_is_the_reference_format_and_resume_continues_identically(tmp
     a = make(str(tmp_path / "a"))
     a.training_loop(nb_epochs=3)                          # epochs 1, 2
     assert a.epoch == 2 and len(a.losses["val"]) == 2
-    ck = torch.load(tmp_path / "a" / "last_epoch.pt", weights_only=False)
+    from musicfpaugment_amd.training.train import _RefEarlyStopping
+    with torch.serialization.safe_globals([_RefEarlyStopping]):
+        ck = torch.load(tmp_path / "a" / "last_epoch.pt", weights_only=True)      # tensors, containers and the ONE allow-listed class
+    assert type(ck["early_stopping"]).__module__ == "training.train" and type(ck["early_stopping"]).__name__ == "EarlyStopping"
     assert {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "early_stopping", "train_loss", "val_losses",
             "best_val_loss"} <= set(ck)
     assert ck["epoch"] == 2 and ck["best_val_loss"] == min(a.losses["val"]) == a.best_val_loss       # updated BEFORE last_epoch.pt
@@ -273,6 +276,7 @@ def test_checkpoint_is_the_reference_format_and_resume_continues_identically(tmp
     assert abs(la - lb) <= 1e-6 * abs(la) and rel <= 2.1e-3         # float-atomic weight gradients: not bit-reproducible run to run
     # a private-format optimizer state (round 1 of this package) is refused with a clear message
     ck["optimizer_state_dict"] = {"exp_avg": a.engine.flat_m, "exp_avg_sq": a.engine.flat_v, "step": 1, "lr": 1e-3}
+    ck["early_stopping"] = dict(vars(ck["early_stopping"]))          # a plain dict is read as well (and pickles without the class)
     torch.save(ck, tmp_path / "a" / "last_epoch.pt")
     with pytest.raises(ValueError, match="torch.optim.Adam state_dict"):
         make(str(tmp_path / "a")).load_checkpoint()

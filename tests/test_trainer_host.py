@@ -2,6 +2,8 @@
 torch's own semantics (training/train.py:582-612, :662-666)."""
 import math
 
+import pytest
+
 import torch
 
 from musicfpaugment_amd.training.train import EarlyStopping, ReduceLROnPlateau
@@ -56,3 +58,33 @@ def test_plateau_scheduler_matches_torch_and_round_trips_its_state():
     other = ReduceLROnPlateau(_Eng(), factor=0.5, patience=9)
     other.load_state_dict(ref.state_dict())               # torch's own state loads
     assert (other.best, other.num_bad) == (ref.best, ref.num_bad_epochs) and (other.factor, other.patience) == (0.1, 2)
+
+
+def test_early_stopping_is_pickled_under_the_reference_name_and_read_with_weights_only():
+    """last_epoch.pt's "early_stopping" entry (training/train.py:215 pickles the OBJECT): written under the reference's class name,
+    so the reference unpickles it into its own class, and read back with torch.load(weights_only=True) plus that one allow-listed
+    name -- no arbitrary unpickling, no sys.modules alias left behind."""
+    import io
+    import sys
+    import torch
+    from musicfpaugment_amd.training.train import _MainEarlyStopping, _RefEarlyStopping, _early_stopping_for_pickle
+    es = EarlyStopping(7, 0.01)
+    es(1.0)
+    es(1.5)
+    obj, alias = _early_stopping_for_pickle(es)
+    sys.modules.update(alias)
+    try:
+        buf = io.BytesIO()
+        torch.save({"early_stopping": obj, "t": torch.ones(3)}, buf)
+    finally:
+        for k in alias:
+            sys.modules.pop(k, None)
+    assert "training.train" not in sys.modules and b"training.train" in buf.getvalue()
+    buf.seek(0)
+    with pytest.raises(Exception):
+        torch.load(buf, weights_only=True)                               # not allow-listed: refused
+    buf.seek(0)
+    with torch.serialization.safe_globals([_RefEarlyStopping, _MainEarlyStopping]):
+        got = torch.load(buf, weights_only=True)["early_stopping"]
+    assert vars(got) == dict(patience=7, min_delta=0.01, counter=1, best_loss=1.0, early_stop=False)
+    assert (type(got).__module__, type(got).__name__) == ("training.train", "EarlyStopping")
