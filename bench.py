@@ -342,7 +342,10 @@ def bench_metrics(args, rank, world, dev, dist):
             "config": {"workload": f"{N} synthetic 8 s queries (AugmentFP on the device), denoiser {args.denoiser}, Audfprint "
                                    "peaks, per-query precision/recall/F1/PSNR means", "queries": N,
                        "parallelism": f"queries sharded x{world}, one all-gather of the per-query rows"},
-            "result": {k: round(v, 6) for k, v in res.items()}})
+            # strict JSON: a mean that is not finite (psnr_no_den_spec is +inf as soon as ONE query was left untouched by AugmentFP: mse 0
+            # against its clean clip, 10 log10(range^2 / 0), as in the reference) is written as null and named in `non_finite`
+            "result": {k: (round(v, 6) if np.isfinite(v) else None) for k, v in res.items()},
+            "non_finite": {k: repr(float(v)) for k, v in res.items() if not np.isfinite(v)}})
     return result
 
 
@@ -790,12 +793,17 @@ def main():
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick; launch-check: launcher plumbing only (tests)")
+    ap.add_argument("--no-weights-direct", action="store_true",
+                    help="A/B runs: the UNet's 128-channel-tile layers on the LDS-staged weight tiles instead of the weights-direct kernel")
     ap.add_argument("--lib", default=None, help="experiments only: bind another build of the library (e.g. musicfpaugment_amd/libmfpa_exp.so)")
     args = ap.parse_args()
     args.sub_config = False
     if args.lib:
         from musicfpaugment_amd import _lib
         _lib.set_library_path(args.lib)
+    if args.no_weights_direct:
+        from musicfpaugment_amd import ops_unet
+        ops_unet.USE_WEIGHTS_DIRECT = False
     if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
         args.precision = "bf16x3"
     if args.wgrad is None:
@@ -860,7 +868,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             result["configs"] = other_configs(args, dev)
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result, allow_nan=False), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

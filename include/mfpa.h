@@ -227,8 +227,15 @@ typedef struct mfpa_conv_desc {
    * in HBM (unet.py:8-24, 86). */
   const float* c1_x32; const double* c1_spec64; const double* c1_denom;
   const float* c1_w; const float* c1_scale; const float* c1_shift;
+  /* precision 1, mode 0: which bf16x3 image `w` holds.  0 = the row image ([tap][Cin / 32][Cout][128 B], staged through LDS);
+   * 1 = the FRAGMENT-ORDERED image ([tap][Cin / 32][Cout / 32][substep 2][hi | lo][lane 64][16 B]: a wave reads the MFMA B
+   * operand of a 32-channel column tile straight from L1 / L2, no weight tile in LDS, one barrier per 32-channel chunk instead
+   * of one per tap) -- only for shapes where mfpa_conv_weight_layout() returns 1, MFPA_EINVAL otherwise. */
+  int w_layout;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
+/* HOST function: 1 when the fastest kernel for a (H, W) convolution of this shape reads the fragment-ordered image, else 0. */
+int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision);
 
 /* First layer: 3x3 conv from ONE input channel (inc.double_conv.0, unet.py:86) fused with the
  * spectrogram normalisation: x = (float)(spec / denom) when spec64 != NULL, else x32 as is.

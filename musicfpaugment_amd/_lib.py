@@ -58,6 +58,7 @@ _SIGNATURES = {
                        c_void_p], c_int),
     "mfpa_conv1x1_out": ([c_void_p, c_longlong, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "mfpa_conv_mfma": ([c_void_p, c_void_p], c_int),
+    "mfpa_conv_weight_layout": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int),
     "mfpa_gemm_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_lowpass_taps": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_fir": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
@@ -155,7 +156,7 @@ class ConvDesc(ctypes.Structure):
                 ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int),
                 ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p),
                 ("c1_x32", c_void_p), ("c1_spec64", c_void_p), ("c1_denom", c_void_p),
-                ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p)]
+                ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int)]
 
 
 class GemmDesc(ctypes.Structure):

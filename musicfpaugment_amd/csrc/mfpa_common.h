@@ -37,7 +37,11 @@
 // this toolchain (profiles/r02_pk_fma_op_sel.md), so the product library contains none: every kernel in which hipcc chose it carries
 // this attribute (same IEEE results: a packed FMA is two scalar FMAs), and tests/test_isa_scan.py disassembles the shipped
 // libmfpa.so and fails on any packed-fp32 instruction with an op_sel:[...] operand selection.
+#if defined(__HIP_DEVICE_COMPILE__)
 #define MFPA_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MFPA_NO_PK_F32      // host pass of the same translation unit: the attribute names a gfx950 feature
+#endif
 
 // One scalar v_fma_f32, kept from being paired into v_pk_fma_f32 (the empty asm): for a few FMAs inside a large templated kernel
 // whose other packed arithmetic should stay packed.

@@ -110,6 +110,7 @@ struct ConvArgs {
   const float* w1x1;                 // optional fused OutConv 1x1 to one class (needs the whole Cout in one workgroup):
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
+  int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
   int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
   // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
   // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
@@ -142,7 +143,15 @@ struct ConvArgs {
 // MT_ = 32-pixel MFMA tiles per wave: 2 (a wave owns 64 pixels), or 4 -- 128 pixels x (BN / WN) channels per wave, FOUR waves for the
 // 256 x 128 tile, one per SIMD with the whole register file (256 VGPRs + 206 AGPRs, no scratch): 12 fragment reads per 24 MFMAs
 // instead of 16, a quarter less LDS traffic.  Measured 3-17 % slower per layer than two 64-pixel waves per SIMD (MFPA_CONV_MT4).
-template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false, int MT_ = 2>
+// BDIR ("weights direct"): the pipelined loop with NO weight tile in LDS.  8 waves = WM 2 x WN 4, a wave owns 128 pixels x 32
+// channels (MT 4, NT 1): its B operand -- [2 substeps][hi, lo] fragments of ONE 32-channel column tile per (tap, chunk) -- comes
+// straight from L1 / L2 into the MFMA operand registers out of a FRAGMENT-ORDERED weight image ("wf": [tap][chunk][Cout / 32]
+// [substep][hi | lo][lane][16 B], built by ops_unet.split_bf16x3_frag; a wave-load is 1 KB contiguous), two iterations ahead
+// through a ring of three register sets.  What that buys: no weight staging (2 global loads + 2 ds_write_b128 per thread and
+// tap), no B-fragment LDS reads (the A side reads 8 ds_read_b128 per substep, as many as A + B did), and above all no barrier
+// per tap -- the only LDS hand-off left is the halo tile, one barrier per 32-channel chunk (nine taps).  The column tile is
+// fetched by the two waves that share it (wm 0 / 1): 32 KB per iteration through the CU's L1 instead of 16 KB.
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false, int MT_ = 2, bool BDIR = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT_)) ? 1 : 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HALO = (MODE == 0) ? 1 : 0;
@@ -162,7 +171,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   // PIPE (the bf16x3 3x3 convolution on the 8-wave shapes, one workgroup per CU): software-pipelined main loop with the halo
   // tile double-buffered in LDS, see step_pipe below.  The 4-wave shapes keep the plain loop: with 256 threads the staging
   // registers are twice as many per thread and the second fragment set spills (measured: 2x slower).
-  constexpr bool PIPE = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);
+  static_assert(!BDIR || (MODE == 0 && PREC == 1 && WM * WN == 8 && MT_ == 4 && BN == 32 * WN && !C1SRC), "BDIR: 8 waves of 128 px x 32 ch, bf16x3 3x3 convolution");
+  constexpr bool PIPE = BDIR || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);
   constexpr int A_STAGES = PIPE ? 2 : 1;
   // PIPE: a halo stage has a row for every staging slot (A_F4 * THREADS / 8 >= HP), so the split / store pass needs no tail
   // predicate: every halo load is consumed on every path and hipcc keeps no "maybe pending" state across iterations
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);         // [A_STAGES][HPS][LDK]
-  constexpr int B_STAGES = 2, B_STAGE = BN * LDK;     // weight-tile stages: [2][BN][LDK] padded rows, written through registers
+  constexpr int B_STAGES = BDIR ? 0 : 2, B_STAGE = BN * LDK;     // weight-tile stages: [2][BN][LDK] padded rows, written through registers (BDIR: none)
   float* Bs0 = As + A_STAGES * HPS * LDK;
   constexpr int SW = PW + 4, SH = PH + 4;             // C1SRC: spectrogram patch with a 2-pixel halo, then the (9, 64) weights
   float* Sp = Bs0 + B_STAGES * B_STAGE;               // [SH][SW]
@@ -582,6 +592,74 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     if (tap == 2 && !MFPA_EXP_FLAG(a.dbg, 16)) store_a(chunk_n, As + ((chunk + 1) & 1) * (HPS * LDK));
   };
 
+  // ---- BDIR: weights straight from L1 / L2 into the operand registers (see the template's header comment) -------------------
+  struct AFrags { bf16x8 ah[MT], al[MT]; };
+  AFrags fa0, fa1;
+  bf16x8 bq[3][2][2];                                  // [ring slot = tap % 3][substep][hi, lo]
+  const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+  auto load_bq = [&](int chunk, int tap, auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
+    // 4 KB per (tap, chunk, 32-channel column tile): [substep][hi | lo][lane][16 B]
+    const char* wb = reinterpret_cast<const char*>(a.w) + ((((size_t)tap * nchunks + chunk) * (size_t)(a.Cout / 32) + (size_t)(n0 / 32 + wn_s)) << 12) + lane * 16;
+    bq[slot][0][0] = *reinterpret_cast<const bf16x8*>(wb);
+    bq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+    bq[slot][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
+    bq[slot][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+  };
+  auto read_afrags = [&](AFrags& f, const float* Asb, int tap_off, int sub) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      f.al[mt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Asb + a_base[mt] + tap_off) + 32 * sub + 64);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      f.ah[mt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Asb + a_base[mt] + tap_off) + 32 * sub);
+  };
+  auto mfma_d = [&](const AFrags& f, const bf16x8 bh, const bf16x8 bl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mt], bh, acc[mt][0], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], bl, acc[mt][0], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], bh, acc[mt][0], 0, 0, 0);
+  };
+  // One tap: phase A = read A frags(it, s=1) || MFMA(s=0), request the weights of tile it+2 (slot (tap+2) % 3, whose tile it-1 was
+  // consumed by the previous phase B); phase B = read A frags(it+1, s=0) || MFMA(s=1).  The chunk's ONE barrier sits between the
+  // phases of tap 8: before it every wave has read the last fragments of this chunk's halo stage (rewritten at tap 2 of the next
+  // chunk), behind it the next chunk's stage -- split at tap 2 of this chunk by every wave -- is complete.
+  auto tap_body_d = [&](auto TAP, int chunk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(TAP)::value;
+    constexpr int ntap = (tap + 1) % TAPS;
+    constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * LDK, ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * LDK;
+    constexpr int N_AR = 2 * MT, N_M = 3 * MT;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const float* Asb = As + (chunk & 1) * (HPS * LDK);
+    const float* Asn = (tap == TAPS - 1) ? As + ((chunk + 1) & 1) * (HPS * LDK) : Asb;
+    read_afrags(fa1, Asb, tap_off, 1);
+    mfma_d(fa0, bq[tap % 3][0][0], bq[tap % 3][0][1]);
+    {
+      constexpr int t2 = (tap + 2) % TAPS;
+      load_bq((tap + 2 >= TAPS) ? chunk_n : chunk, t2, std::integral_constant<int, (tap + 2) % 3>{});
+    }
+    // pinned interleave: one fragment read behind each of the first MFMAs, the four weight loads behind the next, the rest bare
+    pin_reads<N_M - 1, N_AR>();
+    constexpr int used_a = pin_read_slots(N_M - 1, N_AR);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    if constexpr (N_M - used_a - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - used_a - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == TAPS - 1) {
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tap == 0) load_a(chunk_n, 0);
+    read_afrags(fa0, Asn, ntap_off, 0);
+    mfma_d(fa1, bq[tap % 3][1][0], bq[tap % 3][1][1]);
+    pin_reads<N_M, N_AR>();
+    if constexpr (N_M - pin_read_slots(N_M, N_AR) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_AR), 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == 2) store_a(chunk_n, As + ((chunk + 1) & 1) * (HPS * LDK));
+  };
+
   if (C1SRC) {
     const double den = a.c1_denom ? a.c1_denom[b] : 1.0;
     for (int i = tid; i < SH * SW; i += THREADS) {
@@ -597,7 +675,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     __syncthreads();
   }
   load_a(0, 0);
-  if constexpr (PIPE) {
+  if constexpr (BDIR) {
+    load_bq(0, 0, Set0{});
+    load_bq(0, 1, Set1{});
+    store_a(0, As);
+    __syncthreads();
+    read_afrags(fa0, As, 0, 0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      tap_body_d(std::integral_constant<int, 0>{}, chunk);
+      tap_body_d(std::integral_constant<int, 1>{}, chunk);
+      tap_body_d(std::integral_constant<int, 2>{}, chunk);
+      tap_body_d(std::integral_constant<int, 3>{}, chunk);
+      tap_body_d(std::integral_constant<int, 4>{}, chunk);
+      tap_body_d(std::integral_constant<int, 5>{}, chunk);
+      tap_body_d(std::integral_constant<int, 6>{}, chunk);
+      tap_body_d(std::integral_constant<int, 7>{}, chunk);
+      tap_body_d(std::integral_constant<int, 8>{}, chunk);
+    }
+  } else if constexpr (PIPE) {
     using Set2 = std::integral_constant<int, 2>;
     load_b_ct(0, 0, Set0{});
     store_a(0, As);
@@ -1062,7 +1157,7 @@ __global__ __launch_bounds__(256) void conv1x1_out_kernel(const float* __restric
   }
 }
 
-template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false, int MT = 2>
+template <int BN, int PH, int PW, int WM, int WN, int MODE, int PREC, bool C1SRC = false, int MT = 2, bool BDIR = false>
 int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   constexpr int HALO = (MODE == 0) ? 1 : 0;
   constexpr int HP = (PW + 2 * HALO) * (PH + 2 * HALO);
@@ -1071,14 +1166,27 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);
   a.dbg = dbg_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
-  constexpr bool ADB = conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);    // PIPE of the kernel: two padded halo stages
+  constexpr bool ADB = BDIR || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);    // PIPE of the kernel: two padded halo stages
   constexpr int THREADS = 64 * WM * WN;
   constexpr int HPS = ADB ? ((HP * (KC / 4) + THREADS - 1) / THREADS) * (THREADS / (KC / 4)) : HP;
-  const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HPS * LDK + 2 * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
+  const size_t lds = sizeof(float) * ((size_t)(ADB ? 2 : 1) * HPS * LDK + (BDIR ? 0 : 2) * (size_t)BN * LDK + (C1SRC ? (PH + 4) * (PW + 4) + 9 * 64 : 0));
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(taps_y * (a.Cout / BN)));
-  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC, MT>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BN, PH, PW, WM, WN, MODE, PREC, C1SRC, MT, BDIR>), grid, dim3(64 * WM * WN), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
+}
+
+// Which bf16x3 weight image does the fastest kernel for this shape read?  1 = the fragment-ordered image (BDIR kernels: 3x3
+// convolution, 128-channel output tiles, >= 64 input channels, the 8 x 32 patches of the wide levels or the 16 x 16 patches of the
+// 16 x 15 level), 0 = the row image.
+static int conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision) {
+#ifdef MFPA_CONV_NO_BDIR
+  return 0;
+#endif
+  if (mode != 0 || precision != 1 || Cout % 128 || Cin < MFPA_CONV_BIG_MIN_CIN) return 0;
+  if (W > 16 && H >= 8) return 1;
+  if (W <= 16 && H >= 16 && MFPA_CONV_BOTTLENECK8) return 1;
+  return 0;
 }
 
 // Tile choice.  Waves always own 64 pixels x 64 channels.
@@ -1093,6 +1201,13 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   if (MODE == 1 && !ct_old) return a.W > 16 ? launch_convT<4, 32, PREC>(a, s) : launch_convT<8, 16, PREC>(a, s);
   const int taps_y = (MODE == 1) ? 4 : 1;
   const bool bn128 = (a.Cout % 128 == 0);
+  if constexpr (MODE == 0 && PREC == 1) {
+    if (a.w_frag) {        // the caller packed the fragment-ordered image: only the BDIR kernels read it (conv_weight_layout() said so)
+      if (!conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) || a.c1_x32 || a.c1_spec64) return MFPA_EINVAL;
+      if (a.W > 16) return launch_conv<128, 8, 32, 2, 4, 0, 1, false, 4, true>(a, 1, s);
+      return launch_conv<128, 16, 16, 2, 4, 0, 1, false, 4, true>(a, 1, s);
+    }
+  }
   static const int wm_env = MFPA_EXP_ENV("MFPA_CONV_WM", 0);   // experiments
   const int cin = a.C0 + a.C1;
   const bool big = (wm_env == 4) || (wm_env == 0 && cin >= ((PREC == 1 && MODE == 0) ? MFPA_CONV_BIG_MIN_CIN : 256));   // the plain loop keeps round 1's measured threshold
@@ -1199,10 +1314,18 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
     a.c1_w = d->c1_w; a.c1_scale = d->c1_scale; a.c1_shift = d->c1_shift;
   }
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
+  if (d->w_layout != 0 && d->w_layout != 1) return MFPA_EINVAL;
+  if (d->w_layout == 1 && (d->mode != 0 || d->precision != 1 || d->in_scale0)) return MFPA_EINVAL;
+  a.w_frag = d->w_layout;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);
   if (d->mode == 1) return dispatch_conv<1>(a, s, d->precision);
   return dispatch_conv<2>(a, s, d->precision);
+}
+
+int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision) {
+  if (H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;
+  return conv_weight_layout(H, W, Cin, Cout, mode, precision);
 }
 
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,

@@ -243,8 +243,9 @@ def lstm_results_ok(dev) -> bool:
     _LSTM_TOUCHED[idx] = []
     if not bad:
         return True
-    for buf, host in bad:
-        buf[off:off + 1].zero_()
+    for key, ent in _LSTM_WORK.items():              # the word is sticky (it ends every later wait): clear it in every scratch of the device
+        if key[0] == idx:
+            ent[0][off:off + 1].zero_()
     PERSISTENT_LSTM = False
     PERSISTENT_LSTM_BWD = False
     import warnings

@@ -55,8 +55,23 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return img.view(torch.float32).reshape(t, co, ci)
 
 
+def split_bf16x3_frag(w: torch.Tensor) -> torch.Tensor:
+    """Kernel-layout fp32 weights [taps][Cout][Cin] (Cout % 32 == 0, Cin % 32 == 0) -> the FRAGMENT-ORDERED bf16x3 image of the
+    "weights direct" convolution kernels (csrc/unet.hip, BDIR; mfpa_conv_desc.w_layout = 1):
+    [tap][chunk = Cin / 32][Cout / 32][substep 2][hi | lo][lane 64][8 bf16] -- the 16 bytes of lane (lh * 32 + li) are the MFMA B
+    operand of output channel 32 n + li, input channels 32 chunk + 16 substep + 8 lh .. + 7, so a wave reads a fragment as 1 KB
+    contiguous.  Same split w = hi + lo as split_bf16x3 (the two kernels give the same bits).  Opaque float32 tensor of w's shape."""
+    t, co, ci = w.shape
+    w6 = w.reshape(t, co // 32, 32, ci // 32, 2, 2, 8)                             # [t][n32][li][chunk][s][lh][j]
+    hi = w6.to(torch.bfloat16)
+    lo = (w6 - hi.float()).to(torch.bfloat16)
+    img = torch.stack([hi, lo], dim=0).permute(1, 4, 2, 5, 0, 6, 3, 7).contiguous()    # [t][chunk][n32][s][hl][lh][li][j]
+    return img.view(torch.float32).reshape(t, co, ci)
+
+
 def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[str, torch.Tensor]:
-    """precision 0: fp32 MFMA weights; 1: additionally pre-split (bf16x3) copies under '<name>.w3'."""
+    """precision 0: fp32 MFMA weights; 1: additionally pre-split (bf16x3) copies under '<name>.w3', and for the layers the
+    "weights direct" kernels can take (128-channel output tiles, >= 64 input channels) the fragment-ordered image '<name>.wf'."""
     pw: Dict[str, torch.Tensor] = {"precision": precision}
 
     def dconv(prefix, first_layer=False):
@@ -81,6 +96,8 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[s
     if precision == 1:
         for k in [k for k in pw if isinstance(pw[k], torch.Tensor) and pw[k].dim() == 3]:
             pw[k + "3"] = split_bf16x3(pw[k])
+            if pw[k].shape[0] == 9 and pw[k].shape[1] % 128 == 0 and pw[k].shape[2] >= 64:
+                pw[k + "f"] = split_bf16x3_frag(pw[k])
     return pw
 
 
@@ -143,12 +160,17 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
     return y
 
 
-def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None):
+USE_WEIGHTS_DIRECT = True     # False: always the row image / LDS-staged weight tiles (A/B runs)
+
+
+def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None, wf=None):
     """3x3 conv + folded BN + ReLU through mfpa_conv_mfma with optional fused epilogues: `pool` also writes
     MaxPool2d(2) of the output, `out1x1 = (w (64,), bias)` also writes the OutConv result (B,H,W); `store=False`
     skips the full-resolution output.  `w` must already be in the layout of `precision` (pre-split for bf16x3).
     `c1 = dict(x32= | spec64=, denom=, w, scale, shift)` (x0 None): the 64 input channels are the UNet's first layer, computed
     from the 1-channel input while the tile is staged (mfpa_conv_desc.c1_*).
+    `wf`: the fragment-ordered image of the same weights (split_bf16x3_frag); used instead of `w` where
+    mfpa_conv_weight_layout says the "weights direct" kernel serves this shape.
     Returns (y | None, y_pool | None, y1x1 | None)."""
     if c1 is not None:
         src = c1.get("x32") if c1.get("x32") is not None else c1["spec64"]
@@ -158,6 +180,10 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     Cout = w.shape[1]
     C1 = 0 if x1 is None else x1.shape[3]
     dev = w.device
+    layout = 0
+    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None
+            and lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == 1):
+        w, layout = wf, 1
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev) if store else None
     yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=dev) if pool else None
     y1 = torch.empty((B, H, W), dtype=torch.float32, device=dev) if out1x1 is not None else None
@@ -165,7 +191,7 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
                  y=ptr(y), C0=C0, C1=C1, H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=1, yH=H, yW=W, mode=0, drop_seed=0, drop_thresh=0, drop_scale=1.0,
                  precision=precision, y_pool=ptr(yp), w1x1=ptr(out1x1[0]) if out1x1 is not None else 0,
-                 b1x1=float(out1x1[1]) if out1x1 is not None else 0.0, y1x1=ptr(y1))
+                 b1x1=float(out1x1[1]) if out1x1 is not None else 0.0, y1x1=ptr(y1), w_layout=layout)
     if c1 is not None:
         d.c1_x32, d.c1_spec64, d.c1_denom = ptr(c1.get("x32")), ptr(c1.get("spec64")), ptr(c1.get("denom"))
         d.c1_w, d.c1_scale, d.c1_shift = ptr(c1["w"]), ptr(c1["scale"]), ptr(c1["shift"])
@@ -227,7 +253,7 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
 
     def c(x, prefix, idx, **kw):
         return conv3x3_fused(x, pw[f"{prefix}.{idx}.w{sfx}"], pw[f"{prefix}.{idx}.scale"], pw[f"{prefix}.{idx}.shift"],
-                             precision=prec, **kw)
+                             precision=prec, wf=pw.get(f"{prefix}.{idx}.wf") if prec == 1 else None, **kw)
 
     p = ENC[0]
     skips = []

@@ -352,21 +352,28 @@ def test_resident_guard_orders_persistent_grids_that_do_not_fit_side_by_side():
     torch.cuda.synchronize()
 
     def run(first_wgs, second_wgs):
+        """-> how many device-side waits did the guard put in front of the second launch (stream b) while the first (stream a)
+        was still running?  (Observing the ordering through event timestamps does not work: two streams may share a hardware
+        queue, which orders them anyway.)"""
+        waits = []
+        orig = torch.cuda.Stream.wait_event
         with torch.cuda.stream(a):
             done = guard.admit(dev, first_wgs)
-            for _ in range(6):
-                big @ big                                              # tens of milliseconds on stream a
+            for _ in range(8):
+                big @ big                                              # ~100 ms of work on stream a
             done()
-            end_a = torch.cuda.Event(enable_timing=True)
-            end_a.record(a)
-        with torch.cuda.stream(b):
-            guard.admit(dev, second_wgs)()
-            at_b = torch.cuda.Event(enable_timing=True)
-            at_b.record(b)
+        torch.cuda.Stream.wait_event = lambda self, ev: (waits.append(self.cuda_stream), orig(self, ev))[1]
+        try:
+            with torch.cuda.stream(b):
+                guard.admit(dev, second_wgs)()
+        finally:
+            torch.cuda.Stream.wait_event = orig
         torch.cuda.synchronize()
-        return end_a.elapsed_time(at_b)                                # > 0: stream b got past its admit only after a's work ended
+        assert all(w == b.cuda_stream for w in waits)
+        return len(waits)
 
-    assert run(cus - 64, 128) >= 0.0                                   # 192 + 128 > 256 CUs: b waits for a
-    assert run(64, 64) < 0.0                                           # fits side by side: b does not wait
+    assert run(cus - 64, 128) == 1                                     # 192 + 128 > 256 CUs: b waits (device-side) for a's grid
+    assert run(64, 64) == 0                                            # fits side by side: no wait
+    assert run(cus, 1) == 1 and run(0, cus) == 0                       # a full chip admits nothing beside it; nothing in flight, no wait
     assert D.lstm_seq_workgroups(256, 768) == 4 * 48 and D.lstm_seq_workgroups(64, 768, cus // 2) == 2 * 48
     assert D.lstm_seq_workgroups(96, 768, cus // 2) == 2 * 48 and D.lstm_seq_workgroups(4096, 768) == 0      # too many slabs: per-step path

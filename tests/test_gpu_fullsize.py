@@ -429,9 +429,10 @@ def test_config5_peak_metrics_experiment_at_size_sampled_queries_vs_oracle(net, 
     try:
         clean, aug = bench.metric_queries(N, dev)
         res, rows = compute_peaks_metrics(clean, aug, an_no, an_den, batch=256, per_query=True)
-        assert rows.shape == (N, 8) and bool(torch.isfinite(rows).all())
+        assert rows.shape == (N, 8) and bool(torch.isfinite(rows[:, [0, 1, 2, 4, 5, 6]]).all()) and not bool(torch.isnan(rows).any())
+        # (a query that AugmentFP left untouched has mse 0 against its clean clip: PSNR +inf, as 10 log10(range^2 / 0) gives the reference)
         keys = ["precision_no_den", "recall_no_den", "f1_score_no_den", "psnr_no_den_spec", "prec_den", "rec_den", "f1_den", "psnr_den_spec"]
-        np.testing.assert_allclose([res[k] for k in keys], rows.mean(dim=0).cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose([res[k] for k in keys], rows.mean(dim=0).cpu().numpy(), rtol=1e-12)      # inf == inf passes
         assert 0.0 < res["precision_no_den"] < 1.0 and 0.0 < res["recall_no_den"] < 1.0      # AugmentFP really changed the peaks
         rows = rows.cpu().numpy()
         for q in (0, 63, 256, 1023, N // 2 + 5, N - 257, N - 2, N - 1):
@@ -443,7 +444,9 @@ def test_config5_peak_metrics_experiment_at_size_sampled_queries_vs_oracle(net, 
             want = [om.precision(ma, mc), om.recall(ma, mc), om.f1score(ma, mc)]
             np.testing.assert_allclose(rows[q, :3], want, rtol=0, atol=1e-12)
             psnr = lambda x, t: 10 * np.log10((t.max() - t.min()) ** 2 / np.mean((x.astype(np.float64) - t) ** 2))
-            assert abs(rows[q, 3] - psnr(sg_aug, sg_clean)) < 1e-8
+            same = lambda got, want, tol: got == want or abs(got - want) < tol          # +inf for an untouched query
+            with np.errstate(divide="ignore"):
+                assert same(rows[q, 3], psnr(sg_aug, sg_clean), 1e-8)
             # the denoised third: the device's denoiser output of this query inside its own batch, then the oracle picker
             blk = aug[s:s + 256].contiguous()
             if denoiser == "demucs":
@@ -455,6 +458,6 @@ def test_config5_peak_metrics_experiment_at_size_sampled_queries_vs_oracle(net, 
             md = np.asarray(m_den).T[None]
             want_d = [om.precision(md, mc), om.recall(md, mc), om.f1score(md, mc)]
             np.testing.assert_allclose(rows[q, 4:7], want_d, rtol=0, atol=1e-12)
-            assert abs(rows[q, 7] - psnr(sg_den, sg_clean)) < (1e-8 if denoiser == "demucs" else 1e-4)
+            assert same(rows[q, 7], psnr(sg_den, sg_clean), 1e-8 if denoiser == "demucs" else 1e-4)
     finally:
         net.precision = 0

@@ -136,3 +136,38 @@ def test_bf16x3_precision_meets_the_tolerance(net, golden):
         net.precision = 0
     assert r1 <= TOL and r2 <= TOL, (r1, r2)
     assert r1 > 1e-7          # it really is the split path
+
+
+def test_weights_direct_kernel_gives_the_bits_of_the_lds_staged_kernel():
+    """The "weights direct" bf16x3 convolution (csrc/unet.hip BDIR: B fragments from a fragment-ordered image straight into the MFMA
+    operand registers, no weight tile in LDS, one barrier per chunk) against the pipelined kernel with LDS-staged weight tiles:
+    same products, same accumulation order per output element -> identical bits.  Ragged patch edges, the zero-padded second
+    source of the decoder, the fused max-pool, the 16 x 16 patches of the 16 x 15 level, far more workgroups than CUs, and torch."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd._lib import lib
+    from oracle.unet import relative_l1
+    g = torch.Generator().manual_seed(7)
+    for (B, H, W, C0, C1, Cout, pool) in [(2, 9, 37, 64, 0, 128, False), (3, 33, 31, 128, 128, 128, False), (2, 16, 15, 512, 0, 1024, False),
+                                          (1, 64, 62, 256, 0, 256, True), (40, 128, 125, 64, 0, 128, True), (1, 17, 16, 128, 0, 256, False)]:
+        assert lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == 1
+        x0 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x1 = torch.randn(B, H - 1, W - 1, C1, generator=g).cuda() if C1 else None
+        w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))
+        sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+        wk = K.pack_conv3x3(w).cuda()
+        w3, wf = K.split_bf16x3(wk), K.split_bf16x3_frag(wk)
+        ref, ref_p, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool)
+        for _ in range(2):
+            got, got_p, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, wf=wf)
+            assert torch.equal(got, ref), (B, H, W, C0, C1, Cout)
+            assert (not pool) or torch.equal(got_p, ref_p)
+        if B <= 3:
+            xin = x0.permute(0, 3, 1, 2).cpu()
+            if C1:
+                xin = torch.cat([xin, F.pad(x1.permute(0, 3, 1, 2).cpu(), [0, 1, 0, 1])], dim=1)
+            want = F.relu(F.conv2d(xin, w, padding=1) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
+            assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-4
+    # shapes the kernel does not take keep the row image (w_layout 1 is refused there)
+    assert lib().mfpa_conv_weight_layout(257, 251, 64, 64, 0, 1) == 0 and lib().mfpa_conv_weight_layout(128, 125, 32, 128, 0, 1) == 0
+    assert lib().mfpa_conv_weight_layout(128, 125, 64, 128, 0, 0) == 0 and lib().mfpa_conv_weight_layout(128, 125, 64, 128, 1, 1) == 0
