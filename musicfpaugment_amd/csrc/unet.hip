@@ -50,6 +50,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define MFPA_CONV_MT4 0             // 1: the 256 x 128 tile on FOUR waves of 128 px x 64 ch (8 x 32 patches); 2: also the 16 x 16 patches of the bottleneck
                                     // (measured per layer: 3-17 % SLOWER than the 8-wave shape -- a quarter less LDS traffic does not pay for one wave per SIMD)
 #endif
+#ifndef MFPA_BDIR_SPREAD_SPLIT
+#define MFPA_BDIR_SPREAD_SPLIT 1    // weights-direct kernels: the halo split one staging slot per tap inside the MFMA phases (0: one block at tap 2)
+#endif
 #ifndef MFPA_CONV_BOTTLENECK8
 #define MFPA_CONV_BOTTLENECK8 1     // the 16x15 level on the 8-wave shape with 16x16-pixel patches (0: round 1's 4-wave 8x16 shape)
 #endif
@@ -622,6 +625,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], bh, acc[mt][0], 0, 0, 0);
   };
+  // one halo staging slot of chunk `chunk`: zero padding, bf16 hi / lo split, two 8-byte LDS stores (store_a for a single slot; the
+  // weights-direct kernels run without the on-load affine)
+  auto split_slot = [&](auto IT, int chunk, float* Asn) __attribute__((always_inline)) {
+    constexpr int it = decltype(IT)::value;
+    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const bool inside = (chunk * KC < a.C0) ? (apix[it] >= 0) : src1_inside(apix[it]);
+    f32x4 v = areg[it];
+    if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    char* row = reinterpret_cast<char*>(Asn + pix * LDK);
+    *reinterpret_cast<bf16x4*>(row + 8 * aq) = hi;
+    *reinterpret_cast<bf16x4*>(row + 64 + 8 * aq) = lo;
+  };
   // One tap: phase A = read A frags(it, s=1) || MFMA(s=0), request the weights of tile it+2 (slot (tap+2) % 3, whose tile it-1 was
   // consumed by the previous phase B); phase B = read A frags(it+1, s=0) || MFMA(s=1).  The chunk's ONE barrier sits between the
   // phases of tap 8: before it every wave has read the last fragments of this chunk's halo stage (rewritten at tap 2 of the next
@@ -654,10 +675,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     if (tap == 0) load_a(chunk_n, 0);
     read_afrags(fa0, Asn, ntap_off, 0);
     mfma_d(fa1, bq[tap % 3][1][0], bq[tap % 3][1][1]);
-    pin_reads<N_M, N_AR>();
-    if constexpr (N_M - pin_read_slots(N_M, N_AR) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_AR), 0);
+#if MFPA_BDIR_SPREAD_SPLIT
+    // The next chunk's halo (requested at tap 0) is split and stored ONE staging slot per tap, taps 2 .. 2 + A_F4 - 1, inside this
+    // phase's scheduling region: its ~20 vector instructions and two LDS stores ride in the MFMA gaps instead of forming a block
+    // of vector work that both waves of a SIMD reach together (they run the same program almost in lockstep) with the matrix
+    // pipe idle.  All of it lies before tap 8's barrier.
+    static_assert(A_F4 <= TAPS - 3, "one halo staging slot per tap, taps 2 .. 7");
+    if constexpr (tap >= 2 && tap - 2 < A_F4) {
+      split_slot(std::integral_constant<int, tap - 2>{}, chunk_n, As + ((chunk + 1) & 1) * (HPS * LDK));
+      // MFMA, fragment read, two vector instructions ... then the stores behind two more MFMAs
+#pragma unroll
+      for (int i = 0; i < N_AR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_AR - 2, 0);
+    } else
+#endif
+    {
+      pin_reads<N_M, N_AR>();
+      if constexpr (N_M - pin_read_slots(N_M, N_AR) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_AR), 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
+#if !MFPA_BDIR_SPREAD_SPLIT
     if (tap == 2) store_a(chunk_n, As + ((chunk + 1) & 1) * (HPS * LDK));
+#endif
   };
 
   if (C1SRC) {

@@ -9,6 +9,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--precision", type=int, default=1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--clips", type=int, default=64)
+ap.add_argument("--both", action="store_true", help="precision 1: time the LDS-staged kernel and the weights-direct kernel side by side")
 args = ap.parse_args()
 if args.lib:
     from musicfpaugment_amd import _lib
@@ -22,6 +23,34 @@ layers = [("inc.3   64->64   @257x251", 257, 251, 64, 64), ("up4.0  128->64   @2
           ("d3.0   256->512  @32x31", 32, 31, 256, 512), ("d3.3   512->512  @32x31", 32, 31, 512, 512),
           ("up1.0 1024->512  @32x31", 32, 31, 1024, 512), ("d4.0   512->1024 @16x15", 16, 15, 512, 1024),
           ("d4.3  1024->1024 @16x15", 16, 15, 1024, 1024)]
+def timed(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / args.reps * 1e-3
+
+if args.both:
+    from musicfpaugment_amd._lib import lib
+    tl = td = 0.0
+    for name, H, W, Ci, Co in layers:
+        x = torch.randn(B, H, W, Ci, device="cuda")
+        w = torch.randn(9, Co, Ci, device="cuda") * 0.05
+        w3 = K.split_bf16x3(w)
+        sc = torch.ones(Co, device="cuda"); sh = torch.zeros(Co, device="cuda")
+        fl = 2.0 * B * H * W * Ci * Co * 9
+        a = timed(lambda: K.conv3x3_fused(x, w3, sc, sh, precision=1))
+        if lib().mfpa_conv_weight_layout(H, W, Ci, Co, 0, 1) == 1:
+            wf = K.split_bf16x3_frag(w)
+            d = timed(lambda: K.conv3x3_fused(x, w3, sc, sh, precision=1, wf=wf))
+        else:
+            d = a
+        tl += a; td += d
+        print(f"{name:28s} lds {a*1e6:8.1f} us {fl/a/1e12:6.1f} TF/s | direct {d*1e6:8.1f} us {fl/d/1e12:6.1f} TF/s  ({(a/d-1)*100:+.1f} %)", flush=True)
+    print(f"sum lds {tl*1e3:.3f} ms direct {td*1e3:.3f} ms")
+    sys.exit(0)
+
 tot = 0.0
 for name, H, W, Ci, Co in layers:
     x = torch.randn(B, H, W, Ci, device="cuda")
