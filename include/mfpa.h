@@ -354,7 +354,8 @@ int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dp
 /* Operand image of a convolution's weights, rebuilt from the master fp32 parameters after every optimiser step (replaces the
  * host-side flip / transpose / bf16 split of the packing code).  w: [taps][Co][Ci] fp32.  out, precision 0: [taps][nrows][K] float rows;
  * precision 1: the bf16x3 image [taps][K / 32][nrows][128 B], a row = 32 bf16 hi | 32 bf16 lo in eight 16-byte slots stored at slot
- * index (logical ^ ((row >> 1) & 7)) -- a (tap, chunk, 128-row) tile is 16 KB contiguous (csrc/unet.hip).  flip_transpose = 0: rows = output
+ * index (logical ^ ((row >> 1) & 7)) -- a (tap, chunk, 128-row) tile is 16 KB contiguous (csrc/unet.hip); precision 2: the same split in
+ * the FRAGMENT-ORDERED layout of mfpa_conv_desc.w_layout = 1 ([taps][K / 32][nrows / 32][substep][hi | lo][lane][8 bf16]).  flip_transpose = 0: rows = output
  * channels row0 .. row0+nrows-1, K = Ci (forward operand).  flip_transpose = 1: rows = input channels row0 .. row0+nrows-1,
  * K = Co, and for taps == 9 the kernel is flipped (tap t <- 8 - t): the input-gradient operand (training/unet.py's Conv2d /
  * ConvTranspose2d backward).  Co, Ci, row0, nrows multiples of 32. */

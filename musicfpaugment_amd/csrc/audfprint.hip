@@ -180,7 +180,7 @@ struct Best {
 // lexicographic max on (value, bin); p < 0 means "none"
 __device__ __forceinline__ Best best_of(Best a, Best b) {
   const bool take_b = (a.p < 0) || (b.p >= 0 && (b.v > a.v || (b.v == a.v && b.p > a.p)));
-  return take_b ? b : a;
+  return Best{take_b ? b.v : a.v, take_b ? b.p : a.p};      // field by field: a struct select goes through scratch memory
 }
 
 // v of lane `src` (wave-uniform index) through v_readlane: a scalar-path broadcast, ~10x the speed of the LDS-crossbar
@@ -213,14 +213,28 @@ __device__ __forceinline__ Best wave_best(Best x) {
   return best;
 }
 
+// One wavefront per clip (the scan over frames is sequential: every threshold depends on every earlier peak; parallelism exists
+// across the 256 bins -- 4 per lane -- and across clips).  At BASELINE's 256 clips that is ONE wave per CU, so what counts is the
+// latency of a frame step, not throughput (profiles/r03_prune_sq.md: 55 % of the wave's cycles were waits on dependent LDS round
+// trips -- per-frame peak lists, the Gaussian row -- and 154 vector instructions went into a frame pair):
+//   * forward: a frame in which no bin exceeds its threshold (35-45 % of the frames) costs four compares and the decay; the
+//     neighbour exchange of locmax runs only otherwise; a frame with ONE candidate (most of the rest) takes it straight from the
+//     ballot mask -- no arg-max loop;
+//   * peaks go into ONE compact list (value, frame << 8 | bin) plus a frame -> first-entry table, 12 bytes per peak instead of
+//     [T][8] slots (LDS 25 -> 20 KB per clip: 8 instead of 6 resident clips per CU at large batches);
+//   * backward: the entries of frame c-1 and the table cells of frame c-2 are read from LDS while frame c is processed (a
+//     two-deep software pipeline: no LDS round trip on the critical path except the Gaussian row of a surviving peak); a frame's
+//     entries sit in lanes 0..7 and are visited with scalar broadcasts; the "delete the following peak in the same bin" rule
+//     compares against the previous frame's bins held in registers.
 __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ filtered, int R, int T,
                                                    const double* __restrict__ gauss, double a_dec, int maxpks,
                                                    uint8_t* __restrict__ mask, int32_t* __restrict__ npeaks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* G = reinterpret_cast<double*>(smem);               // [2R+1]
-  double* lv = G + (2 * R + 2);                              // [T][MAXP] peak values
-  short* lb = reinterpret_cast<short*>(lv + (size_t)T * MAXP);  // [T][MAXP] peak bins (-1 = pruned)
-  short* ln = lb + (size_t)T * MAXP;                         // [T] peaks recorded per frame
+  const int cap = T * maxpks;                                  // most peaks a clip can record
+  double* G = reinterpret_cast<double*>(smem);                 // [2R+2]
+  double* ev = G + (2 * R + 2);                                // [cap] peak values, in recording order (frame, then rank)
+  int* ep = reinterpret_cast<int*>(ev + cap);                  // [cap] frame << 8 | bin; sign bit set = pruned
+  short* fs = reinterpret_cast<short*>(ep + cap);              // [T + 2] first entry of every frame, fs[T] = number of entries
 
   const int lane = threadIdx.x, b = blockIdx.x;
   const double* S = filtered + (size_t)b * T * R;
@@ -228,7 +242,6 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   const bool own = k0 < R;  // R % 4 == 0: a lane owns 4 bins or none
 
   for (int i = lane; i < 2 * R + 1; i += 64) G[i] = gauss[i];
-  for (int i = lane; i < T; i += 64) ln[i] = 0;
   __syncthreads();
 
   auto load_col = [&](int c, double (&v)[4]) {
@@ -282,6 +295,12 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
       }
     }
   };
+  int ne = 0;                                                  // entries recorded so far (wave-uniform)
+  auto record = [&](int c, double val, int p) {
+    ev[ne] = val;                                              // every lane stores the same (wave-uniform) value to the same address:
+    ep[ne] = (c << 8) | p;                                     // cheaper than switching the exec mask to one lane and back
+    ++ne;
+  };
 
   // ---- forward pass (peak_extractor.py:173-204)
   {
@@ -305,29 +324,47 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
     for (int q = 0; q < 4; ++q) {
       const int c = c0 + q;
       if (c < T) {
-        bool cand[4];
-        locmax4(cur[q], cand);
+        fs[c] = (short)ne;                                       // (uniform store, as in record)
+        bool ex[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) cand[s] = cand[s] && (cur[q][s] > th[s]);  // against the pre-update threshold
-        int cnt = 0;
-        while (cnt < maxpks) {
-          Best mine{0.0, -1};
+        for (int s = 0; s < 4; ++s) ex[s] = own && (cur[q][s] > th[s]);    // against the pre-update threshold
+        if (__ballot(ex[0] || ex[1] || ex[2] || ex[3]) != 0ull) {           // else: no candidate in this frame, whatever locmax says
+          bool cand[4];
+          locmax4(cur[q], cand);
+          unsigned long long m[4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (cand[s]) mine = best_of(mine, Best{cur[q][s], k0 + s});
-          if (__ballot(mine.p >= 0) == 0ull) break;
-          const Best w = wave_best(mine);
-          raise(w.v, w.p);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (k0 + s == w.p) cand[s] = false;
-          if (lane == 0) {
-            lv[(size_t)c * MAXP + cnt] = w.v;
-            lb[(size_t)c * MAXP + cnt] = (short)w.p;
+          for (int s = 0; s < 4; ++s) {
+            cand[s] = cand[s] && ex[s];
+            m[s] = __ballot(cand[s]);
           }
-          ++cnt;
+          const int total = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+          if (total == 1) {                                                  // the common case: take it from the masks
+            const int s1 = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
+            const unsigned long long mm = m[0] | m[1] | m[2] | m[3];
+            const int src = __ffsll((long long)mm) - 1;
+            const double sel = s1 == 0 ? cur[q][0] : (s1 == 1 ? cur[q][1] : (s1 == 2 ? cur[q][2] : cur[q][3]));
+            const double val = readlane_f64(sel, src);
+            const int p = 4 * src + s1;
+            raise(val, p);
+            record(c, val, p);
+          } else if (total > 1) {
+            int cnt = 0;
+            while (cnt < maxpks) {
+              Best mine{0.0, -1};
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                if (cand[s]) mine = best_of(mine, Best{cur[q][s], k0 + s});
+              if (__ballot(mine.p >= 0) == 0ull) break;
+              const Best w = wave_best(mine);
+              raise(w.v, w.p);
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                if (k0 + s == w.p) cand[s] = false;
+              record(c, w.v, w.p);
+              ++cnt;
+            }
+          }
         }
-        if (lane == 0) ln[c] = (short)cnt;
 #pragma unroll
         for (int s = 0; s < 4; ++s) th[s] = th[s] * a_dec;
       }
@@ -337,6 +374,8 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
 #pragma unroll
       for (int s = 0; s < 4; ++s) cur[q][s] = nxt[q][s];
   }
+  fs[T] = (short)ne;
+  fs[T + 1] = (short)ne;
   __syncthreads();
 
   // ---- backward pass (peak_extractor.py:206-234)
@@ -345,40 +384,57 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
     load_col(T - 1, v);
     spread_init(v);
   }
+  // entries of a frame in lanes 0..7: (value, frame << 8 | bin, entry index); -1 bin = none / pruned
+  auto fetch = [&](int start, int n, double& fv, int& fp) {
+    fv = 0.0; fp = -1;
+    if (lane < n) { fv = ev[start + lane]; fp = ep[start + lane]; }
+  };
+  auto ufs = [&](int i) { return __builtin_amdgcn_readfirstlane((int)fs[i]); };      // wave-uniform table cell
+  int st_c = ufs(T - 1), st_c1 = ufs(T);                       // frame T-1: entries [st_c, st_c1)
+  double cv; int cp;
+  fetch(st_c, st_c1 - st_c, cv, cp);
+  int st_n = T >= 2 ? ufs(T - 2) : 0;                          // frame T-2 starts here (its end is st_c)
+  int prev_p = -1, prev_idx = 0;                               // frame c+1's entries in lanes 0..7 (bin, entry index), -1 = none
   for (int c = T - 1; c >= 0; --c) {
-    const int n = ln[c];
+    const int n = st_c1 - st_c;
+    // requests for the next iterations go out first: entries of frame c-1, the table cell of frame c-2
+    double nv = 0.0; int np = -1;
+    if (c >= 1) fetch(st_n, st_c - st_n, nv, np);
+    const short st_nn_raw = c >= 2 ? fs[c - 2] : (short)0;     // consumed (made uniform) at the end of the iteration
+    int my_p = (lane < n) ? (cp & 255) : -1;                   // this frame's bins (lane i = rank i), -1 once pruned
     for (int i = 0; i < n; ++i) {
-      const double val = lv[(size_t)c * MAXP + i];
-      const int p = lb[(size_t)c * MAXP + i];
+      const double val = readlane_f64(cv, i);
+      const int p = __builtin_amdgcn_readlane(cp, i) & 255;    // wave-uniform
       const int s_sel = p & 3;
       const double mine = s_sel == 0 ? th[0] : (s_sel == 1 ? th[1] : (s_sel == 2 ? th[2] : th[3]));
       const double thp = readlane_f64(mine, p >> 2);
       if (val >= thp) {
         raise(val, p);
-        if (c + 1 < T) {  // delete any following peak in the same bin
-          if (lane < ln[c + 1] && lb[(size_t)(c + 1) * MAXP + lane] == (short)p) lb[(size_t)(c + 1) * MAXP + lane] = -1;
+        if (prev_p == p) {                                     // delete any following peak in the same bin (frame c+1)
+          ep[prev_idx] |= (int)0x80000000;
+          prev_p = -1;
         }
-      } else if (lane == 0) {
-        lb[(size_t)c * MAXP + i] = -1;
+      } else if (lane == i) {
+        ep[st_c + i] = cp | (int)0x80000000;
+        my_p = -1;
       }
-      // (no barrier: the workgroup is ONE wavefront, whose LDS operations complete in program order)
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) th[s] = a_dec * th[s];
+    prev_p = my_p; prev_idx = st_c + lane;
+    st_c1 = st_c; st_c = st_n; st_n = __builtin_amdgcn_readfirstlane((int)st_nn_raw);
+    cv = nv; cp = np;
   }
   __syncthreads();
 
   // ---- emit: mask (R, T) uint8 was zeroed by the host-side memset on the same stream
   uint8_t* M = mask + (size_t)b * R * T;
   int count = 0;
-  for (int e = lane; e < T * MAXP; e += 64) {
-    const int c = e / MAXP, i = e % MAXP;
-    if (i < ln[c]) {
-      const int p = lb[e];
-      if (p >= 0) {
-        M[(size_t)p * T + c] = 1;
-        ++count;
-      }
+  for (int e = lane; e < ne; e += 64) {
+    const int pe = ep[e];
+    if (pe >= 0) {
+      M[(size_t)(pe & 255) * T + (pe >> 8)] = 1;
+      ++count;
     }
   }
 #pragma unroll
@@ -419,7 +475,7 @@ int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const doub
   if (R < 4 || R > 256 || (R % 4) != 0 || T < 1 || T > 1500 || maxpks < 1 || maxpks > MAXP) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   MFPA_HIP(hipMemsetAsync(mask, 0, (size_t)B * R * T, s));
-  const size_t lds = sizeof(double) * (2 * R + 2) + (size_t)T * MAXP * (sizeof(double) + sizeof(short)) + sizeof(short) * T;
+  const size_t lds = sizeof(double) * (2 * R + 2) + (size_t)T * maxpks * (sizeof(double) + sizeof(int)) + sizeof(short) * (T + 2);
   hipLaunchKernelGGL(prune_kernel, dim3(B), dim3(64), lds, s, filtered, R, T, gauss, a_dec, maxpks, mask, npeaks);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;

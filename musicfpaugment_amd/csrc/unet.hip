@@ -625,14 +625,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mt], bh, acc[mt][0], 0, 0, 0);
   };
-  // one halo staging slot of chunk `chunk`: zero padding, bf16 hi / lo split, two 8-byte LDS stores (store_a for a single slot; the
-  // weights-direct kernels run without the on-load affine)
+  // one halo staging slot of chunk `chunk`: zero padding, the on-load affine + ReLU + dropout of the training forward, bf16 hi / lo
+  // split, two 8-byte LDS stores (store_a for a single slot)
   auto split_slot = [&](auto IT, int chunk, float* Asn) __attribute__((always_inline)) {
     constexpr int it = decltype(IT)::value;
     const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
-    const bool inside = (chunk * KC < a.C0) ? (apix[it] >= 0) : src1_inside(apix[it]);
+    const int c0 = chunk * KC;
+    const bool inside = (c0 < a.C0) ? (apix[it] >= 0) : src1_inside(apix[it]);
     f32x4 v = areg[it];
     if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {           // training: the producer's BatchNorm + ReLU (+ dropout) on load; padding stays 0
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * aq);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * aq);
+      v = v * sc + sh;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      if (a.drop_thresh) {
+        const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;
+        const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * aq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+      }
+    }
     bf16x4 hi, lo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1364,7 +1378,7 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   }
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
   if (d->w_layout != 0 && d->w_layout != 1) return MFPA_EINVAL;
-  if (d->w_layout == 1 && (d->mode != 0 || d->precision != 1 || d->in_scale0)) return MFPA_EINVAL;
+  if (d->w_layout == 1 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
   a.w_frag = d->w_layout;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);

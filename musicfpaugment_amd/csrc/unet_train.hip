@@ -987,6 +987,16 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
     const float v = TR ? tile[tx][r] : tile[r][tx];                  // (n = n0 + r, k = k0 + tx)
     if (precision == 0) {
       out[((size_t)t * nrows + n0 + r) * K + k0 + tx] = v;             // [tap][row][K] floats
+    } else if (precision == 2) {
+      // the FRAGMENT-ORDERED bf16x3 image of the weights-direct kernels (csrc/unet.hip BDIR, ops_unet.split_bf16x3_frag):
+      // [tap][chunk][row / 32][substep][hi | lo][lane = (k % 16 / 8) * 32 + row % 32][k % 8]
+      const int row = n0 + r, k = tx;                                  // k0 is a multiple of 32: k = position inside the chunk
+      __bf16* ob = reinterpret_cast<__bf16*>(out) + ((((size_t)t * (K / 32) + k0 / 32) * (nrows / 32) + row / 32) << 11);
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      const int at = ((k >> 4) << 10) + ((((k >> 3) & 1) * 32 + (row & 31)) << 3) + (k & 7);
+      ob[at] = hi;
+      ob[at + 512] = lo;
     } else {
       // the bf16x3 image of csrc/unet.hip: [tap][chunk][row][8 slots of 16 B], logical slot (hi: 0-3, lo: 4-7) at physical slot ^ swz(row)
       const int row = n0 + r, swz = (row >> 1) & 7;
@@ -1316,7 +1326,7 @@ int mfpa_pack_conv_weights(const float* w, int taps, int Co, int Ci, int flip_tr
                             float* out, void* stream) {
   if (!w || !out || taps < 1 || Co < 32 || Ci < 32 || Co % 32 || Ci % 32 || nrows < 32 || nrows % 32 || row0 < 0 || row0 % 32)
     return MFPA_EINVAL;
-  if (precision != 0 && precision != 1) return MFPA_EINVAL;
+  if (precision != 0 && precision != 1 && precision != 2) return MFPA_EINVAL;     // 2: the fragment-ordered bf16x3 image
   if (row0 + nrows > (flip_transpose ? Ci : Co)) return MFPA_EINVAL;
   const int K = flip_transpose ? Co : Ci;
   dim3 grid(K / 32, nrows / 32, taps);

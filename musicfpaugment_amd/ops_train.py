@@ -54,9 +54,11 @@ def _drop(st):
 DEVICE_PACK = True    # operand images of the weights built by mfpa_pack_conv_weights (False: the torch flip / transpose / split ops)
 
 
-def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, row0: int = 0, nrows: Optional[int] = None):
+def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, row0: int = 0, nrows: Optional[int] = None,
+                 layout: int = 0):
     """Master weights [taps][Co][Ci] -> the operand image of one conv launch (see mfpa_pack_conv_weights): forward operand, or with
-    flip_transpose the input-gradient operand [taps][ci in row0..row0+nrows][Co] (3x3 kernels flipped)."""
+    flip_transpose the input-gradient operand [taps][ci in row0..row0+nrows][Co] (3x3 kernels flipped).  `layout` 1 (precision 1
+    only): the fragment-ordered image of the weights-direct kernels (mfpa_conv_desc.w_layout)."""
     taps, Co, Ci = w.shape
     if nrows is None:
         nrows = (Ci if flip_transpose else Co) - row0
@@ -65,20 +67,27 @@ def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, 
             w = (w.flip(0) if taps == 9 else w).transpose(1, 2)[:, row0:row0 + nrows].contiguous()
         else:
             w = w[:, row0:row0 + nrows].contiguous()
-        return K.split_bf16x3(w) if precision == 1 else w
+        if precision != 1:
+            return w
+        return K.split_bf16x3_frag(w) if layout == 1 else K.split_bf16x3(w)
     out = torch.empty((taps, nrows, Co if flip_transpose else Ci), dtype=torch.float32, device=w.device)
-    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, precision, ptr(out), stream()),
-          "mfpa_pack_conv_weights")
+    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, 2 if (precision == 1 and layout == 1) else precision,
+                                       ptr(out), stream()), "mfpa_pack_conv_weights")
     return out
 
 
+def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int = 0) -> int:
+    """Which bf16x3 image the fastest kernel for this convolution reads (mfpa_conv_weight_layout): 1 = fragment-ordered."""
+    if precision != 1 or mode != 0 or not K.USE_WEIGHTS_DIRECT:
+        return 0
+    return int(lib().mfpa_conv_weight_layout(H, W, cin, cout, 0, 1) == 1)
+
+
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
-              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False):
+              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False, w_layout: int = 0):
     """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
-    `w` (fp32, kernel layout) is split into the bf16 hi|lo row format here unless it already is an operand image (`packed`)."""
-    if precision == 1 and not packed:
-        w = pack_weights(w, 1) if (DEVICE_PACK and w.is_contiguous() and w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0) \
-            else K.split_bf16x3(w)
+    `w` (fp32, kernel layout) is split into the image the kernel for this shape reads (weight_layout) unless it already is an
+    operand image (`packed`, in the layout `w_layout`)."""
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -86,6 +95,12 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
         H, W = x0.shape[1], x0.shape[2]
     C0 = x0.shape[3]
     C1 = 0 if x1 is None else x1.shape[3]
+    if precision == 1 and not packed:
+        w_layout = weight_layout(H, W, C0 + C1, Cout, precision, mode)
+        if DEVICE_PACK and w.is_contiguous() and w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0:
+            w = pack_weights(w, 1, layout=w_layout)
+        else:
+            w = K.split_bf16x3_frag(w) if w_layout else K.split_bf16x3(w)
     if mode == 1:
         oh, ow = 2 * H, 2 * W
     else:
@@ -97,7 +112,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2], precision=precision)
+                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout)
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -439,8 +454,9 @@ class UNetTrainEngine:
         cout = r["z3"].shape[-1]
         dz3 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b")
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision)
-        wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True)   # [tap'][ci][co]
-        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True)
+        lay = weight_layout(dz3.shape[1], dz3.shape[2], cout, cout, self.precision)
+        wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True, layout=lay)   # [tap'][ci][co]
+        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay)
         del dz3
         dz0 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b")
         if r["first_input"] is not None:
@@ -455,12 +471,14 @@ class UNetTrainEngine:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
         c0 = r["src0"].shape[-1]
-        d0 = conv_mfma(dz0, pack_weights(w0, self.precision, True, 0, c0), c0, precision=self.precision, packed=True)
+        lay = weight_layout(dz0.shape[1], dz0.shape[2], cout, c0, self.precision)
+        d0 = conv_mfma(dz0, pack_weights(w0, self.precision, True, 0, c0, layout=lay), c0, precision=self.precision, packed=True, w_layout=lay)
         d1 = None
         if r["src1"] is not None:
             c1 = r["src1"].shape[-1]
-            d1 = conv_mfma(dz0, pack_weights(w0, self.precision, True, c0, c1), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
-                           precision=self.precision, packed=True)
+            lay = weight_layout(dz0.shape[1], dz0.shape[2], cout, c1, self.precision)
+            d1 = conv_mfma(dz0, pack_weights(w0, self.precision, True, c0, c1, layout=lay), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
+                           precision=self.precision, packed=True, w_layout=lay)
         return d0, d1
 
     def backward(self, dpred):
