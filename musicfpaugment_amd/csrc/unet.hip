@@ -50,6 +50,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define MFPA_CONV_MT4 0             // 1: the 256 x 128 tile on FOUR waves of 128 px x 64 ch (8 x 32 patches); 2: also the 16 x 16 patches of the bottleneck
                                     // (measured per layer: 3-17 % SLOWER than the 8-wave shape -- a quarter less LDS traffic does not pay for one wave per SIMD)
 #endif
+#ifndef MFPA_CONV_BDIR64
+#define MFPA_CONV_BDIR64 0          // 1: weights-direct form also for 64-channel output tiles (8 waves of 64 px x 32 ch, one workgroup per CU): correct
+                                    // (tests/test_gpu_unet.py runs it when enabled), +1.7 % per layer stand-alone but -2.8 % on the headline (3990 vs 4107 clips/s, two A/B pairs)
+#endif
+#ifndef MFPA_C1_PAIR_FORM
+#define MFPA_C1_PAIR_FORM 2         // fused first layer: 1 = every sample as a full {x, x} pair, 2 = sample in the low half + op_sel_hi broadcast
+#endif
 #ifndef MFPA_BDIR_SPREAD_SPLIT
 #define MFPA_BDIR_SPREAD_SPLIT 1    // weights-direct kernels: the halo split one staging slot per tap inside the MFMA phases (0: one block at tap 2)
 #endif
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   // PIPE (the bf16x3 3x3 convolution on the 8-wave shapes, one workgroup per CU): software-pipelined main loop with the halo
   // tile double-buffered in LDS, see step_pipe below.  The 4-wave shapes keep the plain loop: with 256 threads the staging
   // registers are twice as many per thread and the second fragment set spills (measured: 2x slower).
-  static_assert(!BDIR || (MODE == 0 && PREC == 1 && WM * WN == 8 && MT_ == 4 && BN == 32 * WN && !C1SRC), "BDIR: 8 waves of 128 px x 32 ch, bf16x3 3x3 convolution");
+  static_assert(!BDIR || (MODE == 0 && PREC == 1 && WM * WN == 8 && (MT_ == 4 || MT_ == 2) && BN == 32 * WN && !C1SRC),
+                "BDIR: 8 waves of (32 MT) px x 32 ch, bf16x3 3x3 convolution");
   constexpr bool PIPE = BDIR || conv_is_pipe(BN, PH, PW, WM, WN, MODE, PREC, MT);
   constexpr int A_STAGES = PIPE ? 2 : 1;
   // PIPE: a halo stage has a row for every staging slot (A_F4 * THREADS / 8 >= HP), so the split / store pass needs no tail
@@ -269,6 +277,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
       a_sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * aq);
       a_sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * aq);
     }
+    // C1SRC: a thread keeps ONE channel quad for all of its halo pixels, so the first layer's nine weight quads and its folded
+    // BatchNorm are read once per chunk, not once per staging slot (99 -> 9 LDS reads per chunk and thread)
+    f32x4 c1w[C1SRC ? 9 : 1], c1s = {1.f, 1.f, 1.f, 1.f}, c1h = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (C1SRC) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) c1w[t] = *reinterpret_cast<const f32x4*>(W1s + t * 64 + c0 + 4 * aq);
+      c1s = *reinterpret_cast<const f32x4*>(a.c1_scale + c0 + 4 * aq);
+      c1h = *reinterpret_cast<const f32x4*>(a.c1_shift + c0 + 4 * aq);
+    }
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
       const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4)), q = aq;
@@ -281,16 +298,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
           v = f32x4{0.f, 0.f, 0.f, 0.f};
           if (inside) {                                                    // conv2's zero padding stays exactly zero
             const float* sp = Sp + (pix / HPW) * SW + (pix % HPW);        // 3x3 window of the first layer around (gy, gx)
+            // Packed FMAs on a sample MATERIALISED as an {x, x} pair: written as `v += sv * wv` hipcc keeps two samples in one
+            // register pair and selects the odd one with v_pk_fma_f32 ... op_sel:[1,0,0], the operand-selection form the library
+            // does not ship (mfpa_common.h; tests/test_isa_scan.py).  The pair form costs one v_mov per sample; scalar FMAs in its
+            // place made this kernel 18 % slower (7.0 instead of 5.8 vector instructions per MFMA).
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
               const float sv = sp[(t / 3) * SW + (t % 3)];
-              const f32x4 wv = *reinterpret_cast<const f32x4*>(W1s + t * 64 + c0 + 4 * q);
-              // scalar FMAs on purpose: as `v += sv * wv` hipcc emits v_pk_fma_f32 ... op_sel:[1,0,0] for the odd samples of a pair (mfpa_common.h)
-              v.x = mfpa_fma1(sv, wv.x, v.x); v.y = mfpa_fma1(sv, wv.y, v.y); v.z = mfpa_fma1(sv, wv.z, v.z); v.w = mfpa_fma1(sv, wv.w, v.w);
+#if MFPA_C1_PAIR_FORM == 1
+              f32x2 xx = {sv, sv};
+              asm volatile("" : "+v"(xx));
+#else
+              f32x2 lo;                        // the sample in the LOW half of an (even-aligned) register pair, the high half is never read:
+              lo.x = sv;                       // the broadcast {lo.x, lo.x} is the op_sel_hi form
+              asm volatile("" : "+v"(lo));
+              const f32x2 xx = {lo.x, lo.x};
+#endif
+              const f32x4 wv = c1w[t];
+              v01 += xx * f32x2{wv.x, wv.y};
+              v23 += xx * f32x2{wv.z, wv.w};
             }
-            const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.c1_scale + c0 + 4 * q);
-            const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.c1_shift + c0 + 4 * q);
-            v = v * s1 + h1;
+            v = f32x4{v01[0], v01[1], v23[0], v23[1]};
+            v = v * c1s + c1h;
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           }
         }
@@ -710,7 +741,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_AR - 2, 0);
+      if constexpr (N_M - N_AR - 2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_AR - 2, 0);
     } else
 #endif
     {
@@ -1246,7 +1277,8 @@ static int conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int pre
 #ifdef MFPA_CONV_NO_BDIR
   return 0;
 #endif
-  if (mode != 0 || precision != 1 || Cout % 128 || Cin < MFPA_CONV_BIG_MIN_CIN) return 0;
+  if (mode != 0 || precision != 1 || Cin < MFPA_CONV_BIG_MIN_CIN) return 0;
+  if (Cout % 128) return (MFPA_CONV_BDIR64 && Cout % 64 == 0 && W > 16 && H >= 8) ? 1 : 0;      // 64-channel output tiles
   if (W > 16 && H >= 8) return 1;
   if (W <= 16 && H >= 16 && MFPA_CONV_BOTTLENECK8) return 1;
   return 0;
@@ -1267,6 +1299,7 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   if constexpr (MODE == 0 && PREC == 1) {
     if (a.w_frag) {        // the caller packed the fragment-ordered image: only the BDIR kernels read it (conv_weight_layout() said so)
       if (!conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) || a.c1_x32 || a.c1_spec64) return MFPA_EINVAL;
+      if (!bn128) return launch_conv<64, 8, 32, 4, 2, 0, 1, false, 2, true>(a, 1, s);     // 64-channel layers: 8 waves of 64 px x 32 ch
       if (a.W > 16) return launch_conv<128, 8, 32, 2, 4, 0, 1, false, 4, true>(a, 1, s);
       return launch_conv<128, 16, 16, 2, 4, 0, 1, false, 4, true>(a, 1, s);
     }

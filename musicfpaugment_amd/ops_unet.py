@@ -96,7 +96,7 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[s
     if precision == 1:
         for k in [k for k in pw if isinstance(pw[k], torch.Tensor) and pw[k].dim() == 3]:
             pw[k + "3"] = split_bf16x3(pw[k])
-            if pw[k].shape[0] == 9 and pw[k].shape[1] % 128 == 0 and pw[k].shape[2] >= 64:
+            if pw[k].shape[0] == 9 and pw[k].shape[1] % 64 == 0 and pw[k].shape[2] >= 64:
                 pw[k + "f"] = split_bf16x3_frag(pw[k])
     return pw
 

@@ -168,6 +168,25 @@ def test_weights_direct_kernel_gives_the_bits_of_the_lds_staged_kernel():
                 xin = torch.cat([xin, F.pad(x1.permute(0, 3, 1, 2).cpu(), [0, 1, 0, 1])], dim=1)
             want = F.relu(F.conv2d(xin, w, padding=1) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
             assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-4
+    # 64-channel output tiles (8 waves of 64 px x 32 ch): the decoder's full-resolution layers, incl. the fused max-pool and the fused
+    # OutConv (whose channel sum is associated differently when two waves share a pixel's channels: equal to rounding, not bits)
+    for (B, H, W, C0, C1, pool, outc) in [(2, 40, 70, 64, 64, False, False), (1, 257, 251, 64, 0, True, False), (3, 33, 65, 64, 0, False, True),
+                                          (70, 64, 62, 128, 0, False, False)]:
+        if lib().mfpa_conv_weight_layout(H, W, C0 + C1, 64, 0, 1) != 1:      # built with MFPA_CONV_BDIR64 = 0 (the default: slower on the chain)
+            break
+        x0 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x1 = torch.randn(B, H - 1, W - 1, C1, generator=g).cuda() if C1 else None
+        w = torch.randn(64, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))
+        sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+        wk = K.pack_conv3x3(w).cuda()
+        w3, wf = K.split_bf16x3(wk), K.split_bf16x3_frag(wk)
+        o1 = (torch.randn(64, generator=g).cuda(), 0.25) if outc else None
+        ref, ref_p, ref_1 = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1)
+        got, got_p, got_1 = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1, wf=wf)
+        assert torch.equal(got, ref), (B, H, W, C0, C1)
+        assert (not pool) or torch.equal(got_p, ref_p)
+        if outc:
+            assert (got_1 - ref_1).abs().max().item() <= 1e-5 * ref_1.abs().max().item()
     # shapes the kernel does not take keep the row image (w_layout 1 is refused there)
-    assert lib().mfpa_conv_weight_layout(257, 251, 64, 64, 0, 1) == 0 and lib().mfpa_conv_weight_layout(128, 125, 32, 128, 0, 1) == 0
+    assert lib().mfpa_conv_weight_layout(257, 251, 32, 64, 0, 1) == 0 and lib().mfpa_conv_weight_layout(128, 125, 32, 128, 0, 1) == 0
     assert lib().mfpa_conv_weight_layout(128, 125, 64, 128, 0, 0) == 0 and lib().mfpa_conv_weight_layout(128, 125, 64, 128, 1, 1) == 0

@@ -9,6 +9,8 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--precision", type=int, default=1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--clips", type=int, default=64)
+ap.add_argument("--c64", action="store_true", help="the three 64-channel full-resolution launches exactly as the UNet issues them (fused first layer + pool, "
+                "two-source concat, fused OutConv without store)")
 ap.add_argument("--both", action="store_true", help="precision 1: time the LDS-staged kernel and the weights-direct kernel side by side")
 args = ap.parse_args()
 if args.lib:
@@ -30,6 +32,29 @@ def timed(fn):
     for _ in range(args.reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / args.reps * 1e-3
+
+if args.c64:
+    H, W = 257, 251
+    g = torch.Generator(device="cuda").manual_seed(0)
+    sc = torch.ones(64, device="cuda"); sh = torch.zeros(64, device="cuda")
+    spec = torch.rand(B, H, W, device="cuda", dtype=torch.float64); den = torch.ones(B, device="cuda", dtype=torch.float64)
+    w1 = torch.randn(9, 64, device="cuda") * 0.1
+    w64 = K.split_bf16x3(torch.randn(9, 64, 64, device="cuda") * 0.05)
+    w128 = K.split_bf16x3(torch.randn(9, 64, 128, device="cuda") * 0.05)
+    x = torch.randn(B, H, W, 64, device="cuda"); u = torch.randn(B, H - 1, W - 1, 64, device="cuda")
+    wo = torch.randn(64, device="cuda")
+    runs = [("inc.3  c1src + pool", 64, lambda: K.conv3x3_fused(None, w64, sc, sh, precision=1, pool=True, c1=dict(spec64=spec, denom=den, w=w1, scale=sc, shift=sh))),
+            ("up4.0  skip 64 + up 64 (concat)", 128, lambda: K.conv3x3_fused(x, w128, sc, sh, x1=u, precision=1)),
+            ("up4.3  + OutConv, no store", 64, lambda: K.conv3x3_fused(x, w64, sc, sh, precision=1, out1x1=(wo, 0.1), store=False)),
+            ("plain 64->64 with store", 64, lambda: K.conv3x3_fused(x, w64, sc, sh, precision=1))]
+    tot = 0.0
+    for name, ci, fn in runs:
+        t = timed(fn); tot += t
+        fl = 2.0 * B * H * W * ci * 64 * 9
+        print(f"{name:34s} {t*1e6:8.1f} us {fl/t/1e12:6.1f} TF/s", flush=True)
+    print(f"sum of the first three {sum(0 for _ in ())+0:.0f}", end="")
+    print(f" {tot*1e3:.3f} ms (all four)")
+    sys.exit(0)
 
 if args.both:
     from musicfpaugment_amd._lib import lib
