@@ -1183,7 +1183,7 @@ __global__ MFPA_NO_PK_F32 __launch_bounds__(256) void downsample2_kernel(const f
 }
 
 // First encoder conv: Conv1d(1 -> C, k=8, s=4) + ReLU on (B, Lin) -> (B, Lout, C).  w [8][C] (tap-major), bias [C].
-__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict__ x, int Lin, int Lout, int C,
+__global__ __launch_bounds__(256) void conv1d_c1_kernel(const float* __restrict__ x, int Lin, int Lout, int C,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         float* __restrict__ y, int relu) {
   const int b = blockIdx.y, C4 = C / 4;
@@ -1193,13 +1193,16 @@ __global__ MFPA_NO_PK_F32 __launch_bounds__(256) void conv1d_c1_kernel(const flo
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int cq = (int)(e % C4);
     const int t = (int)(e / C4);
-    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    mfpa_f32x2 a01 = {bv[0], bv[1]}, a23 = {bv[2], bv[3]};       // bias, then taps 0..7: one FMA chain per channel
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float v = xb[4 * t + j];
+      const mfpa_f32x2 v = mfpa_bcast2(xb[4 * t + j]);            // packed FMAs without operand selection (mfpa_common.h)
       const f32x4 ww = *reinterpret_cast<const f32x4*>(w + j * C + 4 * cq);
-      acc += v * ww;
+      a01 += v * mfpa_f32x2{ww[0], ww[1]};
+      a23 += v * mfpa_f32x2{ww[2], ww[3]};
     }
+    f32x4 acc = {a01[0], a01[1], a23[0], a23[1]};
     if (relu) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = acc[k] > 0.f ? acc[k] : 0.f;

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void colsum_any_kernel(const float* __restrict
 // dw[j][c] += sum_{b,t} x[b*ldx + 4t + j] * g[b*strideG + t*ldg + c],  j < 8, t < L   (w (8, C) tap-major)
 // serves encoder.0.0 (x = the upsampled input, g = the masked gradient of its ReLU output) and the last
 // ConvTranspose1d (x = the gradient of its output, g = the GLU output it consumed).
-__global__ MFPA_NO_PK_F32 __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g,
                                                        long long ldg, long long strideG, int L, int C, float* __restrict__ dw,
                                                        int rows_per_block) {
   __shared__ float accs[8 * 256];                        // C <= 256
@@ -429,22 +429,27 @@ __global__ MFPA_NO_PK_F32 __launch_bounds__(256) void c1_wgrad_kernel(const floa
   const int q = tid % Q, rl = tid / Q;
   const int t0 = blockIdx.x * rows_per_block;
   const int t1 = t0 + rows_per_block < L ? t0 + rows_per_block : L;
-  f32x4 acc[8];
+  mfpa_f32x2 acc[8][2];                                  // [tap][channel pair]: packed FMAs without operand selection (mfpa_common.h)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = mfpa_f32x2{0.f, 0.f};
   if (rl < lanes) {
     const float* xb = x + (size_t)b * ldx;
     const float* gb = g + (size_t)b * strideG;
     for (int t = t0 + rl; t < t1; t += lanes) {
       const f32x4 gv = *reinterpret_cast<const f32x4*>(gb + (size_t)t * ldg + 4 * q);
+      const mfpa_f32x2 g01 = {gv[0], gv[1]}, g23 = {gv[2], gv[3]};
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)t), x1 = *reinterpret_cast<const f32x4*>(xb + 4 * (size_t)t + 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[j] += x0[j] * gv; acc[4 + j] += x1[j] * gv; }
+      for (int j = 0; j < 4; ++j) {
+        const mfpa_f32x2 u = mfpa_bcast2(x0[j]), v = mfpa_bcast2(x1[j]);
+        acc[j][0] += u * g01; acc[j][1] += u * g23;
+        acc[4 + j][0] += v * g01; acc[4 + j][1] += v * g23;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) atomicAdd(&accs[j * C + 4 * q + k], acc[j][k]);
+      for (int k = 0; k < 4; ++k) atomicAdd(&accs[j * C + 4 * q + k], acc[j][k >> 1][k & 1]);
   }
   __syncthreads();
   for (int i = tid; i < 8 * C; i += 256) unsafeAtomicAdd(dw + i, accs[i]);

@@ -43,12 +43,16 @@
 #define MFPA_NO_PK_F32      // host pass of the same translation unit: the attribute names a gfx950 feature
 #endif
 
-// One scalar v_fma_f32, kept from being paired into v_pk_fma_f32 (the empty asm): for a few FMAs inside a large templated kernel
-// whose other packed arithmetic should stay packed.
-__device__ __forceinline__ float mfpa_fma1(float a, float b, float c) {
-  float t = __builtin_fmaf(a, b, c);
-  asm volatile("" : "+v"(t));
-  return t;
+// {x, x} for a packed-fp32 multiply-add by a scalar, built so that hipcc CANNOT take x out of the high half of a register pair
+// (the op_sel:[...] form): x is moved into the LOW half of a fresh pair (the empty asm pins it there) and broadcast from it, which is
+// the op_sel_hi form.  One v_mov per scalar; the FMAs stay packed -- hot VALU kernels (conv1d_c1_kernel, c1_wgrad_kernel, the UNet's
+// first layer in the loader) lose far less than under MFPA_NO_PK_F32, which doubles their FMA count.
+typedef float mfpa_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mfpa_f32x2 mfpa_bcast2(float x) {
+  mfpa_f32x2 lo;
+  lo.x = x;                                  // the high half is never read
+  asm volatile("" : "+v"(lo));
+  return mfpa_f32x2{lo.x, lo.x};
 }
 
 // CU count of the CURRENT device (cached per device id: a process may drive several GPUs).  The persistent LSTM kernels size their

@@ -54,9 +54,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define MFPA_CONV_BDIR64 0          // 1: weights-direct form also for 64-channel output tiles (8 waves of 64 px x 32 ch, one workgroup per CU): correct
                                     // (tests/test_gpu_unet.py runs it when enabled), +1.7 % per layer stand-alone but -2.8 % on the headline (3990 vs 4107 clips/s, two A/B pairs)
 #endif
-#ifndef MFPA_C1_PAIR_FORM
-#define MFPA_C1_PAIR_FORM 2         // fused first layer: 1 = every sample as a full {x, x} pair, 2 = sample in the low half + op_sel_hi broadcast
-#endif
 #ifndef MFPA_BDIR_SPREAD_SPLIT
 #define MFPA_BDIR_SPREAD_SPLIT 1    // weights-direct kernels: the halo split one staging slot per tap inside the MFMA phases (0: one block at tap 2)
 #endif
@@ -298,24 +295,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
           v = f32x4{0.f, 0.f, 0.f, 0.f};
           if (inside) {                                                    // conv2's zero padding stays exactly zero
             const float* sp = Sp + (pix / HPW) * SW + (pix % HPW);        // 3x3 window of the first layer around (gy, gx)
-            // Packed FMAs on a sample MATERIALISED as an {x, x} pair: written as `v += sv * wv` hipcc keeps two samples in one
-            // register pair and selects the odd one with v_pk_fma_f32 ... op_sel:[1,0,0], the operand-selection form the library
-            // does not ship (mfpa_common.h; tests/test_isa_scan.py).  The pair form costs one v_mov per sample; scalar FMAs in its
-            // place made this kernel 18 % slower (7.0 instead of 5.8 vector instructions per MFMA).
+            // Packed FMAs on a sample broadcast out of the LOW half of a pair (mfpa_bcast2): written as `v += sv * wv` hipcc keeps two
+            // samples in one register pair and selects the odd one with v_pk_fma_f32 ... op_sel:[1,0,0], the operand-selection form
+            // the library does not ship (mfpa_common.h; tests/test_isa_scan.py).  One v_mov per sample; scalar FMAs in its place made
+            // this kernel 18 % slower (7.0 instead of 5.8 vector instructions per MFMA).
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
               const float sv = sp[(t / 3) * SW + (t % 3)];
-#if MFPA_C1_PAIR_FORM == 1
-              f32x2 xx = {sv, sv};
-              asm volatile("" : "+v"(xx));
-#else
-              f32x2 lo;                        // the sample in the LOW half of an (even-aligned) register pair, the high half is never read:
-              lo.x = sv;                       // the broadcast {lo.x, lo.x} is the op_sel_hi form
-              asm volatile("" : "+v"(lo));
-              const f32x2 xx = {lo.x, lo.x};
-#endif
+              const f32x2 xx = mfpa_bcast2(sv);
               const f32x4 wv = c1w[t];
               v01 += xx * f32x2{wv.x, wv.y};
               v23 += xx * f32x2{wv.z, wv.w};

@@ -212,14 +212,33 @@ def _lstm_work(dev, layer: int, B: int, H: int, backward: bool = False) -> torch
     return ent[0]
 
 
+_LSTM_MARK: Dict[int, "torch.cuda.Event"] = {}     # device index -> event behind the last persistent launches and their error-word copies
+
+
+def lstm_mark(dev) -> None:
+    """Call right behind a group of persistent LSTM launches (on the stream that is ordered after all of them): queues the copy of
+    their scratch buffers' error words to pinned host memory and records the event lstm_results_ok() will wait for.  The wait then
+    ends as soon as the GPU has passed the RECURRENCE -- whatever the operator queues afterwards (the decoder, the encoder's
+    backward) is still in the queue while the host looks at the words, so the GPU never idles on a slow host."""
+    idx = _dev_index(dev)
+    touched = _LSTM_TOUCHED.get(idx)
+    if not touched or torch.cuda.is_current_stream_capturing():
+        return
+    off = lib().mfpa_lstm_seq_error_offset() // 4
+    for buf, host in touched:
+        host.copy_(buf[off:off + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _LSTM_MARK[idx] = ev
+
+
 def lstm_results_ok(dev) -> bool:
     """Did every persistent LSTM launch issued on `dev` since the last call finish its waits?  Called where results leave an operator.
 
     The kernels spin on inter-workgroup counters and need their whole grid co-resident; a wait that gives up (another process on the
     GPU, a grid that could not become resident) raises an error word in the launch's scratch and the kernel finishes with garbage.
-    The word of every scratch buffer used since the last call is copied to pinned host memory behind the launches (stream order) and
-    read after ONE event synchronisation per stream: the host waits until the GPU has passed the recurrence -- everything the operator
-    queued behind it (the decoder, the peak picker) is still in the queue, so the GPU does not idle.
+    lstm_mark() queued the copy of those words behind the launches; here the host waits for that event -- ONE wait, which ends when
+    the GPU has passed the recurrence, with the rest of the operator's launches still queued -- and reads them.
     On error: the words are cleared, the persistent path is switched OFF for the process (PERSISTENT_LSTM / _BWD = False: the
     per-step kernels need no co-residency) and False is returned -- the caller re-runs its launches.  Under HIP-graph capture nothing
     can be checked (no host access): returns True, and the capture's scratch lives in the graph's pool."""
@@ -229,16 +248,13 @@ def lstm_results_ok(dev) -> bool:
     if not touched or torch.cuda.is_current_stream_capturing():
         return True
     off = lib().mfpa_lstm_seq_error_offset() // 4
-    # the buffers were used on the current stream and the side stream: the copy is ordered behind BOTH through an event
-    cur = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(idx)
-    if side is not None and side is not cur:
-        cur.wait_stream(side)
-    for buf, host in touched:
-        host.copy_(buf[off:off + 1], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    ev.synchronize()
+    if _LSTM_MARK.get(idx) is None:          # launches issued without a mark (direct users of the C entry points): mark now
+        cur = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.get(idx)
+        if side is not None and side is not cur:
+            cur.wait_stream(side)
+        lstm_mark(dev)
+    _LSTM_MARK.pop(idx).synchronize()
     bad = [e for e in touched if int(e[1][0]) != 0]
     _LSTM_TOUCHED[idx] = []
     if not bad:
@@ -372,6 +388,8 @@ def lstm_two_layers(x: torch.Tensor, skip: torch.Tensor, wih, bias, whh_grouped,
         _K._TIMER = timer
     if t0ev is not None:
         _K._TIMER.stop(t0ev)
+    if work is not None:
+        lstm_mark(dev)                       # both layers are ordered before this point of the current stream (main.wait_stream(side))
     return xsum, [(x, xp[0], hs[0], cs[0]), (hs[0], xp[1], hs[1], cs[1])]
 
 

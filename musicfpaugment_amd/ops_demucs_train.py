@@ -488,6 +488,8 @@ class DemucsTrainEngine:
             _K._TIMER = timer
         if t0 is not None:
             _K._TIMER.stop(t0)
+        if bwork is not None:
+            D.lstm_mark(dev)                 # the error words of this step's persistent launches, copied right behind the recurrence
         for layer, (seq, gates, hseq) in enumerate(((seq0, g0, hseq0), (seq1, g1, hseq1))):
             gemm_tn(ptr(gates), 4 * H, 0, ptr(seq), H, 0, G[f"lstm{layer}.wih"], H, 1, B * Tn, 4 * H, H, colsum=G[f"lstm{layer}.bih"])
             G[f"lstm{layer}.bhh"].copy_(G[f"lstm{layer}.bih"])

@@ -16,9 +16,9 @@ python tools/summarize_sq.py $O/pmc_s1 conv_mfma_kernel,convT_mfma_kernel $O/pmc
 python tools/summarize_sq.py $O/pmc_s2 conv_mfma_kernel,convT_mfma_kernel $O/pmc_sq_pass2.json > $O/pmc_sq2.txt 2>&1
 python tools/sq_table.py $O/pmc_sq_pass1.json $O/pmc_sq_pass2.json > $O/pmc_sq_table.md 2>&1
 rm -rf $O/pmc_s1 $O/pmc_s2
-timeout -k 10 300 python bench.py --mode train --steps 5 --warmup 2 > $O/train_step_bench_line.json 2>> $O/bench.err
-timeout -k 10 300 python bench.py --mode demucs --steps 5 --warmup 2 > $O/demucs_bench_line.json 2>> $O/bench.err
-timeout -k 10 300 python bench.py --mode demucs-train --steps 5 --warmup 2 > $O/demucs_train_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --mode train --steps 20 --warmup 5 > $O/train_step_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --mode demucs --steps 20 --warmup 5 > $O/demucs_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --mode demucs-train --steps 20 --warmup 5 > $O/demucs_train_bench_line.json 2>> $O/bench.err
 python tools/time_small_kernels.py 256 > $O/small_kernels.txt 2>&1
 python tools/exp_conv.py --both --reps 5 > $O/conv_layers_lds_vs_direct.txt 2>&1
 ls $O; cat $O/pmc_traffic.log | tail -2
