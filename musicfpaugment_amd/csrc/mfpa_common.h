@@ -51,7 +51,8 @@ typedef float mfpa_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ mfpa_f32x2 mfpa_bcast2(float x) {
   mfpa_f32x2 lo;
   lo.x = x;                                  // the high half is never read
-  asm volatile("" : "+v"(lo));
+  asm("" : "+v"(lo));                        // NOT volatile: volatile asm statements keep their program order, which serialised the nine LDS sample
+                                             // reads of the UNet's first layer (each waited for before the next was issued: 7 us per chunk and workgroup)
   return mfpa_f32x2{lo.x, lo.x};
 }
 

@@ -23,6 +23,19 @@
 
 namespace {
 
+#ifdef MFPA_EXPERIMENTS
+// In-kernel timeline (experiments build only; tools/exp_conv_timeline.py): every workgroup's wave 0 stamps s_memrealtime (100 MHz) at five points
+// into a buffer whose address the tool stores in this device symbol.  No output value depends on a stamp.
+__device__ unsigned long long* mfpa_conv_stamps = nullptr;
+#define MFPA_STAMP(slot)                                                                                                   \
+  do {                                                                                                                     \
+    if (mfpa_conv_stamps && threadIdx.x == 0)                                                                              \
+      mfpa_conv_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+#else
+#define MFPA_STAMP(slot) do { } while (0)
+#endif
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   float* Sp = Bs0 + B_STAGES * B_STAGE;               // [SH][SW]
   float* W1s = Sp + SH * SW;                          // [9][64]
 
+  MFPA_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int li = lane & 31, lh = lane >> 5;
@@ -757,6 +771,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     for (int i = tid; i < 9 * 64; i += THREADS) W1s[i] = a.c1_w[i];
     __syncthreads();
   }
+  MFPA_STAMP(1);                                       // C1SRC: the spectrogram patch and the first layer's weights are staged
   load_a(0, 0);
   if constexpr (BDIR) {
     load_bq(0, 0, Set0{});
@@ -801,6 +816,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     store_b(Set0{}, Bs0);
     if (nit > 1) load_b(1, Set0{});
     __syncthreads();
+    MFPA_STAMP(2);                                     // first halo tile (C1SRC: the first layer on it) and weight tile in LDS
     if constexpr (MODE == 0 && MFPA_CONV_STATIC_TAPS != 0) {
       // nine is odd: the parity of a chunk's first iteration alternates from chunk to chunk
       int chunk = 0;
@@ -817,6 +833,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     }
   }
 
+  MFPA_STAMP(3);                                       // main loop done
   // epilogue: out = relu(acc * scale[n] + shift[n]); D[row = pixel][col = channel]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -896,13 +913,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     }
   }
   if (MODE == 0 && WN <= 2 && a.w1x1 != nullptr) {
-    // OutConv 1x1 to one class: a wave holds BN / WN channels of its 64 pixels; reduce over the 32 channel lanes, and with
-    // WN == 2 add the two waves' halves through LDS (the staging buffers are free once every wave has left the main loop)
+    // OutConv 1x1 to one class: a wave holds BN / WN channels of its pixels, one channel per lane of a 32-lane half.  The channel
+    // sum is a DPP reduction (row_shr 1 / 2 / 4 / 8, then row_bcast:15 into the odd rows: five vector adds, no LDS crossbar -- the
+    // ds_bpermute butterfly of __shfl_xor cost 126 waits per workgroup here), the totals of lanes 31 / 63 meet in LDS (the staging
+    // buffers are free once every wave has left the main loop; with WN == 2 two waves contribute to a pixel) and are written out
+    // one pixel per thread, coalesced along the patch rows.
     float wv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wv[nt] = a.w1x1[n0 + wn * (NT * 32) + nt * 32 + li];
-    float* red = As;                                     // [BM] partial sums of the wn == 1 waves
-    if (WN == 2) __syncthreads();
+    float* red = As;                                     // [WN][BM] channel sums
+    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -910,25 +930,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
         float p = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) p += acc[mt][nt][r] * wv[nt];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x111, 0xf, 0xf, false));      // row_shr:1
+        p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x112, 0xf, 0xf, false));      // row_shr:2
+        p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x114, 0xf, 0xf, false));      // row_shr:4
+        p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x118, 0xf, 0xf, false));      // row_shr:8: lane 15 of a row = its total
+        p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
         const int m = wm * WPX + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (WN == 2 && wn == 1 && li == 0) red[m] = p;
-        acc[mt][0][r] = p;                               // kept for the second half below
+        if (li == 31) red[wn * BM + m] = p;
       }
-    if (WN == 2) __syncthreads();
-    if (wn == 0) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = wm * WPX + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int gy = y0 + m / PW, gx = x0p + m % PW;
-          const float p = acc[mt][0][r] + (WN == 2 ? red[m] : 0.f);
-          if (li == 0 && gy < a.H && gx < a.W) a.y1x1[((size_t)b * a.H + gy) * a.W + gx] = p + a.b1x1;
-        }
+    __syncthreads();
+    for (int m = tid; m < BM; m += THREADS) {
+      const int gy = y0 + m / PW, gx = x0p + m % PW;
+      const float p = red[m] + (WN == 2 ? red[BM + m] : 0.f);
+      if (gy < a.H && gx < a.W) a.y1x1[((size_t)b * a.H + gy) * a.W + gx] = p + a.b1x1;
     }
   }
+  MFPA_STAMP(4);
 }
 
 // ConvTranspose2d(k = 2, s = 2) forward: out[2y+dy, 2x+dx][co] = sum_ci x[y,x][ci] * w[dy,dx][co][ci] + bias[co].
@@ -1407,6 +1424,12 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->mode == 1) return dispatch_conv<1>(a, s, d->precision);
   return dispatch_conv<2>(a, s, d->precision);
 }
+
+#ifdef MFPA_EXPERIMENTS
+int mfpa_exp_conv_stamps(unsigned long long* buf) {       // experiments build only (not in include/mfpa.h): timeline buffer, 8 slots per workgroup
+  return hipMemcpyToSymbol(HIP_SYMBOL(mfpa_conv_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision) {
   if (H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;
