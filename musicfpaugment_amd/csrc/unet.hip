@@ -63,6 +63,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define MFPA_CONV_MT4 0             // 1: the 256 x 128 tile on FOUR waves of 128 px x 64 ch (8 x 32 patches); 2: also the 16 x 16 patches of the bottleneck
                                     // (measured per layer: 3-17 % SLOWER than the 8-wave shape -- a quarter less LDS traffic does not pay for one wave per SIMD)
 #endif
+#ifndef MFPA_CONV_LDS_EPI
+#define MFPA_CONV_LDS_EPI 0         // 1: 64-channel tiles of the plain loop write their output (and the fused max-pool) through LDS as 16-byte pieces.
+                                    // Correct (all GPU tests pass with it) and the in-kernel timeline shows the epilogue shrink 7.8 -> 5.6-6.3 us per
+                                    // workgroup, but three same-call A/B pairs read 4082 / 4088 / 4091 vs 4091 / 4090 / 4093 clips/s: the stores of one
+                                    // workgroup already overlap the partner workgroup's loop -- off.
+#endif
 #ifndef MFPA_CONV_BDIR64
 #define MFPA_CONV_BDIR64 0          // 1: weights-direct form also for 64-channel output tiles (8 waves of 64 px x 32 ch, one workgroup per CU): correct
                                     // (tests/test_gpu_unet.py runs it when enabled), +1.7 % per layer stand-alone but -2.8 % on the headline (3990 vs 4107 clips/s, two A/B pairs)
@@ -849,7 +855,57 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
         acc[mt][nt][r] = v;
       }
   }
-  if (a.y != nullptr) {
+  // 64-channel tiles of the plain loop (the full-resolution layers: 64 KB of output + 16 KB of pooled output per workgroup): the tile goes
+  // through LDS -- free once every wave has left the main loop -- and out as 16-byte pieces, a pixel's 64 channels by 16 adjacent lanes:
+  // 16 dwordx4 stores per thread instead of 64 scalar ones (the in-kernel timeline put the epilogue at 7.8 us of a 34-56 us workgroup
+  // lifetime), and the 2x2 max-pool reads its windows from the same tile.
+  constexpr bool LDS_EPI = MFPA_CONV_LDS_EPI && (MODE == 0 && !PIPE && BN == 64 && BM == 256 && PW == 32);
+  if constexpr (LDS_EPI) {
+    if (a.y != nullptr || a.y_pool != nullptr) {
+      float* T = reinterpret_cast<float*>(smem);                       // [BM][BN]
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = wm * WPX + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) T[m * BN + wn * (NT * 32) + nt * 32 + li] = acc[mt][nt][r];
+        }
+      __syncthreads();
+      constexpr int Q = BN / 4;                                        // 16-byte pieces per pixel
+      if (a.y != nullptr && !MFPA_EXP_FLAG(a.dbg, 4)) {
+        char* yb = reinterpret_cast<char*>(a.y + (size_t)b * a.yH * a.yW * a.Cout);
+#pragma unroll
+        for (int it = 0; it < BM * Q / THREADS; ++it) {
+          const int idx = tid + it * THREADS, p = idx / Q, q = idx % Q;
+          const int gy = y0 + p / PW, gx = x0p + p % PW;
+          if (gy < a.yH && gx < a.yW)
+            *reinterpret_cast<f32x4*>(yb + (((unsigned)gy * (unsigned)a.yW + (unsigned)gx) * (unsigned)a.Cout + (unsigned)(n0 + 4 * q)) * 4u) =
+                *reinterpret_cast<const f32x4*>(T + p * BN + 4 * q);
+        }
+      }
+      if (a.y_pool != nullptr) {
+        const int Ho = a.H / 2, Wo = a.W / 2;
+#pragma unroll
+        for (int it = 0; it < (BM / 4) * Q / THREADS; ++it) {
+          const int idx = tid + it * THREADS, pp = idx / Q, q = idx % Q;
+          const int ly = pp / (PW / 2), lx = pp % (PW / 2);
+          const int py = y0 / 2 + ly, px = x0p / 2 + lx;
+          if (py < Ho && px < Wo) {
+            const float* t0 = T + ((2 * ly) * PW + 2 * lx) * BN + 4 * q;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(t0), v01 = *reinterpret_cast<const f32x4*>(t0 + BN);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(t0 + PW * BN), v11 = *reinterpret_cast<const f32x4*>(t0 + PW * BN + BN);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+            *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)b * Ho + py) * Wo + px) * a.Cout + n0 + 4 * q) = o;
+          }
+        }
+      }
+    }
+  }
+  if (!LDS_EPI && a.y != nullptr) {
     // 32-bit byte offsets from a scalar per-clip base (the host checks that one clip's output fits 4 GB), the pixel offset
     // computed once for all of a lane's channels, and no bounds checks on interior tiles: the first form of this loop (64-bit
     // index arithmetic and an exec-mask branch per element) was up to 13 % of the 64-channel layers
@@ -877,7 +933,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
       }
     }
   }
-  if (MODE == 0 && a.y_pool != nullptr) {
+  if (!LDS_EPI && MODE == 0 && a.y_pool != nullptr) {
     // MaxPool2d(2) (floor): every 2x2 window lives in ONE lane's accumulators (the two rows of a window are the
     // wave's two 32-pixel MFMA tiles for 32-wide patches, registers r / r+8 for 16-wide ones; the two columns are
     // registers r / r+1), so pooling needs no cross-lane traffic.
