@@ -784,6 +784,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
     load_bq(0, 1, Set1{});
     store_a(0, As);
     __syncthreads();
+    MFPA_STAMP(2);
     read_afrags(fa0, As, 0, 0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       tap_body_d(std::integral_constant<int, 0>{}, chunk);

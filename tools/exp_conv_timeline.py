@@ -19,6 +19,15 @@ wo = torch.randn(64, device="cuda")
 runs = [("inc.3  c1src + pool", lambda: K.conv3x3_fused(None, w64, sc, sh, precision=1, pool=True, c1=dict(spec64=spec, denom=den, w=w1, scale=sc, shift=sh))),
         ("up4.0  concat", lambda: K.conv3x3_fused(x, w128, sc, sh, x1=u, precision=1)),
         ("up4.3  + OutConv", lambda: K.conv3x3_fused(x, w64, sc, sh, precision=1, out1x1=(wo, 0.1), store=False))]
+def wd(H_, W_, ci, co):
+    xx = torch.randn(B, H_, W_, ci, device="cuda"); w = torch.randn(9, co, ci, device="cuda") * 0.05
+    w3, wf = K.split_bf16x3(w), K.split_bf16x3_frag(w)
+    s1 = torch.ones(co, device="cuda"); h1 = torch.zeros(co, device="cuda")
+    return lambda: K.conv3x3_fused(xx, w3, s1, h1, precision=1, wf=wf)
+if "--direct" in sys.argv:          # the weights-direct kernel on representative layers
+    runs = [("d1.3  128->128 @128x125", wd(128, 125, 128, 128)), ("up3.0 256->128 @128x125", wd(128, 125, 256, 128)),
+            ("d2.3  256->256 @64x62", wd(64, 62, 256, 256)), ("d3.3  512->512 @32x31", wd(32, 31, 512, 512)),
+            ("up1.0 1024->512 @32x31", wd(32, 31, 1024, 512)), ("d4.3 1024->1024 @16x15", wd(16, 15, 1024, 1024))]
 nwg = 8 * 33 * B
 buf = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
 for name, fn in runs:
