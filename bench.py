@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
-PMC_TRAFFIC_BF16X3 = "r02_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
+PMC_TRAFFIC_BF16X3 = "r03_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
 PMC_TRAFFIC_DEMUCS = "r02_pmc_traffic_demucs.json"   # the same for the Demucs forward (GEMM family + LSTM launches)
 
 
@@ -652,8 +652,8 @@ def bench_infer(args, rank, world, dev, dist):
                 "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                 "mfma_flops_issued_per_algorithmic_flop": 3,
                 "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                "kernel": "conv_mfma_kernel<PREC 1> + convT_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 "
-                          "per fp32 product)",
+                "kernel": "conv_mfma_kernel<PREC 1> (weights-direct form on the >= 128-channel layers, plain loop on the 64-channel ones) + "
+                          "convT_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 per fp32 product)",
                 "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
 
     if net is not None and timer.launches():
@@ -712,8 +712,8 @@ def other_configs(args, dev):
         ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
         ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
         ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
-        ("config4_unet_train_step", bench_train, dict(mode="train", steps=3, warmup=1, clips=64, seconds=8.0)),
-        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=3, warmup=1, clips=256)),
+        ("config4_unet_train_step", bench_train, dict(mode="train", steps=6, warmup=2, clips=64, seconds=8.0)),
+        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=6, warmup=2, clips=256)),
         # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
         # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
         ("config5_peak_metrics", bench_metrics, dict(mode="metrics", queries=10000, denoiser="demucs", steps=1, warmup=1, clips=256)),

@@ -34,6 +34,15 @@ def valid_length(length: int) -> int:
     return int(math.ceil(length / RESAMPLE))
 
 
+PAD_N_TO_WIDE_TILE = True   # K >= 128 layers with 128 < N, N % 128 != 0 (the two N = 192 layers): weight rows zero-padded to a multiple of
+                            # 128 so that the pipelined 256 x 128 tile serves them (a third of the second column tile is idle) instead of
+                            # the round-1 128 x 64 tile
+
+
+def _wide_mult(n: int, k: int) -> int:
+    return 128 if (PAD_N_TO_WIDE_TILE and n > 128 and n % 128 and k >= 128 and k % 64 == 0) else 64
+
+
 def _pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
     n = w.shape[0]
     npad = (n + mult - 1) // mult * mult
@@ -68,8 +77,10 @@ def pack_demucs_weights(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.
             pw["enc0.w"] = w[:, 0, :].t().contiguous()         # (8, h) tap-major
             pw["enc0.b"] = f("encoder.0.0.bias").contiguous()
         else:
-            pw[f"enc{i}.w"] = _pad_rows(w.permute(0, 2, 1).reshape(w.shape[0], -1))    # [co][j][c]: K = j*cin + c
-            pw[f"enc{i}.b"] = _pad_rows(f(f"encoder.{i}.0.bias"))
+            wk = w.permute(0, 2, 1).reshape(w.shape[0], -1)                          # [co][j][c]: K = j*cin + c
+            mult = _wide_mult(wk.shape[0], wk.shape[1])
+            pw[f"enc{i}.w"] = _pad_rows(wk, mult)
+            pw[f"enc{i}.b"] = _pad_rows(f(f"encoder.{i}.0.bias"), mult)
         pw[f"enc{i}.gw"], pw[f"enc{i}.gb"] = _pack_glu(f(f"encoder.{i}.2.weight")[:, :, 0], f(f"encoder.{i}.2.bias"))
     for d in range(DEPTH):
         pw[f"dec{d}.gw"], pw[f"dec{d}.gb"] = _pack_glu(f(f"decoder.{d}.0.weight")[:, :, 0], f(f"decoder.{d}.0.bias"))
@@ -89,8 +100,9 @@ def pack_demucs_weights(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.
         else:
             # row n = j*cout + co, K = [previous row g[t-1] -> tap j+4 | current row g[t] -> tap j]
             wt = torch.cat([w[:, :, 4:8].permute(2, 1, 0), w[:, :, 0:4].permute(2, 1, 0)], dim=2)   # (4, cout, 2h)
-            pw[f"dec{d}.w"] = _pad_rows(wt.reshape(4 * cout, 2 * h))
-            pw[f"dec{d}.b"] = _pad_rows(f(f"decoder.{d}.2.bias").repeat(4))
+            mult = _wide_mult(4 * cout, 2 * h)
+            pw[f"dec{d}.w"] = _pad_rows(wt.reshape(4 * cout, 2 * h), mult)
+            pw[f"dec{d}.b"] = _pad_rows(f(f"decoder.{d}.2.bias").repeat(4), mult)
     for layer in range(2):
         pw[f"lstm{layer}.wih"] = f(f"lstm.lstm.weight_ih_l{layer}").contiguous()
         whh = f(f"lstm.lstm.weight_hh_l{layer}")                # (4H, H), gate blocks i | f | g | o
