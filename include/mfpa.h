@@ -228,13 +228,15 @@ typedef struct mfpa_conv_desc {
   const float* c1_x32; const double* c1_spec64; const double* c1_denom;
   const float* c1_w; const float* c1_scale; const float* c1_shift;
   /* precision 1, mode 0: which bf16x3 image `w` holds.  0 = the row image ([tap][Cin / 32][Cout][128 B], staged through LDS);
-   * 1 = the FRAGMENT-ORDERED image ([tap][Cin / 32][Cout / 32][substep 2][hi | lo][lane 64][16 B]: a wave reads the MFMA B
-   * operand of a 32-channel column tile straight from L1 / L2, no weight tile in LDS, one barrier per 32-channel chunk instead
-   * of one per tap) -- only for shapes where mfpa_conv_weight_layout() returns 1, MFPA_EINVAL otherwise. */
+   * 1, 2 = FRAGMENT-ORDERED images of the weights-direct kernels (a wave reads the MFMA weight operand of its column tile straight
+   * from L1 / L2: no weight tile in LDS, one barrier per 32-channel chunk instead of one per tap): 2 = [tap][Cin / 32][Cout / 16]
+   * [hi | lo][lane 64][16 B] for v_mfma_f32_16x16x32_bf16 (conv_wd16_kernel), 1 = [tap][Cin / 32][Cout / 32][substep 2][hi | lo]
+   * [lane 64][16 B] for v_mfma_f32_32x32x16_bf16 -- valid exactly where mfpa_conv_weight_layout() returns that number,
+   * MFPA_EINVAL otherwise. */
   int w_layout;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
-/* HOST function: 1 when the fastest kernel for a (H, W) convolution of this shape reads the fragment-ordered image, else 0. */
+/* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */
 int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision);
 
 /* First layer: 3x3 conv from ONE input channel (inc.double_conv.0, unet.py:86) fused with the
@@ -355,7 +357,8 @@ int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dp
  * host-side flip / transpose / bf16 split of the packing code).  w: [taps][Co][Ci] fp32.  out, precision 0: [taps][nrows][K] float rows;
  * precision 1: the bf16x3 image [taps][K / 32][nrows][128 B], a row = 32 bf16 hi | 32 bf16 lo in eight 16-byte slots stored at slot
  * index (logical ^ ((row >> 1) & 7)) -- a (tap, chunk, 128-row) tile is 16 KB contiguous (csrc/unet.hip); precision 2: the same split in
- * the FRAGMENT-ORDERED layout of mfpa_conv_desc.w_layout = 1 ([taps][K / 32][nrows / 32][substep][hi | lo][lane][8 bf16]).  flip_transpose = 0: rows = output
+ * the FRAGMENT-ORDERED layout of mfpa_conv_desc.w_layout = 1 ([taps][K / 32][nrows / 32][substep][hi | lo][lane][8 bf16]); precision 3:
+ * that of w_layout = 2 ([taps][K / 32][nrows / 16][hi | lo][lane][8 bf16]).  flip_transpose = 0: rows = output
  * channels row0 .. row0+nrows-1, K = Ci (forward operand).  flip_transpose = 1: rows = input channels row0 .. row0+nrows-1,
  * K = Co, and for taps == 9 the kernel is flipped (tap t <- 8 - t): the input-gradient operand (training/unet.py's Conv2d /
  * ConvTranspose2d backward).  Co, Ci, row0, nrows multiples of 32. */

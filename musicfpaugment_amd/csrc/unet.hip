@@ -69,6 +69,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                                     // workgroup, but three same-call A/B pairs read 4082 / 4088 / 4091 vs 4091 / 4090 / 4093 clips/s: the stores of one
                                     // workgroup already overlap the partner workgroup's loop -- off.
 #endif
+#ifndef MFPA_CONV_WD16
+#define MFPA_CONV_WD16 1            // >= 128-channel weights-direct layers on v_mfma_f32_16x16x32_bf16 (0: the 32 x 32 x 16 BDIR form of round 3's first half)
+#endif
 #ifndef MFPA_CONV_BDIR64
 #define MFPA_CONV_BDIR64 0          // 1: weights-direct form also for 64-channel output tiles (8 waves of 64 px x 32 ch, one workgroup per CU): correct
                                     // (tests/test_gpu_unet.py runs it when enabled), +1.7 % per layer stand-alone but -2.8 % on the headline (3990 vs 4107 clips/s, two A/B pairs)
@@ -1005,6 +1008,319 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
   MFPA_STAMP(4);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weights-direct 3x3 convolution on v_mfma_f32_16x16x32_bf16 ("WD16", mfpa_conv_desc.w_layout 2).  Same structure as the BDIR form of
+// conv_mfma_kernel -- 8 waves = 2 pixel halves x 4 column tiles, a wave owns 128 pixels x 32 channels, the weight operand straight from
+// L1 / L2 out of a fragment-ordered image two taps ahead through a ring of three register sets, the halo tile double-buffered in LDS,
+// ONE barrier per 32-channel chunk, the next chunk's halo split one staging slot per tap inside the MFMA phases -- but the matrix
+// instruction is the 16 x 16 x 32 one: a whole 32-channel chunk is ONE k-step, and a quarter of the accumulator rows per instruction.
+// The weights-direct loop is clock (power) limited, and under the same loop with the same operand traffic the chip holds a higher clock
+// on this shape: a timing experiment with the 32 x 32 x 16 instructions of the BDIR kernel replaced one for two (wrong results) ran the
+// eleven >= 128-channel layers in 11.07-11.10 ms instead of 11.93-12.00 ms (64 clips), which is what this kernel is built on.
+//   roles: A operand = weights (16 output channels x 32 k), B operand = pixels (32 k x 16 pixels), so D[channel][pixel]: a lane holds FOUR
+//          CONSECUTIVE CHANNELS of one pixel -- the epilogue stores 16-byte pieces (16 stores per wave instead of 64 scalar ones) and the
+//          2 x 2 max-pool needs one DPP swap of adjacent lanes;
+//   LDS:   per halo stage eight planes [hi | lo][k-group 0..3] of (pixel x 16 B): a fragment read is 16 consecutive pixels of one plane per
+//          k-group -- conflict-free for ds_read_b128's lane groups exactly when the k-group planes are a multiple of 256 B apart; planes 2, 3
+//          sit another 128 B further so that the split's 8-byte stores conflict 2-way instead of 4-way.
+//   image: [tap][chunk = Cin / 32][Cout / 16][hi | lo][lane 64][16 B], lane (g = l >> 4, c = l & 15) = channel 16 t + c, k 32 chunk + 8 g .. + 7
+//          (ops_unet.split_bf16x3_frag(w, 2), mfpa_pack_conv_weights(precision 3)).
+// Not bit-identical to the 32 x 32 x 16 kernels (a k-step sums 32 products inside the instruction); same products, fp32 accumulate.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int PH, int PW>
+__global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
+  constexpr int THREADS = 512, BN = 128, TAPS = 9;
+  constexpr int HPW = PW + 2, HPH = PH + 2, HP = HPW * HPH, BM = PH * PW;
+  static_assert(BM == 256 && (PW == 32 || PW == 16), "two waves of 128 pixels: eight 16-pixel tiles each");
+  constexpr int A_F4 = (HP * (KC / 4) + THREADS - 1) / THREADS;
+  constexpr int HPS = A_F4 * (THREADS / (KC / 4));                     // staged pixels (>= HP): every staging slot has a row
+  constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;                // bytes of one (hi|lo, k-group) plane, a multiple of 256
+  constexpr int HLS = 4 * PLANE + 256;                                 // hi -> lo distance (planes 2, 3 sit 128 B further: room for that)
+  constexpr int STAGE = 2 * HLS;
+  constexpr int PT = 8;                                                // 16-pixel tiles per wave
+  static_assert(A_F4 <= TAPS - 3, "one halo staging slot per tap, taps 2 .. 7");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int p = lane & 15, g = lane >> 4;
+  auto plane_off = [](int hl, int kg) { return hl * HLS + kg * PLANE + (kg >> 1) * 128; };
+
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+  const int b = bx;
+  const int n0 = blockIdx.y * BN;
+  const int y0 = ty * PH, x0p = tx * PW;
+  const int Cin = a.C0 + a.C1;
+  const int nchunks = Cin / KC;
+
+  // ---- halo loader (as conv_mfma_kernel's: unconditional clamped loads, padding zeroed when the slot is split)
+  const int aq = tid % (KC / 4);
+  int apix[A_F4];
+#pragma unroll
+  for (int it = 0; it < A_F4; ++it) {
+    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const int gy = y0 + pix / HPW - 1, gx = x0p + pix % HPW - 1;
+    const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+    apix[it] = (in ? 0 : (int)0x80000000) | (cy << 16) | cx;
+  }
+  const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * sizeof(float);
+  const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
+  auto src1_inside = [&](int pp) __attribute__((always_inline)) {
+    const int y1 = ((pp >> 16) & 0x7fff) - a.oy1, x1 = (pp & 0xffff) - a.ox1;
+    return pp >= 0 && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
+  };
+  f32x4 areg[A_F4];
+  auto load_a = [&](int chunk) __attribute__((always_inline)) {
+    const int c0 = chunk * KC;
+    const bool from0 = c0 < a.C0;
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) {
+      const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;
+      if (from0) {
+        const unsigned off = ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
+        areg[it] = *reinterpret_cast<const f32x4*>(xb0 + off);
+      } else {
+        const int y1 = min(max(gy - a.oy1, 0), a.H1 - 1), x1 = min(max(gx - a.ox1, 0), a.W1 - 1);
+        const unsigned off = ((unsigned)(y1 * a.W1 + x1) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
+        areg[it] = *reinterpret_cast<const f32x4*>(xb1 + off);
+      }
+    }
+  };
+  // one staging slot: zero padding, the training forward's on-load affine + ReLU + dropout, bf16 hi / lo split, two 8-byte stores
+  // into the (hi, k-group) and (lo, k-group) planes (a thread's channel quad is half of k-group aq >> 1)
+  auto split_slot = [&](auto IT, int chunk, char* stage) __attribute__((always_inline)) {
+    constexpr int it = decltype(IT)::value;
+    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const int c0 = chunk * KC;
+    const bool inside = (c0 < a.C0) ? (apix[it] >= 0) : src1_inside(apix[it]);
+    f32x4 v = areg[it];
+    if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * aq);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * aq);
+      v = v * sc + sh;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      if (a.drop_thresh) {
+        const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;
+        const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * aq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
+      }
+    }
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    char* at = stage + plane_off(0, aq >> 1) + pix * 16 + 8 * (aq & 1);
+    *reinterpret_cast<bf16x4*>(at) = hi;
+    *reinterpret_cast<bf16x4*>(at + HLS) = lo;
+  };
+
+  // ---- weight fragments: ring of three sets, [slot][16-channel tile][hi, lo]
+  bf16x8 wq[3][2][2];
+  auto load_w = [&](int chunk, int tap, auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
+    const char* wb = reinterpret_cast<const char*>(a.w) +
+                     ((((size_t)tap * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
+    wq[slot][0][0] = *reinterpret_cast<const bf16x8*>(wb);
+    wq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+    wq[slot][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
+    wq[slot][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+  };
+
+  // ---- pixel fragments: two sets of four 16-pixel tiles (hi, lo)
+  struct XFrags { bf16x8 h[4], l[4]; };
+  XFrags fx0, fx1;
+  // byte offset of the lane's row of pixel tile 0 in plane (hi, g) at tap (0, 0); the other tiles are compile-time displacements of it
+  // (a 16-pixel tile is half a patch row of the 32-wide patches, a whole row of the 16-wide ones)
+  const int xbase = (((wm * 128 + p) / PW) * HPW + ((wm * 128 + p) % PW)) * 16 + plane_off(0, g);
+  auto tile_disp = [](int pt) { return (PW == 32) ? ((pt >> 1) * HPW + (pt & 1) * 16) * 16 : pt * HPW * 16; };
+  auto read_x = [&](XFrags& f, const char* stage, int tap_off, int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* r = stage + xbase + tile_disp(4 * half + i) + tap_off;
+      f.l[i] = *reinterpret_cast<const bf16x8*>(r + HLS);
+      f.h[i] = *reinterpret_cast<const bf16x8*>(r);
+    }
+  };
+  floatx4 acc[2][PT];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half) __attribute__((always_inline)) {
+    // term-major: an accumulator is touched every eighth instruction
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][1], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.l[i], acc[ct][4 * half + i], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  constexpr int N_R = 8, N_M = 24;                                     // fragment reads / MFMAs of one phase
+  // One tap.  Phase A: MFMA(pixel tiles 0..3 of tap t) || read tiles 4..7 of tap t, request the weights of tap t + 2.  Phase B: MFMA(tiles
+  // 4..7) || read tiles 0..3 of tap t + 1, (tap 0) request the next chunk's halo, (taps 2..7) split one staging slot of it.  The chunk's
+  // one barrier sits between the phases of tap 8 (see BDIR).
+  auto tap_body = [&](auto TAP, int chunk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(TAP)::value;
+    constexpr int ntap = (tap + 1) % TAPS;
+    constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * 16, ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * 16;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const char* cur = smem + (chunk & 1) * STAGE;
+    const char* nxt = (tap == TAPS - 1) ? smem + ((chunk + 1) & 1) * STAGE : cur;
+    read_x(fx1, cur, tap_off, 1);
+    mfma_half(fx0, wq[tap % 3], 0);
+    load_w((tap + 2 >= TAPS) ? chunk_n : chunk, (tap + 2) % TAPS, std::integral_constant<int, (tap + 2) % 3>{});
+    pin_reads<N_M - 1, N_R>();
+    constexpr int used_a = pin_read_slots(N_M - 1, N_R);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    if constexpr (N_M - used_a - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - used_a - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == TAPS - 1) {
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tap == 0) load_a(chunk_n);
+    read_x(fx0, nxt, ntap_off, 0);
+    mfma_half(fx1, wq[tap % 3], 1);
+    if constexpr (tap >= 2 && tap - 2 < A_F4) {
+      split_slot(std::integral_constant<int, tap - 2>{}, chunk_n, smem + ((chunk + 1) & 1) * STAGE);
+#pragma unroll
+      for (int i = 0; i < N_R; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 4, 0);
+    } else {
+      pin_reads<N_M, N_R>();
+      if constexpr (N_M - pin_read_slots(N_M, N_R) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_R), 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  load_a(0);
+  load_w(0, 0, S0{});
+  load_w(0, 1, S1{});
+  {
+    using I0 = std::integral_constant<int, 0>;
+    split_slot(I0{}, 0, smem);
+    if constexpr (A_F4 > 1) split_slot(std::integral_constant<int, 1>{}, 0, smem);
+    if constexpr (A_F4 > 2) split_slot(std::integral_constant<int, 2>{}, 0, smem);
+    if constexpr (A_F4 > 3) split_slot(std::integral_constant<int, 3>{}, 0, smem);
+    if constexpr (A_F4 > 4) split_slot(std::integral_constant<int, 4>{}, 0, smem);
+    if constexpr (A_F4 > 5) split_slot(std::integral_constant<int, 5>{}, 0, smem);
+  }
+  __syncthreads();
+  read_x(fx0, smem, 0, 0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    tap_body(std::integral_constant<int, 0>{}, chunk);
+    tap_body(std::integral_constant<int, 1>{}, chunk);
+    tap_body(std::integral_constant<int, 2>{}, chunk);
+    tap_body(std::integral_constant<int, 3>{}, chunk);
+    tap_body(std::integral_constant<int, 4>{}, chunk);
+    tap_body(std::integral_constant<int, 5>{}, chunk);
+    tap_body(std::integral_constant<int, 6>{}, chunk);
+    tap_body(std::integral_constant<int, 7>{}, chunk);
+    tap_body(std::integral_constant<int, 8>{}, chunk);
+  }
+
+  // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int ch = n0 + wn * 32 + ct * 16 + 4 * g;
+    const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4*>(a.shift + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[ct][pt][j] * sc[j] + sh[j];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        acc[ct][pt][j] = v;
+      }
+  }
+  if (a.y != nullptr) {
+    char* yb = reinterpret_cast<char*>(a.y + (size_t)b * a.yH * a.yW * a.Cout);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int m = wm * 128 + pt * 16 + p;
+      const int gy = y0 + m / PW, gx = x0p + m % PW;
+      if (gy < a.yH && gx < a.yW) {
+        char* yp = yb + (((unsigned)gy * (unsigned)a.yW + (unsigned)gx) * (unsigned)a.Cout + (unsigned)(n0 + wn * 32 + 4 * g)) * 4u;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
+          *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
+        }
+      }
+    }
+  }
+  if (a.y_pool != nullptr) {
+    // MaxPool2d(2) (floor): the window's two rows are two of the wave's pixel tiles, its two columns adjacent lanes (one DPP swap)
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    constexpr int ROWSTEP = (PW == 32) ? 2 : 1;                        // pixel tiles per patch row
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int row = pt / ROWSTEP;                                  // patch row inside the wave's block
+        if (row & 1) continue;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = fmaxf(acc[ct][pt][j], acc[ct][pt + ROWSTEP][j]);
+          const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+          v[j] = fmaxf(t, o);
+        }
+        const int m = wm * 128 + pt * 16 + p;
+        const int py = (y0 + m / PW) / 2, px = (x0p + m % PW) / 2;
+        if (!(p & 1) && py < Ho && px < Wo)
+          *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)b * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32 + ct * 16 + 4 * g) = v;
+      }
+  }
+}
+
+template <int PH, int PW>
+int launch_wd16(ConvArgs& a, hipStream_t s) {
+  a.tiles_x = (a.W + PW - 1) / PW;
+  a.tiles_y = (a.H + PH - 1) / PH;
+  if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
+  constexpr int HP = (PW + 2) * (PH + 2);
+  constexpr int A_F4 = (HP * (KC / 4) + 511) / 512;
+  constexpr int HPS = A_F4 * 64;
+  constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
+  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256));
+  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / 128));
+  hipLaunchKernelGGL((conv_wd16_kernel<PH, PW>), grid, dim3(512), lds, s, a);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
 // ConvTranspose2d(k = 2, s = 2) forward: out[2y+dy, 2x+dx][co] = sum_ci x[y,x][ci] * w[dy,dx][co][ci] + bias[co].
 // K = C_in only, so the generic kernel's one-tap-per-workgroup form re-staged the same input tile four times around a
 // 4..32-iteration loop.  Here a workgroup keeps FOUR accumulator sets (one per tap) for 128 input pixels x 64 output
@@ -1333,17 +1649,18 @@ int launch_conv(ConvArgs& a, int taps_y, hipStream_t s) {
   return MFPA_OK;
 }
 
-// Which bf16x3 weight image does the fastest kernel for this shape read?  1 = the fragment-ordered image (BDIR kernels: 3x3
-// convolution, 128-channel output tiles, >= 64 input channels, the 8 x 32 patches of the wide levels or the 16 x 16 patches of the
-// 16 x 15 level), 0 = the row image.
+// Which bf16x3 weight image does the fastest kernel for this shape read?  2 = the fragment-ordered image of the 16 x 16 x 32
+// weights-direct kernel (conv_wd16_kernel: 3x3 convolution, 128-channel output tiles, >= 64 input channels, the 8 x 32 patches of the
+// wide levels or the 16 x 16 patches of the 16 x 15 level), 1 = the image of the 32 x 32 x 16 weights-direct form (BDIR; with
+// MFPA_CONV_WD16 = 0, and the 64-channel tiles with MFPA_CONV_BDIR64), 0 = the row image.
 static int conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision) {
 #ifdef MFPA_CONV_NO_BDIR
   return 0;
 #endif
   if (mode != 0 || precision != 1 || Cin < MFPA_CONV_BIG_MIN_CIN) return 0;
   if (Cout % 128) return (MFPA_CONV_BDIR64 && Cout % 64 == 0 && W > 16 && H >= 8) ? 1 : 0;      // 64-channel output tiles
-  if (W > 16 && H >= 8) return 1;
-  if (W <= 16 && H >= 16 && MFPA_CONV_BOTTLENECK8) return 1;
+  if (W > 16 && H >= 8) return MFPA_CONV_WD16 ? 2 : 1;
+  if (W <= 16 && H >= 16 && MFPA_CONV_BOTTLENECK8) return MFPA_CONV_WD16 ? 2 : 1;
   return 0;
 }
 
@@ -1360,6 +1677,11 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   const int taps_y = (MODE == 1) ? 4 : 1;
   const bool bn128 = (a.Cout % 128 == 0);
   if constexpr (MODE == 0 && PREC == 1) {
+    if (a.w_frag == 2) {   // the 16 x 16 x 32 weights-direct kernel and its image
+      if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || a.c1_x32 || a.c1_spec64 || a.w1x1) return MFPA_EINVAL;
+      if (a.W > 16) return launch_wd16<8, 32>(a, s);
+      return launch_wd16<16, 16>(a, s);
+    }
     if (a.w_frag) {        // the caller packed the fragment-ordered image: only the BDIR kernels read it (conv_weight_layout() said so)
       if (!conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) || a.c1_x32 || a.c1_spec64) return MFPA_EINVAL;
       if (!bn128) return launch_conv<64, 8, 32, 4, 2, 0, 1, false, 2, true>(a, 1, s);     // 64-channel layers: 8 waves of 64 px x 32 ch
@@ -1473,8 +1795,8 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
     a.c1_w = d->c1_w; a.c1_scale = d->c1_scale; a.c1_shift = d->c1_shift;
   }
   if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
-  if (d->w_layout != 0 && d->w_layout != 1) return MFPA_EINVAL;
-  if (d->w_layout == 1 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
+  if (d->w_layout < 0 || d->w_layout > 2) return MFPA_EINVAL;
+  if (d->w_layout != 0 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
   a.w_frag = d->w_layout;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);

@@ -987,6 +987,16 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
     const float v = TR ? tile[tx][r] : tile[r][tx];                  // (n = n0 + r, k = k0 + tx)
     if (precision == 0) {
       out[((size_t)t * nrows + n0 + r) * K + k0 + tx] = v;             // [tap][row][K] floats
+    } else if (precision == 3) {
+      // the fragment-ordered image of the 16 x 16 x 32 weights-direct kernel (conv_wd16_kernel, ops_unet.split_bf16x3_frag(w, 2)):
+      // [tap][chunk][row / 16][hi | lo][lane = (k / 8) * 16 + row % 16][k % 8]
+      const int row = n0 + r, k = tx;
+      __bf16* ob = reinterpret_cast<__bf16*>(out) + ((((size_t)t * (K / 32) + k0 / 32) * (nrows / 16) + row / 16) << 10);
+      const __bf16 hi = (__bf16)v;
+      const __bf16 lo = (__bf16)(v - (float)hi);
+      const int at = (((k >> 3) * 16 + (row & 15)) << 3) + (k & 7);
+      ob[at] = hi;
+      ob[at + 512] = lo;
     } else if (precision == 2) {
       // the FRAGMENT-ORDERED bf16x3 image of the weights-direct kernels (csrc/unet.hip BDIR, ops_unet.split_bf16x3_frag):
       // [tap][chunk][row / 32][substep][hi | lo][lane = (k % 16 / 8) * 32 + row % 32][k % 8]
@@ -1326,7 +1336,7 @@ int mfpa_pack_conv_weights(const float* w, int taps, int Co, int Ci, int flip_tr
                             float* out, void* stream) {
   if (!w || !out || taps < 1 || Co < 32 || Ci < 32 || Co % 32 || Ci % 32 || nrows < 32 || nrows % 32 || row0 < 0 || row0 % 32)
     return MFPA_EINVAL;
-  if (precision != 0 && precision != 1 && precision != 2) return MFPA_EINVAL;     // 2: the fragment-ordered bf16x3 image
+  if (precision < 0 || precision > 3) return MFPA_EINVAL;     // 2 / 3: the fragment-ordered bf16x3 images (w_layout 1 / 2)
   if (row0 + nrows > (flip_transpose ? Ci : Co)) return MFPA_EINVAL;
   const int K = flip_transpose ? Co : Ci;
   dim3 grid(K / 32, nrows / 32, taps);

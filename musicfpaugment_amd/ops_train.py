@@ -69,18 +69,19 @@ def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, 
             w = w[:, row0:row0 + nrows].contiguous()
         if precision != 1:
             return w
-        return K.split_bf16x3_frag(w) if layout == 1 else K.split_bf16x3(w)
+        return K.split_bf16x3_frag(w, layout) if layout else K.split_bf16x3(w)
     out = torch.empty((taps, nrows, Co if flip_transpose else Ci), dtype=torch.float32, device=w.device)
-    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, 2 if (precision == 1 and layout == 1) else precision,
+    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, (1 + layout) if precision == 1 else precision,
                                        ptr(out), stream()), "mfpa_pack_conv_weights")
     return out
 
 
 def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int = 0) -> int:
-    """Which bf16x3 image the fastest kernel for this convolution reads (mfpa_conv_weight_layout): 1 = fragment-ordered."""
+    """Which bf16x3 image the fastest kernel for this convolution reads (mfpa_conv_weight_layout): 0 = the row image, 1 / 2 = the
+    fragment-ordered images of the weights-direct kernels."""
     if precision != 1 or mode != 0 or not K.USE_WEIGHTS_DIRECT:
         return 0
-    return int(lib().mfpa_conv_weight_layout(H, W, cin, cout, 0, 1) == 1)
+    return int(lib().mfpa_conv_weight_layout(H, W, cin, cout, 0, 1))
 
 
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
@@ -100,7 +101,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
         if DEVICE_PACK and w.is_contiguous() and w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0:
             w = pack_weights(w, 1, layout=w_layout)
         else:
-            w = K.split_bf16x3_frag(w) if w_layout else K.split_bf16x3(w)
+            w = K.split_bf16x3_frag(w, w_layout) if w_layout else K.split_bf16x3(w)
     if mode == 1:
         oh, ow = 2 * H, 2 * W
     else:

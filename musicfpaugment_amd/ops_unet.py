@@ -55,13 +55,30 @@ def split_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return img.view(torch.float32).reshape(t, co, ci)
 
 
-def split_bf16x3_frag(w: torch.Tensor) -> torch.Tensor:
-    """Kernel-layout fp32 weights [taps][Cout][Cin] (Cout % 32 == 0, Cin % 32 == 0) -> the FRAGMENT-ORDERED bf16x3 image of the
-    "weights direct" convolution kernels (csrc/unet.hip, BDIR; mfpa_conv_desc.w_layout = 1):
-    [tap][chunk = Cin / 32][Cout / 32][substep 2][hi | lo][lane 64][8 bf16] -- the 16 bytes of lane (lh * 32 + li) are the MFMA B
-    operand of output channel 32 n + li, input channels 32 chunk + 16 substep + 8 lh .. + 7, so a wave reads a fragment as 1 KB
-    contiguous.  Same split w = hi + lo as split_bf16x3 (the two kernels give the same bits).  Opaque float32 tensor of w's shape."""
+def frag_layout() -> int:
+    """Which fragment-ordered image the library's weights-direct kernels read (mfpa_conv_weight_layout on a representative shape):
+    2 = the 16 x 16 x 32 form (conv_wd16_kernel), 1 = the 32 x 32 x 16 form (BDIR), 0 = none."""
+    return int(lib().mfpa_conv_weight_layout(128, 125, 128, 128, 0, 1))
+
+
+def split_bf16x3_frag(w: torch.Tensor, layout: int = 2) -> torch.Tensor:
+    """Kernel-layout fp32 weights [taps][Cout][Cin] (Cout % 32 == 0, Cin % 32 == 0) -> a FRAGMENT-ORDERED bf16x3 image of the
+    "weights direct" convolution kernels (csrc/unet.hip; mfpa_conv_desc.w_layout = `layout`): a wave reads the MFMA weight operand of a
+    column tile as 1 KB contiguous pieces, one 16-byte fragment per lane.  Same split w = hi + lo as split_bf16x3.
+      layout 2 (v_mfma_f32_16x16x32_bf16, conv_wd16_kernel): [tap][chunk = Cin / 32][Cout / 16][hi | lo][lane 64][8 bf16], lane
+               (g = l >> 4, c = l & 15) = output channel 16 t + c, input channels 32 chunk + 8 g .. + 7;
+      layout 1 (v_mfma_f32_32x32x16_bf16, BDIR): [tap][chunk][Cout / 32][substep 2][hi | lo][lane 64][8 bf16], lane (lh = l >> 5,
+               li = l & 31) = output channel 32 n + li, input channels 32 chunk + 16 substep + 8 lh .. + 7.
+    Opaque float32 tensor of w's shape."""
     t, co, ci = w.shape
+    if layout == 2:
+        w6 = w.reshape(t, co // 16, 16, ci // 32, 4, 8)                            # [t][ct16][c][chunk][g][j]
+        hi = w6.to(torch.bfloat16)
+        lo = (w6 - hi.float()).to(torch.bfloat16)
+        img = torch.stack([hi, lo], dim=0).permute(1, 4, 2, 0, 5, 3, 6).contiguous()    # [t][chunk][ct16][hl][g][c][j]
+        return img.view(torch.float32).reshape(t, co, ci)
+    if layout != 1:
+        raise ValueError("layout must be 1 or 2")
     w6 = w.reshape(t, co // 32, 32, ci // 32, 2, 2, 8)                             # [t][n32][li][chunk][s][lh][j]
     hi = w6.to(torch.bfloat16)
     lo = (w6 - hi.float()).to(torch.bfloat16)
@@ -94,10 +111,11 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[s
     pw["outc.b"] = sd["outc.conv.bias"].detach().float().reshape(-1).contiguous()
     pw["outc.b_host"] = float(sd["outc.conv.bias"].detach().float().reshape(-1)[0].item())
     if precision == 1:
+        lay = frag_layout()
         for k in [k for k in pw if isinstance(pw[k], torch.Tensor) and pw[k].dim() == 3]:
             pw[k + "3"] = split_bf16x3(pw[k])
-            if pw[k].shape[0] == 9 and pw[k].shape[1] % 64 == 0 and pw[k].shape[2] >= 64:
-                pw[k + "f"] = split_bf16x3_frag(pw[k])
+            if lay and pw[k].shape[0] == 9 and pw[k].shape[1] % 64 == 0 and pw[k].shape[2] >= 64:
+                pw[k + "f"] = (lay, split_bf16x3_frag(pw[k], lay))
     return pw
 
 
@@ -169,8 +187,8 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     skips the full-resolution output.  `w` must already be in the layout of `precision` (pre-split for bf16x3).
     `c1 = dict(x32= | spec64=, denom=, w, scale, shift)` (x0 None): the 64 input channels are the UNet's first layer, computed
     from the 1-channel input while the tile is staged (mfpa_conv_desc.c1_*).
-    `wf`: the fragment-ordered image of the same weights (split_bf16x3_frag); used instead of `w` where
-    mfpa_conv_weight_layout says the "weights direct" kernel serves this shape.
+    `wf` = (layout, image): a fragment-ordered image of the same weights (split_bf16x3_frag); used instead of `w` where
+    mfpa_conv_weight_layout says the "weights direct" kernel reading that layout serves this shape.
     Returns (y | None, y_pool | None, y1x1 | None)."""
     if c1 is not None:
         src = c1.get("x32") if c1.get("x32") is not None else c1["spec64"]
@@ -181,9 +199,9 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     C1 = 0 if x1 is None else x1.shape[3]
     dev = w.device
     layout = 0
-    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None
-            and lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == 1):
-        w, layout = wf, 1
+    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None and out1x1 is None
+            and lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == wf[0]):
+        layout, w = wf
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev) if store else None
     yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=dev) if pool else None
     y1 = torch.empty((B, H, W), dtype=torch.float32, device=dev) if out1x1 is not None else None

@@ -372,9 +372,9 @@ def test_device_weight_pack_equals_the_host_packing():
                 want = T.pack_weights(w, prec, ft, row0, nrows)
                 T.DEVICE_PACK = True
                 assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), (taps, co, ci, prec, ft)
-                if prec == 1:            # the fragment-ordered image of the weights-direct kernels (mfpa_conv_desc.w_layout = 1)
-                    got = T.pack_weights(w, 1, ft, row0, nrows, layout=1)
+                for lay in ((1, 2) if prec == 1 else ()):        # the fragment-ordered images of the weights-direct kernels (mfpa_conv_desc.w_layout)
+                    got = T.pack_weights(w, 1, ft, row0, nrows, layout=lay)
                     T.DEVICE_PACK = False
-                    want = T.pack_weights(w, 1, ft, row0, nrows, layout=1)
+                    want = T.pack_weights(w, 1, ft, row0, nrows, layout=lay)
                     T.DEVICE_PACK = True
-                    assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), (taps, co, ci, "frag", ft)
+                    assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), (taps, co, ci, "frag", lay, ft)

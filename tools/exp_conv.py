@@ -66,8 +66,8 @@ if args.both:
         sc = torch.ones(Co, device="cuda"); sh = torch.zeros(Co, device="cuda")
         fl = 2.0 * B * H * W * Ci * Co * 9
         a = timed(lambda: K.conv3x3_fused(x, w3, sc, sh, precision=1))
-        if lib().mfpa_conv_weight_layout(H, W, Ci, Co, 0, 1) == 1:
-            wf = K.split_bf16x3_frag(w)
+        if lib().mfpa_conv_weight_layout(H, W, Ci, Co, 0, 1) == K.frag_layout() and K.frag_layout():
+            wf = (K.frag_layout(), K.split_bf16x3_frag(w, K.frag_layout()))
             d = timed(lambda: K.conv3x3_fused(x, w3, sc, sh, precision=1, wf=wf))
         else:
             d = a

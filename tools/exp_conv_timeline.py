@@ -21,7 +21,7 @@ runs = [("inc.3  c1src + pool", lambda: K.conv3x3_fused(None, w64, sc, sh, preci
         ("up4.3  + OutConv", lambda: K.conv3x3_fused(x, w64, sc, sh, precision=1, out1x1=(wo, 0.1), store=False))]
 def wd(H_, W_, ci, co):
     xx = torch.randn(B, H_, W_, ci, device="cuda"); w = torch.randn(9, co, ci, device="cuda") * 0.05
-    w3, wf = K.split_bf16x3(w), K.split_bf16x3_frag(w)
+    w3, wf = K.split_bf16x3(w), (K.frag_layout(), K.split_bf16x3_frag(w, K.frag_layout()))
     s1 = torch.ones(co, device="cuda"); h1 = torch.zeros(co, device="cuda")
     return lambda: K.conv3x3_fused(xx, w3, s1, h1, precision=1, wf=wf)
 if "--direct" in sys.argv:          # the weights-direct kernel on representative layers
