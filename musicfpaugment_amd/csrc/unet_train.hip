@@ -771,6 +771,225 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
     }
 }
 
+// 3x3 weight gradient from bf16 operands, one bf16 MFMA per product ("V2" of the PLAIN + BF16IN form above; precision 3, mode 0).
+// What the skip experiments on that form said (tools/exp_wgrad.py, 512 -> 512 @ 32 x 31, 64 clips, 453 us): fragment reads + MFMAs alone
+// 220 us, the staging chain alone 176 us, the two together 369 -- the staging sat in front of the MFMA block as a bubble all eight
+// waves share (they are in lockstep behind the barriers) -- and the final atomics 130 us of every launch.  Here:
+//   * a workgroup owns 32 COT output channels x 64 input channels x 9 taps; with COT = 4 (C_out % 128 == 0) the eight waves are 4 x 2
+//     tiles and every wave walks all 128 pixels of a patch -- no two waves hold the same (co, ci) tile, so half the atomics and half the
+//     operand bytes per MFMA of the 64 x 64 form (COT = 2: two pixel halves, as before);
+//   * two LDS stages, ONE barrier per patch: the staging registers (patch n + 1, requested most of an iteration ago) are written to the
+//     other stage between the MFMAs of k-step 0, and take patch n + 2 between the MFMAs of k-step 1 (sched_group_barrier-pinned; the
+//     staging code is branch-free so that it can sit inside the MFMA block);
+//   * the three dx taps of a halo row share their transposing reads: a lane's pixels P .. P+9 of one x column come from THREE
+//     ds_read_b64_tr_b16 (r0..r4 = pixel pairs); tap dx = 0 is r0..r3, dx = 2 is r1..r4 (no instruction), dx = 1 four v_alignbit --
+//     11 reads per k-step instead of 20, 22 fragment registers instead of 80, so the next k-step's reads run under this one's MFMAs;
+//   * one workgroup per CU and as few patch groups as fill the chip once or twice: the atomics are per workgroup.
+template <int PW, int COT>
+__global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(WgradArgs a) {
+  constexpr int THREADS = 512, PIX = 128, PH_ = PIX / PW, TAPS = 9;
+  constexpr int PHS = 4 / COT;                                         // pixel halves (waves that share a (co, ci) tile)
+  constexpr int KS = PIX / PHS / 16;                                   // k-steps per wave and patch
+  constexpr int COW = 32 * COT;                                        // output channels per workgroup
+  constexpr int ROW_D = COW * 2 + 64, ROW_X = 192;                     // staged pixel rows: data + 64 B (the four rows of a transposing block
+                                                                       // land on bank offsets 0 / 64 / 128 / 192)
+  constexpr int HPW = PW + 2, HPH = PH_ + 2, HP = HPW * HPH;
+  constexpr int XROWS = HP + 4;                                        // the third read of a row block runs two pixels past the halo tile
+  constexpr int STAGE = PIX * ROW_D + XROWS * ROW_X;
+  constexpr int DPP = COW / 8;                                         // 16-byte pieces per dz pixel
+  constexpr int D_L = PIX * DPP / THREADS, X_L = (HP * 8 + THREADS - 1) / THREADS;
+  static_assert(KS % 2 == 0 && KS >= 4, "fragment sets alternate; k-steps 0 and 1 carry the staging");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cot = wave % COT, cit = (wave / COT) & 1, ph = wave / (2 * COT);
+  unsigned bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  {                                                                     // XCD k owns a contiguous range of the (patch group, tile) order
+    const unsigned tiles = gridDim.x * gridDim.y, total = tiles * gridDim.z;
+    if (a.xcd && total % 8 == 0) {
+      const unsigned hw = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned lin = (hw % 8) * (total / 8) + hw / 8;
+      const unsigned tile = lin % tiles;
+      bzi = lin / tiles; bxi = tile % gridDim.x; byi = tile / gridDim.x;
+    }
+  }
+  const int co0 = bxi * COW, ci0 = byi * WG_T;
+  const int Cin = a.C0 + a.C1;
+  const bool from0 = ci0 < a.C0;
+  const long long npatch = (long long)a.B * a.tiles_x * a.tiles_y;
+  const int gl = lane & 15, tq = gl >> 2, tp = gl & 3, gsel = (lane >> 4) & 1;
+  const char* a_lane = smem + ((PIX / PHS) * ph + 8 * lh + tq) * ROW_D + (32 * cot + 16 * gsel + 4 * tp) * 2;
+  const char* b_lane = smem + PIX * ROW_D + ((PIX / PHS / PW) * ph * HPW + 8 * lh + tq) * ROW_X + (32 * cit + 16 * gsel + 4 * tp) * 2;
+
+  floatx16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- staging: one code path for both sources of the input (extent, channel count and zero-pad offset of the one this tile reads)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int sH = from0 ? a.H : a.H1, sW = from0 ? a.W : a.W1, sC = from0 ? a.C0 : a.C1, soy = from0 ? 0 : a.oy1, sox = from0 ? 0 : a.ox1;
+  const int c8 = tid % 8, t8 = tid / 8, cd = tid % DPP, td = tid / DPP;
+  const char* xsrc = (from0 ? reinterpret_cast<const char*>(a.x0) + (size_t)(ci0 + 8 * c8) * 2
+                            : reinterpret_cast<const char*>(a.x1) + (size_t)(ci0 - a.C0 + 8 * c8) * 2);
+  const char* dsrc = reinterpret_cast<const char*>(a.dz) + (size_t)(co0 + 8 * cd) * 2;
+  u32x4 xr[X_L], dr[D_L];
+  int pb = 0, py = 0, px = 0;                                           // patch in the staging registers
+  auto decode = [&](long long patch) __attribute__((always_inline)) {
+    long long q = patch;
+    const int tx = (int)(q % a.tiles_x); q /= a.tiles_x;
+    const int ty = (int)(q % a.tiles_y);
+    pb = (int)(q / a.tiles_y); py = ty * PH_; px = tx * PW;
+  };
+  auto load = [&]() __attribute__((always_inline)) {                    // clamped addresses; what lies outside is zeroed by stage()
+    const char* xb = xsrc + (size_t)pb * sH * sW * sC * 2;
+#pragma unroll
+    for (int it = 0; it < X_L; ++it) {
+      const int pix = t8 + it * (THREADS / 8);
+      const int gy = min(max(py + pix / HPW - 1 - soy, 0), sH - 1), gx = min(max(px + pix % HPW - 1 - sox, 0), sW - 1);
+      xr[it] = *reinterpret_cast<const u32x4*>(xb + (size_t)((gy * sW + gx) * sC) * 2);
+    }
+    const char* db = dsrc + (size_t)pb * a.H * a.W * a.Cout * 2;
+#pragma unroll
+    for (int it = 0; it < D_L; ++it) {
+      const int pix = td + it * (THREADS / DPP);
+      const int gy = min(py + pix / PW, a.H - 1), gx = min(px + pix % PW, a.W - 1);
+      dr[it] = *reinterpret_cast<const u32x4*>(db + (size_t)((gy * a.W + gx) * a.Cout) * 2);
+    }
+  };
+  auto stage = [&](int soff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < X_L; ++it) {
+      const int pix = t8 + it * (THREADS / 8);
+      const unsigned sy = (unsigned)(py + pix / HPW - 1 - soy), sx = (unsigned)(px + pix % HPW - 1 - sox);
+      const bool inside = (int)(pix < HP) & (int)(sy < (unsigned)sH) & (int)(sx < (unsigned)sW);
+      // slots past the tile write zeros into its last slack row
+      *reinterpret_cast<u32x4*>(smem + soff + PIX * ROW_D + min(pix, XROWS - 1) * ROW_X + 16 * c8) = inside ? xr[it] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int it = 0; it < D_L; ++it) {
+      const int pix = td + it * (THREADS / DPP);
+      const bool in = (int)(py + pix / PW < a.H) & (int)(px + pix % PW < a.W);
+      *reinterpret_cast<u32x4*>(smem + soff + pix * ROW_D + 16 * cd) = in ? dr[it] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  // ---- fragments
+  typedef wg_s16x4 __attribute__((address_space(3))) * lds_ptr;
+  struct Fr { wg_bf16x8 a; unsigned r[3][5]; };
+  auto read_fr = [&](Fr& f, int soff, int ks) __attribute__((always_inline)) {
+    const char* ap = a_lane + soff + (16 * ks) * ROW_D;
+    f.a = wg_tr_frag(ap, ap + 4 * ROW_D);
+    const char* bk = b_lane + soff + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * ROW_X;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const char* bp = bk + dy * HPW * ROW_X;
+      union { wg_s16x4 s; unsigned u[2]; } u0, u1, u2;
+      u0.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(bp));
+      u1.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(bp + 4 * ROW_X));
+      u2.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(bp + 8 * ROW_X));
+      f.r[dy][0] = u0.u[0]; f.r[dy][1] = u0.u[1]; f.r[dy][2] = u1.u[0]; f.r[dy][3] = u1.u[1]; f.r[dy][4] = u2.u[0];
+    }
+  };
+  auto mfma9 = [&](const Fr& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      union { unsigned u[4]; wg_bf16x8 b; } f0, f1, f2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f0.u[j] = f.r[dy][j];
+        f1.u[j] = __builtin_amdgcn_alignbit(f.r[dy][j + 1], f.r[dy][j], 16);
+        f2.u[j] = f.r[dy][j + 1];
+      }
+      acc[3 * dy + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f0.b, acc[3 * dy + 0], 0, 0, 0);
+      acc[3 * dy + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f1.b, acc[3 * dy + 1], 0, 0, 0);
+      acc[3 * dy + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a, f2.b, acc[3 * dy + 2], 0, 0, 0);
+    }
+  };
+
+  long long patch = bzi;
+  if (patch < npatch) {
+    decode(patch);
+    load();
+    stage(0);
+    decode(patch + gridDim.z < npatch ? patch + gridDim.z : patch);     // past the end: the same patch again, never used
+    load();
+  }
+  __syncthreads();
+  int sel = 0;
+  Fr fa, fb;
+  for (; patch < npatch; patch += gridDim.z) {
+    const int soff = sel * STAGE, noff = (sel ^ 1) * STAGE;
+    read_fr(fa, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 0: MFMAs || k-step 1's reads, the staging registers -> the other stage
+    read_fr(fb, soff, 1);
+    stage(noff);
+    mfma9(fa);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1: MFMAs || k-step 2's reads, the staging registers <- patch n + 2
+    read_fr(fa, soff, 2);
+    {
+      const long long n2 = patch + 2 * (long long)gridDim.z;
+      decode(n2 < npatch ? n2 : patch);
+      load();
+    }
+    mfma9(fb);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 2; ks < KS; ks += 2) {
+      read_fr(fb, soff, ks + 1);
+      mfma9(fa);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < KS) {
+        read_fr(fa, soff, ks + 2);
+        mfma9(fb);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        mfma9(fb);
+      }
+    }
+    __syncthreads();
+    sel ^= 1;
+  }
+  // D[row = co][col = ci]
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int ci = ci0 + cit * 32 + li;
+      atomicAdd(a.dw + ((size_t)t * a.Cout + co) * Cin + ci, acc[t][r]);
+    }
+}
+
 // First layer weight gradient (1 input channel): dW[tap][co] += sum_p dz[p][co] * x[p + tap].
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const float* __restrict__ dz, const float* __restrict__ x32,
                                                        const double* __restrict__ spec64,
@@ -1248,10 +1467,25 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
       else if (pw == 32) MFPA_WG_LAUNCH(1, 32, N, Q);       \
       else MFPA_WG_LAUNCH(1, 16, N, Q);                     \
     } while (0)
-    if (d->precision == 3) {
-      if (d->mode == 0 && pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 32, 8, true, true>), grid, dim3(512), lds, s, a);
-      else if (d->mode == 0) hipLaunchKernelGGL((wgrad_bf16x3_kernel<0, 16, 8, true, true>), grid, dim3(512), lds, s, a);
-      else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32, 8, true, true>), grid, dim3(512), lds, s, a);
+    if (d->precision == 3 && d->mode == 0) {
+      // wgrad_bf16_kernel: 128-channel output tiles when C_out allows; as few patch groups as give every CU one workgroup (the atomics
+      // are per workgroup: 256 / 512 / 1024 workgroups measured 291 / 333 / 385 us on 512 -> 512 @ 32 x 31, 64 clips)
+      const int cot = d->Cout % 128 == 0 ? 4 : 2;
+      const int tiles2 = (d->Cout / (32 * cot)) * ((d->C0 + d->C1) / WG_T);
+      const int cus = mfpa_current_device_cus();
+      const int target = MFPA_EXP_ENV("MFPA_WGRAD_WGS", cus > 0 ? cus : 256);
+      long long split2 = (target + tiles2 - 1) / tiles2;
+      if (split2 > npatch_b) split2 = npatch_b;
+      if (split2 < 1) split2 = 1;
+      if (split2 > 65535) split2 = 65535;
+      const dim3 grid2(d->Cout / (32 * cot), (d->C0 + d->C1) / WG_T, (unsigned)split2);
+      const size_t lds2 = 2 * ((size_t)128 * (64 * cot + 64) + (size_t)((phh + 2) * (pw + 2) + 4) * 192);
+      if (cot == 4 && pw == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<32, 4>), grid2, dim3(512), lds2, s, a);
+      else if (cot == 4) hipLaunchKernelGGL((wgrad_bf16_kernel<16, 4>), grid2, dim3(512), lds2, s, a);
+      else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<32, 2>), grid2, dim3(512), lds2, s, a);
+      else hipLaunchKernelGGL((wgrad_bf16_kernel<16, 2>), grid2, dim3(512), lds2, s, a);
+    } else if (d->precision == 3) {
+      if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32, 8, true, true>), grid, dim3(512), lds, s, a);
       else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 16, 8, true, true>), grid, dim3(512), lds, s, a);
     }
     else if (nw == 8 && plain) MFPA_WG_PICK(8, true);
