@@ -275,11 +275,12 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
                   float* running_mean, float* running_var, double* workspace, void* stream);
 
 /* BatchNorm+ReLU backward: dy (gradient w.r.t. relu(bn(z))) is overwritten with the gradient w.r.t. z;
- * dgamma, dbeta (C) are produced; coef is a (3, C) scratch. */
+ * dgamma, dbeta (C) are produced; coef is a (3, C) scratch.  dz_bf16 (optional, may be NULL): a bf16 copy of the result, written in
+ * the same pass -- the operand mfpa_wgrad_mfma(precision 3) reads. */
 int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma,
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, float* coef, double* workspace,
-                     unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
+                     unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, void* stream);
 
 /* The same two operations split for synchronised BatchNorm under data parallelism (statistics over the GLOBAL batch, as the
  * single-GPU reference computes them): *_sums reduces this rank's per-channel pairs into sums[2C] float64 -- (sum z, sum z^2)
@@ -296,7 +297,7 @@ int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C
 int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
-                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, void* stream);
 
 /* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
 int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class MfpaError(RuntimeError):
@@ -118,7 +118,7 @@ _SIGNATURES = {
     "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
     "mfpa_bn_stats_sums": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_stats_finish": ([c_void_p, c_double, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p], c_int),
@@ -126,7 +126,7 @@ _SIGNATURES = {
                                c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
     "mfpa_bn_relu_bwd_finish": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
-                                 c_void_p], c_int),
+                                 c_void_p, c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
                            c_void_p], c_int),

@@ -1113,11 +1113,20 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       }
     }
     bf16x4 hi, lo;
+#ifdef MFPA_EXP_WD16_NOSPLIT                                            // timing experiment only (wrong results): no bf16 split arithmetic
+    {                                                                  // valid data (truncated hi in both planes), two permutes instead of the split
+      union { unsigned u[2]; bf16x4 h; } t;
+      t.u[0] = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+      t.u[1] = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
+      hi = t.h; lo = t.h;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       hi[k] = (__bf16)v[k];
       lo[k] = (__bf16)(v[k] - (float)hi[k]);
     }
+#endif
     char* at = stage + plane_off(0, aq >> 1) + pix * 16 + 8 * (aq & 1);
     *reinterpret_cast<bf16x4*>(at) = hi;
     *reinterpret_cast<bf16x4*>(at + HLS) = lo;
@@ -1129,6 +1138,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int slot = decltype(SLOT)::value;
     const char* wb = reinterpret_cast<const char*>(a.w) +
                      ((((size_t)tap * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
+#ifdef MFPA_EXP_WD16_NOWLOAD                                            // timing experiment only (wrong results): weights loaded once
+    if (chunk > 0 || tap > 2) return;                                  // all three ring slots hold real weights
+#endif
     wq[slot][0][0] = *reinterpret_cast<const bf16x8*>(wb);
     wq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
     wq[slot][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
@@ -1145,6 +1157,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   auto read_x = [&](XFrags& f, const char* stage, int tap_off, int half) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#ifdef MFPA_EXP_WD16_HALFREADS                                          // timing experiment only (wrong results): half of the fragment reads
+      if (i >= 2) { f.l[i] = f.l[i - 2]; f.h[i] = f.h[i - 2]; continue; }
+#endif
       const char* r = stage + xbase + tile_disp(4 * half + i) + tap_off;
       f.l[i] = *reinterpret_cast<const bf16x8*>(r + HLS);
       f.h[i] = *reinterpret_cast<const bf16x8*>(r);
@@ -1157,6 +1172,21 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
   auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half) __attribute__((always_inline)) {
     // term-major: an accumulator is touched every eighth instruction
+#ifdef MFPA_EXP_WD16_ORDER_B                                            // experiment: consecutive instructions share the pixel operand
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][1], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.l[i], acc[ct][4 * half + i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+    return;
+#endif
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1172,7 +1202,11 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+#ifdef MFPA_EXP_WD16_HALFREADS
+  constexpr int N_R = 4, N_M = 24;
+#else
   constexpr int N_R = 8, N_M = 24;                                     // fragment reads / MFMAs of one phase
+#endif
   // One tap.  Phase A: MFMA(pixel tiles 0..3 of tap t) || read tiles 4..7 of tap t, request the weights of tap t + 2.  Phase B: MFMA(tiles
   // 4..7) || read tiles 0..3 of tap t + 1, (tap 0) request the next chunk's halo, (taps 2..7) split one staging slot of it.  The chunk's
   // one barrier sits between the phases of tap 8 (see BDIR).
@@ -1224,6 +1258,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   load_a(0);
   load_w(0, 0, S0{});
   load_w(0, 1, S1{});
+#ifdef MFPA_EXP_WD16_NOWLOAD
+  load_w(0, 2, std::integral_constant<int, 2>{});
+#endif
   {
     using I0 = std::integral_constant<int, 0>;
     split_slot(I0{}, 0, smem);

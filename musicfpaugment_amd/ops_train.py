@@ -121,7 +121,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
-BF16_WGRAD_MIN_CH = 256     # plain-bf16 weight gradients: layers with at least this many channels on both sides read bf16 copies
+BF16_WGRAD_MIN_CH = 128     # plain-bf16 weight gradients: layers with at least this many channels on both sides read bf16 copies
 
 
 def act_to_bf16(z: torch.Tensor, in_affine: Optional[Stats] = None) -> torch.Tensor:
@@ -133,13 +133,18 @@ def act_to_bf16(z: torch.Tensor, in_affine: Optional[Stats] = None) -> torch.Ten
     return out
 
 
-def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0):
+def bf16_wgrad(Cout, cin, precision) -> bool:
+    """Does wgrad_mfma read bf16 copies of its operands for this layer?"""
+    return precision == 2 and min(Cout, cin) >= BF16_WGRAD_MIN_CH
+
+
+def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0, dz_bf16=None):
     B, H, W, C0 = x0.shape
     cin = C0 + (0 if x1 is None else x1.shape[3])
-    if precision == 2 and min(Cout, cin) >= BF16_WGRAD_MIN_CH:
-        # every (co, ci) tile re-reads both operands: with >= 4 tiles per side one cast pass to bf16 (activation applied) halves what
-        # the tiles pull through L2; same products as precision 2 (one bf16 MFMA each, fp32 accumulate)
-        dz, x0, in_affine = act_to_bf16(dz), act_to_bf16(x0, in_affine), None
+    if bf16_wgrad(Cout, cin, precision):
+        # every (co, ci) tile re-reads both operands: bf16 copies (activation applied) halve what the tiles pull through L2; same
+        # products as precision 2 (one bf16 MFMA each, fp32 accumulate).  dz's copy comes with the BatchNorm backward (dz_bf16).
+        dz, x0, in_affine = (dz_bf16 if dz_bf16 is not None else act_to_bf16(dz)), act_to_bf16(x0, in_affine), None
         x1 = None if x1 is None else act_to_bf16(x1)
         precision = 3
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
@@ -377,9 +382,12 @@ class UNetTrainEngine:
                                   ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
         return st
 
-    def _bn_relu_bwd(self, dy, z, st: Stats, g, b):
+    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False):
+        """dy <- gradient w.r.t. z, in place; with bf16_copy also its bf16 copy, written by the same pass (the weight-gradient
+        kernel's operand).  Returns (dz, dz_bf16 or None)."""
         C = z.shape[-1]
         coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
+        dz16 = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device) if bf16_copy else None
         if self.sync_bn:
             loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
             check(lib().mfpa_bn_relu_bwd_sums(ptr(dy), ptr(z), _npix(z), C, ptr(st.scale), ptr(st.shift), ptr(st.mean),
@@ -388,14 +396,14 @@ class UNetTrainEngine:
             glob = self._all_reduce_sums(loc.clone())
             check(lib().mfpa_bn_relu_bwd_finish(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                                 ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
-                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], stream()),
+                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), stream()),
                   "mfpa_bn_relu_bwd_finish")
-            return dy
+            return dy, dz16
         check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                      ptr(st.mean), ptr(st.invstd), ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
-                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], stream()),
+                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), stream()),
               "mfpa_bn_relu_bwd")
-        return dy
+        return dy, dz16
 
     # ------------------------------------------------------------------ forward (train mode)
     def _dconv_fwd(self, prefix, src0, aff0: Optional[Stats], src1=None, first_input=None, drop_id=None):
@@ -453,13 +461,17 @@ class UNetTrainEngine:
         """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1)."""
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
-        dz3 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b")
-        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision)
+        dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b",
+                                      bf16_copy=bf16_wgrad(cout, cout, self.wgrad_precision))
+        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16)
+        del dz16
         lay = weight_layout(dz3.shape[1], dz3.shape[2], cout, cout, self.precision)
         wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True, layout=lay)   # [tap'][ci][co]
         dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay)
         del dz3
-        dz0 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b")
+        cin0 = 0 if r["first_input"] is not None else r["src0"].shape[-1] + (0 if r["src1"] is None else r["src1"].shape[-1])
+        dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b",
+                                      bf16_copy=bf16_wgrad(cout, cin0, self.wgrad_precision))
         if r["first_input"] is not None:
             x32, spec64, denom = r["first_input"]
             B, H, W, C = dz0.shape
@@ -467,7 +479,8 @@ class UNetTrainEngine:
                                       stream()), "mfpa_wgrad_c1")
             return None, None
         wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"],
-                   precision=self.wgrad_precision)
+                   precision=self.wgrad_precision, dz_bf16=dz16)
+        del dz16
         if not need_input_grad:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)

@@ -34,12 +34,18 @@ def test_derived_operands_match_the_inference_packing():
     eng = DemucsTrainEngine(sd, "cpu")
     W = eng._derive()
     pw = D.pack_demucs_weights(sd, "cpu")
+    def same_rows(train, packed):
+        # the inference packing may append zero rows (ops_demucs.PAD_N_TO_WIDE_TILE: N padded to the wide GEMM tile); the rows that
+        # carry weights are the training operand's, bit for bit
+        n = train.shape[0]
+        return packed.shape[0] >= n and torch.equal(train, packed[:n]) and not packed[n:].any()
+
     for d in range(4):
-        assert torch.equal(W[f"dec{d}.wf"], pw[f"dec{d}.w"])
-        assert torch.equal(W[f"dec{d}.bf"], pw[f"dec{d}.b"])
-        assert torch.equal(eng.P[f"dec{d}.gw"], pw[f"dec{d}.gw"])
+        assert same_rows(W[f"dec{d}.wf"], pw[f"dec{d}.w"])
+        assert same_rows(W[f"dec{d}.bf"], pw[f"dec{d}.b"])
+        assert same_rows(eng.P[f"dec{d}.gw"], pw[f"dec{d}.gw"])
     for i in range(1, 5):
-        assert torch.equal(eng.P[f"enc{i}.w"], pw[f"enc{i}.w"])
+        assert same_rows(eng.P[f"enc{i}.w"], pw[f"enc{i}.w"])
     for layer in range(2):
         assert torch.equal(W[f"lstm{layer}.whh_grouped"], pw[f"lstm{layer}.whh_grouped"])
         assert torch.equal(W[f"lstm{layer}.b"], pw[f"lstm{layer}.b"])
