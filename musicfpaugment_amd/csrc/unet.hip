@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 // Not bit-identical to the 32 x 32 x 16 kernels (a k-step sums 32 products inside the instruction); same products, fp32 accumulate.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int PH, int PW>
+template <int PH, int PW, bool ROWS>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   constexpr int THREADS = 512, BN = 128, TAPS = 9;
   constexpr int HPW = PW + 2, HPH = PH + 2, HP = HPW * HPH, BM = PH * PW;
@@ -1056,39 +1056,43 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / KC;
 
-  // ---- halo loader (as conv_mfma_kernel's: unconditional clamped loads, padding zeroed when the slot is split)
+  // ---- halo loader (as conv_mfma_kernel's: unconditional clamped loads, padding zeroed when the slot is split).  A thread's staging
+  // slots map to fixed halo pixels; their byte offsets into the two sources live in LDS ([source][slot][thread], read back two or three
+  // at a time in front of the loads) and their inside-the-source flags in ONE register: as loop-invariant registers (12 offsets) the
+  // compiler spilled them to scratch, and a scratch reload in front of a load drains every outstanding weight load (s_waitcnt vmcnt(0)).
   const int aq = tid % (KC / 4);
-  int apix[A_F4];
+  unsigned* aoffs = reinterpret_cast<unsigned*>(smem + 2 * STAGE);     // [2][A_F4][THREADS]
+  unsigned ain = 0;                                                    // bit it: slot inside source 0's image; bit 8 + it: inside source 1
 #pragma unroll
   for (int it = 0; it < A_F4; ++it) {
     const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
     const int gy = y0 + pix / HPW - 1, gx = x0p + pix % HPW - 1;
     const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-    apix[it] = (in ? 0 : (int)0x80000000) | (cy << 16) | cx;
+    aoffs[it * THREADS + tid] = ((unsigned)(cy * a.W + cx) * (unsigned)a.C0 + 4u * aq) * 4u;
+    const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+    const bool in1 = in && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
+    const int c1y = min(max(y1, 0), max(a.H1 - 1, 0)), c1x = min(max(x1, 0), max(a.W1 - 1, 0));
+    aoffs[(A_F4 + it) * THREADS + tid] = ((unsigned)(c1y * a.W1 + c1x) * (unsigned)a.C1 + 4u * aq) * 4u;
+    ain |= (in ? 1u : 0u) << it | (in1 ? 1u : 0u) << (8 + it);
   }
   const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * sizeof(float);
   const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
-  auto src1_inside = [&](int pp) __attribute__((always_inline)) {
-    const int y1 = ((pp >> 16) & 0x7fff) - a.oy1, x1 = (pp & 0xffff) - a.ox1;
-    return pp >= 0 && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
-  };
-  f32x4 areg[A_F4];
-  auto load_a = [&](int chunk) __attribute__((always_inline)) {
+  // ROWS: the staging slots are requested in two halves (slots 0..2 in period 0, 3..5 in period 1) that share three registers
+  constexpr int AHALF = (A_F4 + 1) / 2, AREGS = ROWS ? AHALF : A_F4;
+  f32x4 areg[AREGS];
+  auto load_a_range = [&](int chunk, auto FIRST, auto COUNT) __attribute__((always_inline)) {
+    constexpr int first = decltype(FIRST)::value, count = decltype(COUNT)::value;
     const int c0 = chunk * KC;
-    const bool from0 = c0 < a.C0;
+    const bool from0 = c0 < a.C0;                                      // workgroup-uniform: scalar selects, no branch
+    const char* xb = from0 ? xb0 + (size_t)c0 * 4 : xb1 + (size_t)(c0 - a.C0) * 4;
+    const unsigned* ao = aoffs + (from0 ? 0 : A_F4 * THREADS) + tid;
 #pragma unroll
-    for (int it = 0; it < A_F4; ++it) {
-      const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;
-      if (from0) {
-        const unsigned off = ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * aq)) * 4u;
-        areg[it] = *reinterpret_cast<const f32x4*>(xb0 + off);
-      } else {
-        const int y1 = min(max(gy - a.oy1, 0), a.H1 - 1), x1 = min(max(gx - a.ox1, 0), a.W1 - 1);
-        const unsigned off = ((unsigned)(y1 * a.W1 + x1) * (unsigned)a.C1 + (unsigned)(c0 - a.C0 + 4 * aq)) * 4u;
-        areg[it] = *reinterpret_cast<const f32x4*>(xb1 + off);
-      }
-    }
+    for (int it = first; it < first + count && it < A_F4; ++it)
+      areg[it % AREGS] = *reinterpret_cast<const f32x4*>(xb + ao[it * THREADS]);
+  };
+  auto load_a = [&](int chunk) __attribute__((always_inline)) {
+    load_a_range(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, AREGS>{});
   };
   // one staging slot: zero padding, the training forward's on-load affine + ReLU + dropout, bf16 hi / lo split, two 8-byte stores
   // into the (hi, k-group) and (lo, k-group) planes (a thread's channel quad is half of k-group aq >> 1)
@@ -1096,8 +1100,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int it = decltype(IT)::value;
     const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
     const int c0 = chunk * KC;
-    const bool inside = (c0 < a.C0) ? (apix[it] >= 0) : src1_inside(apix[it]);
-    f32x4 v = areg[it];
+    const bool inside = (ain >> ((c0 < a.C0 ? 0 : 8) + it)) & 1u;
+    f32x4 v = areg[it % AREGS];
     if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * aq);
@@ -1106,27 +1110,18 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
       if (a.drop_thresh) {
-        const int gy = (apix[it] >> 16) & 0x7fff, gx = apix[it] & 0xffff;
+        const int gy = y0 + pix / HPW - 1, gx = x0p + pix % HPW - 1;   // inside the image here
         const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * aq;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
       }
     }
     bf16x4 hi, lo;
-#ifdef MFPA_EXP_WD16_NOSPLIT                                            // timing experiment only (wrong results): no bf16 split arithmetic
-    {                                                                  // valid data (truncated hi in both planes), two permutes instead of the split
-      union { unsigned u[2]; bf16x4 h; } t;
-      t.u[0] = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
-      t.u[1] = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
-      hi = t.h; lo = t.h;
-    }
-#else
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       hi[k] = (__bf16)v[k];
       lo[k] = (__bf16)(v[k] - (float)hi[k]);
     }
-#endif
     char* at = stage + plane_off(0, aq >> 1) + pix * 16 + 8 * (aq & 1);
     *reinterpret_cast<bf16x4*>(at) = hi;
     *reinterpret_cast<bf16x4*>(at + HLS) = lo;
@@ -1138,9 +1133,6 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int slot = decltype(SLOT)::value;
     const char* wb = reinterpret_cast<const char*>(a.w) +
                      ((((size_t)tap * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
-#ifdef MFPA_EXP_WD16_NOWLOAD                                            // timing experiment only (wrong results): weights loaded once
-    if (chunk > 0 || tap > 2) return;                                  // all three ring slots hold real weights
-#endif
     wq[slot][0][0] = *reinterpret_cast<const bf16x8*>(wb);
     wq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
     wq[slot][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
@@ -1157,9 +1149,6 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   auto read_x = [&](XFrags& f, const char* stage, int tap_off, int half) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#ifdef MFPA_EXP_WD16_HALFREADS                                          // timing experiment only (wrong results): half of the fragment reads
-      if (i >= 2) { f.l[i] = f.l[i - 2]; f.h[i] = f.h[i - 2]; continue; }
-#endif
       const char* r = stage + xbase + tile_disp(4 * half + i) + tap_off;
       f.l[i] = *reinterpret_cast<const bf16x8*>(r + HLS);
       f.h[i] = *reinterpret_cast<const bf16x8*>(r);
@@ -1172,21 +1161,6 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
   auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half) __attribute__((always_inline)) {
     // term-major: an accumulator is touched every eighth instruction
-#ifdef MFPA_EXP_WD16_ORDER_B                                            // experiment: consecutive instructions share the pixel operand
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][1], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.l[i], acc[ct][4 * half + i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
-    return;
-#endif
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1202,11 +1176,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-#ifdef MFPA_EXP_WD16_HALFREADS
-  constexpr int N_R = 4, N_M = 24;
-#else
   constexpr int N_R = 8, N_M = 24;                                     // fragment reads / MFMAs of one phase
-#endif
   // One tap.  Phase A: MFMA(pixel tiles 0..3 of tap t) || read tiles 4..7 of tap t, request the weights of tap t + 2.  Phase B: MFMA(tiles
   // 4..7) || read tiles 0..3 of tap t + 1, (tap 0) request the next chunk's halo, (taps 2..7) split one staging slot of it.  The chunk's
   // one barrier sits between the phases of tap 8 (see BDIR).
@@ -1255,13 +1225,152 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  load_a(0);
-  load_w(0, 0, S0{});
-  load_w(0, 1, S1{});
-#ifdef MFPA_EXP_WD16_NOWLOAD
-  load_w(0, 2, std::integral_constant<int, 2>{});
-#endif
-  {
+  // ---- ROWS form of the main loop: the three vertical taps of a column offset dx share their pixel fragments.  A wave's 128 pixels are
+  // R patch rows (4 of 32 pixels, or 8 of 16); tap (dy, dx) of row r reads halo row r + dy, so for one dx the R + 2 halo rows are read
+  // ONCE each (hi and lo) and row h feeds the accumulators of rows h, h - 1, h - 2 with the weights of taps (0, dx), (1, dx), (2, dx):
+  // 72 (60) fragment reads per 32-channel chunk instead of 144 -- the half-reads timing experiment on the tap-by-tap loop returned
+  // 4-7 % on the >= 128-channel layers (the loop is power limited, LDS traffic is part of the power).  A "period" = one dx: 144 MFMAs,
+  // the weights of its three taps in registers, the next period's three taps requested at its start into the other half of a
+  // six-set ring (static indices: the loop body is two chunks = six periods), the next chunk's halo requested in period 0 and split
+  // in periods 1 and 2, the chunk's one barrier in front of the last row step of period 2 (whose prefetch reads the next stage).
+  constexpr int R = BM / 2 / PW, HV = PW / 16;
+  bf16x8 wr[2][3][2][2];                                               // [ring half][dy][16-channel tile][hi, lo]
+  auto load_wr = [&](int chunk, auto DX, auto PAR) __attribute__((always_inline)) {
+    constexpr int dx = decltype(DX)::value, par = decltype(PAR)::value;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const char* wb = reinterpret_cast<const char*>(a.w) +
+                       ((((size_t)(dy * 3 + dx) * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
+      wr[par][dy][0][0] = *reinterpret_cast<const bf16x8*>(wb);
+      wr[par][dy][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+      wr[par][dy][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
+      wr[par][dy][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+    }
+  };
+  // pixel fragments: one "unit" = 16 pixels of one halo row (hi and lo); a ring of NB units, read NB - 1 units ahead of their MFMAs (a
+  // unit carries only 6 .. 18 MFMAs: one unit of distance is shorter than the LDS latency).  NU units per period, NB divides NU.
+  constexpr int NU = (R + 2) * HV, NB = (PW == 32) ? 4 : 5;
+  static_assert(NU % NB == 0, "static ring indices");
+  auto load_wr1 = [&](int chunk, auto DX, auto PAR, auto DY) __attribute__((always_inline)) {
+    constexpr int dx = decltype(DX)::value, par = decltype(PAR)::value, dy = decltype(DY)::value;
+    const char* wb = reinterpret_cast<const char*>(a.w) +
+                     ((((size_t)(dy * 3 + dx) * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
+    wr[par][dy][0][0] = *reinterpret_cast<const bf16x8*>(wb);
+    wr[par][dy][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+    wr[par][dy][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
+    wr[par][dy][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+  };
+  struct XUnit { bf16x8 h, l; };
+  XUnit xu[NB];
+  auto read_unit = [&](XUnit& f, const char* stage, int u, int dx) __attribute__((always_inline)) {
+    const char* r = stage + xbase + ((u / HV) * HPW + (u % HV) * 16 + dx) * 16;
+    f.l = *reinterpret_cast<const bf16x8*>(r + HLS);
+    f.h = *reinterpret_cast<const bf16x8*>(r);
+  };
+  // unit u = (halo row h, half hv): every (dy, r = h - dy) pair it serves, term-major (an accumulator is touched once per term)
+  auto mfma_unit = [&](auto U, const XUnit& f, auto PAR) __attribute__((always_inline)) {
+    constexpr int h = decltype(U)::value / HV, hv = decltype(U)::value % HV, par = decltype(PAR)::value;
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        if (h - dy < 0 || h - dy >= R) continue;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          floatx4& c = acc[ct][(h - dy) * HV + hv];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[par][dy][ct][term == 0 ? 1 : 0], term == 1 ? f.l : f.h, c, 0, 0, 0);
+        }
+      }
+  };
+  auto unit_mfmas = [](int u) { const int h = u / HV; int n = 0; for (int dy = 0; dy < 3; ++dy) n += (h - dy >= 0 && h - dy < R) ? 1 : 0; return n * 6; };
+  constexpr int BARU = NU - NB + 1;                                    // first unit whose prefetch reads the next period
+  constexpr int SA = NU / 2, SB = BARU - AHALF;                        // first split units of periods 1 and 2
+  static_assert(SA + AHALF < NU && SB >= 0, "staging schedule");
+  auto unit_step = [&](auto U, auto DX, auto PAR, int chunk) __attribute__((always_inline)) {
+    constexpr int u = decltype(U)::value, dx = decltype(DX)::value, par = decltype(PAR)::value;
+    constexpr int n_m = unit_mfmas(u);
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const char* cur = smem + (chunk & 1) * STAGE;
+    char* nxs = smem + ((chunk + 1) & 1) * STAGE;
+    if constexpr (u == BARU && dx == 2) {
+      __syncthreads();                                                 // the next stage is complete, this one is read out
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int pu = u + NB - 1;                                     // the unit requested now
+    if constexpr (pu < NU) read_unit(xu[pu % NB], cur, pu, dx);
+    else read_unit(xu[pu % NB], dx == 2 ? nxs : cur, pu - NU, (dx + 1) % 3);
+    mfma_unit(U, xu[u % NB], PAR);
+    // the period's other work: the next period's weights (one tap per unit, units 1 .. 3), the next chunk's halo (first half requested
+    // in period 0, split in period 1; second half requested in period 1 behind that, split in period 2 in front of the barrier)
+    constexpr int split_it = dx == 1 ? u - SA : dx == 2 ? AHALF + u - SB : -1;
+    constexpr bool do_split = (dx == 1 && u >= SA && u < SA + AHALF) || (dx == 2 && u >= SB && u < SB + AHALF && split_it < A_F4);
+    if constexpr (u == 0 && dx == 0) load_a_range(chunk_n, std::integral_constant<int, 0>{}, std::integral_constant<int, AHALF>{});
+    if constexpr (u == SA + AHALF && dx == 1) load_a_range(chunk_n, std::integral_constant<int, AHALF>{}, std::integral_constant<int, AHALF>{});
+    if constexpr (u >= 1 && u <= 3) {
+      if constexpr (dx < 2) load_wr1(chunk, std::integral_constant<int, (dx + 1) % 3>{}, std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, (u >= 1 && u <= 3) ? u - 1 : 0>{});
+      else load_wr1(chunk_n, std::integral_constant<int, 0>{}, std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, (u >= 1 && u <= 3) ? u - 1 : 0>{});
+    }
+    if constexpr (do_split) split_slot(std::integral_constant<int, do_split ? split_it : 0>{}, chunk_n, nxs);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    if constexpr (do_split) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+      if constexpr (n_m - 5 > 0) __builtin_amdgcn_sched_group_barrier(0x008, n_m - 5, 0);
+    } else if constexpr (u >= 1 && u <= 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if constexpr (n_m - 5 > 0) __builtin_amdgcn_sched_group_barrier(0x008, n_m - 5, 0);
+    } else {
+      if constexpr (n_m - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, n_m - 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto period = [&](auto DX, auto PAR, int chunk) __attribute__((always_inline)) {
+    unit_step(std::integral_constant<int, 0>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 1>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 2>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 3>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 4>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 5>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 6>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 7>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 8>{}, DX, PAR, chunk);
+    unit_step(std::integral_constant<int, 9>{}, DX, PAR, chunk);
+    if constexpr (NU == 12) {
+      unit_step(std::integral_constant<int, NU == 12 ? 10 : 0>{}, DX, PAR, chunk);
+      unit_step(std::integral_constant<int, NU == 12 ? 11 : 0>{}, DX, PAR, chunk);
+    }
+  };
+
+  if constexpr (ROWS) {
+    // chunk 0: all the staging slots in ONE round trip (the second half through temporaries: the fragment ring is not live yet)
+    f32x4 keep[AREGS];
+    load_a_range(0, std::integral_constant<int, AHALF>{}, std::integral_constant<int, AHALF>{});
+#pragma unroll
+    for (int i = 0; i < AREGS; ++i) keep[i] = areg[i];
+    load_a_range(0, std::integral_constant<int, 0>{}, std::integral_constant<int, AHALF>{});
+    load_wr(0, S0{}, S0{});
+    split_slot(std::integral_constant<int, 0>{}, 0, smem);
+    if constexpr (A_F4 > 1) split_slot(std::integral_constant<int, 1>{}, 0, smem);
+    if constexpr (A_F4 > 2) split_slot(std::integral_constant<int, 2>{}, 0, smem);
+#pragma unroll
+    for (int i = 0; i < AREGS; ++i) areg[i] = keep[i];
+    if constexpr (A_F4 > 3) split_slot(std::integral_constant<int, 3>{}, 0, smem);
+    if constexpr (A_F4 > 4) split_slot(std::integral_constant<int, 4>{}, 0, smem);
+    if constexpr (A_F4 > 5) split_slot(std::integral_constant<int, 5>{}, 0, smem);
+  } else {
+    load_a(0);
+    load_w(0, 0, S0{});
+    load_w(0, 1, S1{});
     using I0 = std::integral_constant<int, 0>;
     split_slot(I0{}, 0, smem);
     if constexpr (A_F4 > 1) split_slot(std::integral_constant<int, 1>{}, 0, smem);
@@ -1271,6 +1380,21 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     if constexpr (A_F4 > 5) split_slot(std::integral_constant<int, 5>{}, 0, smem);
   }
   __syncthreads();
+  if constexpr (ROWS) {
+    using D0 = std::integral_constant<int, 0>;
+    using D1 = std::integral_constant<int, 1>;
+    using D2 = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u) read_unit(xu[u], smem, u, 0);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {                 // nchunks is even (C_in % 64 == 0, checked by the dispatcher)
+      period(D0{}, S0{}, chunk);
+      period(D1{}, S1{}, chunk);
+      period(D2{}, S0{}, chunk);
+      period(D0{}, S1{}, chunk + 1);
+      period(D1{}, S0{}, chunk + 1);
+      period(D2{}, S1{}, chunk + 1);
+    }
+  } else {
   read_x(fx0, smem, 0, 0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     tap_body(std::integral_constant<int, 0>{}, chunk);
@@ -1282,6 +1406,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     tap_body(std::integral_constant<int, 6>{}, chunk);
     tap_body(std::integral_constant<int, 7>{}, chunk);
     tap_body(std::integral_constant<int, 8>{}, chunk);
+  }
   }
 
   // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
@@ -1342,6 +1467,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   }
 }
 
+#ifndef MFPA_CONV_WD16_ROWS
+#define MFPA_CONV_WD16_ROWS 512
+#endif
 template <int PH, int PW>
 int launch_wd16(ConvArgs& a, hipStream_t s) {
   a.tiles_x = (a.W + PW - 1) / PW;
@@ -1351,9 +1479,15 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   constexpr int A_F4 = (HP * (KC / 4) + 511) / 512;
   constexpr int HPS = A_F4 * 64;
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
-  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256));
+  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)2 * A_F4 * 512 * sizeof(unsigned);      // two halo stages + the slot offsets
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / 128));
-  hipLaunchKernelGGL((conv_wd16_kernel<PH, PW>), grid, dim3(512), lds, s, a);
+  // the ROWS loop form from 512 input channels up (MFPA_CONV_WD16_ROWS = that threshold; 0 = never): same-call pairs on the UNet's layers,
+  // 64 clips: +2 .. +4 % at 512 / 1024 input channels, -1 .. -4 % at 64 .. 256 (its longer pipeline fill costs more than the halved
+  // fragment reads return when a tile has only 2 .. 8 chunks)
+  static const int rows_min = MFPA_EXP_ENV("MFPA_CONV_WD16_ROWS", MFPA_CONV_WD16_ROWS);
+  const int cin = a.C0 + a.C1;
+  if (rows_min > 0 && cin % 64 == 0 && cin >= rows_min) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false>), grid, dim3(512), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
