@@ -533,7 +533,7 @@ def bench_train(args, rank, world, dev, dist):
                           # forward + input gradients (2/3 of the FLOPs) issue 3 bf16 MFMAs per product, the weight gradients 3 or 1
                           "mfma_flops_issued_per_algorithmic_flop": round(issue_x, 3),
                           "mfma_issue_frac": round(issue_x * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                          "kernel": f"conv_mfma_kernel<PREC 1> + wgrad_bf16x3_kernel ({args.wgrad} products)", "launches": timer.launches(),
+                          "kernel": f"conv_wd16_kernel / conv_mfma_kernel<PREC 1> + wgrad_bf16_kernel / wgrad_bf16x3_kernel ({args.wgrad} products)", "launches": timer.launches(),
                           "kernel_ms_per_step": round(conv_ms / args.steps, 3)} if args.precision == "bf16x3" else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -652,8 +652,9 @@ def bench_infer(args, rank, world, dev, dist):
                 "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                 "mfma_flops_issued_per_algorithmic_flop": 3,
                 "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                "kernel": "conv_mfma_kernel<PREC 1> (weights-direct form on the >= 128-channel layers, plain loop on the 64-channel ones) + "
-                          "convT_mfma_kernel<PREC 1> (3x3 / transposed 2x2 implicit GEMM, 3x v_mfma_f32_32x32x16_bf16 per fp32 product)",
+                "kernel": "conv_wd16_kernel (weights-direct, v_mfma_f32_16x16x32_bf16: the >= 128-channel layers) + conv_mfma_kernel<PREC 1> "
+                          "(plain loop, v_mfma_f32_32x32x16_bf16: the 64-channel layers) + convT_mfma_kernel<PREC 1>: 3x3 / transposed 2x2 "
+                          "implicit GEMM, 3 bf16 MFMAs per fp32 product",
                 "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
 
     if net is not None and timer.launches():

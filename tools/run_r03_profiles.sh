@@ -19,6 +19,9 @@ rm -rf $O/pmc_s1 $O/pmc_s2
 timeout -k 10 300 python bench.py --mode train --steps 20 --warmup 5 > $O/train_step_bench_line.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --mode demucs --steps 20 --warmup 5 > $O/demucs_bench_line.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --mode demucs-train --steps 20 --warmup 5 > $O/demucs_train_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -o p -- python3 bench.py --mode train --steps 10 --warmup 3 --cpu-seconds 0 > $O/train_step_bench_under_rocprof.json 2>> $O/bench.err
+cp $(find $O/ktt -name "*kernel_stats.csv" | head -1) $O/train_step_kernel_stats.csv; rm -rf $O/ktt
+python tools/exp_wgrad.py > $O/wgrad_layers.txt 2>&1
 python tools/time_small_kernels.py 256 > $O/small_kernels.txt 2>&1
 python tools/exp_conv.py --both --reps 5 > $O/conv_layers_lds_vs_direct.txt 2>&1
 ls $O; cat $O/pmc_traffic.log | tail -2
