@@ -1028,9 +1028,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 // Not bit-identical to the 32 x 32 x 16 kernels (a k-step sums 32 products inside the instruction); same products, fp32 accumulate.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int PH, int PW, bool ROWS>
+template <int PH, int PW, bool ROWS, int WMW = 2>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
-  constexpr int THREADS = 512, BN = 128, TAPS = 9;
+  // WMW = 2: 2 x 4 waves of 128 px x 32 ch (128-channel output tiles); WMW = 4: 4 x 2 waves of 64 px x 32 ch (the 64-channel layers)
+  constexpr int THREADS = 512, WNW = 8 / WMW, BN = 32 * WNW, WPXW = 256 / WMW, TAPS = 9;
+  static_assert((WMW == 2 || WMW == 4) && (!ROWS || WMW == 2), "wave grid");
   constexpr int HPW = PW + 2, HPH = PH + 2, HP = HPW * HPH, BM = PH * PW;
   static_assert(BM == 256 && (PW == 32 || PW == 16), "two waves of 128 pixels: eight 16-pixel tiles each");
   constexpr int A_F4 = (HP * (KC / 4) + THREADS - 1) / THREADS;
@@ -1038,12 +1040,12 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;                // bytes of one (hi|lo, k-group) plane, a multiple of 256
   constexpr int HLS = 4 * PLANE + 256;                                 // hi -> lo distance (planes 2, 3 sit 128 B further: room for that)
   constexpr int STAGE = 2 * HLS;
-  constexpr int PT = 8;                                                // 16-pixel tiles per wave
+  constexpr int PT = WPXW / 16;                                        // 16-pixel tiles per wave
   static_assert(A_F4 <= TAPS - 3, "one halo staging slot per tap, taps 2 .. 7");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int wm = wave % WMW, wn = __builtin_amdgcn_readfirstlane(wave / WMW);
   const int p = lane & 15, g = lane >> 4;
   auto plane_off = [](int hl, int kg) { return hl * HLS + kg * PLANE + (kg >> 1) * 128; };
 
@@ -1076,6 +1078,15 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     aoffs[(A_F4 + it) * THREADS + tid] = ((unsigned)(c1y * a.W1 + c1x) * (unsigned)a.C1 + 4u * aq) * 4u;
     ain |= (in ? 1u : 0u) << it | (in1 ? 1u : 0u) << (8 + it);
   }
+  // training forward: the producer's per-channel (scale, shift) of source 0, copied to LDS once ([scale C0 | shift C0])
+  float* aff = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * A_F4 * THREADS * sizeof(unsigned));
+  if (a.in_scale0 != nullptr) {
+    for (int i = tid; i < a.C0; i += THREADS) {
+      aff[i] = a.in_scale0[i];
+      aff[a.C0 + i] = a.in_shift0[i];
+    }
+    __syncthreads();
+  }
   const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * sizeof(float);
   const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
   // ROWS: the staging slots are requested in two halves (slots 0..2 in period 0, 3..5 in period 1) that share three registers
@@ -1104,8 +1115,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     f32x4 v = areg[it % AREGS];
     if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale0 + c0 + 4 * aq);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift0 + c0 + 4 * aq);
+      // from the LDS copy: a global load here is followed by s_waitcnt vmcnt(0), which also waits for every weight load in flight
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + c0 + 4 * aq);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + a.C0 + c0 + 4 * aq);
       v = v * sc + sh;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
@@ -1144,7 +1156,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   XFrags fx0, fx1;
   // byte offset of the lane's row of pixel tile 0 in plane (hi, g) at tap (0, 0); the other tiles are compile-time displacements of it
   // (a 16-pixel tile is half a patch row of the 32-wide patches, a whole row of the 16-wide ones)
-  const int xbase = (((wm * 128 + p) / PW) * HPW + ((wm * 128 + p) % PW)) * 16 + plane_off(0, g);
+  const int xbase = (((wm * WPXW + p) / PW) * HPW + ((wm * WPXW + p) % PW)) * 16 + plane_off(0, g);
   auto tile_disp = [](int pt) { return (PW == 32) ? ((pt >> 1) * HPW + (pt & 1) * 16) * 16 : pt * HPW * 16; };
   auto read_x = [&](XFrags& f, const char* stage, int tap_off, int half) __attribute__((always_inline)) {
 #pragma unroll
@@ -1221,6 +1233,61 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     } else {
       pin_reads<N_M, N_R>();
       if constexpr (N_M - pin_read_slots(N_M, N_R) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_R), 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // WMW = 4 (a wave owns four pixel tiles): ONE phase per tap -- MFMA(tiles 0..3 of tap t, fragment set t & 1) || read tiles 0..3 of tap
+  // t + 1 into the other set, request the weights of tap t + 2, (tap 0) request the next chunk's halo, (taps 2..7) split one staging
+  // slot.  Nine taps per chunk: the set parity flips with the chunk, so the loop body is two chunks (PAR = parity of tap 0's set).
+  auto tap_body4 = [&](auto TAP, auto PAR, int chunk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(TAP)::value, par = (decltype(PAR)::value + tap) & 1;
+    constexpr int ntap = (tap + 1) % TAPS;
+    constexpr int ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * 16;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const char* cur = smem + (chunk & 1) * STAGE;
+    const char* nxt = (tap == TAPS - 1) ? smem + ((chunk + 1) & 1) * STAGE : cur;
+    if (tap == TAPS - 1) {
+      __syncthreads();                                                 // the next stage is complete, this one is read out
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tap == 0) load_a(chunk_n);
+    read_x(par ? fx0 : fx1, nxt, ntap_off, 0);
+    mfma_half(par ? fx1 : fx0, wq[tap % 3], 0);
+    load_w((tap + 2 >= TAPS) ? chunk_n : chunk, (tap + 2) % TAPS, std::integral_constant<int, (tap + 2) % 3>{});
+    if constexpr (tap >= 2 && tap - 2 < A_F4) {
+      split_slot(std::integral_constant<int, tap - 2>{}, chunk_n, smem + ((chunk + 1) & 1) * STAGE);
+#pragma unroll
+      for (int i = 0; i < N_R; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 8, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N_R; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 4, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1394,6 +1461,28 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       period(D1{}, S0{}, chunk + 1);
       period(D2{}, S1{}, chunk + 1);
     }
+  } else if constexpr (WMW == 4) {
+    read_x(fx0, smem, 0, 0);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {                 // nchunks is even (C_in % 64 == 0, checked by the dispatcher)
+      tap_body4(std::integral_constant<int, 0>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 1>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 2>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 3>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 4>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 5>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 6>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 7>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 8>{}, S0{}, chunk);
+      tap_body4(std::integral_constant<int, 0>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 1>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 2>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 3>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 4>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 5>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 6>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 7>{}, S1{}, chunk + 1);
+      tap_body4(std::integral_constant<int, 8>{}, S1{}, chunk + 1);
+    }
   } else {
   read_x(fx0, smem, 0, 0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -1428,7 +1517,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     char* yb = reinterpret_cast<char*>(a.y + (size_t)b * a.yH * a.yW * a.Cout);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int m = wm * 128 + pt * 16 + p;
+      const int m = wm * WPXW + pt * 16 + p;
       const int gy = y0 + m / PW, gx = x0p + m % PW;
       if (gy < a.yH && gx < a.yW) {
         char* yp = yb + (((unsigned)gy * (unsigned)a.yW + (unsigned)gx) * (unsigned)a.Cout + (unsigned)(n0 + wn * 32 + 4 * g)) * 4u;
@@ -1459,7 +1548,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
           const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
           v[j] = fmaxf(t, o);
         }
-        const int m = wm * 128 + pt * 16 + p;
+        const int m = wm * WPXW + pt * 16 + p;
         const int py = (y0 + m / PW) / 2, px = (x0p + m % PW) / 2;
         if (!(p & 1) && py < Ho && px < Wo)
           *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)b * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32 + ct * 16 + 4 * g) = v;
@@ -1467,10 +1556,13 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   }
 }
 
+#ifndef MFPA_CONV_WD16_64
+#define MFPA_CONV_WD16_64 128        // conv_wd16_kernel<.., WMW = 4> for 64-channel layers with at least this many input channels (no fused first layer / OutConv); 0 = off
+#endif
 #ifndef MFPA_CONV_WD16_ROWS
 #define MFPA_CONV_WD16_ROWS 512
 #endif
-template <int PH, int PW>
+template <int PH, int PW, int WMW = 2>
 int launch_wd16(ConvArgs& a, hipStream_t s) {
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + PH - 1) / PH;
@@ -1479,14 +1571,18 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   constexpr int A_F4 = (HP * (KC / 4) + 511) / 512;
   constexpr int HPS = A_F4 * 64;
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
-  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)2 * A_F4 * 512 * sizeof(unsigned);      // two halo stages + the slot offsets
-  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / 128));
+  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
+                     (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0);                                  // + the on-load affine
+  dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / (32 * (8 / WMW))));
   // the ROWS loop form from 512 input channels up (MFPA_CONV_WD16_ROWS = that threshold; 0 = never): same-call pairs on the UNet's layers,
   // 64 clips: +2 .. +4 % at 512 / 1024 input channels, -1 .. -4 % at 64 .. 256 (its longer pipeline fill costs more than the halved
   // fragment reads return when a tile has only 2 .. 8 chunks)
   static const int rows_min = MFPA_EXP_ENV("MFPA_CONV_WD16_ROWS", MFPA_CONV_WD16_ROWS);
   const int cin = a.C0 + a.C1;
-  if (rows_min > 0 && cin % 64 == 0 && cin >= rows_min) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true>), grid, dim3(512), lds, s, a);
+  if constexpr (WMW == 4) {
+    if (cin % 64) return MFPA_EINVAL;
+    hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4>), grid, dim3(512), lds, s, a);
+  } else if (rows_min > 0 && cin % 64 == 0 && cin >= rows_min) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true>), grid, dim3(512), lds, s, a);
   else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false>), grid, dim3(512), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
@@ -1829,7 +1925,13 @@ static int conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int pre
   return 0;
 #endif
   if (mode != 0 || precision != 1 || Cin < MFPA_CONV_BIG_MIN_CIN) return 0;
-  if (Cout % 128) return (MFPA_CONV_BDIR64 && Cout % 64 == 0 && W > 16 && H >= 8) ? 1 : 0;      // 64-channel output tiles
+  if (Cout % 128) {                                                    // 64-channel output tiles
+    static const int wd64 = MFPA_EXP_ENV("MFPA_CONV_WD16_64", MFPA_CONV_WD16_64);
+    // (wd64 = the smallest C_in that takes it: with two chunks per tile the tile's prologue and epilogue dominate, and two co-resident
+    // workgroups of the plain-loop kernel hide them better than one workgroup of this one)
+    if (MFPA_CONV_WD16 && wd64 > 0 && Cin >= wd64 && Cout % 64 == 0 && Cin % 64 == 0 && W > 16 && H >= 8) return 2;
+    return (MFPA_CONV_BDIR64 && Cout % 64 == 0 && W > 16 && H >= 8) ? 1 : 0;
+  }
   if (W > 16 && H >= 8) return MFPA_CONV_WD16 ? 2 : 1;
   if (W <= 16 && H >= 16 && MFPA_CONV_BOTTLENECK8) return MFPA_CONV_WD16 ? 2 : 1;
   return 0;
@@ -1850,6 +1952,7 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   if constexpr (MODE == 0 && PREC == 1) {
     if (a.w_frag == 2) {   // the 16 x 16 x 32 weights-direct kernel and its image
       if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || a.c1_x32 || a.c1_spec64 || a.w1x1) return MFPA_EINVAL;
+      if (!bn128) return launch_wd16<8, 32, 4>(a, s);                   // 64-channel output tiles: 4 x 2 waves of 64 px x 32 ch
       if (a.W > 16) return launch_wd16<8, 32>(a, s);
       return launch_wd16<16, 16>(a, s);
     }
