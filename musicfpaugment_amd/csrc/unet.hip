@@ -1049,37 +1049,52 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   const int p = lane & 15, g = lane >> 4;
   auto plane_off = [](int hl, int kg) { return hl * HLS + kg * PLANE + (kg >> 1) * 128; };
 
-  int bx = blockIdx.x;
-  const int tx = bx % a.tiles_x; bx /= a.tiles_x;
-  const int ty = bx % a.tiles_y; bx /= a.tiles_y;
-  const int b = bx;
+  // PERSIST (WMW = 4): a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the halo of the next tile's first chunk is
+  // requested and split under the last chunk of the current one, so a tile's prologue (a global round trip) and most of its epilogue
+  // disappear behind the neighbours' MFMAs -- with 2 .. 4 chunks per tile they were a third of a workgroup's life.
+  constexpr bool PERSIST = (WMW == 4);
   const int n0 = blockIdx.y * BN;
-  const int y0 = ty * PH, x0p = tx * PW;
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / KC;
+  const int ntiles = a.tiles_x * a.tiles_y * a.B;
 
   // ---- halo loader (as conv_mfma_kernel's: unconditional clamped loads, padding zeroed when the slot is split).  A thread's staging
   // slots map to fixed halo pixels; their byte offsets into the two sources live in LDS ([source][slot][thread], read back two or three
   // at a time in front of the loads) and their inside-the-source flags in ONE register: as loop-invariant registers (12 offsets) the
   // compiler spilled them to scratch, and a scratch reload in front of a load drains every outstanding weight load (s_waitcnt vmcnt(0)).
   const int aq = tid % (KC / 4);
-  unsigned* aoffs = reinterpret_cast<unsigned*>(smem + 2 * STAGE);     // [2][A_F4][THREADS]
-  unsigned ain = 0;                                                    // bit it: slot inside source 0's image; bit 8 + it: inside source 1
+  constexpr int TBL = 2 * A_F4 * THREADS;                              // one offset table: [2][A_F4][THREADS]
+  unsigned* const aoffs0 = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
+  struct Tile { int b, y0, x0p; unsigned ain; const char* xb0; const char* xb1; unsigned* aoffs; };
+  // decode tile t, build its offset table in `table`, return its state (ain bit it: slot inside source 0's image; bit 8 + it: source 1)
+  auto make_tile = [&](int t, unsigned* table) __attribute__((always_inline)) {
+    Tile T;
+    int bx = t;
+    const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+    T.b = bx; T.y0 = ty * PH; T.x0p = tx * PW; T.aoffs = table; T.ain = 0;
 #pragma unroll
-  for (int it = 0; it < A_F4; ++it) {
-    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
-    const int gy = y0 + pix / HPW - 1, gx = x0p + pix % HPW - 1;
-    const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-    aoffs[it * THREADS + tid] = ((unsigned)(cy * a.W + cx) * (unsigned)a.C0 + 4u * aq) * 4u;
-    const int y1 = gy - a.oy1, x1 = gx - a.ox1;
-    const bool in1 = in && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
-    const int c1y = min(max(y1, 0), max(a.H1 - 1, 0)), c1x = min(max(x1, 0), max(a.W1 - 1, 0));
-    aoffs[(A_F4 + it) * THREADS + tid] = ((unsigned)(c1y * a.W1 + c1x) * (unsigned)a.C1 + 4u * aq) * 4u;
-    ain |= (in ? 1u : 0u) << it | (in1 ? 1u : 0u) << (8 + it);
-  }
+    for (int it = 0; it < A_F4; ++it) {
+      const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+      const int gy = T.y0 + pix / HPW - 1, gx = T.x0p + pix % HPW - 1;
+      const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+      table[it * THREADS + tid] = ((unsigned)(cy * a.W + cx) * (unsigned)a.C0 + 4u * aq) * 4u;
+      const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+      const bool in1 = in && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
+      const int c1y = min(max(y1, 0), max(a.H1 - 1, 0)), c1x = min(max(x1, 0), max(a.W1 - 1, 0));
+      table[(A_F4 + it) * THREADS + tid] = ((unsigned)(c1y * a.W1 + c1x) * (unsigned)a.C1 + 4u * aq) * 4u;
+      T.ain |= (in ? 1u : 0u) << it | (in1 ? 1u : 0u) << (8 + it);
+    }
+    T.xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)T.b * a.H * a.W * a.C0 * sizeof(float);
+    T.xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)T.b * a.H1 * a.W1 * a.C1 * sizeof(float);
+    return T;
+  };
+  int tile = blockIdx.x;
+  Tile S = make_tile(tile, aoffs0);                                    // the tile whose halo is being requested / split
+  int eb = S.b, ey0 = S.y0, ex0p = S.x0p;                              // the tile being computed (epilogue coordinates)
   // training forward: the producer's per-channel (scale, shift) of source 0, copied to LDS once ([scale C0 | shift C0])
-  float* aff = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * A_F4 * THREADS * sizeof(unsigned));
+  float* aff = reinterpret_cast<float*>(smem + 2 * STAGE + (PERSIST ? 2 : 1) * TBL * sizeof(unsigned));
   if (a.in_scale0 != nullptr) {
     for (int i = tid; i < a.C0; i += THREADS) {
       aff[i] = a.in_scale0[i];
@@ -1087,8 +1102,6 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     }
     __syncthreads();
   }
-  const char* xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * sizeof(float);
-  const char* xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)b * a.H1 * a.W1 * a.C1 * sizeof(float);
   // ROWS: the staging slots are requested in two halves (slots 0..2 in period 0, 3..5 in period 1) that share three registers
   constexpr int AHALF = (A_F4 + 1) / 2, AREGS = ROWS ? AHALF : A_F4;
   f32x4 areg[AREGS];
@@ -1096,8 +1109,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int first = decltype(FIRST)::value, count = decltype(COUNT)::value;
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;                                      // workgroup-uniform: scalar selects, no branch
-    const char* xb = from0 ? xb0 + (size_t)c0 * 4 : xb1 + (size_t)(c0 - a.C0) * 4;
-    const unsigned* ao = aoffs + (from0 ? 0 : A_F4 * THREADS) + tid;
+    const char* xb = from0 ? S.xb0 + (size_t)c0 * 4 : S.xb1 + (size_t)(c0 - a.C0) * 4;
+    const unsigned* ao = S.aoffs + (from0 ? 0 : A_F4 * THREADS) + tid;
 #pragma unroll
     for (int it = first; it < first + count && it < A_F4; ++it)
       areg[it % AREGS] = *reinterpret_cast<const f32x4*>(xb + ao[it * THREADS]);
@@ -1111,7 +1124,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int it = decltype(IT)::value;
     const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
     const int c0 = chunk * KC;
-    const bool inside = (ain >> ((c0 < a.C0 ? 0 : 8) + it)) & 1u;
+    const bool inside = (S.ain >> ((c0 < a.C0 ? 0 : 8) + it)) & 1u;
     f32x4 v = areg[it % AREGS];
     if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {
@@ -1122,8 +1135,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
       if (a.drop_thresh) {
-        const int gy = y0 + pix / HPW - 1, gx = x0p + pix % HPW - 1;   // inside the image here
-        const unsigned long long e0 = (((unsigned long long)b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * aq;
+        const int gy = S.y0 + pix / HPW - 1, gx = S.x0p + pix % HPW - 1;   // inside the image here
+        const unsigned long long e0 = (((unsigned long long)S.b * a.H + gy) * a.W + gx) * a.C0 + c0 + 4 * aq;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? v[k] * a.drop_scale : 0.f;
       }
@@ -1244,7 +1257,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int tap = decltype(TAP)::value, par = (decltype(PAR)::value + tap) & 1;
     constexpr int ntap = (tap + 1) % TAPS;
     constexpr int ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * 16;
-    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : 0;          // past the tile's last chunk: chunk 0 of the next tile (S is that tile by then)
     const char* cur = smem + (chunk & 1) * STAGE;
     const char* nxt = (tap == TAPS - 1) ? smem + ((chunk + 1) & 1) * STAGE : cur;
     if (tap == TAPS - 1) {
@@ -1446,6 +1459,66 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     if constexpr (A_F4 > 4) split_slot(std::integral_constant<int, 4>{}, 0, smem);
     if constexpr (A_F4 > 5) split_slot(std::integral_constant<int, 5>{}, 0, smem);
   }
+  auto epilogue = [&]() __attribute__((always_inline)) {
+  // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
+  #pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int ch = n0 + wn * 32 + ct * 16 + 4 * g;
+      const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4*>(a.shift + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[ct][pt][j] * sc[j] + sh[j];
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          acc[ct][pt][j] = v;
+        }
+    }
+    if (a.y != nullptr) {
+      char* yb = reinterpret_cast<char*>(a.y + (size_t)eb * a.yH * a.yW * a.Cout);
+  #pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int m = wm * WPXW + pt * 16 + p;
+        const int gy = ey0 + m / PW, gx = ex0p + m % PW;
+        if (gy < a.yH && gx < a.yW) {
+          char* yp = yb + (((unsigned)gy * (unsigned)a.yW + (unsigned)gx) * (unsigned)a.Cout + (unsigned)(n0 + wn * 32 + 4 * g)) * 4u;
+  #pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            f32x4 o;
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
+            *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
+          }
+        }
+      }
+    }
+    if (a.y_pool != nullptr) {
+      // MaxPool2d(2) (floor): the window's two rows are two of the wave's pixel tiles, its two columns adjacent lanes (one DPP swap)
+      const int Ho = a.H / 2, Wo = a.W / 2;
+      constexpr int ROWSTEP = (PW == 32) ? 2 : 1;                        // pixel tiles per patch row
+  #pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+  #pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const int row = pt / ROWSTEP;                                  // patch row inside the wave's block
+          if (row & 1) continue;
+          f32x4 v;
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = fmaxf(acc[ct][pt][j], acc[ct][pt + ROWSTEP][j]);
+            const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+            v[j] = fmaxf(t, o);
+          }
+          const int m = wm * WPXW + pt * 16 + p;
+          const int py = (ey0 + m / PW) / 2, px = (ex0p + m % PW) / 2;
+          if (!(p & 1) && py < Ho && px < Wo)
+            *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)eb * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32 + ct * 16 + 4 * g) = v;
+        }
+    }
+  
+  };
+
   __syncthreads();
   if constexpr (ROWS) {
     using D0 = std::integral_constant<int, 0>;
@@ -1461,27 +1534,43 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       period(D1{}, S0{}, chunk + 1);
       period(D2{}, S1{}, chunk + 1);
     }
+    epilogue();
   } else if constexpr (WMW == 4) {
     read_x(fx0, smem, 0, 0);
-    for (int chunk = 0; chunk < nchunks; chunk += 2) {                 // nchunks is even (C_in % 64 == 0, checked by the dispatcher)
-      tap_body4(std::integral_constant<int, 0>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 1>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 2>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 3>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 4>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 5>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 6>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 7>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 8>{}, S0{}, chunk);
-      tap_body4(std::integral_constant<int, 0>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 1>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 2>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 3>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 4>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 5>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 6>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 7>{}, S1{}, chunk + 1);
-      tap_body4(std::integral_constant<int, 8>{}, S1{}, chunk + 1);
+    unsigned* const aoffs1 = aoffs0 + TBL;
+    for (;;) {
+      // the next tile of this workgroup (past the end: this tile again -- its first chunk is requested once more and never used)
+      const int tile_n = tile + (int)gridDim.x;
+      const bool has_next = tile_n < ntiles;
+      const Tile N = make_tile(has_next ? tile_n : tile, S.aoffs == aoffs0 ? aoffs1 : aoffs0);
+      for (int chunk = 0; chunk < nchunks; chunk += 2) {                 // nchunks is even (C_in % 64 == 0, checked by the dispatcher)
+        tap_body4(std::integral_constant<int, 0>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 1>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 2>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 3>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 4>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 5>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 6>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 7>{}, S0{}, chunk);
+        tap_body4(std::integral_constant<int, 8>{}, S0{}, chunk);
+        if (chunk + 2 >= nchunks) S = N;                                 // the tile's last chunk stages the next tile's first
+        tap_body4(std::integral_constant<int, 0>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 1>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 2>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 3>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 4>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 5>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 6>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 7>{}, S1{}, chunk + 1);
+        tap_body4(std::integral_constant<int, 8>{}, S1{}, chunk + 1);
+      }
+      epilogue();
+      if (!has_next) break;
+      tile = tile_n; eb = S.b; ey0 = S.y0; ex0p = S.x0p;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
   } else {
   read_x(fx0, smem, 0, 0);
@@ -1496,63 +1585,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     tap_body(std::integral_constant<int, 7>{}, chunk);
     tap_body(std::integral_constant<int, 8>{}, chunk);
   }
-  }
-
-  // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int ch = n0 + wn * 32 + ct * 16 + 4 * g;
-    const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
-    const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4*>(a.shift + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = acc[ct][pt][j] * sc[j] + sh[j];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        acc[ct][pt][j] = v;
-      }
-  }
-  if (a.y != nullptr) {
-    char* yb = reinterpret_cast<char*>(a.y + (size_t)b * a.yH * a.yW * a.Cout);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const int m = wm * WPXW + pt * 16 + p;
-      const int gy = y0 + m / PW, gx = x0p + m % PW;
-      if (gy < a.yH && gx < a.yW) {
-        char* yp = yb + (((unsigned)gy * (unsigned)a.yW + (unsigned)gx) * (unsigned)a.Cout + (unsigned)(n0 + wn * 32 + 4 * g)) * 4u;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          f32x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
-          *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
-        }
-      }
-    }
-  }
-  if (a.y_pool != nullptr) {
-    // MaxPool2d(2) (floor): the window's two rows are two of the wave's pixel tiles, its two columns adjacent lanes (one DPP swap)
-    const int Ho = a.H / 2, Wo = a.W / 2;
-    constexpr int ROWSTEP = (PW == 32) ? 2 : 1;                        // pixel tiles per patch row
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) {
-        const int row = pt / ROWSTEP;                                  // patch row inside the wave's block
-        if (row & 1) continue;
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = fmaxf(acc[ct][pt][j], acc[ct][pt + ROWSTEP][j]);
-          const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
-          v[j] = fmaxf(t, o);
-        }
-        const int m = wm * WPXW + pt * 16 + p;
-        const int py = (y0 + m / PW) / 2, px = (x0p + m % PW) / 2;
-        if (!(p & 1) && py < Ho && px < Wo)
-          *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)b * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32 + ct * 16 + 4 * g) = v;
-      }
+  epilogue();
   }
 }
 
@@ -1571,9 +1604,15 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   constexpr int A_F4 = (HP * (KC / 4) + 511) / 512;
   constexpr int HPS = A_F4 * 64;
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
-  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
-                     (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0);                                  // + the on-load affine
+  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)(WMW == 4 ? 2 : 1) * 2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
+                     (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0);                                                        // + the on-load affine
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / (32 * (8 / WMW))));
+  static const int persist_env = MFPA_EXP_ENV("MFPA_CONV_WD16_PERSIST", 1);      // experiments: 0 = one workgroup per tile
+  if (WMW == 4 && persist_env) {                                       // persistent: one workgroup per CU (and output-channel tile) walks the tiles
+    const int cus = mfpa_current_device_cus();
+    const unsigned per = (unsigned)((cus > 0 ? cus : 256) / (int)grid.y);
+    if (per >= 1 && grid.x > per) grid.x = per;
+  }
   // the ROWS loop form from 512 input channels up (MFPA_CONV_WD16_ROWS = that threshold; 0 = never): same-call pairs on the UNet's layers,
   // 64 clips: +2 .. +4 % at 512 / 1024 input channels, -1 .. -4 % at 64 .. 256 (its longer pipeline fill costs more than the halved
   // fragment reads return when a tile has only 2 .. 8 chunks)
