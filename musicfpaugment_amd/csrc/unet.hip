@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 }
 
 #ifndef MFPA_CONV_WD16_64
-#define MFPA_CONV_WD16_64 128        // conv_wd16_kernel<.., WMW = 4> for 64-channel layers with at least this many input channels (no fused first layer / OutConv); 0 = off
+#define MFPA_CONV_WD16_64 64         // conv_wd16_kernel<.., WMW = 4> for 64-channel layers with at least this many input channels (no fused first layer / OutConv); 0 = off
 #endif
 #ifndef MFPA_CONV_WD16_ROWS
 #define MFPA_CONV_WD16_ROWS 512
@@ -1966,8 +1966,9 @@ static int conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int pre
   if (mode != 0 || precision != 1 || Cin < MFPA_CONV_BIG_MIN_CIN) return 0;
   if (Cout % 128) {                                                    // 64-channel output tiles
     static const int wd64 = MFPA_EXP_ENV("MFPA_CONV_WD16_64", MFPA_CONV_WD16_64);
-    // (wd64 = the smallest C_in that takes it: with two chunks per tile the tile's prologue and epilogue dominate, and two co-resident
-    // workgroups of the plain-loop kernel hide them better than one workgroup of this one)
+    // (wd64 = the smallest C_in that takes it.  Before its tile loop was persistent, two-chunk tiles ran better on the plain-loop
+    // kernel, whose two co-resident workgroups hide each other's prologue and epilogue; with the persistent loop: 64 -> 64 @ 257 x 251,
+    // 64 clips, 1366 -> 1008 us)
     if (MFPA_CONV_WD16 && wd64 > 0 && Cin >= wd64 && Cout % 64 == 0 && Cin % 64 == 0 && W > 16 && H >= 8) return 2;
     return (MFPA_CONV_BDIR64 && Cout % 64 == 0 && W > 16 && H >= 8) ? 1 : 0;
   }

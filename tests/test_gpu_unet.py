@@ -164,8 +164,8 @@ def test_weights_direct_kernels_against_the_lds_staged_kernel():
                                           (2, 16, 16, 128, 0, 128, True),
                                           # >= 512 input channels: the loop form in which the three vertical taps share their fragment reads
                                           (1, 33, 31, 512, 0, 128, True), (1, 9, 34, 512, 512, 128, False),
-                                          # 64-channel output tiles from 128 input channels up (4 x 2 waves of 64 pixels x 32 channels)
-                                          (2, 9, 37, 128, 0, 64, False), (2, 33, 31, 64, 64, 64, False), (2, 16, 34, 128, 0, 64, True),
+                                          # 64-channel output tiles (4 x 2 waves of 64 pixels x 32 channels, persistent tile loop: more tiles than CUs below)
+                                          (2, 9, 37, 64, 0, 64, False), (2, 33, 31, 64, 64, 64, False), (70, 64, 62, 128, 0, 64, True), (2, 16, 34, 128, 0, 64, True),
                                           (24, 257, 251, 64, 64, 64, False)]:
         assert lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == lay
         x0 = torch.randn(B, H, W, C0, generator=g).cuda()
