@@ -234,10 +234,23 @@ typedef struct mfpa_conv_desc {
    * [lane 64][16 B] for v_mfma_f32_32x32x16_bf16 -- valid exactly where mfpa_conv_weight_layout() returns that number,
    * MFPA_EINVAL otherwise. */
   int w_layout;
+  /* w_layout 2, mode 0, optional (training forward): a bf16 copy of source 0 AS THE CONVOLUTION SAW IT (in_scale0 / in_shift0 / ReLU /
+   * dropout applied), (B,H,W,C0), written by the halo loader of the first output-channel tile -- the operand mfpa_wgrad_mfma(precision 3)
+   * reads in the backward pass, without a cast pass of its own.  MFPA_EINVAL with any other kernel. */
+  void* x0_bf16;
+  /* w_layout 2, mode 0, optional (training forward): per-wave partial BatchNorm statistics of the stored output, [rows][2][Cout] floats
+   * with rows = mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout): (sum, sum of squares) per channel over each wave's pixels.
+   * mfpa_conv_stats_reduce sums the rows in float64 (fixed order) into the `sums` of mfpa_bn_stats_finish -- the statistics without a
+   * pass over the output.  MFPA_EINVAL with any other kernel. */
+  float* stats_part;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 /* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */
 int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision);
+/* HOST function: rows of mfpa_conv_desc.stats_part for this shape (0: its kernel does not write them). */
+int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout);
+/* stats_part (rows, 2, C) -> sums[2C] float64 as mfpa_bn_stats_sums produces them; workspace as for mfpa_bn_stats. */
+int mfpa_conv_stats_reduce(const float* part, long long rows, int C, double* sums, double* workspace, void* stream);
 
 /* First layer: 3x3 conv from ONE input channel (inc.double_conv.0, unet.py:86) fused with the
  * spectrogram normalisation: x = (float)(spec / denom) when spec64 != NULL, else x32 as is.

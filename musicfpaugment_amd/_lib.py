@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 24
+ABI_VERSION = 26
 
 
 class MfpaError(RuntimeError):
@@ -119,6 +119,8 @@ _SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
+    "mfpa_conv_stats_rows": ([c_int, c_int, c_int, c_int, c_int], c_int),
+    "mfpa_conv_stats_reduce": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_stats_sums": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_stats_finish": ([c_void_p, c_double, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p], c_int),
@@ -156,7 +158,8 @@ class ConvDesc(ctypes.Structure):
                 ("drop_seed", c_uint), ("drop_thresh", c_uint), ("drop_scale", c_float), ("precision", c_int),
                 ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p),
                 ("c1_x32", c_void_p), ("c1_spec64", c_void_p), ("c1_denom", c_void_p),
-                ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int)]
+                ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int),
+                ("x0_bf16", c_void_p), ("stats_part", c_void_p)]
 
 
 class GemmDesc(ctypes.Structure):

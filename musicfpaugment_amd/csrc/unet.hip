@@ -140,6 +140,9 @@ struct ConvArgs {
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
   int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
+  __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
+  float* stats_part;                 // conv_wd16_kernel: optional per-wave partial (sum, sum of squares) of the stored output per channel:
+                                     //   [tile * WMW + wm][2][Cout] (mfpa_conv_desc.stats_part; rows = mfpa_conv_stats_rows())
   int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
   // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
   // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
@@ -1028,6 +1031,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 // Not bit-identical to the 32 x 32 x 16 kernels (a k-step sums 32 products inside the instruction); same products, fp32 accumulate.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_add(float v) {               // v + (v of the lane CTRL names; 0 where there is none)
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 template <int PH, int PW, bool ROWS, int WMW = 2>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // WMW = 2: 2 x 4 waves of 128 px x 32 ch (128-channel output tiles); WMW = 4: 4 x 2 waves of 64 px x 32 ch (the 64-channel layers)
@@ -1150,6 +1158,15 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     char* at = stage + plane_off(0, aq >> 1) + pix * 16 + 8 * (aq & 1);
     *reinterpret_cast<bf16x4*>(at) = hi;
     *reinterpret_cast<bf16x4*>(at + HLS) = lo;
+    // training forward: the bf16 copy of the activated source 0 the weight gradient reads -- the hi half is exactly that.  Every pixel
+    // is interior (not halo) to one tile; the first output-channel tile writes it.
+    if (a.x0_bf16 != nullptr && c0 < a.C0 && blockIdx.y == 0) {
+      const int py = pix / HPW, px = pix % HPW;
+      if (inside && py >= 1 && py <= PH && px >= 1 && px <= PW) {
+        const size_t e = (((size_t)S.b * a.H + (S.y0 + py - 1)) * a.W + (S.x0p + px - 1)) * (size_t)a.C0 + c0 + 4 * aq;
+        *reinterpret_cast<bf16x4*>(a.x0_bf16 + e) = hi;
+      }
+    }
   };
 
   // ---- weight fragments: ring of three sets, [slot][16-channel tile][hi, lo]
@@ -1474,6 +1491,39 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
           if (a.relu) v = v > 0.f ? v : 0.f;
           acc[ct][pt][j] = v;
         }
+    }
+    if (a.stats_part != nullptr) {
+      // training forward: the BatchNorm statistics of this output, one partial row per wave -- (sum, sum of squares) over the wave's
+      // stored pixels for each of its 32 channels; rows are summed in float64 by mfpa_conv_stats_reduce (fixed order: deterministic)
+      float vm[PT];
+  #pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int m = wm * WPXW + pt * 16 + p;
+        vm[pt] = (ey0 + m / PW < a.yH && ex0p + m % PW < a.yW) ? 1.f : 0.f;
+      }
+      float* row = a.stats_part + ((size_t)tile * WMW + wm) * 2 * a.Cout + n0 + wn * 32 + 4 * g;
+  #pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = acc[ct][pt][j] * vm[pt];
+            sv[j] += v;
+            qv[j] += v * v;
+          }
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // row_shr 1, 2, 4, 8: lane 15 of a 16-lane row ends with its total
+          sv[j] = dpp_row_add<0x118>(dpp_row_add<0x114>(dpp_row_add<0x112>(dpp_row_add<0x111>(sv[j]))));
+          qv[j] = dpp_row_add<0x118>(dpp_row_add<0x114>(dpp_row_add<0x112>(dpp_row_add<0x111>(qv[j]))));
+        }
+        if (p == 15) {
+          *reinterpret_cast<f32x4*>(row + ct * 16) = sv;
+          *reinterpret_cast<f32x4*>(row + a.Cout + ct * 16) = qv;
+        }
+      }
     }
     if (a.y != nullptr) {
       char* yb = reinterpret_cast<char*>(a.y + (size_t)eb * a.yH * a.yW * a.Cout);
@@ -2112,6 +2162,10 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->w_layout < 0 || d->w_layout > 2) return MFPA_EINVAL;
   if (d->w_layout != 0 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
   a.w_frag = d->w_layout;
+  if (d->x0_bf16 != nullptr && (d->w_layout != 2 || !d->x0)) return MFPA_EINVAL;       // only conv_wd16_kernel's loader writes it
+  a.x0_bf16 = reinterpret_cast<__bf16*>(d->x0_bf16);
+  if (d->stats_part != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;       // only conv_wd16_kernel's epilogue writes them
+  a.stats_part = d->stats_part;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);
   if (d->mode == 1) return dispatch_conv<1>(a, s, d->precision);
@@ -2127,6 +2181,14 @@ int mfpa_exp_conv_stamps(unsigned long long* buf) {       // experiments build o
 int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision) {
   if (H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;
   return conv_weight_layout(H, W, Cin, Cout, mode, precision);
+}
+
+int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout) {
+  if (B < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;
+  if (conv_weight_layout(H, W, Cin, Cout, 0, 1) != 2) return 0;       // no kernel that writes the partials for this shape
+  const int pw = W > 16 ? 32 : 16, ph = 256 / pw;
+  const long long rows = (long long)((W + pw - 1) / pw) * ((H + ph - 1) / ph) * B * (Cout % 128 == 0 ? 2 : 4);
+  return rows > 0x7fffffffLL ? MFPA_EINVAL : (int)rows;
 }
 
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,

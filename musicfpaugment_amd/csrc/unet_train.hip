@@ -177,6 +177,30 @@ __global__ __launch_bounds__(256) void pair_sums_kernel(const double* __restrict
   if (lane == 0) { sums[2 * c] = s; sums[2 * c + 1] = ss; }
 }
 
+// per-wave partial rows of conv_wd16_kernel ([rows][2][C] floats) -> (sum, sum of squares) pairs in float64: a block walks its rows with
+// one channel per lane (coalesced), the blocks' results go through the two-stage float64 reduction the other statistics use
+__global__ __launch_bounds__(256) void conv_stats_rows_kernel(const float* __restrict__ part, long long rows, int C,
+                                                              double* __restrict__ partial) {
+  const int lanes = C < 256 ? C : 256, groups = 256 / lanes;
+  const int c0 = threadIdx.x % lanes, gq = threadIdx.x / lanes;
+  __shared__ double sh[2 * 256];
+  for (int c = c0; c < C; c += lanes) {
+    double s = 0, q = 0;
+    for (long long r = (long long)blockIdx.x * groups + gq; r < rows; r += (long long)gridDim.x * groups) {
+      s += (double)part[(size_t)r * 2 * C + c];
+      q += (double)part[(size_t)r * 2 * C + C + c];
+    }
+    sh[threadIdx.x] = s; sh[256 + threadIdx.x] = q;
+    __syncthreads();
+    if (gq == 0) {
+      for (int k = 1; k < groups; ++k) { s += sh[k * lanes + c0]; q += sh[256 + k * lanes + c0]; }
+      partial[((size_t)blockIdx.x * C + c) * 2] = s;
+      partial[((size_t)blockIdx.x * C + c) * 2 + 1] = q;
+    }
+    __syncthreads();
+  }
+}
+
 // ... and the backward finish from LOCAL sums (this rank's dgamma / dbeta: the gradient all-reduce adds the ranks) and GLOBAL
 // sums over `count` pixels of all ranks (the mean terms of the input gradient).
 __global__ __launch_bounds__(256) void bn_bwd_finish_sync_kernel(const double* __restrict__ local, const double* __restrict__ global,
@@ -1331,6 +1355,18 @@ int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, doub
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
                      nullptr, nullptr, workspace, 0u, 0u, 1.f);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, sums);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_conv_stats_reduce(const float* part, long long rows, int C, double* sums, double* workspace, void* stream) {
+  if (!part || !sums || !workspace || rows < 1 || C < 1 || (C < 256 && 256 % C) || (C > 256 && C % 256)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int groups = 256 / (C < 256 ? C : 256);
+  const int nblk = grid_for(rows, groups * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(conv_stats_rows_kernel, dim3(nblk), dim3(256), 0, s, part, rows, C, workspace);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, sums);
   MFPA_CHECK_LAUNCH();

@@ -85,10 +85,13 @@ def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int
 
 
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
-              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False, w_layout: int = 0):
+              relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False, w_layout: int = 0,
+              x0_bf16_out: Optional[list] = None, stats_out: Optional[list] = None):
     """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
     `w` (fp32, kernel layout) is split into the image the kernel for this shape reads (weight_layout) unless it already is an
-    operand image (`packed`, in the layout `w_layout`)."""
+    operand image (`packed`, in the layout `w_layout`).  `x0_bf16_out` (a list): when the kernel for this shape can write it
+    (w_layout 2), the bf16 copy of the activated source 0 is appended -- the weight gradient's operand, for free.  `stats_out` (a
+    list): likewise the kernel's per-wave partial BatchNorm statistics of the output ((rows, 2, Cout) float32, mfpa_conv_stats_reduce)."""
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -107,13 +110,23 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     else:
         oh, ow = out_hw if out_hw is not None else (H, W)
     y = torch.empty((B, oh, ow, Cout), dtype=torch.float32, device=x0.device)
+    xb = None
+    if x0_bf16_out is not None and w_layout == 2 and mode == 0:
+        xb = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
+        x0_bf16_out.append(xb)
+    part = None
+    if stats_out is not None and w_layout == 2 and mode == 0 and out_scale is None and out_shift is None and not relu and out_hw is None:
+        rows = int(lib().mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout))
+        if rows > 0:
+            part = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x0.device)
+            stats_out.append(part)
     d = ConvDesc(x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
                  in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), w=ptr(w),
                  out_scale=ptr(out_scale), out_shift=ptr(out_shift), y=ptr(y), C0=C0, C1=C1,
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout)
+                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout, x0_bf16=ptr(xb), stats_part=ptr(part))
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -133,18 +146,21 @@ def act_to_bf16(z: torch.Tensor, in_affine: Optional[Stats] = None) -> torch.Ten
     return out
 
 
-def bf16_wgrad(Cout, cin, precision) -> bool:
-    """Does wgrad_mfma read bf16 copies of its operands for this layer?"""
-    return precision == 2 and min(Cout, cin) >= BF16_WGRAD_MIN_CH
+def bf16_wgrad(Cout, cin, precision, have_x0_copy: bool = False) -> bool:
+    """Does wgrad_mfma read bf16 copies of its operands for this layer?  From BF16_WGRAD_MIN_CH channels up -- and below that when
+    the forward convolution already wrote the copy of the activated input (then no cast pass is paid for it)."""
+    return precision == 2 and (have_x0_copy or min(Cout, cin) >= BF16_WGRAD_MIN_CH)
 
 
-def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0, dz_bf16=None):
+def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0, dz_bf16=None, x0_bf16=None):
     B, H, W, C0 = x0.shape
     cin = C0 + (0 if x1 is None else x1.shape[3])
-    if bf16_wgrad(Cout, cin, precision):
+    if bf16_wgrad(Cout, cin, precision, x0_bf16 is not None):
         # every (co, ci) tile re-reads both operands: bf16 copies (activation applied) halve what the tiles pull through L2; same
-        # products as precision 2 (one bf16 MFMA each, fp32 accumulate).  dz's copy comes with the BatchNorm backward (dz_bf16).
-        dz, x0, in_affine = (dz_bf16 if dz_bf16 is not None else act_to_bf16(dz)), act_to_bf16(x0, in_affine), None
+        # products as precision 2 (one bf16 MFMA each, fp32 accumulate).  dz's copy comes with the BatchNorm backward (dz_bf16), the
+        # activated input's with the forward convolution (x0_bf16); what is missing is cast here.
+        dz = dz_bf16 if dz_bf16 is not None else act_to_bf16(dz)
+        x0, in_affine = (x0_bf16 if x0_bf16 is not None else act_to_bf16(x0, in_affine)), None
         x1 = None if x1 is None else act_to_bf16(x1)
         precision = 3
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
@@ -361,16 +377,23 @@ class UNetTrainEngine:
         self.comm_calls += 1; self.comm_bytes += sums_and_count.numel() * sums_and_count.element_size()
         return sums_and_count
 
-    def _bn_stats(self, z, bn, g, b) -> Stats:
+    def _bn_stats(self, z, bn, g, b, part=None) -> Stats:
+        """Batch statistics of z.  `part`: the producing convolution's per-wave partial sums (conv_mfma(stats_out=...)) -- then z is not
+        read again."""
         C = z.shape[-1]
         st = Stats(C, z.device)
-        if self.sync_bn:
+        if self.sync_bn or part is not None:
             # statistics over the GLOBAL batch (the single-GPU reference's semantics): local (sum, sum^2) + pixel count,
             # one small SUM all-reduce, finish from the global sums
             sc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
-            check(lib().mfpa_bn_stats_sums(ptr(z), _npix(z), C, ptr(sc), ptr(self.workspace), stream()), "mfpa_bn_stats_sums")
-            self._all_reduce_sums(sc)
-            count = float(_npix(z)) * self._global_over_local_batch      # every rank holds clips of the same H x W
+            if part is not None:
+                check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(sc), ptr(self.workspace), stream()),
+                      "mfpa_conv_stats_reduce")
+            else:
+                check(lib().mfpa_bn_stats_sums(ptr(z), _npix(z), C, ptr(sc), ptr(self.workspace), stream()), "mfpa_bn_stats_sums")
+            if self.sync_bn:
+                self._all_reduce_sums(sc)
+            count = float(_npix(z)) * (self._global_over_local_batch if self.sync_bn else 1.0)   # every rank holds clips of the same H x W
             check(lib().mfpa_bn_stats_finish(ptr(sc), count, C, ptr(self.P[g]), ptr(self.P[b]), BN_EPS, BN_MOMENTUM,
                                              ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
                                              ptr(self.running[bn + ".running_mean"]), ptr(self.running[bn + ".running_var"]),
@@ -408,18 +431,25 @@ class UNetTrainEngine:
     # ------------------------------------------------------------------ forward (train mode)
     def _dconv_fwd(self, prefix, src0, aff0: Optional[Stats], src1=None, first_input=None, drop_id=None):
         cout = self.P[prefix + ".3.w"].shape[1]
+        # bf16 copies of the activated inputs, written by the forward convolutions' loaders where their kernel can (the weight
+        # gradients' operands; only when those are computed from bf16 operands at all)
+        want = self.wgrad_precision == 2
+        xb0, xb3 = ([] if want else None), ([] if want else None)
+        sp0, sp3 = [], []                    # the convolutions' partial BatchNorm statistics (where their kernel writes them)
         if first_input is not None:
             x32, spec64, denom = first_input
             z0 = K.conv3x3_c1_bn_relu(self.P[prefix + ".0.w"], None, None, x32=x32, spec64=spec64, denom=denom,
                                       per_clip=True, relu=False)
         else:
-            z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1, precision=self.precision)
-        st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b")
-        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0, precision=self.precision)
-        st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b")
+            z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1, precision=self.precision, x0_bf16_out=xb0,
+                           stats_out=sp0)
+        st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b", part=sp0[0] if sp0 else None)
+        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0, precision=self.precision, x0_bf16_out=xb3, stats_out=sp3)
+        st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b", part=sp3[0] if sp3 else None)
         if drop_id is not None and self.rate > 0:
             st3.drop = dropout_spec(self.drop_seed + 16 * self.step_count + drop_id, self.rate)
-        return dict(prefix=prefix, src0=src0, aff0=aff0, src1=src1, first_input=first_input, z0=z0, st0=st0, z3=z3, st3=st3)
+        return dict(prefix=prefix, src0=src0, aff0=aff0, src1=src1, first_input=first_input, z0=z0, st0=st0, z3=z3, st3=st3,
+                    xb0=xb0[0] if xb0 else None, xb3=xb3[0] if xb3 else None)
 
     def forward(self, x32=None, spec64=None, denom=None):
         """Train-mode forward.  Input (B,F,T): float32 spectrogram, or raw float64 |STFT| + per-clip denominators
@@ -462,16 +492,18 @@ class UNetTrainEngine:
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
         dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b",
-                                      bf16_copy=bf16_wgrad(cout, cout, self.wgrad_precision))
-        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16)
+                                      bf16_copy=bf16_wgrad(cout, cout, self.wgrad_precision, r["xb3"] is not None))
+        wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16,
+                   x0_bf16=r["xb3"])
         del dz16
+        r["xb3"] = None
         lay = weight_layout(dz3.shape[1], dz3.shape[2], cout, cout, self.precision)
         wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True, layout=lay)   # [tap'][ci][co]
         dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay)
         del dz3
         cin0 = 0 if r["first_input"] is not None else r["src0"].shape[-1] + (0 if r["src1"] is None else r["src1"].shape[-1])
         dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b",
-                                      bf16_copy=bf16_wgrad(cout, cin0, self.wgrad_precision))
+                                      bf16_copy=cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None))
         if r["first_input"] is not None:
             x32, spec64, denom = r["first_input"]
             B, H, W, C = dz0.shape
@@ -479,8 +511,9 @@ class UNetTrainEngine:
                                       stream()), "mfpa_wgrad_c1")
             return None, None
         wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"],
-                   precision=self.wgrad_precision, dz_bf16=dz16)
+                   precision=self.wgrad_precision, dz_bf16=dz16, x0_bf16=r["xb0"])
         del dz16
+        r["xb0"] = None
         if not need_input_grad:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
