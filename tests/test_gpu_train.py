@@ -93,6 +93,47 @@ def _g7_inputs():
     return am, aug_den, clean_spec
 
 
+def test_forward_conv_side_outputs_bf16_input_copy_and_batchnorm_partials():
+    """What the bf16x3 forward convolution (conv_wd16_kernel) hands the backward pass: x0_bf16 -- the bf16 copy of its ACTIVATED source 0
+    (affine + ReLU + dropout as its loader applied them), bit-equal to mfpa_act_to_bf16 -- and stats_part -- per-wave partial (sum, sum
+    of squares) of the stored output, which mfpa_conv_stats_reduce turns into the float64 sums mfpa_bn_stats_sums computes from z.
+    64- and 128-channel output tiles, ragged edges, a zero-padded second source, dropout, more tiles than CUs (persistent tile loop),
+    the 16 x 16 patches; then the weight gradient from the two bf16 copies against the fp32 kernel."""
+    from musicfpaugment_amd import ops_train as T
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(11)
+    ws = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device="cuda")
+    for (B, H, W, C0, C1, Cout, drop) in [(2, 9, 37, 64, 0, 64, 0.0), (3, 33, 31, 64, 64, 128, 0.0), (70, 64, 62, 64, 0, 64, 0.25),
+                                          (2, 16, 15, 128, 0, 256, 0.0), (1, 40, 70, 128, 0, 128, 0.3)]:
+        x0 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x1 = torch.randn(B, H - 1, W - 1, C1, generator=g).cuda() if C1 else None
+        w = K.pack_conv3x3(torch.randn(Cout, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))).cuda()
+        st = T.Stats(C0, "cuda")
+        st.scale.copy_(torch.rand(C0, generator=g) + 0.5); st.shift.copy_(torch.randn(C0, generator=g) * 0.3)
+        st.drop = T.dropout_spec(1234, drop)
+        assert T.weight_layout(H, W, C0 + C1, Cout, 1) == 2
+        xb, sp = [], []
+        z = T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=1, x0_bf16_out=xb, stats_out=sp)
+        assert len(xb) == 1 and len(sp) == 1 and sp[0].shape[0] == lib().mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout)
+        assert torch.equal(z, T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=1))                   # the output does not change
+        assert torch.equal(xb[0].view(torch.int16), T.act_to_bf16(x0, st).view(torch.int16)), (B, H, W, C0, C1, Cout)
+        got = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
+        ref = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
+        check(lib().mfpa_conv_stats_reduce(ptr(sp[0]), sp[0].shape[0], Cout, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
+        check(lib().mfpa_bn_stats_sums(ptr(z), B * H * W, Cout, ptr(ref), ptr(ws), stream()), "mfpa_bn_stats_sums")
+        zz = z.double().reshape(-1, Cout)
+        assert torch.allclose(ref.view(Cout, 2)[:, 0], zz.sum(0), rtol=1e-9, atol=1e-9)
+        scale = ref.view(Cout, 2).abs().max(0).values
+        assert ((got - ref).view(Cout, 2).abs() / scale).max().item() < 2e-6, (B, H, W, C0, C1, Cout)      # fp32 partials over <= 128 pixels
+        # the weight gradient from the two copies (dz's comes from the BatchNorm backward in the engine; cast here)
+        dz = torch.randn(B, H, W, Cout, generator=g).cuda()
+        dw_ref, dw = torch.zeros_like(w), torch.zeros_like(w)
+        T.wgrad_mfma(dz, x0, dw_ref, Cout, in_affine=st, x1=x1)
+        T.wgrad_mfma(dz, x0, dw, Cout, in_affine=st, x1=x1, precision=2, dz_bf16=T.act_to_bf16(dz), x0_bf16=xb[0])
+        assert rel(dw, dw_ref) < 2e-2, (B, H, W, C0, C1, Cout, rel(dw, dw_ref))
+
+
 def test_train_step_matches_reference_golden(golden):
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
