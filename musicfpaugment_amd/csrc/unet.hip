@@ -1567,6 +1567,31 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         }
     }
   
+    if constexpr (WMW == 4) {
+      if (a.w1x1 != nullptr) {
+        // fused OutConv 1x1 to one class (the whole C_out = 64 is in this workgroup): a lane's eight channels times their weights,
+        // the four channel groups of a wave through two ds_bpermute butterflies, the two channel-tile waves through LDS; then one
+        // pixel per thread, stored coalesced
+        float* red = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * TBL * sizeof(unsigned)) + (a.in_scale0 ? 2 * a.C0 : 0);   // [2][256]
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.w1x1 + wn * 32 + 4 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x1 + wn * 32 + 16 + 4 * g);
+  #pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          float v = 0.f;
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) v += acc[0][pt][j] * w0[j] + acc[1][pt][j] * w1[j];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          if (g == 0) red[wn * 256 + wm * WPXW + pt * 16 + p] = v;
+        }
+        __syncthreads();
+        if (tid < 256) {
+          const int gy = ey0 + tid / PW, gx = ex0p + tid % PW;
+          if (gy < a.H && gx < a.W) a.y1x1[((size_t)eb * a.H + gy) * a.W + gx] = red[tid] + red[256 + tid] + a.b1x1;
+        }
+        __syncthreads();                                               // red is reused by the next tile
+      }
+    }
   };
 
   __syncthreads();
@@ -1655,7 +1680,8 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   constexpr int HPS = A_F4 * 64;
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
   const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)(WMW == 4 ? 2 : 1) * 2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
-                     (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0);                                                        // + the on-load affine
+                     (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0) +                                                       // + the on-load affine
+                     (a.w1x1 ? (size_t)2 * 256 * sizeof(float) : 0);                                                              // + the fused OutConv's partial sums
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / (32 * (8 / WMW))));
   static const int persist_env = MFPA_EXP_ENV("MFPA_CONV_WD16_PERSIST", 1);      // experiments: 0 = one workgroup per tile
   if (WMW == 4 && persist_env) {                                       // persistent: one workgroup per CU (and output-channel tile) walks the tiles
@@ -2041,7 +2067,7 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   const bool bn128 = (a.Cout % 128 == 0);
   if constexpr (MODE == 0 && PREC == 1) {
     if (a.w_frag == 2) {   // the 16 x 16 x 32 weights-direct kernel and its image
-      if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || a.c1_x32 || a.c1_spec64 || a.w1x1) return MFPA_EINVAL;
+      if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || a.c1_x32 || a.c1_spec64 || (a.w1x1 && bn128)) return MFPA_EINVAL;
       if (!bn128) return launch_wd16<8, 32, 4>(a, s);                   // 64-channel output tiles: 4 x 2 waves of 64 px x 32 ch
       if (a.W > 16) return launch_wd16<8, 32>(a, s);
       return launch_wd16<16, 16>(a, s);

@@ -199,7 +199,7 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     C1 = 0 if x1 is None else x1.shape[3]
     dev = w.device
     layout = 0
-    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None and out1x1 is None
+    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None and (out1x1 is None or (wf[0] == 2 and Cout == 64))
             and lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == wf[0]):
         layout, w = wf
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev) if store else None
