@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer timing of the UNet's 3x3 weight-gradient launches (64 clips, random operands, HIP events on the launch stream).
-Layers with >= 256 channels on both sides take pre-cast bf16 operands (precision 3), the others fp32 operands with the on-load affine
-(precision 2) -- as ops_train.wgrad_mfma issues them, without the cast passes.
+Every layer takes bf16 operands (precision 3) -- the copies the forward convolution and the BatchNorm backward write in the engine.
 usage: exp_wgrad.py [--lib PATH] [--reps N] [--clips B]"""
 import argparse, os, sys
 import torch
@@ -11,6 +10,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--clips", type=int, default=64)
 ap.add_argument("--only", default=None, help="substring of the layer names to run")
+ap.add_argument("--fp32-operands", action="store_true", help="layers below ops_train.BF16_WGRAD_MIN_CH channels on the fp32-operand kernel (the engine before the forward convolutions wrote the bf16 copies)")
 args = ap.parse_args()
 if args.lib:
     from musicfpaugment_amd import _lib
@@ -42,8 +42,8 @@ for name, H, W, C0, C1, Co in layers:
     dw = torch.zeros(9, Co, C0 + C1, device="cuda")
     aff = T.Stats(C0, "cuda")
     aff.scale.copy_(torch.rand(C0, device="cuda") + 0.5); aff.shift.copy_(torch.randn(C0, device="cuda") * 0.1)
-    prec = 3 if min(Co, C0 + C1) >= T.BF16_WGRAD_MIN_CH else 2
-    if prec == 3:
+    prec = 2 if args.fp32_operands and min(Co, C0 + C1) < T.BF16_WGRAD_MIN_CH else 3
+    if prec == 3:                                # as the engine issues them: both operands as the bf16 copies its other kernels wrote
         dzb, x0b = T.act_to_bf16(dz), T.act_to_bf16(x0, aff)
         x1b = None if x1 is None else T.act_to_bf16(x1)
         fn = lambda: T.wgrad_mfma(dzb, x0b, dw, Co, x1=x1b, precision=3)
@@ -52,4 +52,4 @@ for name, H, W, C0, C1, Co in layers:
     t = timed(fn); tot[prec] += t
     fl = 2.0 * B * H * W * (C0 + C1) * Co * 9
     print(f"{name:30s} precision {prec} {t*1e6:8.1f} us {fl/t/1e12:6.1f} TF/s", flush=True)
-print(f"sum fp32-in {tot[2]*1e3:.3f} ms  bf16-in {tot[3]*1e3:.3f} ms")
+print(f"sum fp32 operands {tot[2]*1e3:.3f} ms  bf16 operands {tot[3]*1e3:.3f} ms")
