@@ -115,7 +115,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
         xb = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
         x0_bf16_out.append(xb)
     part = None
-    if stats_out is not None and w_layout == 2 and mode == 0 and out_scale is None and out_shift is None and not relu and out_hw is None:
+    if stats_out is not None and w_layout == 2 and mode == 0 and out_scale is None and out_shift is None and not relu:
         rows = int(lib().mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout))
         if rows > 0:
             part = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x0.device)
@@ -524,8 +524,10 @@ class UNetTrainEngine:
         if r["src1"] is not None:
             c1 = r["src1"].shape[-1]
             lay = weight_layout(dz0.shape[1], dz0.shape[2], cout, c1, self.precision)
+            sp = []                          # per-channel sums of d1 (the transposed convolution's bias gradient) from the kernel's epilogue
             d1 = conv_mfma(dz0, pack_weights(w0, self.precision, True, c0, c1, layout=lay), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
-                           precision=self.precision, packed=True, w_layout=lay)
+                           precision=self.precision, packed=True, w_layout=lay, stats_out=sp)
+            r["d1_sums"] = sp[0] if sp else None
         return d0, d1
 
     def backward(self, dpred):
@@ -546,8 +548,15 @@ class UNetTrainEngine:
             dskip[enc_of_dec[name]] = d_skip
             # transposed conv: bias, weight and input gradients
             cout = d_u.shape[-1]
-            check(lib().mfpa_colsum(ptr(d_u), _npix(d_u), cout, ptr(self.G[name + ".up.b"]), ptr(self.workspace),
-                                    stream()), "mfpa_colsum")
+            if r.get("d1_sums") is not None:                              # sum over pixels of d_u: the convolution that produced it already has it
+                sums = torch.empty(2 * cout, dtype=torch.float64, device=d_u.device)
+                check(lib().mfpa_conv_stats_reduce(ptr(r["d1_sums"]), r["d1_sums"].shape[0], cout, ptr(sums), ptr(self.workspace),
+                                                   stream()), "mfpa_conv_stats_reduce")
+                self.G[name + ".up.b"].copy_(sums.view(cout, 2)[:, 0])
+                r["d1_sums"] = None
+            else:
+                check(lib().mfpa_colsum(ptr(d_u), _npix(d_u), cout, ptr(self.G[name + ".up.b"]), ptr(self.workspace),
+                                        stream()), "mfpa_colsum")
             prev = r["up_in"]
             wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"],
                        precision=self.wgrad_precision)
