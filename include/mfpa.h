@@ -238,6 +238,10 @@ typedef struct mfpa_conv_desc {
    * dropout applied), (B,H,W,C0), written by the halo loader of the first output-channel tile -- the operand mfpa_wgrad_mfma(precision 3)
    * reads in the backward pass, without a cast pass of its own.  MFPA_EINVAL with any other kernel. */
   void* x0_bf16;
+  /* the same for the zero-padded source 1, (B,H1,W1,C1) (plain cast: source 1 carries no on-load transform), and for the OUTPUT,
+   * (B,yH,yW,Cout) -- when the output is itself an operand of a later mfpa_wgrad_mfma(precision 3) (the transposed convolution's). */
+  void* x1_bf16;
+  void* y_bf16;
   /* w_layout 2, mode 0, optional (training forward): per-wave partial BatchNorm statistics of the stored output, [rows][2][Cout] floats
    * with rows = mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout): (sum, sum of squares) per channel over each wave's pixels.
    * mfpa_conv_stats_reduce sums the rows in float64 (fixed order) into the `sums` of mfpa_bn_stats_finish -- the statistics without a

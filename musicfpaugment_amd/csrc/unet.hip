@@ -141,6 +141,8 @@ struct ConvArgs {
   float* y1x1;
   int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
   __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
+  __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)
+  __bf16* y_bf16;                    // ... of the stored output, (B,yH,yW,Cout)
   float* stats_part;                 // conv_wd16_kernel: optional per-wave partial (sum, sum of squares) of the stored output per channel:
                                      //   [tile * WMW + wm][2][Cout] (mfpa_conv_desc.stats_part; rows = mfpa_conv_stats_rows())
   int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
@@ -1167,6 +1169,13 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         *reinterpret_cast<bf16x4*>(a.x0_bf16 + e) = hi;
       }
     }
+    if (a.x1_bf16 != nullptr && c0 >= a.C0 && blockIdx.y == 0) {      // source 1: its own (smaller, offset) geometry
+      const int py = pix / HPW, px = pix % HPW;
+      if (inside && py >= 1 && py <= PH && px >= 1 && px <= PW) {
+        const size_t e = (((size_t)S.b * a.H1 + (S.y0 + py - 1 - a.oy1)) * a.W1 + (S.x0p + px - 1 - a.ox1)) * (size_t)a.C1 + (c0 - a.C0) + 4 * aq;
+        *reinterpret_cast<bf16x4*>(a.x1_bf16 + e) = hi;
+      }
+    }
   };
 
   // ---- weight fragments: ring of three sets, [slot][16-channel tile][hi, lo]
@@ -1539,6 +1548,16 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
             *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
+          }
+          if (a.y_bf16 != nullptr) {
+            __bf16* hp = a.y_bf16 + (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + n0 + wn * 32 + 4 * g;
+  #pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              bf16x4 h;
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) h[j] = (__bf16)acc[ct][pt][j];
+              *reinterpret_cast<bf16x4*>(hp + ct * 16) = h;
+            }
           }
         }
       }
@@ -2189,7 +2208,11 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->w_layout != 0 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
   a.w_frag = d->w_layout;
   if (d->x0_bf16 != nullptr && (d->w_layout != 2 || !d->x0)) return MFPA_EINVAL;       // only conv_wd16_kernel's loader writes it
+  if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
+  if (d->y_bf16 != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;
   a.x0_bf16 = reinterpret_cast<__bf16*>(d->x0_bf16);
+  a.x1_bf16 = reinterpret_cast<__bf16*>(d->x1_bf16);
+  a.y_bf16 = reinterpret_cast<__bf16*>(d->y_bf16);
   if (d->stats_part != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;       // only conv_wd16_kernel's epilogue writes them
   a.stats_part = d->stats_part;
   hipStream_t s = mfpa_stream(stream);

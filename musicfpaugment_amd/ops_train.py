@@ -86,12 +86,14 @@ def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int
 
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
               relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False, w_layout: int = 0,
-              x0_bf16_out: Optional[list] = None, stats_out: Optional[list] = None):
+              x0_bf16_out: Optional[list] = None, stats_out: Optional[list] = None, x1_bf16_out: Optional[list] = None,
+              y_bf16_out: Optional[list] = None):
     """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
     `w` (fp32, kernel layout) is split into the image the kernel for this shape reads (weight_layout) unless it already is an
     operand image (`packed`, in the layout `w_layout`).  `x0_bf16_out` (a list): when the kernel for this shape can write it
     (w_layout 2), the bf16 copy of the activated source 0 is appended -- the weight gradient's operand, for free.  `stats_out` (a
-    list): likewise the kernel's per-wave partial BatchNorm statistics of the output ((rows, 2, Cout) float32, mfpa_conv_stats_reduce)."""
+    list): likewise the kernel's per-wave partial BatchNorm statistics of the output ((rows, 2, Cout) float32, mfpa_conv_stats_reduce).
+    `x1_bf16_out` / `y_bf16_out`: likewise bf16 copies of source 1 and of the output."""
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -114,6 +116,13 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     if x0_bf16_out is not None and w_layout == 2 and mode == 0:
         xb = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
         x0_bf16_out.append(xb)
+    x1b = yb16 = None
+    if x1_bf16_out is not None and x1 is not None and w_layout == 2 and mode == 0:
+        x1b = torch.empty(x1.shape, dtype=torch.bfloat16, device=x0.device)
+        x1_bf16_out.append(x1b)
+    if y_bf16_out is not None and w_layout == 2 and mode == 0:
+        yb16 = torch.empty(y.shape, dtype=torch.bfloat16, device=x0.device)
+        y_bf16_out.append(yb16)
     part = None
     if stats_out is not None and w_layout == 2 and mode == 0 and out_scale is None and out_shift is None and not relu:
         rows = int(lib().mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout))
@@ -126,7 +135,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout, x0_bf16=ptr(xb), stats_part=ptr(part))
+                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part))
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -152,7 +161,8 @@ def bf16_wgrad(Cout, cin, precision, have_x0_copy: bool = False) -> bool:
     return precision == 2 and (have_x0_copy or min(Cout, cin) >= BF16_WGRAD_MIN_CH)
 
 
-def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0, dz_bf16=None, x0_bf16=None):
+def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, precision=0, dz_bf16=None, x0_bf16=None,
+               x1_bf16=None):
     B, H, W, C0 = x0.shape
     cin = C0 + (0 if x1 is None else x1.shape[3])
     if bf16_wgrad(Cout, cin, precision, x0_bf16 is not None):
@@ -161,7 +171,7 @@ def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x
         # activated input's with the forward convolution (x0_bf16); what is missing is cast here.
         dz = dz_bf16 if dz_bf16 is not None else act_to_bf16(dz)
         x0, in_affine = (x0_bf16 if x0_bf16 is not None else act_to_bf16(x0, in_affine)), None
-        x1 = None if x1 is None else act_to_bf16(x1)
+        x1 = None if x1 is None else (x1_bf16 if x1_bf16 is not None else act_to_bf16(x1))
         precision = 3
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
                   in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), dw=ptr(dw), C0=C0,
@@ -434,7 +444,7 @@ class UNetTrainEngine:
         # bf16 copies of the activated inputs, written by the forward convolutions' loaders where their kernel can (the weight
         # gradients' operands; only when those are computed from bf16 operands at all)
         want = self.wgrad_precision == 2
-        xb0, xb3 = ([] if want else None), ([] if want else None)
+        xb0, xb3, xb1 = ([] if want else None), ([] if want else None), ([] if want else None)
         sp0, sp3 = [], []                    # the convolutions' partial BatchNorm statistics (where their kernel writes them)
         if first_input is not None:
             x32, spec64, denom = first_input
@@ -442,14 +452,14 @@ class UNetTrainEngine:
                                       per_clip=True, relu=False)
         else:
             z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1, precision=self.precision, x0_bf16_out=xb0,
-                           stats_out=sp0)
+                           stats_out=sp0, x1_bf16_out=xb1)
         st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b", part=sp0[0] if sp0 else None)
         z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0, precision=self.precision, x0_bf16_out=xb3, stats_out=sp3)
         st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b", part=sp3[0] if sp3 else None)
         if drop_id is not None and self.rate > 0:
             st3.drop = dropout_spec(self.drop_seed + 16 * self.step_count + drop_id, self.rate)
         return dict(prefix=prefix, src0=src0, aff0=aff0, src1=src1, first_input=first_input, z0=z0, st0=st0, z3=z3, st3=st3,
-                    xb0=xb0[0] if xb0 else None, xb3=xb3[0] if xb3 else None)
+                    xb0=xb0[0] if xb0 else None, xb3=xb3[0] if xb3 else None, xb1=xb1[0] if xb1 else None)
 
     def forward(self, x32=None, spec64=None, denom=None):
         """Train-mode forward.  Input (B,F,T): float32 spectrogram, or raw float64 |STFT| + per-clip denominators
@@ -511,9 +521,9 @@ class UNetTrainEngine:
                                       stream()), "mfpa_wgrad_c1")
             return None, None
         wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"],
-                   precision=self.wgrad_precision, dz_bf16=dz16, x0_bf16=r["xb0"])
+                   precision=self.wgrad_precision, dz_bf16=dz16, x0_bf16=r["xb0"], x1_bf16=r["xb1"])
         del dz16
-        r["xb0"] = None
+        r["xb0"] = r["xb1"] = None
         if not need_input_grad:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
@@ -525,9 +535,11 @@ class UNetTrainEngine:
             c1 = r["src1"].shape[-1]
             lay = weight_layout(dz0.shape[1], dz0.shape[2], cout, c1, self.precision)
             sp = []                          # per-channel sums of d1 (the transposed convolution's bias gradient) from the kernel's epilogue
+            yb = [] if self.wgrad_precision == 2 else None       # and its bf16 copy (the transposed convolution's weight gradient reads it)
             d1 = conv_mfma(dz0, pack_weights(w0, self.precision, True, c0, c1, layout=lay), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
-                           precision=self.precision, packed=True, w_layout=lay, stats_out=sp)
+                           precision=self.precision, packed=True, w_layout=lay, stats_out=sp, y_bf16_out=yb)
             r["d1_sums"] = sp[0] if sp else None
+            r["d1_bf16"] = yb[0] if yb else None
         return d0, d1
 
     def backward(self, dpred):
@@ -559,7 +571,8 @@ class UNetTrainEngine:
                                         stream()), "mfpa_colsum")
             prev = r["up_in"]
             wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"],
-                       precision=self.wgrad_precision)
+                       precision=self.wgrad_precision, dz_bf16=r.get("d1_bf16"))
+            r["d1_bf16"] = None
             wt = pack_weights(self.P[name + ".up.w"], self.precision, flip_transpose=True)   # (4, cin, cout), taps kept
             dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision, packed=True)
             handles.append(self._reduce_bucket(name))

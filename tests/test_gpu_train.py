@@ -113,9 +113,11 @@ def test_forward_conv_side_outputs_bf16_input_copy_and_batchnorm_partials():
         st.scale.copy_(torch.rand(C0, generator=g) + 0.5); st.shift.copy_(torch.randn(C0, generator=g) * 0.3)
         st.drop = T.dropout_spec(1234, drop)
         assert T.weight_layout(H, W, C0 + C1, Cout, 1) == 2
-        xb, sp = [], []
-        z = T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=1, x0_bf16_out=xb, stats_out=sp)
+        xb, sp, x1b, yb = [], [], [], []
+        z = T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=1, x0_bf16_out=xb, stats_out=sp, x1_bf16_out=x1b, y_bf16_out=yb)
         assert len(xb) == 1 and len(sp) == 1 and sp[0].shape[0] == lib().mfpa_conv_stats_rows(B, H, W, C0 + C1, Cout)
+        assert torch.equal(yb[0].view(torch.int16), T.act_to_bf16(z).view(torch.int16))                       # the output's bf16 copy
+        assert (x1 is None and not x1b) or torch.equal(x1b[0].view(torch.int16), T.act_to_bf16(x1).view(torch.int16))   # source 1's
         assert torch.equal(z, T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=1))                   # the output does not change
         assert torch.equal(xb[0].view(torch.int16), T.act_to_bf16(x0, st).view(torch.int16)), (B, H, W, C0, C1, Cout)
         got = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
