@@ -1038,8 +1038,10 @@ __device__ __forceinline__ float dpp_row_add(float v) {               // v + (v 
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int PH, int PW, bool ROWS, int WMW = 2>
+template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
+  // SIDE: the training step's side outputs (x0_bf16 / x1_bf16 / y_bf16 / stats_part) -- their own instantiations, so that the inference
+  // kernels carry none of their code (it cost the 128-channel form 9 registers and 18 spills)
   // WMW = 2: 2 x 4 waves of 128 px x 32 ch (128-channel output tiles); WMW = 4: 4 x 2 waves of 64 px x 32 ch (the 64-channel layers)
   constexpr int THREADS = 512, WNW = 8 / WMW, BN = 32 * WNW, WPXW = 256 / WMW, TAPS = 9;
   static_assert((WMW == 2 || WMW == 4) && (!ROWS || WMW == 2), "wave grid");
@@ -1162,17 +1164,17 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     *reinterpret_cast<bf16x4*>(at + HLS) = lo;
     // training forward: the bf16 copy of the activated source 0 the weight gradient reads -- the hi half is exactly that.  Every pixel
     // is interior (not halo) to one tile; the first output-channel tile writes it.
-    if (a.x0_bf16 != nullptr && c0 < a.C0 && blockIdx.y == 0) {
+    if constexpr (SIDE) {
+      // (the pixel's element offset inside its clip is the loader's byte offset / 4, read back from the LDS table: as registers the six
+      // per-slot offsets would be loop invariants the compiler keeps -- and spills)
       const int py = pix / HPW, px = pix % HPW;
-      if (inside && py >= 1 && py <= PH && px >= 1 && px <= PW) {
-        const size_t e = (((size_t)S.b * a.H + (S.y0 + py - 1)) * a.W + (S.x0p + px - 1)) * (size_t)a.C0 + c0 + 4 * aq;
+      const bool interior = inside && py >= 1 && py <= PH && px >= 1 && px <= PW && blockIdx.y == 0;
+      if (a.x0_bf16 != nullptr && c0 < a.C0 && interior) {
+        const size_t e = (size_t)S.b * a.H * a.W * a.C0 + (S.aoffs[it * THREADS + tid] >> 2) + c0;
         *reinterpret_cast<bf16x4*>(a.x0_bf16 + e) = hi;
       }
-    }
-    if (a.x1_bf16 != nullptr && c0 >= a.C0 && blockIdx.y == 0) {      // source 1: its own (smaller, offset) geometry
-      const int py = pix / HPW, px = pix % HPW;
-      if (inside && py >= 1 && py <= PH && px >= 1 && px <= PW) {
-        const size_t e = (((size_t)S.b * a.H1 + (S.y0 + py - 1 - a.oy1)) * a.W1 + (S.x0p + px - 1 - a.ox1)) * (size_t)a.C1 + (c0 - a.C0) + 4 * aq;
+      if (a.x1_bf16 != nullptr && c0 >= a.C0 && interior) {            // source 1: its own (smaller, offset) geometry
+        const size_t e = (size_t)S.b * a.H1 * a.W1 * a.C1 + (S.aoffs[(A_F4 + it) * THREADS + tid] >> 2) + (c0 - a.C0);
         *reinterpret_cast<bf16x4*>(a.x1_bf16 + e) = hi;
       }
     }
@@ -1501,7 +1503,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
           acc[ct][pt][j] = v;
         }
     }
-    if (a.stats_part != nullptr) {
+    if (SIDE && a.stats_part != nullptr) {
       // training forward: the BatchNorm statistics of this output, one partial row per wave -- (sum, sum of squares) over the wave's
       // stored pixels for each of its 32 channels; rows are summed in float64 by mfpa_conv_stats_reduce (fixed order: deterministic)
       float vm[PT];
@@ -1549,7 +1551,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
             for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
             *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
           }
-          if (a.y_bf16 != nullptr) {
+          if (SIDE && a.y_bf16 != nullptr) {
             __bf16* hp = a.y_bf16 + (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + n0 + wn * 32 + 4 * g;
   #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -1713,11 +1715,19 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   // fragment reads return when a tile has only 2 .. 8 chunks)
   static const int rows_min = MFPA_EXP_ENV("MFPA_CONV_WD16_ROWS", MFPA_CONV_WD16_ROWS);
   const int cin = a.C0 + a.C1;
+  const bool side = a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part;
+  const bool rows = WMW == 2 && rows_min > 0 && cin % 64 == 0 && cin >= rows_min;
   if constexpr (WMW == 4) {
     if (cin % 64) return MFPA_EINVAL;
-    hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4>), grid, dim3(512), lds, s, a);
-  } else if (rows_min > 0 && cin % 64 == 0 && cin >= rows_min) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true>), grid, dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false>), grid, dim3(512), lds, s, a);
+    if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, false>), grid, dim3(512), lds, s, a);
+  } else if (rows) {
+    if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, false>), grid, dim3(512), lds, s, a);
+  } else {
+    if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, false>), grid, dim3(512), lds, s, a);
+  }
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
