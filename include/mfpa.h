@@ -236,7 +236,8 @@ typedef struct mfpa_conv_desc {
   int w_layout;
   /* w_layout 2, mode 0, optional (training forward): a bf16 copy of source 0 AS THE CONVOLUTION SAW IT (in_scale0 / in_shift0 / ReLU /
    * dropout applied), (B,H,W,C0), written by the halo loader of the first output-channel tile -- the operand mfpa_wgrad_mfma(precision 3)
-   * reads in the backward pass, without a cast pass of its own.  MFPA_EINVAL with any other kernel. */
+   * reads in the backward pass, without a cast pass of its own.  Also written by the bf16x3 transposed convolution (mode 1, precision 1).
+   * MFPA_EINVAL with any other kernel. */
   void* x0_bf16;
   /* the same for the zero-padded source 1, (B,H1,W1,C1) (plain cast: source 1 carries no on-load transform), and for the OUTPUT,
    * (B,yH,yW,Cout) -- when the output is itself an operand of a later mfpa_wgrad_mfma(precision 3) (the transposed convolution's). */

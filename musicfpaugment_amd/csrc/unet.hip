@@ -1813,6 +1813,11 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
         char* row = reinterpret_cast<char*>(As + pix * LDK);
         *reinterpret_cast<bf16x4*>(row + 8 * q) = hi;
         *reinterpret_cast<bf16x4*>(row + 64 + 8 * q) = lo;
+        if (a.x0_bf16 != nullptr && blockIdx.y == 0) {                 // training forward: the activated input's bf16 copy (its weight gradient's operand)
+          const int gy = y0 + pix / PW, gx = x0p + pix % PW;
+          if (gy < a.H && gx < a.W)
+            *reinterpret_cast<bf16x4*>(a.x0_bf16 + (((size_t)b * a.H + gy) * a.W + gx) * (size_t)a.C0 + c0 + 4 * q) = hi;
+        }
       }
     }
 #pragma unroll
@@ -2217,7 +2222,7 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->w_layout < 0 || d->w_layout > 2) return MFPA_EINVAL;
   if (d->w_layout != 0 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
   a.w_frag = d->w_layout;
-  if (d->x0_bf16 != nullptr && (d->w_layout != 2 || !d->x0)) return MFPA_EINVAL;       // only conv_wd16_kernel's loader writes it
+  if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision == 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
   if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
   if (d->y_bf16 != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;
   a.x0_bf16 = reinterpret_cast<__bf16*>(d->x0_bf16);

@@ -113,7 +113,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
         oh, ow = out_hw if out_hw is not None else (H, W)
     y = torch.empty((B, oh, ow, Cout), dtype=torch.float32, device=x0.device)
     xb = None
-    if x0_bf16_out is not None and w_layout == 2 and mode == 0:
+    if x0_bf16_out is not None and ((w_layout == 2 and mode == 0) or (mode == 1 and precision == 1)):
         xb = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
         x0_bf16_out.append(xb)
     x1b = yb16 = None
@@ -479,13 +479,15 @@ class UNetTrainEngine:
             prev = r
         skips = [recs[ENC[3]], recs[ENC[2]], recs[ENC[1]], recs["inc"]]
         for name, skip in zip(DEC, skips):
+            xbu = [] if self.wgrad_precision == 2 else None          # bf16 copy of the activated input: the weight gradient's operand
             u = conv_mfma(prev["z3"], self.P[name + ".up.w"], self.P[name + ".up.w"].shape[1], mode=1,
-                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"], precision=self.precision)
+                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"], precision=self.precision, x0_bf16_out=xbu)
             if skip["z3"].shape[1] - u.shape[1] > 1 or skip["z3"].shape[2] - u.shape[2] > 1:
                 raise NotImplementedError("skip/upsample size difference > 1 (needs top/left padding offsets)")
             r = self._dconv_fwd(name + ".conv.double_conv", skip["z3"], skip["st3"], src1=u,
                                 drop_id=4 if name == DEC[0] else None)  # x = dropout(up1(x5, x4))
             r["up_in"], r["up_name"], r["u"] = prev, name, u
+            r["up_xb"] = xbu[0] if xbu else None
             recs[name] = r
             prev = r
         z, st = prev["z3"], prev["st3"]
@@ -571,8 +573,8 @@ class UNetTrainEngine:
                                         stream()), "mfpa_colsum")
             prev = r["up_in"]
             wgrad_mfma(d_u, prev["z3"], self.G[name + ".up.w"], cout, mode=1, in_affine=prev["st3"],
-                       precision=self.wgrad_precision, dz_bf16=r.get("d1_bf16"))
-            r["d1_bf16"] = None
+                       precision=self.wgrad_precision, dz_bf16=r.get("d1_bf16"), x0_bf16=r.get("up_xb"))
+            r["d1_bf16"] = r["up_xb"] = None
             wt = pack_weights(self.P[name + ".up.w"], self.precision, flip_transpose=True)   # (4, cin, cout), taps kept
             dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision, packed=True)
             handles.append(self._reduce_bucket(name))
