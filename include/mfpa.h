@@ -248,6 +248,11 @@ typedef struct mfpa_conv_desc {
    * mfpa_conv_stats_reduce sums the rows in float64 (fixed order) into the `sums` of mfpa_bn_stats_finish -- the statistics without a
    * pass over the output.  MFPA_EINVAL with any other kernel. */
   float* stats_part;
+  /* with stats_part, optional (training backward): the output is the gradient dy w.r.t. relu(bn(bwd_z)) -- bwd_z (B,yH,yW,Cout) the
+   * BatchNorm's input, bwd_scale / bwd_shift / bwd_mean / bwd_invstd (Cout) its statistics, no dropout behind it -- and the partials are
+   * (sum g, sum g * xhat) with g = dy where bwd_z * scale + shift > 0 else 0: after mfpa_conv_stats_reduce the `local_sums` of
+   * mfpa_bn_relu_bwd_finish, without the reduction pass over (dy, z). */
+  const float* bwd_z; const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 /* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */

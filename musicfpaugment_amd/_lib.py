@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 class MfpaError(RuntimeError):
@@ -159,7 +159,8 @@ class ConvDesc(ctypes.Structure):
                 ("y_pool", c_void_p), ("w1x1", c_void_p), ("b1x1", c_float), ("y1x1", c_void_p),
                 ("c1_x32", c_void_p), ("c1_spec64", c_void_p), ("c1_denom", c_void_p),
                 ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int),
-                ("x0_bf16", c_void_p), ("x1_bf16", c_void_p), ("y_bf16", c_void_p), ("stats_part", c_void_p)]
+                ("x0_bf16", c_void_p), ("x1_bf16", c_void_p), ("y_bf16", c_void_p), ("stats_part", c_void_p),
+                ("bwd_z", c_void_p), ("bwd_scale", c_void_p), ("bwd_shift", c_void_p), ("bwd_mean", c_void_p), ("bwd_invstd", c_void_p)]
 
 
 class GemmDesc(ctypes.Structure):

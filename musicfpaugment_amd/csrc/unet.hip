@@ -143,6 +143,11 @@ struct ConvArgs {
   __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
   __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)
   __bf16* y_bf16;                    // ... of the stored output, (B,yH,yW,Cout)
+  const float* bz;                   // conv_wd16_kernel + stats_part: the output is a gradient dy w.r.t. relu(bn(bz)), bz (B,yH,yW,Cout): the partials are
+  const float* bz_scale;             //   (sum g, sum g * xhat), g = dy where bz * bz_scale + bz_shift > 0 else 0, xhat = (bz - bz_mean) * bz_invstd --
+  const float* bz_shift;             //   the two reductions of the BatchNorm backward (mfpa_conv_desc.bwd_z ...)
+  const float* bz_mean;
+  const float* bz_invstd;
   float* stats_part;                 // conv_wd16_kernel: optional per-wave partial (sum, sum of squares) of the stored output per channel:
                                      //   [tile * WMW + wm][2][Cout] (mfpa_conv_desc.stats_part; rows = mfpa_conv_stats_rows())
   int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
@@ -1516,6 +1521,24 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         f32x4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bz != nullptr) {
+          // the output is dy of a BatchNorm + ReLU whose input bz has this tensor's shape: (sum g, sum g * xhat) instead (see ConvArgs)
+          const int ch = n0 + wn * 32 + ct * 16 + 4 * g;
+          const f32x4 bsc = *reinterpret_cast<const f32x4*>(a.bz_scale + ch), bsh = *reinterpret_cast<const f32x4*>(a.bz_shift + ch);
+          const f32x4 bmu = *reinterpret_cast<const f32x4*>(a.bz_mean + ch), bis = *reinterpret_cast<const f32x4*>(a.bz_invstd + ch);
+  #pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            const int m = wm * WPXW + pt * 16 + p;
+            const int gy = min(ey0 + m / PW, a.yH - 1), gx = min(ex0p + m % PW, a.yW - 1);      // clamped; masked by vm
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(a.bz + (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + ch);
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float gg = (zz[j] * bsc[j] + bsh[j] > 0.f) ? acc[ct][pt][j] * vm[pt] : 0.f;
+              sv[j] += gg;
+              qv[j] += gg * ((zz[j] - bmu[j]) * bis[j]);
+            }
+          }
+        } else {
   #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
   #pragma unroll
@@ -1524,6 +1547,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
             sv[j] += v;
             qv[j] += v * v;
           }
+        }
   #pragma unroll
         for (int j = 0; j < 4; ++j) {
           // row_shr 1, 2, 4, 8: lane 15 of a 16-lane row ends with its total
@@ -2230,6 +2254,8 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   a.y_bf16 = reinterpret_cast<__bf16*>(d->y_bf16);
   if (d->stats_part != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;       // only conv_wd16_kernel's epilogue writes them
   a.stats_part = d->stats_part;
+  if (d->bwd_z != nullptr && (!d->stats_part || !d->bwd_scale || !d->bwd_shift || !d->bwd_mean || !d->bwd_invstd)) return MFPA_EINVAL;
+  a.bz = d->bwd_z; a.bz_scale = d->bwd_scale; a.bz_shift = d->bwd_shift; a.bz_mean = d->bwd_mean; a.bz_invstd = d->bwd_invstd;
   hipStream_t s = mfpa_stream(stream);
   if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);
   if (d->mode == 1) return dispatch_conv<1>(a, s, d->precision);

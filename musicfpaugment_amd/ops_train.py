@@ -87,13 +87,14 @@ def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
               relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False, w_layout: int = 0,
               x0_bf16_out: Optional[list] = None, stats_out: Optional[list] = None, x1_bf16_out: Optional[list] = None,
-              y_bf16_out: Optional[list] = None):
+              y_bf16_out: Optional[list] = None, bwd_of=None):
     """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
     `w` (fp32, kernel layout) is split into the image the kernel for this shape reads (weight_layout) unless it already is an
     operand image (`packed`, in the layout `w_layout`).  `x0_bf16_out` (a list): when the kernel for this shape can write it
     (w_layout 2), the bf16 copy of the activated source 0 is appended -- the weight gradient's operand, for free.  `stats_out` (a
     list): likewise the kernel's per-wave partial BatchNorm statistics of the output ((rows, 2, Cout) float32, mfpa_conv_stats_reduce).
-    `x1_bf16_out` / `y_bf16_out`: likewise bf16 copies of source 1 and of the output."""
+    `x1_bf16_out` / `y_bf16_out`: likewise bf16 copies of source 1 and of the output.  `bwd_of` = (z, Stats) with `stats_out`: the
+    output is dy of relu(bn(z)) and the partials are the BatchNorm backward's two reductions (mfpa_conv_desc.bwd_z)."""
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -135,7 +136,12 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part))
+                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part),
+                 bwd_z=ptr(bwd_of[0]) if (bwd_of and part is not None) else 0,
+                 bwd_scale=ptr(bwd_of[1].scale) if (bwd_of and part is not None) else 0,
+                 bwd_shift=ptr(bwd_of[1].shift) if (bwd_of and part is not None) else 0,
+                 bwd_mean=ptr(bwd_of[1].mean) if (bwd_of and part is not None) else 0,
+                 bwd_invstd=ptr(bwd_of[1].invstd) if (bwd_of and part is not None) else 0)
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -415,18 +421,24 @@ class UNetTrainEngine:
                                   ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
         return st
 
-    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False):
+    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False, part=None):
         """dy <- gradient w.r.t. z, in place; with bf16_copy also its bf16 copy, written by the same pass (the weight-gradient
         kernel's operand).  Returns (dz, dz_bf16 or None)."""
         C = z.shape[-1]
         coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
         dz16 = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device) if bf16_copy else None
-        if self.sync_bn:
+        if self.sync_bn or part is not None:
             loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
-            check(lib().mfpa_bn_relu_bwd_sums(ptr(dy), ptr(z), _npix(z), C, ptr(st.scale), ptr(st.shift), ptr(st.mean),
-                                              ptr(st.invstd), ptr(loc), ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2],
-                                              stream()), "mfpa_bn_relu_bwd_sums")
-            glob = self._all_reduce_sums(loc.clone())
+            if part is not None:             # the convolution that produced dy reduced (sum g, sum g * xhat) in its epilogue (conv_mfma(bwd_of=))
+                check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(loc), ptr(self.workspace), stream()),
+                      "mfpa_conv_stats_reduce")
+            else:
+                check(lib().mfpa_bn_relu_bwd_sums(ptr(dy), ptr(z), _npix(z), C, ptr(st.scale), ptr(st.shift), ptr(st.mean),
+                                                  ptr(st.invstd), ptr(loc), ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2],
+                                                  stream()), "mfpa_bn_relu_bwd_sums")
+            glob = self._all_reduce_sums(loc.clone()) if self.sync_bn else loc
+            if not self.sync_bn:
+                st.count_host = float(_npix(z))
             check(lib().mfpa_bn_relu_bwd_finish(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                                 ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
                                                 ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), stream()),
@@ -511,11 +523,13 @@ class UNetTrainEngine:
         r["xb3"] = None
         lay = weight_layout(dz3.shape[1], dz3.shape[2], cout, cout, self.precision)
         wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True, layout=lay)   # [tap'][ci][co]
-        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay)
+        spm = [] if r["st0"].drop[1] == 0 else None      # dmid is dy of relu(bn(z0)): the BatchNorm backward's reductions in the epilogue
+        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay, stats_out=spm, bwd_of=(r["z0"], r["st0"]))
         del dz3
         cin0 = 0 if r["first_input"] is not None else r["src0"].shape[-1] + (0 if r["src1"] is None else r["src1"].shape[-1])
         dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b",
-                                      bf16_copy=cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None))
+                                      bf16_copy=cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None),
+                                      part=spm[0] if spm else None)
         if r["first_input"] is not None:
             x32, spec64, denom = r["first_input"]
             B, H, W, C = dz0.shape

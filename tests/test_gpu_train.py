@@ -128,6 +128,19 @@ def test_forward_conv_side_outputs_bf16_input_copy_and_batchnorm_partials():
         assert torch.allclose(ref.view(Cout, 2)[:, 0], zz.sum(0), rtol=1e-9, atol=1e-9)
         scale = ref.view(Cout, 2).abs().max(0).values
         assert ((got - ref).view(Cout, 2).abs() / scale).max().item() < 2e-6, (B, H, W, C0, C1, Cout)      # fp32 partials over <= 128 pixels
+        # the same epilogue as the BatchNorm backward's reduction: the output taken as dy of relu(bn(zb)) -> (sum g, sum g * xhat)
+        zb = torch.randn(B, H, W, Cout, generator=g).cuda()
+        sb = T.Stats(Cout, "cuda")
+        sb.scale.copy_(torch.rand(Cout, generator=g) + 0.5); sb.shift.copy_(torch.randn(Cout, generator=g) * 0.3)
+        sb.mean.copy_(torch.randn(Cout, generator=g) * 0.2); sb.invstd.copy_(torch.rand(Cout, generator=g) + 0.5)
+        spb = []
+        z2 = T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=1, stats_out=spb, bwd_of=(zb, sb))
+        assert torch.equal(z2, z)
+        check(lib().mfpa_conv_stats_reduce(ptr(spb[0]), spb[0].shape[0], Cout, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
+        check(lib().mfpa_bn_relu_bwd_sums(ptr(z), ptr(zb), B * H * W, Cout, ptr(sb.scale), ptr(sb.shift), ptr(sb.mean), ptr(sb.invstd),
+                                          ptr(ref), ptr(ws), 0, 0, 1.0, stream()), "mfpa_bn_relu_bwd_sums")
+        scale = ref.view(Cout, 2).abs().max(0).values
+        assert ((got - ref).view(Cout, 2).abs() / scale).max().item() < 5e-6, (B, H, W, C0, C1, Cout, "bwd sums")
         # the weight gradient from the two copies (dz's comes from the BatchNorm backward in the engine; cast here)
         dz = torch.randn(B, H, W, Cout, generator=g).cuda()
         dw_ref, dw = torch.zeros_like(w), torch.zeros_like(w)
