@@ -713,8 +713,8 @@ def other_configs(args, dev):
         ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
         ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
         ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
-        ("config4_unet_train_step", bench_train, dict(mode="train", steps=6, warmup=2, clips=64, seconds=8.0)),
-        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=6, warmup=2, clips=256)),
+        ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0)),
+        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=10, warmup=3, clips=256)),
         # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
         # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
         ("config5_peak_metrics", bench_metrics, dict(mode="metrics", queries=10000, denoiser="demucs", steps=1, warmup=1, clips=256)),
