@@ -177,6 +177,60 @@ def cpu_baseline(budget_s: float, seed: int):
     return out
 
 
+def _sanitise(obj, path="", bad=None):
+    """Strict JSON for the whole result tree: non-finite floats -> null, their paths listed under `non_finite` (one NaN in a
+    sub-config must not throw the measured line away at json.dumps(allow_nan=False))."""
+    bad = [] if bad is None else bad
+    if isinstance(obj, dict):
+        return {k: _sanitise(v, f"{path}.{k}" if path else str(k), bad)[0] for k, v in obj.items()}, bad
+    if isinstance(obj, (list, tuple)):
+        return [_sanitise(v, f"{path}[{i}]", bad)[0] for i, v in enumerate(obj)], bad
+    if isinstance(obj, (float, np.floating)):
+        if not np.isfinite(obj):
+            bad.append(f"{path}={float(obj)!r}")
+            return None, bad
+        return float(obj), bad
+    if isinstance(obj, np.integer):
+        return int(obj), bad
+    return obj, bad
+
+
+def _sanitised(result):
+    out, bad = _sanitise(result)
+    if bad:
+        out["non_finite_paths"] = bad
+    return out
+
+
+def device_sample(local_rank: int = 0):
+    """Clock / power / temperature of this rank's GPU from `rocm-smi` (a child process; read before and after the timed region,
+    never inside it) -- the pool's boxes differ by several % on the power-limited convolutions, this puts the reason in the record.
+    None when rocm-smi is absent or refuses."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "-d", str(local_rank), "--showclocks", "--showpower", "--showtemp", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+    except Exception:
+        return None
+    out = {}
+    for k, v in card.items():
+        kl = k.lower()
+        if "sclk" in kl and "level" not in kl or kl.startswith("sclk"):
+            out["sclk"] = v
+        elif "mclk" in kl:
+            out["mclk"] = v
+        elif "power" in kl and "(w)" in kl:
+            out["power_w"] = v
+        elif "temperature" in kl and ("hotspot" in kl or "junction" in kl):
+            out["temp_hotspot_c"] = v
+    return out or {"raw_keys": sorted(card)[:12]}
+
+
 def _rank_report(dist, dev, world, units, dt):
     """N > 1 lines verify themselves: `ranks_seen` = a SUM all-reduce of 1 over the process group on the device (RCCL under the
     driver's launch) -- it must equal n_gpus --, and every rank's own units/s (all-gathered), so that a rank that did no work, a
@@ -597,6 +651,27 @@ def bench_infer(args, rank, world, dev, dist):
         net.precision = 1 - net.precision
         other = (dt_o, timer_o)
 
+    parity = None
+    if net is not None and args.picker == "audfprint":
+        # every line certifies the arithmetic it was measured in (outside the timed region, device only): the first 8 clips of this
+        # very batch through the chain in BOTH arithmetic variants -- relative L1 of the bf16x3 UNet output against the exact-fp32
+        # MFMA output (the reference's arithmetic; gate 1e-4) and how many of the 8 peak masks are identical
+        from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+        ext = Audfprint_peaks(None, denoising=True, denoising_model="unet", unet=net, device=dev)
+        keep, got = net.precision, {}
+        for prec in (1, 0):
+            net.precision = prec
+            m_, _, sp_ = ext.find_peaks_batch(wav[:8].contiguous())
+            got[prec] = (m_, sp_.double())
+        net.precision = keep
+        num = (got[1][1] - got[0][1]).abs().sum()
+        den = got[0][1].abs().sum()
+        same = (got[1][0] == got[0][0]).reshape(got[0][0].shape[0], -1).all(dim=1).double().mean()
+        differ = (got[1][0] != got[0][0]).sum()
+        parity = {"rel_l1_bf16x3_vs_fp32": float(num / den), "gate": 1e-4, "masks_equal_frac": float(same),
+                  "mask_cells_differing": int(differ), "peaks_fp32": int(got[0][0].sum()), "clips": int(got[0][0].shape[0]),
+                  "weights": "formula_state_dict(0); the stressed / trained families are gated in tests/test_gpu_unet.py"}
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -659,6 +734,8 @@ def bench_infer(args, rank, world, dev, dist):
 
     if net is not None and timer.launches():
         out["roofline"] = roofline(timer, args.precision)
+    if parity is not None:
+        out["parity_in_run"] = parity
     if net is None:
         # fused STFT -> magnitude -> mask moves 578 284 algorithmic bytes per clip (256 000 B of samples in,
         # the float32 spectrogram out and back in, 64 256 B of mask out).  The chain is three short launches whose
@@ -690,10 +767,16 @@ def bench_launch_check(args, rank, world, dist):
         rep = _rank_report(dist, torch.device("cpu"), world, 1.0 + rank, 1.0)
     if rank != 0:
         return None
-    return {**(rep or {}), "metric": "launch-check (launcher / rendezvous / JSON relay only; no kernel ran, nothing was measured)", "value": None,
-            "unit": "clips/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
-            "config": {"workload": "none", "max_rank_seen": int(t.item())}}
+    out = {**(rep or {}), "metric": "launch-check (launcher / rendezvous / JSON relay only; no kernel ran, nothing was measured)", "value": None,
+           "unit": "clips/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+           "config": {"workload": "none", "max_rank_seen": int(t.item())}}
+    if world > 1:
+        # the shape of the N > 1 headline line: the nested train-step entries (dist_configs) with their keys, values unmeasured
+        skel = {k: None for k in TRAIN_LINE_KEYS}
+        skel.update(ranks_seen=rep["ranks_seen"], per_rank_value=rep["per_rank_value"])
+        out["configs"] = {"config4_unet_train_step": dict(skel, scaling="weak"), "config4_unet_train_step_strong": dict(skel, scaling="strong")}
+    return out
 
 
 def _sub_args(args, **kw):
@@ -713,7 +796,10 @@ def other_configs(args, dev):
         ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
         ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
         ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
-        ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0)),
+        # BASELINE config 4 as worded: "AugmentFP synthetic noise + L1 loss + Adam" -- the AugmentFP chain runs on the device INSIDE
+        # every timed step; the same step on pre-mixed noisy clips is kept beside it
+        ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True)),
+        ("config4_unet_train_step_premixed", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=False)),
         ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=10, warmup=3, clips=256)),
         # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
         # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
@@ -735,6 +821,55 @@ def other_configs(args, dev):
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
     return out
+
+
+TRAIN_LINE_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline",
+                   "ranks_seen", "per_rank_value", "allreduce_calls_per_step", "allreduce_bytes_per_step",
+                   "allreduce_exposed_wait_ms_per_step", "clips_per_gpu_per_step", "clips_per_step_all_gpus")
+MAX_TRAIN_CLIPS_PER_PASS = 128     # largest per-GPU batch of the train engine that is exercised (tests/test_gpu_train.py)
+
+
+def dist_configs(args, rank, world, dev, dist):
+    """N > 1: the one collective of the path -- the RCCL all-reduce of the UNet's 31.0 M gradients (BASELINE config 4) -- rides in the
+    SAME line as the collective-free inference headline, so that one driver command per N yields the 1/2/4/8 curve of both: the
+    train step weak-scaled (--dist-train-clips per GPU, default 64) and strong-scaled (global --dist-strong-global, default 512,
+    split over the ranks).  Every rank runs this; rank 0 returns the entries, each carrying `ranks_seen`, `per_rank_value`,
+    `allreduce_bytes_per_step`, `allreduce_exposed_wait_ms_per_step` at its top level."""
+    import gc
+    out = {}
+    plan = [("config4_unet_train_step", dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_train_clips,
+                                             seconds=args.dist_train_seconds, augment=True, scaling="weak")),
+            ("config4_unet_train_step_strong", dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_strong_global,
+                                                    seconds=args.dist_train_seconds, augment=True, scaling="strong"))]
+    for name, kw in plan:
+        per_rank = kw["clips"] if kw["scaling"] == "weak" else kw["clips"] // world
+        if per_rank > MAX_TRAIN_CLIPS_PER_PASS or per_rank < 1:
+            r = {"skipped": f"{per_rank} clips per GPU at N = {world}: outside the train engine's exercised per-pass batch (1..{MAX_TRAIN_CLIPS_PER_PASS})"} if rank == 0 else None
+        else:
+            t0 = time.perf_counter()
+            err = None
+            try:
+                r = bench_train(_sub_args(args, **kw), rank, world, dev, dist)
+            except Exception as e:                                   # never take the headline down; every rank reports its own failure
+                r, err = None, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([1.0 if err else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                if flag.item() > 0 or r is None:
+                    r = {"error": err or f"{int(flag.item())} rank(s) failed"}
+                else:
+                    for k in ("higher_is_better", "vs_baseline", "data", "n_gpus"):
+                        r.pop(k, None)
+                    for k in ("allreduce_calls_per_step", "allreduce_bytes_per_step", "allreduce_exposed_wait_ms_per_step",
+                              "clips_per_gpu_per_step", "clips_per_step_all_gpus"):
+                        r[k] = r["config"].get(k)
+                    r["wall_s_including_setup"] = round(time.perf_counter() - t0, 2)
+        if rank == 0:
+            out[name] = r
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 def _self_launch(n: int, argv) -> int:
@@ -796,6 +931,10 @@ def main():
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick; launch-check: launcher plumbing only (tests)")
     ap.add_argument("--no-weights-direct", action="store_true",
                     help="A/B runs: the UNet's 128-channel-tile layers on the LDS-staged weight tiles instead of the weights-direct kernel")
+    ap.add_argument("--dist-train-clips", type=int, default=64, help="N > 1 infer line: clips per GPU of the nested weak-scaled train step")
+    ap.add_argument("--dist-strong-global", type=int, default=512, help="N > 1 infer line: global batch of the nested strong-scaled train step")
+    ap.add_argument("--dist-train-steps", type=int, default=8, help="N > 1 infer line: timed steps of each nested train-step entry")
+    ap.add_argument("--dist-train-seconds", type=float, default=8.0, help="N > 1 infer line: clip length of the nested train step")
     ap.add_argument("--lib", default=None, help="experiments only: bind another build of the library (e.g. musicfpaugment_amd/libmfpa_exp.so)")
     args = ap.parse_args()
     args.sub_config = False
@@ -859,17 +998,39 @@ def main():
 
     fn = {"train": bench_train, "demucs": bench_demucs, "demucs-train": bench_demucs_train, "metrics": bench_metrics,
           "infer": bench_infer}[args.mode]
+    dev_before = device_sample(local_rank) if rank == 0 else None
     result = fn(args, rank, world, dev, dist)
+    dev_after = device_sample(local_rank) if rank == 0 else None
+    nested = None
+    if world > 1 and args.mode == "infer" and not args.no_unet and not args.no_configs:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        nested = dist_configs(args, rank, world, dev, dist)        # every rank: the gradient all-reduce is a collective
     if rank == 0:
         result["dist_backend"] = ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None
+        result["device_sample"] = {"before": dev_before, "after": dev_after,
+                                   "note": "rocm-smi on rank 0's GPU just outside the timed region of the headline"}
+        try:
+            from musicfpaugment_amd import ops_demucs
+            result["persistent_lstm_fallbacks"] = int(getattr(ops_demucs, "persistent_lstm_fallbacks", 0))
+        except Exception:
+            pass
         if cpu is not None:
             result["cpu_baseline"] = cpu
+        if nested is not None:
+            result["configs"] = nested
         if world == 1 and args.mode == "infer" and not args.no_unet and not args.no_configs:
             import gc
             gc.collect()
             torch.cuda.empty_cache()
             result["configs"] = other_configs(args, dev)
-        print(json.dumps(result, allow_nan=False), flush=True)
+            try:
+                from musicfpaugment_amd import ops_demucs
+                result["persistent_lstm_fallbacks"] = int(getattr(ops_demucs, "persistent_lstm_fallbacks", 0))
+            except Exception:
+                pass
+        print(json.dumps(_sanitised(result), allow_nan=False), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -58,7 +58,7 @@ def fingerprint(channel_samples, Fs: float = afp_settings["dejavu"]["samplerate"
     # later peaks: `peaks` bounds the peak list (the kernel's limit is 16384 per call), `cap` only sizes the hash output -- a full
     # song has more than 16384 hashes long before it has 16384 peaks
     peaks = max(16, 257 * max(n_frames, 1) // 64)
-    cap = max(16, peaks * max(int(fan_value) - 1, 1))
+    cap = max(16, min(peaks, 16384) * max(int(fan_value) - 1, 1))      # more hashes can never come out under the kernel's peak limit
     dig, t1, counts, mask, spec = fingerprint_batch(x, amp_min=amp_min, fan_value=fan_value, cap=cap, scale_in=1.0,
                                                     peak_cap=min(peaks, 16384),
                                                     denoising=net is not None, denoising_model="unet", unet=net)

@@ -224,6 +224,7 @@ def _lstm_work(dev, layer: int, B: int, H: int, backward: bool = False) -> torch
     return ent[0]
 
 
+persistent_lstm_fallbacks = 0      # how often a persistent launch gave up and the per-step kernels took over (bench.py puts it in its line)
 _LSTM_MARK: Dict[int, "torch.cuda.Event"] = {}     # device index -> event behind the last persistent launches and their error-word copies
 
 
@@ -254,7 +255,7 @@ def lstm_results_ok(dev) -> bool:
     On error: the words are cleared, the persistent path is switched OFF for the process (PERSISTENT_LSTM / _BWD = False: the
     per-step kernels need no co-residency) and False is returned -- the caller re-runs its launches.  Under HIP-graph capture nothing
     can be checked (no host access): returns True, and the capture's scratch lives in the graph's pool."""
-    global PERSISTENT_LSTM, PERSISTENT_LSTM_BWD
+    global PERSISTENT_LSTM, PERSISTENT_LSTM_BWD, persistent_lstm_fallbacks
     idx = _dev_index(dev)
     touched = _LSTM_TOUCHED.get(idx)
     if not touched or torch.cuda.is_current_stream_capturing():
@@ -271,9 +272,12 @@ def lstm_results_ok(dev) -> bool:
     _LSTM_TOUCHED[idx] = []
     if not bad:
         return True
+    torch.cuda.synchronize(dev)                      # the scratch buffers are keyed per stream: nothing may still be using them
     for key, ent in _LSTM_WORK.items():              # the word is sticky (it ends every later wait): clear it in every scratch of the device
         if key[0] == idx:
             ent[0][off:off + 1].zero_()
+    torch.cuda.synchronize(dev)
+    persistent_lstm_fallbacks += 1
     PERSISTENT_LSTM = False
     PERSISTENT_LSTM_BWD = False
     import warnings

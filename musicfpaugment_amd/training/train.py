@@ -69,23 +69,63 @@ _MainEarlyStopping.__module__ = "__main__"
 _MainEarlyStopping.__qualname__ = _MainEarlyStopping.__name__ = "EarlyStopping"
 
 
-def _early_stopping_for_pickle(es: EarlyStopping):
-    """(object to pickle, sys.modules entries to hold while pickling).  pickle resolves `training.train.EarlyStopping` when it
-    WRITES too: inside a process that has the reference imported that is the reference's own class, otherwise a stub module."""
-    import sys
-    import types
-    ref = sys.modules.get("training.train")
-    if ref is not None and hasattr(ref, "EarlyStopping"):
-        cls, alias = ref.EarlyStopping, {}
-    else:
-        stub = types.ModuleType("training.train")
-        stub.EarlyStopping = _RefEarlyStopping
-        cls, alias = _RefEarlyStopping, {"training.train": stub}
-        if "training" not in sys.modules:
-            alias["training"] = types.ModuleType("training")
-    obj = cls.__new__(cls)
-    obj.__dict__.update(patience=es.patience, min_delta=es.min_delta, counter=es.counter, best_loss=es.best_loss, early_stop=es.early_stop)
-    return obj, alias
+_PICKLE_LOCK = __import__("threading").Lock()
+
+
+class _pickling_as_reference_class:
+    """Context: `training.train.EarlyStopping` resolves while pickle WRITES (it looks the class up by name to verify it).  Inside a
+    process that has the reference imported that is the reference's own class and nothing is touched.  Otherwise the missing
+    names -- and only those -- are provided for the duration of the write and removed again: an existing `training` /
+    `training.train` module is never replaced or popped (a real module that merely lacks the attribute gets it set, then deleted).
+    Serialised by a lock (DataLoader workers importing `training.*` see either the old or the restored state)."""
+
+    def __init__(self, es: EarlyStopping):
+        self.es = es
+
+    def __enter__(self):
+        import sys
+        import types
+        _PICKLE_LOCK.acquire()
+        self.added_modules, self.added_attr = [], None
+        mod = sys.modules.get("training.train")
+        if mod is not None and hasattr(mod, "EarlyStopping"):
+            cls = mod.EarlyStopping
+        else:
+            cls = _RefEarlyStopping
+            if "training" not in sys.modules:
+                sys.modules["training"] = types.ModuleType("training")
+                self.added_modules.append("training")
+            if mod is None:
+                mod = types.ModuleType("training.train")
+                sys.modules["training.train"] = mod
+                self.added_modules.append("training.train")
+            mod.EarlyStopping = cls
+            self.added_attr = mod
+        es = self.es
+        obj = cls.__new__(cls)
+        obj.__dict__.update(patience=es.patience, min_delta=es.min_delta, counter=es.counter, best_loss=es.best_loss, early_stop=es.early_stop)
+        return obj
+
+    def __exit__(self, *exc):
+        import sys
+        try:
+            if self.added_attr is not None and "training.train" not in self.added_modules:
+                try:
+                    delattr(self.added_attr, "EarlyStopping")
+                except AttributeError:
+                    pass
+            for k in self.added_modules:
+                sys.modules.pop(k, None)
+        finally:
+            _PICKLE_LOCK.release()
+        return False
+
+
+def _atomic_save(obj, path: str) -> None:
+    """torch.save to `<path>.tmp`, then os.replace: a crash mid-write never leaves an unreadable resume file."""
+    tmp = path + ".tmp"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
 
 
 class ReduceLROnPlateau:
@@ -385,20 +425,14 @@ class Trainer:
                 os.makedirs(self.ckpt_path, exist_ok=True)
                 sd = self.model.state_dict()
                 if best:
-                    torch.save({"model_state_dict": sd, "best_val_loss": self.best_val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
-                import sys
-                es_obj, alias = _early_stopping_for_pickle(self.early_stopping)
-                sys.modules.update(alias)
-                try:
-                    torch.save({"epoch": self.epoch, "model_state_dict": sd, "optimizer_state_dict": self._optimizer_state_dict(),
-                                "scheduler_state_dict": self.scheduler.state_dict(), "early_stopping": es_obj,
-                                "train_loss": train_loss if train_loss is not None else {"loss": self.losses["train"][-1] if self.losses["train"] else None},
-                                "val_losses": val_losses if val_losses is not None else {"loss": val_loss},
-                                "best_val_loss": self.best_val_loss, "losses": self.losses},
-                               os.path.join(self.ckpt_path, "last_epoch.pt"))
-                finally:
-                    for k in alias:
-                        sys.modules.pop(k, None)
+                    _atomic_save({"model_state_dict": sd, "best_val_loss": self.best_val_loss}, os.path.join(self.ckpt_path, "best_epoch.pt"))
+                with _pickling_as_reference_class(self.early_stopping) as es_obj:
+                    _atomic_save({"epoch": self.epoch, "model_state_dict": sd, "optimizer_state_dict": self._optimizer_state_dict(),
+                                  "scheduler_state_dict": self.scheduler.state_dict(), "early_stopping": es_obj,
+                                  "train_loss": train_loss if train_loss is not None else {"loss": self.losses["train"][-1] if self.losses["train"] else None},
+                                  "val_losses": val_losses if val_losses is not None else {"loss": val_loss},
+                                  "best_val_loss": self.best_val_loss, "losses": self.losses},
+                                 os.path.join(self.ckpt_path, "last_epoch.pt"))
             except Exception as e:            # the other ranks are waiting: tell them before raising
                 err = e
         if world > 1:

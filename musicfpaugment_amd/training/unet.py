@@ -22,6 +22,47 @@ from .. import ops_unet as K
 from .._lib import MfpaError, require_gpu
 
 
+class _UNetTrainFn(torch.autograd.Function):
+    """Autograd node around UNetTrainEngine.forward / .backward (no autograd inside: the engine keeps its own activations)."""
+
+    @staticmethod
+    def run_forward(module, eng, x):
+        B, _, F_, T_ = x.shape
+        eng.step_count = eng.fwd_count                 # the stateless dropout masks are keyed by (seed, forward count, layer)
+        pred = eng.forward(x32=x.contiguous().view(B, F_, T_))
+        eng.fwd_count += 1
+        # BatchNorm side effects of a train-mode forward (running statistics, num_batches_tracked) land in the module's buffers
+        names = [k for k in eng.running]
+        bufs = dict(module.named_buffers())
+        torch._foreach_copy_([bufs[k] for k in names], [eng.running[k] for k in names])
+        torch._foreach_add_([b for k, b in bufs.items() if k.endswith("num_batches_tracked")], 1)
+        return pred.view(B, 1, F_, T_)
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module.train_engine()
+        pred = _UNetTrainFn.run_forward(module, eng, x)
+        ctx.module, ctx.eng, ctx.token = module, eng, eng.fwd_count
+        ctx.names = [k for k, _ in module.named_parameters()]
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        eng = ctx.eng
+        if eng.fwd_count != ctx.token or eng._recs is None:
+            raise RuntimeError("UNet backward: the activations of this forward are gone (another train-mode forward ran, or backward "
+                               "was already called); the engine keeps ONE forward's activations")
+        B = dpred.shape[0]
+        eng.backward(dpred.contiguous().view(B, dpred.shape[2], dpred.shape[3]).float())
+        grads = eng.named_grads()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(eng.group) > 1:
+            # the engine all-reduced (SUM) its gradient buckets over the data-parallel group: hand autograd the mean, like DDP
+            inv = 1.0 / dist.get_world_size(eng.group)
+            grads = {k: v * inv for k, v in grads.items()}
+        return (None, None) + tuple(grads[k] for k in ctx.names)      # the 1-channel input gets no gradient (its layer's is skipped)
+
+
 class DoubleConv(nn.Module):
     """(convolution => [BN] => ReLU) * 2 -- parameter container (training/unet.py:8-25)."""
 
@@ -111,13 +152,10 @@ class UNet(nn.Module):
         require_gpu(x, "UNet input")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError("expected (B, 1, F, T)")
-        if self.training:
-            raise NotImplementedError(
-                "train-mode forward + backward run without autograd through musicfpaugment_amd.training.train.Trainer "
-                "(ops_train.UNetTrainEngine: BatchNorm batch statistics, Dropout, L1, backward, Adam as HIP kernels); "
-                "call .eval() for inference")
         if x.dtype != torch.float32:
             raise TypeError("UNet input must be float32 (the reference casts with .float(), training/train.py:272)")
+        if self.training:
+            return self._forward_train(x)
         pw = self.packed_weights()
         B = x.shape[0]
         outs: List[torch.Tensor] = []
@@ -126,6 +164,43 @@ class UNet(nn.Module):
             outs.append(K.unet_forward_eval(pw, x32=xs.view(xs.shape[0], xs.shape[2], xs.shape[3])))
         y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         return y.view(B, 1, x.shape[2], x.shape[3])
+
+    # ------------------------------------------------------------------ train-mode forward under torch.autograd
+    def train_engine(self):
+        """The hand-written training engine (ops_train.UNetTrainEngine) bound to this module's parameters; created on first use,
+        re-created when the module moved to another device."""
+        from ..ops_train import UNetTrainEngine
+        dev = next(self.parameters()).device
+        eng = self.__dict__.get("_engine")
+        if eng is None or eng.device != dev:
+            eng = UNetTrainEngine(self, lr=1e-3, precision=self.train_precision, wgrad_precision=self.train_wgrad_precision)
+            eng.fwd_count = 0
+            self.__dict__["_engine"] = eng          # not a sub-module: no parameters of its own, nothing for state_dict()
+            self.__dict__["_engine_key"] = None
+        return eng
+
+    train_precision = 0            # arithmetic of the training convolutions (0 = fp32 MFMA like the reference, 1 = bf16x3)
+    train_wgrad_precision = 0      # arithmetic of the weight-gradient kernels (0 = fp32, 1 = bf16x3, 2 = bf16)
+
+    def _forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's training lines run unchanged on this module (training/train.py:273-316):
+
+            predicted = model(x); loss = criterion(predicted, clean); optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+        Train-mode forward (BatchNorm batch statistics + running-stat update, nn.Dropout(rate) on x2..x5 and up1's output,
+        training/unet.py:97-108) runs the engine's HIP kernels; the returned tensor carries a grad_fn whose backward runs the
+        hand-written backward pass and hands the gradients of all 60 parameters (reference shapes) to autograd, which accumulates
+        them into `param.grad` like any other op -- so torch.optim.Adam(model.parameters()) works as in the reference.  The fused
+        Adam of training.train.Trainer stays the fast path (no per-step re-layout of the weights)."""
+        eng = self.train_engine()
+        params = [p for _, p in self.named_parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self.__dict__.get("_engine_key"):     # an optimiser step / load_state_dict changed the weights: re-lay them out
+            eng.load_from_module()
+            self.__dict__["_engine_key"] = key
+        if not torch.is_grad_enabled():
+            return _UNetTrainFn.run_forward(self, eng, x)
+        return _UNetTrainFn.apply(self, x, *params)
 
     def denoise_spectrogram(self, spec64: torch.Tensor, clip_max: torch.Tensor, per_clip: bool) -> torch.Tensor:
         """Fused entry for the pipeline: raw float64 |STFT| (B,F,T) + maxima -> denoised (B,F,T) float32.

@@ -80,6 +80,57 @@ def formula_state_dict(seed: int = 0, n_channels: int = 1, n_classes: int = 1) -
     return sd
 
 
+FAMILIES = ("formula", "bn_spread", "heavy_tail")
+
+
+def stress_state_dict(family: str, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Weight families that stress the bf16x3 arithmetic of the convolutions the way a trained checkpoint can (the 1e-4
+    forward gate must not rest on one benign family; training/unet.py:97-108 has no output activation, so cancelling sums
+    reach the output):
+      "formula"     formula_state_dict(seed);
+      "bn_spread"   BatchNorm gamma log-uniform over [0.03, 30] with a random sign-free spread per channel, running_var
+                    log-uniform over [1e-2, 1e2], running_mean uniform in [-2, 2], beta in [-0.5, 0.5]: per-channel scales
+                    gamma / sqrt(var) spread over five decades, so a few channels dominate every sum and ReLU thresholds sit
+                    far from zero;
+      "heavy_tail"  conv / transposed-conv weights = He scale x |Cauchy| (clipped at 20) x random sign: a handful of taps carry
+                    most of each output, the rest cancel.
+    (A third stressed family, weights after 50 optimiser steps of UNetTrainEngine, needs the GPU: tests/test_gpu_unet.py.)"""
+    if family == "formula":
+        return formula_state_dict(seed)
+    if family not in FAMILIES:
+        raise ValueError(f"unknown weight family {family!r}")
+    sd = formula_state_dict(seed)
+    for stream, (key, v) in enumerate(sd.items()):
+        shape = tuple(v.shape)
+        n = v.numel()
+        if key.endswith("num_batches_tracked"):
+            continue
+        u = _unit(seed, 900 + stream, n)
+        u2 = _unit(seed, 1900 + stream, n)
+        if family == "bn_spread" and len(shape) == 1 and ".up." not in key and not key.startswith("outc"):
+            if key.endswith("running_var"):
+                w = 10.0 ** (2.0 * u)                                   # log-uniform [1e-2, 1e2]
+            elif key.endswith("running_mean"):
+                w = 2.0 * u
+            elif key.endswith(".weight"):
+                w = 10.0 ** (1.5 * u)                                   # log-uniform [0.03, 30] (x the layer's normaliser below)
+            else:
+                w = 0.5 * u
+            sd[key] = torch.from_numpy(w.astype(np.float32).reshape(shape))
+        elif family == "heavy_tail" and len(shape) == 4:
+            fan_in = shape[0] if ".up." in key else shape[1] * shape[2] * shape[3]
+            cauchy = np.minimum(np.abs(np.tan(0.5 * np.pi * np.clip(u, -0.999999, 0.999999))), 20.0)
+            sign = np.where(u2 < 0, -1.0, 1.0)
+            w = sign * cauchy * np.sqrt(2.0 / fan_in) / np.sqrt(np.mean(cauchy ** 2))      # He variance, heavy-tailed shape
+            sd[key] = torch.from_numpy(w.astype(np.float32).reshape(shape))
+    if family == "bn_spread":              # keep activations O(1): every BatchNorm layer's rms scale gamma / sqrt(var + eps) is 1
+        for key in [k for k in sd if k.endswith("running_var")]:
+            g = key[:-len("running_var")] + "weight"
+            scale = sd[g].double() / torch.sqrt(sd[key].double() + 1e-5)
+            sd[g] = (sd[g].double() / torch.sqrt((scale ** 2).mean())).float()
+    return sd
+
+
 def n_parameters(sd: Dict[str, torch.Tensor]) -> int:
     return sum(v.numel() for k, v in sd.items()
                if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")))

@@ -77,3 +77,32 @@ def relative_l1(y: torch.Tensor, ref: torch.Tensor) -> float:
     y = y.double()
     ref = ref.double()
     return float((y - ref).abs().sum() / ref.abs().sum())
+
+
+def forward_bf16x3_model(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Arithmetic MODEL of the device's bf16x3 convolutions (csrc/unet.hip, PREC 1) on the CPU, eval mode: every fp32 operand of
+    the MFMA layers is split x = hi + lo into two bfloat16 values and a product is hi*hi + hi*lo + lo*hi (the lo*lo term is
+    dropped), accumulated wide; the 1-channel first layer and the 1x1 OutConv stay fp32 (they run on the vector ALUs).  Test
+    infrastructure: lets the CPU suite bound the error of the headline arithmetic on any weight family before a GPU is involved
+    (tests/test_oracle_golden.py); the device itself is compared with forward() in tests/test_gpu_unet.py."""
+    conv2d, conv_t = F.conv2d, F.conv_transpose2d
+
+    def split(t):
+        hi = t.to(torch.bfloat16).float()
+        return hi.double(), (t - hi).to(torch.bfloat16).double()
+
+    def conv3(inp, w, *a, **k):
+        if w.shape[1] == 1 or w.shape[2] == 1:
+            return conv2d(inp, w, *a, **k)
+        (xh, xl), (wh, wl) = split(inp), split(w)
+        return (conv2d(xh, wh, *a, **k) + conv2d(xh, wl, *a, **k) + conv2d(xl, wh, *a, **k)).float()
+
+    def convt3(inp, w, b, **k):
+        (xh, xl), (wh, wl) = split(inp), split(w)
+        return (conv_t(xh, wh, None, **k) + conv_t(xh, wl, None, **k) + conv_t(xl, wh, None, **k)).float() + b[None, :, None, None]
+
+    F.conv2d, F.conv_transpose2d = conv3, convt3
+    try:
+        return forward(x, sd)
+    finally:
+        F.conv2d, F.conv_transpose2d = conv2d, conv_t

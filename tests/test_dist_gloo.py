@@ -119,3 +119,11 @@ def test_bench_line_verifies_itself_with_eight_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["config"]["max_rank_seen"] == 7
     assert out["per_rank_value"] == [float(k + 1) for k in range(8)]
+    # the shape of the N > 1 headline line: both nested train-step entries (the path's one collective) with every key the driver's
+    # 1/2/4/8 curve needs, in the same line as the inference headline (bench.dist_configs fills the values on GPUs)
+    sys.path.insert(0, root)
+    import bench
+    for name, scaling in (("config4_unet_train_step", "weak"), ("config4_unet_train_step_strong", "strong")):
+        ent = out["configs"][name]
+        assert set(bench.TRAIN_LINE_KEYS) <= set(ent) and ent["scaling"] == scaling and ent["ranks_seen"] == 8
+        assert len(ent["per_rank_value"]) == 8

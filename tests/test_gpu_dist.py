@@ -20,6 +20,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # torch.distributed.run binds its own rendezvous port (c10d endpoint 127.0.0.1:0 under --standalone): no fixed port to clash on a
 # shared box.  Workers still find MASTER_ADDR / MASTER_PORT in their environment.
 RDZV = ("--standalone", "--local-addr", "127.0.0.1")
+# small nested train-step entries for the N > 1 inference line (bench.dist_configs; the defaults are 64 clips per GPU / global 512, 8 s)
+DIST_SMALL = ("--dist-train-clips", "4", "--dist-strong-global", "8", "--dist-train-steps", "2", "--dist-train-seconds", "1")
+
+
+def _check_nested_train_entries(out, world):
+    """The N > 1 inference line carries the path's one collective: the train step weak- and strong-scaled, each with its own
+    self-verification and all-reduce accounting."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for name, scaling, per_gpu in (("config4_unet_train_step", "weak", 4), ("config4_unet_train_step_strong", "strong", 8 // world)):
+        ent = out["configs"][name]
+        assert "error" not in ent and "skipped" not in ent, ent
+        assert set(bench.TRAIN_LINE_KEYS) <= set(ent), sorted(set(bench.TRAIN_LINE_KEYS) - set(ent))
+        assert ent["scaling"] == scaling and ent["ranks_seen"] == world and len(ent["per_rank_value"]) == world
+        assert ent["clips_per_gpu_per_step"] == per_gpu and ent["clips_per_step_all_gpus"] == per_gpu * world
+        assert ent["allreduce_bytes_per_step"] >= 31_036_481 * 4 and ent["allreduce_exposed_wait_ms_per_step"] >= 0
+        assert ent["value"] > 0 and "AugmentFP chain on the device inside the step" in ent["config"]["workload"]
+        assert np.isfinite(ent["config"]["loss_last"])
 
 
 def _check(r):
@@ -104,7 +122,7 @@ def test_bench_runs_under_torchrun_with_two_ranks(mode):
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MFPA_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", *RDZV, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8",
-           "--mode", mode]
+           "--mode", mode, *DIST_SMALL]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     _check(r)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -119,6 +137,8 @@ def test_bench_runs_under_torchrun_with_two_ranks(mode):
     assert sum(out["per_rank_value"]) >= 0.99 * out["value"]                     # value uses the MAX time over ranks
     if mode == "train":
         assert out["config"]["allreduce_exposed_wait_ms_per_step"] is not None and out["config"]["allreduce_exposed_wait_ms_per_step"] >= 0
+    else:
+        _check_nested_train_entries(out, 2)
 
 
 @pytest.mark.parametrize("mode", ["infer", "train"])
@@ -128,7 +148,7 @@ def test_bench_self_launch_with_two_ranks(mode):
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MFPA_DIST_BACKEND="gloo")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8", "--mode", mode]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8", "--mode", mode, *DIST_SMALL]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     _check(r)
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -138,6 +158,9 @@ def test_bench_self_launch_with_two_ranks(mode):
     assert out["config"]["clips_per_gpu_per_step"] == 8
     if mode == "train":
         assert out["config"]["allreduce_bytes_per_step"] >= 31_036_481 * 4
+    else:                                    # `python bench.py --gpus 2`, the driver's own command form: headline + the collective, one line
+        _check_nested_train_entries(out, 2)
+        assert out["parity_in_run"]["rel_l1_bf16x3_vs_fp32"] <= 1e-4
 
 
 @pytest.mark.parametrize("mode", ["train", "infer"])

@@ -397,6 +397,54 @@ def test_headline_chain_256_clips_end_to_end_as_benched(net):
         net.precision = 0
 
 
+@pytest.mark.parametrize("family", ["bn_spread", "heavy_tail", "trained"])
+def test_headline_chain_256_clips_on_stressed_and_trained_weight_families(family, trained_sd):
+    """The headline chain at bench size in the headline arithmetic (bf16x3) with weights that are not the benign formula family
+    (training/weights.py:stress_state_dict, conftest.trained_sd): every clip's mask must still equal the oracle pruner's on the
+    device's denoised spectrogram (bit-exact), and the UNet output of sampled clips must stay inside the 1e-4 gate against the
+    oracle's fp32 chain (the margin is printed)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
+    from musicfpaugment_amd.pipeline import HotPath
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import stress_state_dict
+    from oracle import audfprint as oa
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    B = 256
+    sd = trained_sd() if family == "trained" else stress_state_dict(family, 0)
+    m = UNet(1, 1, rate=0.05)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.precision = 1
+    base = synth.batch(32, seed=synth.BASE_SEED)
+    gains = (1.0 - 0.5 * np.arange(8) / 8).astype(np.float32)
+    wav_np = np.ascontiguousarray(np.concatenate([base * g for g in gains])[:B])
+    wav = torch.from_numpy(wav_np).cuda()
+    picks = [0, 100, 255]
+    with torch.no_grad():
+        torch.set_num_threads(8)
+        sg = np.stack([ostft.magnitude(wav_np[i]) for i in picks])
+        sg = sg / sg.max(axis=(1, 2), keepdims=True)
+        want_den = ou.forward(torch.from_numpy(sg).float()[:, None], sd)[:, 0]
+    mask, npk = HotPath(m)(wav)
+    ext = Audfprint_peaks(None, denoising=True, denoising_model="unet", unet=m, device="cuda")
+    mask_s, npk_s, spec = ext.find_peaks_batch(wav)
+    assert torch.equal(mask_s, mask) and torch.equal(npk_s, npk)
+    rl1 = ou.relative_l1(spec[picks].cpu(), want_den)
+    print(f"[headline, family {family}] UNet relative L1 (bf16x3 vs oracle fp32) {rl1:.3e}, gate 1e-4, margin x{1e-4 / rl1:.1f}; "
+          f"peaks per clip {float(npk.float().mean()):.1f}")
+    assert rl1 <= 1e-4, (family, rl1)
+    spec_np, mask_np = spec.cpu().numpy(), mask.cpu().numpy()
+
+    def one(i):
+        return i, np.array_equal(oa.find_peaks_from_sgram(spec_np[i], order="C")[1].astype(np.uint8), mask_np[i])
+    with ThreadPoolExecutor(8) as ex:
+        bad = [i for i, ok in ex.map(one, range(B)) if not ok]
+    assert not bad, (family, bad)
+    np.testing.assert_array_equal(npk.cpu().numpy(), mask_np.reshape(B, -1).sum(axis=1))
+
+
 @pytest.mark.parametrize("denoiser,N", [("demucs", 10000), ("unet", 2000)])
 def test_config5_peak_metrics_experiment_at_size_sampled_queries_vs_oracle(net, denoiser, N):
     """BASELINE configs[4], second half, at the size bench.py's `configs.config5_peak_metrics*` entries run: the 10 000-query

@@ -187,6 +187,83 @@ def test_train_step_matches_reference_golden(golden):
     assert int(sd["inc.double_conv.1.num_batches_tracked"]) == 1
 
 
+def test_reference_training_lines_run_unchanged_and_reproduce_the_golden_step(golden):
+    """The reference's own loop body (training/train.py:273-316) on the drop-in module:
+
+        predicted = self.model(x); loss = self.criterion(predicted, clean); self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
+
+    with torch.nn.L1Loss and torch.optim.Adam(model.parameters(), lr=1e-3): train-mode UNet.forward returns a tensor with a grad_fn
+    whose backward is the hand-written HIP backward pass; autograd accumulates the gradients into param.grad.  Must reproduce g7 (one
+    step of the REAL reference module) at the golden's tolerances: prediction, loss, per-parameter gradient norms, the first Adam
+    update, BatchNorm running statistics; then a second step must see the updated weights, and eval-mode inference the trained ones."""
+    from musicfpaugment_amd.training.unet import UNet
+    g = golden("g7_unet_train_step")
+    w0 = formula_state_dict(int(g["weight_seed"]))
+    model = UNet(1, 1, rate=0.0)
+    model.load_state_dict(w0)
+    model = model.cuda().train()
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    criterion = torch.nn.L1Loss()
+    am, aug_den, clean = _g7_inputs()
+    x = (am / aug_den[:, None, None]).unsqueeze(1).float()            # train.py:272  x = aug.unsqueeze(1).float()
+    clean = clean.unsqueeze(1)                                         # float64 target (Appendix A.2)
+    predicted = model(x)
+    assert predicted.requires_grad and predicted.grad_fn is not None and predicted.shape == x.shape
+    assert rel(predicted.detach()[:, 0, ::4, ::4], torch.from_numpy(g["pred_sub"])) < 1e-4
+    loss = criterion(predicted, clean)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    optimizer.zero_grad()
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert all(v is not None and v.shape == p.shape for (k, p), v in zip(model.named_parameters(), grads.values()))
+    names = [str(n) for n in g["names"]]
+    gn = np.array([float(grads[n].double().norm()) for n in names])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-3, atol=1e-9)
+    big = [n for n in names if grads[n].numel() >= 4]
+    ghead = np.stack([grads[n].flatten()[:4].double().cpu().numpy() for n in big])
+    scale = np.abs(g["grad_head"]).max(axis=1, keepdims=True) + 1e-12
+    assert np.max(np.abs(ghead - g["grad_head"]) / scale) < 5e-2
+    optimizer.step()
+    sd = model.state_dict()
+    whead = np.stack([sd[n].flatten()[:4].double().cpu().numpy() for n in big])
+    w0head = np.stack([w0[n].flatten()[:4].double().numpy() for n in big])
+    assert np.mean(np.abs((whead - w0head) - (g["weight_head"] - w0head))) < 0.02 * 1e-3
+    rm = np.concatenate([sd[k].cpu().numpy()[:4] for k in sd if k.endswith("running_mean")])
+    rv = np.concatenate([sd[k].cpu().numpy()[:4] for k in sd if k.endswith("running_var")])
+    np.testing.assert_allclose(rm, g["running_mean_head"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rv, g["running_var_head"], rtol=1e-4, atol=1e-6)
+    assert int(sd["inc.double_conv.1.num_batches_tracked"]) == 1
+    # more steps of the same loop: the engine re-reads the weights the optimiser changed; the loss goes down
+    losses = [float(loss)]
+    for _ in range(5):
+        predicted = model(x)
+        loss = criterion(predicted, clean)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
+    assert int(model.state_dict()["inc.double_conv.1.num_batches_tracked"]) == 6
+    # gradient accumulation keeps autograd's semantics (no zero_grad: the second backward ADDS)
+    optimizer.zero_grad()
+    criterion(model(x), clean).backward()
+    g1 = model.outc.conv.weight.grad.clone()
+    criterion(model(x), clean).backward()
+    assert torch.allclose(model.outc.conv.weight.grad, 2 * g1, rtol=1e-3, atol=1e-7)
+    # two forwards, then backward of the first: refused loudly (the engine keeps one forward's activations)
+    p1 = model(x); model(x)
+    with pytest.raises(RuntimeError):
+        criterion(p1, clean).backward()
+    # validation the reference's way (train.py:330-356): eval + no_grad uses the inference kernels on the trained weights
+    model.eval()
+    with torch.no_grad():
+        v = model(x)
+    assert v.grad_fn is None and torch.isfinite(v).all()
+    model.train()
+    with torch.no_grad():                               # train-mode forward without a graph (BatchNorm batch statistics) still runs
+        assert model(x).grad_fn is None
+
+
 def test_train_step_vs_oracle_autograd_and_loss_decreases():
     from oracle import unet as ou
     from musicfpaugment_amd.ops_train import UNetTrainEngine

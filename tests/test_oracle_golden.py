@@ -260,3 +260,24 @@ def test_g12_demucs_train_step(golden):
         want = g["param_head_before"][r][:gh.size] - lr * gh / (np.abs(gh) + 1e-8)
         big = np.abs(gh) > 1e-6
         np.testing.assert_allclose(want[big], g["param_head_after"][r][:gh.size][big], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("family", ["formula", "bn_spread", "heavy_tail"])
+def test_bf16x3_arithmetic_model_meets_the_gate_on_every_weight_family(family):
+    """The headline arithmetic (three bf16 products per fp32 product, oracle.unet.forward_bf16x3_model) against the reference's fp32
+    arithmetic on the benign formula weights AND the stressed families (BatchNorm scales spread over five decades, heavy-tailed
+    weights): relative L1 <= 1e-4 (BASELINE.json north_star) with margin.  The device kernels are held to the same gate on the same
+    families -- and on trained weights -- in tests/test_gpu_unet.py / test_gpu_fullsize.py."""
+    import torch
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.training.weights import stress_state_dict
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    sd = stress_state_dict(family, 0)
+    x = torch.from_numpy(ostft.spectrogram(synth.batch(1, seed=900, n=8000))).float().unsqueeze(1)
+    with torch.no_grad():
+        want = ou.forward(x, sd)
+        got = ou.forward_bf16x3_model(x, sd)
+    assert torch.isfinite(want).all() and float(want.abs().mean()) > 1e-3
+    r = ou.relative_l1(got, want)
+    assert 1e-7 < r <= 0.5e-4, (family, r)

@@ -67,19 +67,26 @@ def test_early_stopping_is_pickled_under_the_reference_name_and_read_with_weight
     import io
     import sys
     import torch
-    from musicfpaugment_amd.training.train import _MainEarlyStopping, _RefEarlyStopping, _early_stopping_for_pickle
+    import types
+    from musicfpaugment_amd.training.train import _MainEarlyStopping, _RefEarlyStopping, _atomic_save, _pickling_as_reference_class
     es = EarlyStopping(7, 0.01)
     es(1.0)
     es(1.5)
-    obj, alias = _early_stopping_for_pickle(es)
-    sys.modules.update(alias)
-    try:
+    with _pickling_as_reference_class(es) as obj:
         buf = io.BytesIO()
         torch.save({"early_stopping": obj, "t": torch.ones(3)}, buf)
+    assert "training.train" not in sys.modules and "training" not in sys.modules and b"training.train" in buf.getvalue()
+    # a real `training.train` that merely lacks the class (e.g. a user package of that name) is neither replaced nor popped
+    real_pkg, real_mod = types.ModuleType("training"), types.ModuleType("training.train")
+    real_mod.marker = 1
+    sys.modules["training"], sys.modules["training.train"] = real_pkg, real_mod
+    try:
+        with _pickling_as_reference_class(es) as obj2:
+            torch.save({"early_stopping": obj2}, io.BytesIO())
+        assert sys.modules["training.train"] is real_mod and sys.modules["training"] is real_pkg
+        assert not hasattr(real_mod, "EarlyStopping") and real_mod.marker == 1
     finally:
-        for k in alias:
-            sys.modules.pop(k, None)
-    assert "training.train" not in sys.modules and b"training.train" in buf.getvalue()
+        sys.modules.pop("training.train", None); sys.modules.pop("training", None)
     buf.seek(0)
     with pytest.raises(Exception):
         torch.load(buf, weights_only=True)                               # not allow-listed: refused
@@ -88,3 +95,18 @@ def test_early_stopping_is_pickled_under_the_reference_name_and_read_with_weight
         got = torch.load(buf, weights_only=True)["early_stopping"]
     assert vars(got) == dict(patience=7, min_delta=0.01, counter=1, best_loss=1.0, early_stop=False)
     assert (type(got).__module__, type(got).__name__) == ("training.train", "EarlyStopping")
+
+
+def test_checkpoints_are_replaced_atomically(tmp_path):
+    """_atomic_save: written to <name>.tmp and os.replace'd -- a failed write leaves the previous file readable."""
+    import torch
+    from musicfpaugment_amd.training.train import _atomic_save
+    path = str(tmp_path / "last_epoch.pt")
+    _atomic_save({"epoch": 1}, path)
+
+    class Boom:
+        def __reduce__(self):
+            raise RuntimeError("disk full")
+    with pytest.raises(RuntimeError):
+        _atomic_save({"epoch": 2, "x": Boom()}, path)
+    assert torch.load(path, weights_only=True)["epoch"] == 1
