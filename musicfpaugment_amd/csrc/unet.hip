@@ -150,6 +150,8 @@ struct ConvArgs {
   const float* bz_invstd;
   float* stats_part;                 // conv_wd16_kernel: optional per-wave partial (sum, sum of squares) of the stored output per channel:
                                      //   [tile * WMW + wm][2][Cout] (mfpa_conv_desc.stats_part; rows = mfpa_conv_stats_rows())
+  int dbg_stagger;                   // -DMFPA_EXPERIMENTS builds only: start delay of persistent workgroup k = (k & 7) x this x 4096 cycles
+  int dbg_lds_stamps;                // -DMFPA_EXPERIMENTS builds only: LDS byte offset of the tap-timeline stamps (0 = none)
   int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
   // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
   // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
@@ -1075,43 +1077,75 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   const int nchunks = Cin / KC;
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
 
-  // ---- halo loader (as conv_mfma_kernel's: unconditional clamped loads, padding zeroed when the slot is split).  A thread's staging
-  // slots map to fixed halo pixels; their byte offsets into the two sources live in LDS ([source][slot][thread], read back two or three
-  // at a time in front of the loads) and their inside-the-source flags in ONE register: as loop-invariant registers (12 offsets) the
-  // compiler spilled them to scratch, and a scratch reload in front of a load drains every outstanding weight load (s_waitcnt vmcnt(0)).
+  // ---- halo loader.  A thread's staging slots map to fixed halo pixels (pix = tid / 8 + 64 it).  Their byte offsets RELATIVE TO THE
+  // TILE'S ORIGIN do not depend on the tile: one table [source][slot][thread] in LDS, built once per kernel (as registers the 12
+  // offsets were spilled to scratch, and a scratch reload in front of a load drains every outstanding weight load); a tile adds its
+  // scalar origin offset.  The loads are raw BUFFER loads through a per-clip descriptor (base = the clip, num_records = its bytes):
+  // halo pixels above the first / below the last image row fall outside the clip and return zero without any clamping, pixels left /
+  // right of the image read a neighbouring row's valid bytes; either way the slot is zeroed when it is split (`ain`: inside flags,
+  // recomputed per tile from the slot's (row, column) and the tile's uniform bounds -- a few compares, no table).  Round 3 rebuilt a
+  // clamped absolute table per tile (12 x (two divisions, four clamps, an LDS store) per thread): 3.7 k cycles per tile in front of the
+  // first tap of every tile of the persistent form (profiles/r04_c64_timeline.txt).
   const int aq = tid % (KC / 4);
-  constexpr int TBL = 2 * A_F4 * THREADS;                              // one offset table: [2][A_F4][THREADS]
+  constexpr int TBL = 2 * A_F4 * THREADS;                              // the offset table: [2][A_F4][THREADS]
   unsigned* const aoffs0 = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
-  struct Tile { int b, y0, x0p; unsigned ain; const char* xb0; const char* xb1; unsigned* aoffs; };
-  // decode tile t, build its offset table in `table`, return its state (ain bit it: slot inside source 0's image; bit 8 + it: source 1)
-  auto make_tile = [&](int t, unsigned* table) __attribute__((always_inline)) {
+#pragma unroll
+  for (int it = 0; it < A_F4; ++it) {
+    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const int py = pix / HPW - 1, px = pix % HPW - 1;
+    aoffs0[it * THREADS + tid] = (unsigned)((py * a.W + px) * a.C0 + 4 * aq) * 4u;                    // may be "negative": wraps, see above
+    aoffs0[(A_F4 + it) * THREADS + tid] = (unsigned)(((py - a.oy1) * a.W1 + (px - a.ox1)) * a.C1 + 4 * aq) * 4u;
+  }
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  const unsigned clip0 = (unsigned)a.H * (unsigned)a.W * (unsigned)a.C0 * 4u, clip1 = (unsigned)a.H1 * (unsigned)a.W1 * (unsigned)a.C1 * 4u;
+  struct Tile { int b, y0, x0p; unsigned ain; unsigned t0, t1; };      // t0 / t1: byte offset of the tile's origin pixel in source 0 / 1
+  // decode tile t (workgroup-uniform scalars) and its inside flags (ain bit it: slot inside source 0's image; bit 8 + it: source 1)
+  auto make_tile = [&](int t) __attribute__((always_inline)) {
     Tile T;
-    int bx = t;
+    int bx = __builtin_amdgcn_readfirstlane(t);
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty = bx % a.tiles_y; bx /= a.tiles_y;
-    T.b = bx; T.y0 = ty * PH; T.x0p = tx * PW; T.aoffs = table; T.ain = 0;
+    T.b = bx; T.y0 = ty * PH; T.x0p = tx * PW; T.ain = 0;
+    T.t0 = (unsigned)((T.y0 * a.W + T.x0p) * a.C0) * 4u;
+    T.t1 = (unsigned)((T.y0 * a.W1 + T.x0p) * a.C1) * 4u;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
       const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
       const int gy = T.y0 + pix / HPW - 1, gx = T.x0p + pix % HPW - 1;
       const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-      table[it * THREADS + tid] = ((unsigned)(cy * a.W + cx) * (unsigned)a.C0 + 4u * aq) * 4u;
       const int y1 = gy - a.oy1, x1 = gx - a.ox1;
       const bool in1 = in && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
-      const int c1y = min(max(y1, 0), max(a.H1 - 1, 0)), c1x = min(max(x1, 0), max(a.W1 - 1, 0));
-      table[(A_F4 + it) * THREADS + tid] = ((unsigned)(c1y * a.W1 + c1x) * (unsigned)a.C1 + 4u * aq) * 4u;
       T.ain |= (in ? 1u : 0u) << it | (in1 ? 1u : 0u) << (8 + it);
     }
-    T.xb0 = reinterpret_cast<const char*>(a.x0) + (size_t)T.b * a.H * a.W * a.C0 * sizeof(float);
-    T.xb1 = reinterpret_cast<const char*>(a.x1) + (size_t)T.b * a.H1 * a.W1 * a.C1 * sizeof(float);
     return T;
   };
+  auto clip_rsrc = [&](const float* base, int b, unsigned clip_bytes) __attribute__((always_inline)) {
+    const char* pb = reinterpret_cast<const char*>(base) + (size_t)b * clip_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, base != nullptr ? (int)clip_bytes : 0, 0x00020000);
+  };
   int tile = blockIdx.x;
-  Tile S = make_tile(tile, aoffs0);                                    // the tile whose halo is being requested / split
+#ifdef MFPA_EXPERIMENTS
+  // tap-level timeline (tools/exp_c64_timeline.py): wave 0 of workgroup (17, 0) stamps s_memtime at every tap start / epilogue start / end of
+  // its first tiles into LDS (tag in the low 8 bits), dumped to the stamp buffer when the kernel ends
+  unsigned long long* const tsbuf = reinterpret_cast<unsigned long long*>(smem + a.dbg_lds_stamps);
+  int stamp_n = 0;
+  const bool stamping = PERSIST && mfpa_conv_stamps != nullptr && a.dbg_lds_stamps != 0 && blockIdx.x == 17 && blockIdx.y == 0 && tid == 0;
+  auto stamp = [&](int tag) __attribute__((always_inline)) {
+    if (stamping && stamp_n < 500) tsbuf[stamp_n++] = (__builtin_amdgcn_s_memtime() & ~0xffull) | (unsigned)tag;
+  };
+#else
+  auto stamp = [](int) {};
+#endif
+#ifdef MFPA_EXPERIMENTS
+  if (PERSIST && a.dbg_stagger > 0) {                                  // experiment: de-synchronise the CUs' tile periods
+    const int units = (int)(blockIdx.x & 7u) * a.dbg_stagger;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(64);      // 64 x 64 cycles per unit
+  }
+#endif
+  Tile S = make_tile(tile);                                            // the tile whose halo is being requested / split
   int eb = S.b, ey0 = S.y0, ex0p = S.x0p;                              // the tile being computed (epilogue coordinates)
   // training forward: the producer's per-channel (scale, shift) of source 0, copied to LDS once ([scale C0 | shift C0])
-  float* aff = reinterpret_cast<float*>(smem + 2 * STAGE + (PERSIST ? 2 : 1) * TBL * sizeof(unsigned));
+  float* aff = reinterpret_cast<float*>(smem + 2 * STAGE + TBL * sizeof(unsigned));
   if (a.in_scale0 != nullptr) {
     for (int i = tid; i < a.C0; i += THREADS) {
       aff[i] = a.in_scale0[i];
@@ -1126,14 +1160,34 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int first = decltype(FIRST)::value, count = decltype(COUNT)::value;
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;                                      // workgroup-uniform: scalar selects, no branch
-    const char* xb = from0 ? S.xb0 + (size_t)c0 * 4 : S.xb1 + (size_t)(c0 - a.C0) * 4;
-    const unsigned* ao = S.aoffs + (from0 ? 0 : A_F4 * THREADS) + tid;
+    const auto rs = clip_rsrc(from0 ? a.x0 : a.x1, S.b, from0 ? clip0 : clip1);
+    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * 4u : S.t1 + (unsigned)(c0 - a.C0) * 4u;
+    const unsigned* ao = aoffs0 + (from0 ? 0 : A_F4 * THREADS) + tid;
 #pragma unroll
     for (int it = first; it < first + count && it < A_F4; ++it)
-      areg[it % AREGS] = *reinterpret_cast<const f32x4*>(xb + ao[it * THREADS]);
+      areg[it % AREGS] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ao[it * THREADS] + toff), 0, 0));
   };
   auto load_a = [&](int chunk) __attribute__((always_inline)) {
+    if (MFPA_EXP_FLAG(a.dbg, 64)) return;
     load_a_range(chunk, std::integral_constant<int, 0>{}, std::integral_constant<int, AREGS>{});
+  };
+  // tap-by-tap forms: the slot offsets of the chunk requested at the next tap 0 are read from the LDS table one tap EARLIER (tap 8, when
+  // the staging registers are dead) into component 0 of the staging registers themselves, so tap 0 issues its six loads without first
+  // waiting for six LDS reads (the wait sat in front of tap 0's MFMAs: tap 0 took twice a steady-state tap, profiles/r04_c64_timeline.txt)
+  auto preload_offsets = [&](int chunk) __attribute__((always_inline)) {
+    const unsigned* ao = aoffs0 + (chunk * KC < a.C0 ? 0 : A_F4 * THREADS) + tid;
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) areg[it % AREGS][0] = __uint_as_float(ao[it * THREADS]);
+  };
+  auto load_a_pre = [&](int chunk) __attribute__((always_inline)) {
+    if (MFPA_EXP_FLAG(a.dbg, 64)) return;
+    const int c0 = chunk * KC;
+    const bool from0 = c0 < a.C0;
+    const auto rs = clip_rsrc(from0 ? a.x0 : a.x1, S.b, from0 ? clip0 : clip1);
+    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * 4u : S.t1 + (unsigned)(c0 - a.C0) * 4u;
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it)
+      areg[it % AREGS] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(__float_as_uint(areg[it % AREGS][0]) + toff), 0, 0));
   };
   // one staging slot: zero padding, the training forward's on-load affine + ReLU + dropout, bf16 hi / lo split, two 8-byte stores
   // into the (hi, k-group) and (lo, k-group) planes (a thread's channel quad is half of k-group aq >> 1)
@@ -1175,11 +1229,11 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       const int py = pix / HPW, px = pix % HPW;
       const bool interior = inside && py >= 1 && py <= PH && px >= 1 && px <= PW && blockIdx.y == 0;
       if (a.x0_bf16 != nullptr && c0 < a.C0 && interior) {
-        const size_t e = (size_t)S.b * a.H * a.W * a.C0 + (S.aoffs[it * THREADS + tid] >> 2) + c0;
+        const size_t e = (size_t)S.b * a.H * a.W * a.C0 + ((aoffs0[it * THREADS + tid] + S.t0) >> 2) + c0;
         *reinterpret_cast<bf16x4*>(a.x0_bf16 + e) = hi;
       }
       if (a.x1_bf16 != nullptr && c0 >= a.C0 && interior) {            // source 1: its own (smaller, offset) geometry
-        const size_t e = (size_t)S.b * a.H1 * a.W1 * a.C1 + (S.aoffs[(A_F4 + it) * THREADS + tid] >> 2) + (c0 - a.C0);
+        const size_t e = (size_t)S.b * a.H1 * a.W1 * a.C1 + ((aoffs0[(A_F4 + it) * THREADS + tid] + S.t1) >> 2) + (c0 - a.C0);
         *reinterpret_cast<bf16x4*>(a.x1_bf16 + e) = hi;
       }
     }
@@ -1258,7 +1312,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (tap == 0) load_a(chunk_n);
+    if (tap == 0) load_a_pre(chunk_n);
+    if (tap == TAPS - 1) preload_offsets(chunk + 2 < nchunks ? chunk + 2 : chunk + 1 < nchunks ? chunk + 1 : chunk);   // what the next tap 0 requests
     read_x(fx0, nxt, ntap_off, 0);
     mfma_half(fx1, wq[tap % 3], 1);
     if constexpr (tap >= 2 && tap - 2 < A_F4) {
@@ -1293,16 +1348,20 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : 0;          // past the tile's last chunk: chunk 0 of the next tile (S is that tile by then)
     const char* cur = smem + (chunk & 1) * STAGE;
     const char* nxt = (tap == TAPS - 1) ? smem + ((chunk + 1) & 1) * STAGE : cur;
+    stamp(tap);
     if (tap == TAPS - 1) {
       __syncthreads();                                                 // the next stage is complete, this one is read out
       __builtin_amdgcn_sched_barrier(0);
+      stamp(9);
     }
-    if (tap == 0) load_a(chunk_n);
+    if (tap == 0) load_a_pre(chunk_n);
+    // what the next tap 0 requests: chunk + 2; from the tile's last-but-one chunk on, the next tile's chunk 0, then its chunk 1
+    if (tap == TAPS - 1) preload_offsets(chunk + 2 < nchunks ? chunk + 2 : chunk + 1 < nchunks ? 0 : 1 < nchunks ? 1 : 0);
     read_x(par ? fx0 : fx1, nxt, ntap_off, 0);
-    mfma_half(par ? fx1 : fx0, wq[tap % 3], 0);
-    load_w((tap + 2 >= TAPS) ? chunk_n : chunk, (tap + 2) % TAPS, std::integral_constant<int, (tap + 2) % 3>{});
+    if (!MFPA_EXP_FLAG(a.dbg, 8)) mfma_half(par ? fx1 : fx0, wq[tap % 3], 0);
+    if (!MFPA_EXP_FLAG(a.dbg, 128)) load_w((tap + 2 >= TAPS) ? chunk_n : chunk, (tap + 2) % TAPS, std::integral_constant<int, (tap + 2) % 3>{});
     if constexpr (tap >= 2 && tap - 2 < A_F4) {
-      split_slot(std::integral_constant<int, tap - 2>{}, chunk_n, smem + ((chunk + 1) & 1) * STAGE);
+      if (!MFPA_EXP_FLAG(a.dbg, 256)) split_slot(std::integral_constant<int, tap - 2>{}, chunk_n, smem + ((chunk + 1) & 1) * STAGE);
 #pragma unroll
       for (int i = 0; i < N_R; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1491,6 +1550,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     if constexpr (A_F4 > 3) split_slot(std::integral_constant<int, 3>{}, 0, smem);
     if constexpr (A_F4 > 4) split_slot(std::integral_constant<int, 4>{}, 0, smem);
     if constexpr (A_F4 > 5) split_slot(std::integral_constant<int, 5>{}, 0, smem);
+    preload_offsets(PERSIST ? (1 < nchunks ? 1 : 0) : (1 < nchunks ? 1 : 0));     // chunk 0's tap 0 requests chunk 1
   }
   auto epilogue = [&]() __attribute__((always_inline)) {
   // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
@@ -1573,7 +1633,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
             f32x4 o;
   #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
-            *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
+            if (MFPA_EXP_FLAG(a.dbg, 512)) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + ct * 64));
+            else if (!(MFPA_EXP_FLAG(a.dbg, 4) && v_never(o[0] + o[3]))) *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
           }
           if (SIDE && a.y_bf16 != nullptr) {
             __bf16* hp = a.y_bf16 + (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + n0 + wn * 32 + 4 * g;
@@ -1617,7 +1678,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         // fused OutConv 1x1 to one class (the whole C_out = 64 is in this workgroup): a lane's eight channels times their weights,
         // the four channel groups of a wave through two ds_bpermute butterflies, the two channel-tile waves through LDS; then one
         // pixel per thread, stored coalesced
-        float* red = reinterpret_cast<float*>(smem + 2 * STAGE + 2 * TBL * sizeof(unsigned)) + (a.in_scale0 ? 2 * a.C0 : 0);   // [2][256]
+        float* red = reinterpret_cast<float*>(smem + 2 * STAGE + TBL * sizeof(unsigned)) + (a.in_scale0 ? 2 * a.C0 : 0);   // [2][256]
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.w1x1 + wn * 32 + 4 * g);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x1 + wn * 32 + 16 + 4 * g);
   #pragma unroll
@@ -1657,12 +1718,11 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     epilogue();
   } else if constexpr (WMW == 4) {
     read_x(fx0, smem, 0, 0);
-    unsigned* const aoffs1 = aoffs0 + TBL;
     for (;;) {
       // the next tile of this workgroup (past the end: this tile again -- its first chunk is requested once more and never used)
       const int tile_n = tile + (int)gridDim.x;
       const bool has_next = tile_n < ntiles;
-      const Tile N = make_tile(has_next ? tile_n : tile, S.aoffs == aoffs0 ? aoffs1 : aoffs0);
+      const Tile N = make_tile(has_next ? tile_n : tile);
       for (int chunk = 0; chunk < nchunks; chunk += 2) {                 // nchunks is even (C_in % 64 == 0, checked by the dispatcher)
         tap_body4(std::integral_constant<int, 0>{}, S0{}, chunk);
         tap_body4(std::integral_constant<int, 1>{}, S0{}, chunk);
@@ -1684,7 +1744,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         tap_body4(std::integral_constant<int, 7>{}, S1{}, chunk + 1);
         tap_body4(std::integral_constant<int, 8>{}, S1{}, chunk + 1);
       }
-      epilogue();
+      stamp(10);
+      if (!(MFPA_EXP_FLAG(a.dbg, 32) && v_never(acc[0][0][0] + acc[1][PT - 1][3]))) epilogue();
+      stamp(11);
       if (!has_next) break;
       tile = tile_n; eb = S.b; ey0 = S.y0; ex0p = S.x0p;
 #pragma unroll
@@ -1692,6 +1754,12 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
+#ifdef MFPA_EXPERIMENTS
+    if (stamping) {
+      for (int i = 0; i < stamp_n; ++i) mfpa_conv_stamps[1 + i] = tsbuf[i];
+      mfpa_conv_stamps[0] = stamp_n;
+    }
+#endif
   } else {
   read_x(fx0, smem, 0, 0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -1719,15 +1787,23 @@ template <int PH, int PW, int WMW = 2>
 int launch_wd16(ConvArgs& a, hipStream_t s) {
   a.tiles_x = (a.W + PW - 1) / PW;
   a.tiles_y = (a.H + PH - 1) / PH;
+  static const int dbg_env = MFPA_EXP_ENV("MFPA_CONV_DBG", 0);         // experiments builds: 8 skip MFMAs, 32 skip the epilogue, 64 skip halo loads,
+  a.dbg = dbg_env;                                                     //   128 weight loads in the prologue only, 256 skip the halo split
+  static const int stagger_env = MFPA_EXP_ENV("MFPA_CONV_STAGGER", 0);
+  a.dbg_stagger = stagger_env;
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
   constexpr int HP = (PW + 2) * (PH + 2);
   constexpr int A_F4 = (HP * (KC / 4) + 511) / 512;
   constexpr int HPS = A_F4 * 64;
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
-  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)(WMW == 4 ? 2 : 1) * 2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
+  const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
                      (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0) +                                                       // + the on-load affine
                      (a.w1x1 ? (size_t)2 * 256 * sizeof(float) : 0);                                                              // + the fused OutConv's partial sums
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / (32 * (8 / WMW))));
+#ifdef MFPA_EXPERIMENTS
+  a.dbg_lds_stamps = (int)lds;
+  const_cast<size_t&>(lds) += 4096;
+#endif
   static const int persist_env = MFPA_EXP_ENV("MFPA_CONV_WD16_PERSIST", 1);      // experiments: 0 = one workgroup per tile
   if (WMW == 4 && persist_env) {                                       // persistent: one workgroup per CU (and output-channel tile) walks the tiles
     const int cus = mfpa_current_device_cus();
