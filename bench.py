@@ -736,6 +736,30 @@ def bench_infer(args, rank, world, dev, dist):
         out["roofline"] = roofline(timer, args.precision)
     if parity is not None:
         out["parity_in_run"] = parity
+    if net is None and args.picker == "audfprint":
+        # per-stage figures of the chain (outside the timed region; HIP events on the launch stream, 5 repetitions each): bytes the
+        # stage moves per clip / its time.
+        from musicfpaugment_amd import ops
+
+        def ev_time(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                r = fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3, r
+        t_stft, (mag, cmax) = ev_time(lambda: ops.stft_mag(wav, torch.float64))
+        a_dec = ops.audfprint_a_dec(hot.extractor.density, hot.extractor.n_hop)
+        t_pick, _ = ev_time(lambda: ops.audfprint_pick(mag, cmax, a_dec, hot.extractor.maxpksperframe, float(hot.extractor.f_sd)))
+        del mag
+        nF = 1 + CLIP_SAMPLES // 256
+        per = {"stft_kernel": (t_stft, 256000.0 + 257 * nF * 8.0),
+               "mfpa_audfprint_pick (memset + prep_sum_kernel + prune_kernel<fused filter>)": (t_pick, 257 * nF * 8.0 * 3 + 256 * nF * 2)}
+        out["kernel_breakdown"] = {k: {"us": round(t * 1e6, 1), "algorithmic_bytes_per_clip": int(by), "GB_per_s": round(by * B / t / 1e9, 1),
+                                       "frac_of_hbm_peak": round(by * B / t / 1e9 / 8000.0, 4)} for k, (t, by) in per.items()}
+        out["kernel_breakdown"]["note"] = ("bytes actually moved with the float64 intermediates of this chain (the spectrogram is written and read as float64: "
+                                           "the reference's dtype), per kernel; the chain-level `roofline` keeps SURVEY's 578 284 B / clip")
     if net is None:
         # fused STFT -> magnitude -> mask moves 578 284 algorithmic bytes per clip (256 000 B of samples in,
         # the float32 spectrogram out and back in, 64 256 B of mask out).  The chain is three short launches whose
@@ -794,6 +818,7 @@ def other_configs(args, dev):
     out = {}
     plan = [
         ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
+        ("config2_stft_peakpick_audfprint_8192", bench_infer, dict(no_unet=True, picker="audfprint", steps=5, warmup=2, clips=8192)),
         ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
         ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
         # BASELINE config 4 as worded: "AugmentFP synthetic noise + L1 loss + Adam" -- the AugmentFP chain runs on the device INSIDE

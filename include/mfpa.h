@@ -123,6 +123,17 @@ int mfpa_audfprint_prepare(const void* spec, int dtype, int B, int F, int T, con
 int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const double* gauss,
                          double a_dec, int maxpks, uint8_t* mask, int32_t* npeaks, void* stream);
 
+/* Stages 1 + 2 in one call for the un-denoised path, Audfprint_peaks.find_peaks(d) without a denoiser
+ * (afp/audfprint/peak_extractor.py:253-311): raw |STFT| + its per-clip maxima as mfpa_stft_mag returned them -> peak mask.
+ * Same arithmetic as mfpa_audfprint_prepare(denom = clip_max, mean_order = 1, log_input = 2) followed by
+ * mfpa_audfprint_prune, as two launches: the log values (frame-major) + the pairwise-tree node sums of np.mean, then a pruner
+ * that applies "- mean, lfilter" to the frames as it walks them -- the filtered spectrogram is never written.
+ *   spec (B, F, T) float64, 141 <= F = R + 1 <= 257, R % 4 == 0, T <= 512, R * T % 16 == 0 (the pruner zeroes the 16-byte aligned mask itself);  clip_max (B) float64
+ *   work (B * F * T + B * 128) float64 workspace;  gauss / a_dec / maxpks / mask / npeaks as for mfpa_audfprint_prune */
+int mfpa_audfprint_pick(const double* spec, const double* clip_max, int B, int F, int T, double pole,
+                        const double* gauss, double a_dec, int maxpks, double* work, uint8_t* mask,
+                        int32_t* npeaks, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Dejavu picker.  mfpa_dejavu_prepare: arr = scale*ln(max(a, max/1e6)) - mean with
  * a = psd / denom (fingerprint.py:68,78-79; scale = 10; mean_order as for mfpa_audfprint_prepare:

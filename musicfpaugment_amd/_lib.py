@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class MfpaError(RuntimeError):
@@ -40,6 +40,8 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_audfprint_prune": ([c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p,
                               c_void_p], c_int),
+    "mfpa_audfprint_pick": ([c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_double, c_int, c_void_p, c_void_p,
+                             c_void_p, c_void_p], c_int),
     "mfpa_dejavu_prepare": ([c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p], c_int),
     "mfpa_dejavu_prepare_f32": ([c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p], c_int),
     "mfpa_localmax2d": ([c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p], c_int),

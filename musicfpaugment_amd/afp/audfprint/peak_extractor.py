@@ -81,6 +81,9 @@ class Audfprint_peaks(object):
             spec = ops.normalize_(mag, cmax, per_clip=True)
             filtered = ops.audfprint_prepare(spec, None, mean_order=1)            # |stft| is a transposed view there
         else:
+            if mag.shape[2] <= 512 and (256 * mag.shape[2]) % 16 == 0:               # stages 1 + 2 fused: no filtered spectrogram in memory
+                mask, npeaks = ops.audfprint_pick(mag, cmax, a_dec, self.maxpksperframe, float(self.f_sd))
+                return mask, npeaks, None
             spec = None
             filtered = ops.audfprint_prepare(mag, cmax, mean_order=1, denom_is_clip_max=True)
         mask, npeaks = ops.audfprint_prune(filtered, a_dec, self.maxpksperframe, float(self.f_sd))

@@ -14,6 +14,7 @@
 //             per-frame top-k by wavefront arg-max (value desc, bin desc), columns prefetched
 //             4 frames ahead.  Latency-bound by design; parallelism comes from clips.
 #include "mfpa_common.h"
+#include "mfpa_fastlog.h"
 #include "mfpa_npsum.h"
 
 namespace {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
         TIn s = has_den ? (TIn)((double)v[u] / den) : v[u];
         if (do_log) {
           s = s > floor_v ? s : floor_v;
-          s = (TIn)log((double)s);
+          s = (TIn)mfpa_log((double)s);
         }
         L[i] = (double)s;
       }
@@ -169,6 +170,218 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------- prepare, low-latency split form
+// The same arithmetic as prepare_kernel<double> for the path whose per-clip maximum is already known (log_input bit 1: config 2's
+// STFT -> peak-pick chain), as TWO launches with 16 workgroups per clip instead of one 512-thread workgroup per clip walking three
+// passes with a global round trip of the log-spectrogram (176 us per 256 clips: a latency chain -- one workgroup per CU).
+//   prep_sum_kernel    : workgroup (clip, chunk, half) = one child of the root of one 8192-element chunk of numpy's pairwise tree
+//                        (memory order = mean_order): the log values of its <= 4096 elements go to LDS (read from `spec` along
+//                        the frames, whatever the order) and are summed in numpy's order; one double out.
+//   prep_filter_kernel : workgroup (clip, 16 bins): mean = sum of the chunk roots (left + right, chunk after chunk: numpy's order)
+//                        / N; log values (written by the first launch: a float64 log is ~150 instructions, recomputing them
+//                        doubled the launch pair's time) minus mean into an LDS tile [16 bins][T]; 16 lanes run the 1-pole filter
+//                        along the frames; the tile is written frame-major.
+constexpr int SPLIT_THREADS = 256;
+constexpr int SPLIT_BINS = 16;
+constexpr int SPLIT_MAX_T = 512;
+
+__device__ __forceinline__ double prep_log_value(double v, double den, bool do_log, double floor_v, const double (*tab)[3]) {
+  double s = v / den;
+  if (do_log) {
+    s = s > floor_v ? s : floor_v;
+    s = mfpa_log_t(s, tab);
+  }
+  return s;
+}
+
+// numpy pairwise sum of n <= 8192 doubles held in LDS (vals[0 .. n)); all threads call; heap: HEAP doubles of LDS
+__device__ __forceinline__ double lds_pairwise_sum(const double* vals, int n, double* heap, int tid, int nthreads) {
+  const int lane8 = tid & 7, grp = tid >> 3;
+  for (int id = 1 + grp; id < HEAP; id += nthreads / 8) {
+    const NodeInfo nd = pw_node(n, id);
+    if (!nd.exists || nd.n > PW_BLOCK) continue;
+    const double* a = vals + nd.off;
+    double res;
+    if (nd.n < 8) {
+      res = 0;
+      for (int i = 0; i < nd.n; ++i) res = res + a[i];
+    } else {
+      const int n8 = nd.n - (nd.n % 8);
+      double acc = a[lane8];
+      for (int j = 1; 8 * j < n8; ++j) acc = acc + a[8 * j + lane8];
+      res = group8_sum(acc);
+      for (int i = n8; i < nd.n; ++i) res = res + a[i];
+    }
+    if (lane8 == 0) heap[id] = res;
+  }
+  __syncthreads();
+  for (int d = 6; d >= 0; --d) {
+    for (int k = tid; k < (1 << d); k += nthreads) {
+      const int id = (1 << d) + k;
+      const NodeInfo nd = pw_node(n, id);
+      if (nd.exists && nd.n > PW_BLOCK) heap[id] = heap[2 * id] + heap[2 * id + 1];
+    }
+    __syncthreads();
+  }
+  return heap[1];
+}
+
+// fm = 0: log values to Lout bin-major (b, F, T) (row F - 1 not written); fm = 1 (mean_order 1 only): frame-major (b, T, F), i.e. in
+// numpy's memory order, written coalesced from LDS.  Node sums to sums_out[b * sum_stride + 2 * chunk + half].
+__global__ __launch_bounds__(SPLIT_THREADS) void prep_sum_kernel(const double* __restrict__ spec, int F, int T,
+                                                                 const double* __restrict__ denom, int mean_order,
+                                                                 double* __restrict__ Lout, int fm, double* __restrict__ sums_out,
+                                                                 long long sum_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* vals = reinterpret_cast<double*>(smem);              // [<= 4096 + 8]
+  double* heap = vals + NPY_BUFSIZE / 2 + 8;                   // [HEAP]
+  const int tid = threadIdx.x, b = blockIdx.x, c = blockIdx.y >> 1, half = blockIdx.y & 1;
+  const int N = F * T;
+  const int cn = min(NPY_BUFSIZE, N - c * NPY_BUFSIZE);
+  double* L = Lout + (size_t)b * N;
+  double* out = sums_out + (size_t)b * sum_stride + 2 * c + half;
+  // this workgroup's node of the chunk's tree: the chunk itself when it is a single leaf (then `half` 1 has nothing to do)
+  int off = 0, n = cn;
+  if (cn > PW_BLOCK) {
+    int n2 = cn / 2;
+    n2 -= n2 % 8;
+    off = half ? n2 : 0;
+    n = half ? cn - n2 : n2;
+  } else if (half) {
+    if (tid == 0) *out = 0.0;
+    return;
+  }
+  const double den = denom[b];
+  const double smax = den > 0.0 ? 1.0 : (double)NAN;          // prepare_kernel: denom[b] is this clip's own maximum
+  const bool do_log = smax > 0.0;
+  const double floor_v = smax / 1e6;
+  const double* x = spec + (size_t)b * N;
+  const int e0 = c * NPY_BUFSIZE + off;                        // first element (memory order) of the node
+  // the log table into LDS (three dependent-address global loads per logarithm would put a memory round trip into every call)
+  double (*tab)[3] = reinterpret_cast<double (*)[3]>(heap + HEAP);
+  for (int i = tid; i < 128 * 3; i += SPLIT_THREADS) (&tab[0][0])[i] = (&mfpa_log_tab[0][0])[i];
+  if (mean_order == 0) {
+    // memory order = the layout of `spec`: the node is one contiguous piece; eight independent loads in flight per thread
+    for (int i0 = tid; i0 < n; i0 += 8 * SPLIT_THREADS) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = i0 + u * SPLIT_THREADS < n ? x[e0 + i0 + u * SPLIT_THREADS] : 1.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * SPLIT_THREADS < n) vals[i0 + u * SPLIT_THREADS] = v[u];
+    }
+  } else {
+    // memory order e = t * F + f: the node covers frames t0 .. t1 (the first and the last partly, nt <= 32 of them).  Gather along the
+    // frames of `spec` (rows of nt doubles) into the node's own order in LDS: thread -> (bin f = idx >> 5, frame slot idx & 31), no
+    // division; lanes of one row write LDS with stride F doubles (odd: conflict-free)
+    const int t0 = e0 / F, t1 = (e0 + n - 1) / F, nt = t1 - t0 + 1;
+    const int tt = tid & 31, fs = tid >> 5;
+    if (nt > 32) return;                                       // (cannot happen: the launcher takes F >= 141 only)
+    for (int f0 = fs; f0 < F; f0 += 8 * (SPLIT_THREADS / 32)) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + u * (SPLIT_THREADS / 32);
+        v[u] = (f < F && tt < nt) ? x[(size_t)f * T + t0 + tt] : 1.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + u * (SPLIT_THREADS / 32);
+        const int e = (t0 + tt) * F + f - e0;
+        if (f < F && tt < nt && e >= 0 && e < n) vals[e] = v[u];
+      }
+    }
+  }
+  __syncthreads();                                             // raw values in memory order, the table in LDS
+  // s = x / max, floor, log: in the node's memory order (what the pairwise sum reads); written out bin-major (fm = 0) or, frame-major,
+  // as the contiguous piece of (T, F) the node is (fm = 1: coalesced)
+  for (int i = tid; i < n; i += SPLIT_THREADS) {
+    const double lv = prep_log_value(vals[i], den, do_log, floor_v, tab);
+    vals[i] = lv;
+    const int e = e0 + i;
+    if (fm) {
+      L[e] = lv;
+    } else {
+      const int a = mean_order == 0 ? e : (e % F) * T + e / F;
+      if (a < (F - 1) * T) L[a] = lv;                          // bin-major like `spec`; row F - 1 (the dropped Nyquist bin) holds the node sums
+    }
+  }
+  __syncthreads();
+  const double r = lds_pairwise_sum(vals, n, heap, tid, SPLIT_THREADS);
+  if (tid == 0) *out = r;
+}
+
+__global__ __launch_bounds__(SPLIT_THREADS) void prep_filter_kernel(const double* __restrict__ spec, int F, int T,
+                                                                    const double* __restrict__ denom,
+                                                                    const double* __restrict__ sums, double pole,
+                                                                    double* __restrict__ filtered) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tp = T | 1;                                        // odd row pitch: the 16 filter lanes hit 16 different bank pairs
+  double* tile = reinterpret_cast<double*>(smem);              // [SPLIT_BINS][Tp]
+  const int tid = threadIdx.x, b = blockIdx.x, r0 = blockIdx.y * SPLIT_BINS;
+  const int R = F - 1, N = F * T;
+  const int nb = min(SPLIT_BINS, R - r0);
+  const bool do_log = denom[b] > 0.0;                          // prepare_kernel: smax = denom / denom = 1 (NaN for an all-zero clip)
+  double mean = 0.0;
+  if (do_log) {                                                // np.mean: acc = 0; acc += pairwise(chunk) for every chunk; / N
+    const int nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
+    double total = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int cn = min(NPY_BUFSIZE, N - c * NPY_BUFSIZE);
+      const double* h = sums + (size_t)b * N + (size_t)(F - 1) * T + 2 * c;
+      total = total + (cn > PW_BLOCK ? h[0] + h[1] : h[0]);
+    }
+    mean = total / (double)N;
+  }
+  const double* x = sums + (size_t)b * N + (size_t)r0 * T;    // the log values of nb rows of T frames, contiguous
+  for (int i0 = tid; i0 < nb * T; i0 += 8 * SPLIT_THREADS) {  // eight independent loads in flight per thread
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * SPLIT_THREADS;
+      v[u] = i < nb * T ? x[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * SPLIT_THREADS;
+      if (i < nb * T) {
+        const int r = i / T, t = i - r * T;
+        tile[r * Tp + t] = v[u] - mean;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nb) {                                              // y[n] = x[n] + z; z = -x[n] - (-pole) * y[n]  (scipy lfilter, DF-II transposed)
+    double* row = tile + tid * Tp;
+    double z = 0.0;
+    const double npole = -pole;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {
+      double xs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xs[u] = row[t + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double yn = xs[u] + z;
+        z = -xs[u] - npole * yn;
+        row[t + u] = yn;
+      }
+    }
+    for (; t < T; ++t) {
+      const double xn = row[t];
+      const double yn = xn + z;
+      z = -xn - npole * yn;
+      row[t] = yn;
+    }
+  }
+  __syncthreads();
+  double* outp = filtered + (size_t)b * T * R + r0;
+  for (int i = tid; i < nb * T; i += SPLIT_THREADS) {
+    const int t = i / nb, r = i - t * nb;
+    outp[(size_t)t * R + r] = tile[r * Tp + t];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- prune
 constexpr int MAXP = 8;
 
@@ -226,9 +439,14 @@ __device__ __forceinline__ Best wave_best(Best x) {
 //     two-deep software pipeline: no LDS round trip on the critical path except the Gaussian row of a surviving peak); a frame's
 //     entries sit in lanes 0..7 and are visited with scalar broadcasts; the "delete the following peak in the same bin" rule
 //     compares against the previous frame's bins held in registers.
+// FUSED: `filtered` holds the LOG values frame-major with pitch R + 1 (prep_sum_kernel, fm = 1) and the kernel applies
+// "minus mean, 1-pole high-pass along the frames" itself while it walks the frames forward (state in registers, exactly prepare's
+// arithmetic) -- the filtered spectrogram never exists in memory and prep_filter_kernel's launch (75 us per 256 clips) is gone.
+template <bool FUSED>
 __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ filtered, int R, int T,
                                                    const double* __restrict__ gauss, double a_dec, int maxpks,
-                                                   uint8_t* __restrict__ mask, int32_t* __restrict__ npeaks) {
+                                                   uint8_t* __restrict__ mask, int32_t* __restrict__ npeaks,
+                                                   const double* __restrict__ node_sums, const double* __restrict__ denom, double pole) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int cap = T * maxpks;                                  // most peaks a clip can record
   double* G = reinterpret_cast<double*>(smem);                 // [2R+2]
@@ -237,18 +455,52 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   short* fs = reinterpret_cast<short*>(ep + cap);              // [T + 2] first entry of every frame, fs[T] = number of entries
 
   const int lane = threadIdx.x, b = blockIdx.x;
-  const double* S = filtered + (size_t)b * T * R;
+  const int P = FUSED ? R + 1 : R;                             // pitch of a frame
+  const double* S = filtered + (size_t)b * T * P;
   const int k0 = 4 * lane;
+  double mean = 0.0, zf[4] = {0.0, 0.0, 0.0, 0.0}, lastcol[4] = {0.0, 0.0, 0.0, 0.0};
+  const double npole = -pole;
+  if (FUSED && denom[b] > 0.0) {                               // np.mean: acc = 0; acc += pairwise(chunk) for every chunk; / N  (prep_filter_kernel)
+    const int N = (R + 1) * T, nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
+    double total = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int cn = min(NPY_BUFSIZE, N - c * NPY_BUFSIZE);
+      const double* h = node_sums + ((size_t)b * MAX_CHUNKS + c) * 2;
+      total = total + (cn > PW_BLOCK ? h[0] + h[1] : h[0]);
+    }
+    mean = total / (double)N;
+  }
+  // y[n] = x[n] + z; z = -x[n] - (-pole) * y[n] on this lane's four bins (scipy lfilter, DF-II transposed), x = log value - mean
+  auto filt = [&](double (&v)[4], double (&z)[4]) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const double xn = v[q4] - mean;
+      const double yn = xn + z[q4];
+      z[q4] = -xn - npole * yn;
+      v[q4] = yn;
+    }
+  };
   const bool own = k0 < R;  // R % 4 == 0: a lane owns 4 bins or none
 
   for (int i = lane; i < 2 * R + 1; i += 64) G[i] = gauss[i];
+  if (FUSED) {
+    // the clip's mask is zeroed here (the stores drain while the frames are scanned) instead of by a memset launch in front of the kernel;
+    // the launcher guarantees 16-byte pieces (R * T % 16 == 0, aligned base)
+    uint4* Z = reinterpret_cast<uint4*>(mask + (size_t)b * R * T);
+    for (int i = lane; i < R * T / 16; i += 64) Z[i] = uint4{0u, 0u, 0u, 0u};
+  }
   __syncthreads();
 
   auto load_col = [&](int c, double (&v)[4]) {
     if (own && c < T) {
-      const double2 a = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0);
-      const double2 d = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0 + 2);
-      v[0] = a.x; v[1] = a.y; v[2] = d.x; v[3] = d.y;
+      if (FUSED) {                                             // pitch R + 1 doubles: 8-byte aligned only
+        const double* q = S + (size_t)c * P + k0;
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+      } else {
+        const double2 a = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0);
+        const double2 d = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0 + 2);
+        v[0] = a.x; v[1] = a.y; v[2] = d.x; v[3] = d.y;
+      }
     } else {
       v[0] = v[1] = v[2] = v[3] = 0.0;
     }
@@ -306,9 +558,11 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   {
     double v10[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     const int n10 = T < 10 ? T : 10;
+    double z10[4] = {0.0, 0.0, 0.0, 0.0};                      // FUSED: the filter over the first frames, run again from zero by the main loop
     for (int c = 0; c < n10; ++c) {
       double v[4];
       load_col(c, v);
+      if (FUSED) filt(v, z10);
 #pragma unroll
       for (int s = 0; s < 4; ++s) v10[s] = v[s] > v10[s] ? v[s] : v10[s];
     }
@@ -324,6 +578,13 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
     for (int q = 0; q < 4; ++q) {
       const int c = c0 + q;
       if (c < T) {
+        if (FUSED) {
+          filt(cur[q], zf);
+          if (c == T - 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) lastcol[s] = cur[q][s];
+          }
+        }
         fs[c] = (short)ne;                                       // (uniform store, as in record)
         bool ex[4];
 #pragma unroll
@@ -381,7 +642,12 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   // ---- backward pass (peak_extractor.py:206-234)
   {
     double v[4];
-    load_col(T - 1, v);
+    if (FUSED) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = lastcol[s];
+    } else {
+      load_col(T - 1, v);
+    }
     spread_init(v);
   }
   // entries of a frame in lanes 0..7: (value, frame << 8 | bin, entry index); -1 bin = none / pruned
@@ -427,7 +693,8 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   }
   __syncthreads();
 
-  // ---- emit: mask (R, T) uint8 was zeroed by the host-side memset on the same stream
+  // ---- emit: mask (R, T) uint8 was zeroed by the host-side memset on the same stream (FUSED: by this wave, above: fence first)
+  if (FUSED) __threadfence();
   uint8_t* M = mask + (size_t)b * R * T;
   int count = 0;
   for (int e = lane; e < ne; e += 64) {
@@ -458,6 +725,18 @@ int mfpa_audfprint_prepare(const void* spec, int dtype, int B, int F, int T, con
   const int nchunks = (int)((N + NPY_BUFSIZE - 1) / NPY_BUFSIZE);
   const size_t lds = sizeof(double) * ((size_t)R * (TT + 1) + (size_t)TT * R) + sizeof(double) * (size_t)nchunks * HEAP;
   hipStream_t s = mfpa_stream(stream);
+  if (dtype == MFPA_F64 && log_input == 2 && denom != nullptr && T <= SPLIT_MAX_T && T >= 2 * nchunks && F <= 257 && F >= 141) {
+    // the per-clip maximum is known: the low-latency split form (16 workgroups per clip, two launches; `scratch` holds the chunk sums)
+    const size_t lds1 = sizeof(double) * (NPY_BUFSIZE / 2 + 8 + HEAP + 128 * 3);
+    hipLaunchKernelGGL(prep_sum_kernel, dim3(B, 2 * nchunks), dim3(SPLIT_THREADS), lds1, s, (const double*)spec, F, T, denom, mean_order, scratch, 0,
+                       scratch + (size_t)(F - 1) * T, (long long)N);        // row F - 1 of the bin-major log values is never read back: its T >= 2 * nchunks doubles hold the node sums
+    MFPA_CHECK_LAUNCH();
+    const size_t lds2 = sizeof(double) * (size_t)SPLIT_BINS * (T | 1);
+    hipLaunchKernelGGL(prep_filter_kernel, dim3(B, (R + SPLIT_BINS - 1) / SPLIT_BINS), dim3(SPLIT_THREADS), lds2, s, (const double*)spec, F, T, denom,
+                       scratch, pole, filtered);
+    MFPA_CHECK_LAUNCH();
+    return MFPA_OK;
+  }
   if (dtype == MFPA_F64)
     hipLaunchKernelGGL(prepare_kernel<double>, dim3(B), dim3(PREP_THREADS), lds, s, (const double*)spec, F, T, denom,
                        mean_order, log_input, pole, filtered, scratch);
@@ -476,7 +755,29 @@ int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const doub
   hipStream_t s = mfpa_stream(stream);
   MFPA_HIP(hipMemsetAsync(mask, 0, (size_t)B * R * T, s));
   const size_t lds = sizeof(double) * (2 * R + 2) + (size_t)T * maxpks * (sizeof(double) + sizeof(int)) + sizeof(short) * (T + 2);
-  hipLaunchKernelGGL(prune_kernel, dim3(B), dim3(64), lds, s, filtered, R, T, gauss, a_dec, maxpks, mask, npeaks);
+  hipLaunchKernelGGL(prune_kernel<false>, dim3(B), dim3(64), lds, s, filtered, R, T, gauss, a_dec, maxpks, mask, npeaks, (const double*)nullptr,
+                     (const double*)nullptr, 0.0);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_audfprint_pick(const double* spec, const double* clip_max, int B, int F, int T, double pole, const double* gauss, double a_dec,
+                        int maxpks, double* work, uint8_t* mask, int32_t* npeaks, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!spec || !clip_max || !gauss || !work || !mask || !npeaks || B < 0) return MFPA_EINVAL;
+  const int R = F - 1;
+  if (F < 141 || F > 257 || (R % 4) != 0 || T < 1 || T > SPLIT_MAX_T || maxpks < 1 || maxpks > MAXP) return MFPA_EINVAL;   // (a half-chunk node spans <= 32 frames)
+  const long long N = (long long)F * T;
+  const int nchunks = (int)((N + NPY_BUFSIZE - 1) / NPY_BUFSIZE);
+  if (nchunks > MAX_CHUNKS) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  if (((size_t)R * T) % 16 != 0 || (reinterpret_cast<uintptr_t>(mask) & 15) != 0) return MFPA_EINVAL;   // the pruner zeroes the mask in 16-byte pieces
+  double* sums = work + (size_t)B * N;
+  const size_t lds1 = sizeof(double) * (NPY_BUFSIZE / 2 + 8 + HEAP + 128 * 3);
+  hipLaunchKernelGGL(prep_sum_kernel, dim3(B, 2 * nchunks), dim3(SPLIT_THREADS), lds1, s, spec, F, T, clip_max, 1, work, 1, sums, (long long)(2 * MAX_CHUNKS));
+  MFPA_CHECK_LAUNCH();
+  const size_t lds = sizeof(double) * (2 * R + 2) + (size_t)T * maxpks * (sizeof(double) + sizeof(int)) + sizeof(short) * (T + 2);
+  hipLaunchKernelGGL(prune_kernel<true>, dim3(B), dim3(64), lds, s, (const double*)work, R, T, gauss, a_dec, maxpks, mask, npeaks, (const double*)sums, clip_max, pole);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

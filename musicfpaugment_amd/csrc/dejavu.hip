@@ -12,6 +12,7 @@
 // for the erosion), then runs the separable row pass and column pass out of LDS.
 // Compiled with -ffp-contract=off (the pre-processing feeds exact comparisons).
 #include "mfpa_common.h"
+#include "mfpa_fastlog.h"
 #include "mfpa_npsum.h"
 
 namespace {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn*
       if (i0 + u * PREP_THREADS < N) {
         TIn s = value(v[u]);
         s = s > floor_v ? s : floor_v;
-        L[i0 + u * PREP_THREADS] = (double)(sc * (TIn)log((double)s));   // float32: the float64 log rounded once (as audfprint.hip)
+        L[i0 + u * PREP_THREADS] = (double)(sc * (TIn)mfpa_log((double)s));   // float32: the float64 log rounded once (as audfprint.hip)
       }
   }
   __syncthreads();

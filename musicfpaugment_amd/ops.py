@@ -193,6 +193,32 @@ def audfprint_prune(filtered: torch.Tensor, a_dec: Optional[float] = None, maxpk
     return mask, npeaks
 
 
+def audfprint_pick(mag: torch.Tensor, clip_max: torch.Tensor, a_dec: Optional[float] = None, maxpks: int = AUDFPRINT_MAX_PKS,
+                   f_sd: float = AUDFPRINT_F_SD, pole: float = AUDFPRINT_POLE):
+    """find_peaks without a denoiser, stages 1 + 2 in one call (mfpa_audfprint_pick): raw float64 |STFT| (B, F, T) and its per-clip
+    maxima (what stft_mag returned) -> (mask (B, F-1, T) uint8, npeaks (B,) int32).  Same arithmetic as
+    audfprint_prepare(mag, clip_max, mean_order=1, denom_is_clip_max=True) + audfprint_prune; the filtered spectrogram is never
+    written (the pruner filters the frames as it walks them)."""
+    require_gpu(mag, "spectrogram")
+    if mag.dim() != 3 or mag.dtype != torch.float64:
+        raise ValueError("spectrogram must be (B, F, T) float64")
+    mag = mag.contiguous()
+    B, F, T = mag.shape
+    if clip_max.shape != (B,) or clip_max.dtype != torch.float64:
+        raise ValueError("clip_max must be (B,) float64")
+    if F < 141 or F > 257 or (F - 1) % 4 or T < 1 or T > 512 or ((F - 1) * T) % 16 or not (1 <= maxpks <= 8):
+        raise ValueError("unsupported shape for the fused picker (141 <= F <= 257, (F - 1) % 4 == 0, T <= 512, maxpks <= 8)")
+    if a_dec is None:
+        a_dec = audfprint_a_dec()
+    gauss = gauss_table(F - 1, f_sd, mag.device)
+    work = torch.empty(B * F * T + B * 128, dtype=torch.float64, device=mag.device)
+    mask = torch.empty((B, F - 1, T), dtype=torch.uint8, device=mag.device)
+    npeaks = torch.empty((B,), dtype=torch.int32, device=mag.device)
+    check(lib().mfpa_audfprint_pick(ptr(mag), ptr(clip_max), B, F, T, float(pole), ptr(gauss), float(a_dec), int(maxpks), ptr(work),
+                                    ptr(mask), ptr(npeaks), stream()), "mfpa_audfprint_pick")
+    return mask, npeaks
+
+
 # ----------------------------------------------------------------------------- Dejavu picker
 DEJAVU_RADIUS = 10   # afp/dejavu/variables.py:19 PEAK_NEIGHBORHOOD_SIZE
 DEJAVU_AMP_MIN = 50  # testing/parameters.py:32

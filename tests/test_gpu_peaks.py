@@ -386,3 +386,27 @@ def test_masks_only_path_equals_the_full_path_bit_for_bit(ops):
         assert none is None and spec is not None
         assert torch.equal(m0, m1) and torch.equal(n0, n1)
         assert int(n0[2]) == 0
+
+
+def test_fused_pick_equals_prepare_plus_prune_bit_for_bit():
+    """mfpa_audfprint_pick (log values frame-major + np.mean's node sums, then a pruner that applies "- mean, lfilter" to the frames as it
+    walks them) against the two-stage path it replaces, mfpa_audfprint_prepare(denom = clip_max, mean_order = 1, log_input = 2) +
+    mfpa_audfprint_prune: identical masks and counts, for full clips, short / ragged frame counts (partial pairwise-tree chunks, fewer
+    than ten frames), tonal and noise clips, a silent and a half-silent clip; and against the oracle's find_peaks."""
+    from musicfpaugment_amd import ops
+    from oracle import audfprint as oa
+    for n, B in ((64000, 12), (24000, 5), (2304, 3), (8000 + 77, 4), (130560, 2)):
+        wav = np.stack([synth.clip(700 + i, n=n, tonal=(i % 3 != 1)) for i in range(B)])
+        if B > 3:
+            wav[1] = 0.0
+            wav[2, : n // 2] = 0.0
+        x = torch.from_numpy(wav).cuda()
+        mag, cmax = ops.stft_mag(x, torch.float64)
+        a_dec = ops.audfprint_a_dec()
+        filt = ops.audfprint_prepare(mag, cmax, mean_order=1, denom_is_clip_max=True)
+        want_mask, want_n = ops.audfprint_prune(filt, a_dec)
+        got_mask, got_n = ops.audfprint_pick(mag, cmax, a_dec)
+        assert torch.equal(got_mask, want_mask) and torch.equal(got_n, want_n), (n, B)
+        for i in (0, B - 1):
+            ref = oa.find_peaks(wav[i])[1]
+            np.testing.assert_array_equal(got_mask[i].cpu().numpy(), np.asarray(ref).astype(np.uint8) if np.size(ref) else 0)
