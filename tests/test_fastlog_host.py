@@ -73,7 +73,7 @@ def test_fast_log_is_within_0_55_ulp_and_matches_numpy_like_glibc_does(lib):
         d = y != ref
         # numpy's own log is not correctly rounded either (0.03 % of the pipeline's range, ~2 % of the arguments within 12 % of 1, where
         # this function returns the correctly rounded value for 99.4 %)
-        assert d.mean() < (3e-2 if name == "near 1" else 2e-3), (name, d.mean())
+        assert d.mean() < (3e-2 if name == "near 1" else 1e-3 if name.startswith("pipeline") else 8e-3), (name, d.mean())
         if d.any():
             assert np.max(np.abs(y[d] - ref[d]) / np.spacing(np.abs(ref[d]))) <= 1.0
     # exact and special values
