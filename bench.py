@@ -500,7 +500,7 @@ def bench_train(args, rank, world, dev, dist):
     net.load_state_dict(formula_state_dict(0))
     net = net.to(dev).train()
     wprec = {"fp32": 0, "bf16x3": 1, "bf16": 2}[args.wgrad]
-    eng = UNetTrainEngine(net, lr=1e-3, precision=1 if args.precision == "bf16x3" else 0, wgrad_precision=wprec,
+    eng = UNetTrainEngine(net, lr=1e-3, precision={"fp32": 0, "bf16x3": 1, "bf16": 2}[args.precision], wgrad_precision=wprec,
                           sync_bn=args.sync_bn, collectives_at_world_one=dist is not None)
     nsamp = int(args.seconds * 8000)
     base = synth.batch(min(B, 16), seed=synth.BASE_SEED + 1000 * rank, n=nsamp)
@@ -565,7 +565,7 @@ def bench_train(args, rank, world, dev, dist):
         mfma_gflop = (280.1 - 3 * 0.082) * (1 + nsamp // 256) / 251.0   # fwd + dgrad + wgrad, minus the 1-channel first layer / outc (VALU); scales with the frames
         conv_ms = timer.total_ms()
         achieved = mfma_gflop * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12
-        issue_x = 2.0 + {"bf16x3": 3, "bf16": 1, "fp32": 0}[args.wgrad] / 3.0      # fp32 weight gradients run on the fp32 cores
+        issue_x = (2.0 if args.precision != "bf16" else 2.0 / 3.0) + {"bf16x3": 3, "bf16": 1, "fp32": 0}[args.wgrad] / 3.0      # fp32 weight gradients run on the fp32 cores
         result = ({**(rep or {}),
             "metric": f"{args.seconds:g}s/8kHz clips/sec (UNet train step: 2xSTFT + fwd + L1 + bwd + Adam)",
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
@@ -573,7 +573,9 @@ def bench_train(args, rank, world, dev, dist):
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": (f"bf16x3 forward and input-gradient convolutions (fp32 operands split into bf16 hi+lo, fp32 accumulate), "
                       f"{args.wgrad} weight gradients, fp32/fp64 reductions and Adam") if args.precision == "bf16x3"
-                     else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
+                     else (f"bf16 (plain bf16 products, fp32 accumulate: one MFMA per product in the 3x3 forward / input-gradient convolutions and "
+                           f"the {args.wgrad} weight gradients; the four transposed convolutions bf16x3; fp32 activations in HBM, fp32/fp64 reductions and Adam)")
+                     if args.precision == "bf16" else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), {args.seconds:g} s clips 257x{1 + nsamp // 256}, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "loss_last": float(loss),
@@ -588,7 +590,7 @@ def bench_train(args, rank, world, dev, dist):
                           "mfma_flops_issued_per_algorithmic_flop": round(issue_x, 3),
                           "mfma_issue_frac": round(issue_x * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                           "kernel": f"conv_wd16_kernel / conv_mfma_kernel<PREC 1> + wgrad_bf16_kernel / wgrad_bf16x3_kernel ({args.wgrad} products)", "launches": timer.launches(),
-                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)} if args.precision == "bf16x3" else
+                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)} if args.precision in ("bf16x3", "bf16") else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           "kernel": "conv_mfma_kernel<PREC 0> + wgrad_mfma_kernel", "launches": timer.launches(),
@@ -823,8 +825,12 @@ def other_configs(args, dev):
         ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
         # BASELINE config 4 as worded: "AugmentFP synthetic noise + L1 loss + Adam" -- the AugmentFP chain runs on the device INSIDE
         # every timed step; the same step on pre-mixed noisy clips is kept beside it
-        ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True)),
-        ("config4_unet_train_step_premixed", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=False)),
+        # every time; arithmetic as BASELINE words it, "bf16 MFMA": plain bf16 products (one MFMA per product) in the 3x3 forward /
+        # input-gradient convolutions and the weight gradients.  Beside it: the same step with bf16x3 products (fp32-accurate: the
+        # arithmetic rounds 1-3 benched), and that one on pre-mixed noisy clips (round 3's figure)
+        ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True, precision="bf16", wgrad="bf16")),
+        ("config4_unet_train_step_bf16x3", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True, precision="bf16x3", wgrad="bf16")),
+        ("config4_unet_train_step_bf16x3_premixed", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=False, precision="bf16x3", wgrad="bf16")),
         ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=10, warmup=3, clips=256)),
         # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
         # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
@@ -863,9 +869,9 @@ def dist_configs(args, rank, world, dev, dist):
     import gc
     out = {}
     plan = [("config4_unet_train_step", dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_train_clips,
-                                             seconds=args.dist_train_seconds, augment=True, scaling="weak")),
+                                             seconds=args.dist_train_seconds, augment=True, scaling="weak", precision="bf16", wgrad="bf16")),
             ("config4_unet_train_step_strong", dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_strong_global,
-                                                    seconds=args.dist_train_seconds, augment=True, scaling="strong"))]
+                                                    seconds=args.dist_train_seconds, augment=True, scaling="strong", precision="bf16", wgrad="bf16"))]
     for name, kw in plan:
         per_rank = kw["clips"] if kw["scaling"] == "weak" else kw["clips"] // world
         if per_rank > MAX_TRAIN_CLIPS_PER_PASS or per_rank < 1:
@@ -934,7 +940,7 @@ def main():
     ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
     ap.add_argument("--picker", choices=["audfprint", "dejavu"], default="audfprint",
                     help="infer mode: the peak picker after the UNet (dejavu: specgram PSD, UNet output squared, 21x21 local maxima)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default=None,
+    ap.add_argument("--precision", choices=["bf16x3", "fp32", "bf16"], default=None,
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
@@ -971,8 +977,11 @@ def main():
         ops_unet.USE_WEIGHTS_DIRECT = False
     if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
         args.precision = "bf16x3"
+    if args.precision == "bf16" and args.mode != "train":
+        raise SystemExit("--precision bf16 (plain bf16 products) is the UNet TRAINING step's arithmetic (BASELINE config 4); the inference "
+                         "chain's 1e-4 gate needs bf16x3 or fp32")
     if args.wgrad is None:
-        args.wgrad = "bf16" if args.precision == "bf16x3" else "fp32"
+        args.wgrad = "bf16" if args.precision in ("bf16x3", "bf16") else "fp32"
     if args.clips is None:
         args.clips = 64 if args.mode in ("train", "demucs-train") else 256
 

@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MFPA_EPI_LDS
+#define MFPA_EPI_LDS 1        // conv_wd16_kernel: the epilogue's per-channel constants from an LDS copy (0: global loads inside the epilogue, A/B builds)
+#endif
 #ifndef MFPA_CONV_PIPE
 #define MFPA_CONV_PIPE 1      // 0: the round-1 main loop for the bf16x3 3x3 convolution too (A/B builds of tools/)
 #endif
@@ -140,6 +143,7 @@ struct ConvArgs {
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
   int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
+  int plain;                         // conv_wd16_kernel: plain bf16 products (hi halves only: mfpa_conv_desc.precision 2, the training step)
   __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
   __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)
   __bf16* y_bf16;                    // ... of the stored output, (B,yH,yW,Cout)
@@ -1045,8 +1049,12 @@ __device__ __forceinline__ float dpp_row_add(float v) {               // v + (v 
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false>
+template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false, bool PLAIN = false>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
+  // PLAIN: plain bf16 products -- one MFMA per product on the hi halves only (the lo planes, their fragment reads, the lo weight
+  // fragments and two of the three MFMA terms are gone): the training step's "bf16 MFMA" arithmetic (BASELINE config 4), relative
+  // error ~2^-9 per product instead of bf16x3's 2^-17.  Never used by the inference chain (its 1e-4 gate needs bf16x3).
+  static_assert(!(PLAIN && ROWS), "the plain-bf16 form uses the tap-by-tap loops");
   // SIDE: the training step's side outputs (x0_bf16 / x1_bf16 / y_bf16 / stats_part) -- their own instantiations, so that the inference
   // kernels carry none of their code (it cost the 128-channel form 9 registers and 18 spills)
   // WMW = 2: 2 x 4 waves of 128 px x 32 ch (128-channel output tiles); WMW = 4: 4 x 2 waves of 64 px x 32 ch (the 64-channel layers)
@@ -1153,6 +1161,16 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     }
     __syncthreads();
   }
+  // the epilogue's per-channel constants (output affine of this workgroup's BN channels, the fused OutConv's weights) into LDS, once per
+  // kernel: as global loads inside the epilogue they were followed by s_waitcnt vmcnt(0) -- which also waits for every halo and weight
+  // load already in flight for the NEXT tile (persistent form) and for the epilogue's own stores of the previous one
+  float* const epi = aff + (a.in_scale0 ? 2 * a.C0 : 0) + (a.w1x1 ? 2 * 256 : 0);      // [scale BN | shift BN | w1x1 64]
+  for (int i = tid; i < BN; i += THREADS) {
+    epi[i] = a.scale ? a.scale[n0 + i] : 1.f;
+    epi[BN + i] = a.shift ? a.shift[n0 + i] : 0.f;
+  }
+  if (a.w1x1 != nullptr && tid < 64) epi[2 * BN + tid] = a.w1x1[tid];
+  // (first read in the first epilogue, behind at least one of the main loop's barriers)
   // ROWS: the staging slots are requested in two halves (slots 0..2 in period 0, 3..5 in period 1) that share three registers
   constexpr int AHALF = (A_F4 + 1) / 2, AREGS = ROWS ? AHALF : A_F4;
   f32x4 areg[AREGS];
@@ -1220,7 +1238,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     }
     char* at = stage + plane_off(0, aq >> 1) + pix * 16 + 8 * (aq & 1);
     *reinterpret_cast<bf16x4*>(at) = hi;
-    *reinterpret_cast<bf16x4*>(at + HLS) = lo;
+    if constexpr (!PLAIN) *reinterpret_cast<bf16x4*>(at + HLS) = lo;
     // training forward: the bf16 copy of the activated source 0 the weight gradient reads -- the hi half is exactly that.  Every pixel
     // is interior (not halo) to one tile; the first output-channel tile writes it.
     if constexpr (SIDE) {
@@ -1246,9 +1264,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     const char* wb = reinterpret_cast<const char*>(a.w) +
                      ((((size_t)tap * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
     wq[slot][0][0] = *reinterpret_cast<const bf16x8*>(wb);
-    wq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+    if constexpr (!PLAIN) wq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
     wq[slot][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
-    wq[slot][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+    if constexpr (!PLAIN) wq[slot][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
   };
 
   // ---- pixel fragments: two sets of four 16-pixel tiles (hi, lo)
@@ -1262,7 +1280,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const char* r = stage + xbase + tile_disp(4 * half + i) + tap_off;
-      f.l[i] = *reinterpret_cast<const bf16x8*>(r + HLS);
+      if constexpr (!PLAIN) f.l[i] = *reinterpret_cast<const bf16x8*>(r + HLS);
       f.h[i] = *reinterpret_cast<const bf16x8*>(r);
     }
   };
@@ -1273,6 +1291,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
   auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half) __attribute__((always_inline)) {
     // term-major: an accumulator is touched every eighth instruction
+    if constexpr (!PLAIN) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1281,6 +1300,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.l[i], acc[ct][4 * half + i], 0, 0, 0);
+    }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1288,7 +1308,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  constexpr int N_R = 8, N_M = 24;                                     // fragment reads / MFMAs of one phase
+  constexpr int N_R = PLAIN ? 4 : 8, N_M = PLAIN ? 8 : 24;             // fragment reads / MFMAs of one phase
+  constexpr int N_W = PLAIN ? 2 : 4;                                   // weight-fragment loads of one tap
   // One tap.  Phase A: MFMA(pixel tiles 0..3 of tap t) || read tiles 4..7 of tap t, request the weights of tap t + 2.  Phase B: MFMA(tiles
   // 4..7) || read tiles 0..3 of tap t + 1, (tap 0) request the next chunk's halo, (taps 2..7) split one staging slot of it.  The chunk's
   // one barrier sits between the phases of tap 8 (see BDIR).
@@ -1305,7 +1326,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     pin_reads<N_M - 1, N_R>();
     constexpr int used_a = pin_read_slots(N_M - 1, N_R);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, N_W, 0);
     if constexpr (N_M - used_a - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - used_a - 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (tap == TAPS - 1) {
@@ -1330,7 +1351,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 4, 0);
+      if constexpr (N_M - N_R - 4 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 4, 0);
     } else {
       pin_reads<N_M, N_R>();
       if constexpr (N_M - pin_read_slots(N_M, N_R) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_R), 0);
@@ -1369,8 +1390,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      for (int i = 0; i < N_W; ++i) {
+        if constexpr (!PLAIN) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
@@ -1380,7 +1401,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 8, 0);
+      if constexpr (N_M - N_R - 8 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 8, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < N_R; ++i) {
@@ -1388,11 +1409,11 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < N_W; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - 4, 0);
+      if constexpr (N_M - N_R - N_W > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_R - N_W, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1556,9 +1577,14 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
   #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const int ch = n0 + wn * 32 + ct * 16 + 4 * g;
-      const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
-      const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4*>(a.shift + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int chl = wn * 32 + ct * 16 + 4 * g;                       // channel inside the workgroup's BN
+#if MFPA_EPI_LDS
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(epi + chl);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(epi + BN + chl);
+#else
+      const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + n0 + chl) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4*>(a.shift + n0 + chl) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
   #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
   #pragma unroll
@@ -1679,8 +1705,13 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         // the four channel groups of a wave through two ds_bpermute butterflies, the two channel-tile waves through LDS; then one
         // pixel per thread, stored coalesced
         float* red = reinterpret_cast<float*>(smem + 2 * STAGE + TBL * sizeof(unsigned)) + (a.in_scale0 ? 2 * a.C0 : 0);   // [2][256]
+#if MFPA_EPI_LDS
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(epi + 2 * BN + wn * 32 + 4 * g);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(epi + 2 * BN + wn * 32 + 16 + 4 * g);
+#else
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.w1x1 + wn * 32 + 4 * g);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.w1x1 + wn * 32 + 16 + 4 * g);
+#endif
   #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           float v = 0.f;
@@ -1798,7 +1829,8 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;
   const size_t lds = 2 * (size_t)(2 * (4 * PLANE + 256)) + (size_t)2 * A_F4 * 512 * sizeof(unsigned) +     // two halo stages + the slot offsets
                      (a.in_scale0 ? (size_t)2 * a.C0 * sizeof(float) : 0) +                                                       // + the on-load affine
-                     (a.w1x1 ? (size_t)2 * 256 * sizeof(float) : 0);                                                              // + the fused OutConv's partial sums
+                     (a.w1x1 ? (size_t)2 * 256 * sizeof(float) : 0) +                                                             // + the fused OutConv's partial sums
+                     (size_t)(2 * 32 * (8 / WMW) + 64) * sizeof(float);                                                           // + the epilogue's constants
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / (32 * (8 / WMW))));
 #ifdef MFPA_EXPERIMENTS
   a.dbg_lds_stamps = (int)lds;
@@ -1819,8 +1851,14 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   const bool rows = WMW == 2 && rows_min > 0 && cin % 64 == 0 && cin >= rows_min;
   if constexpr (WMW == 4) {
     if (cin % 64) return MFPA_EINVAL;
-    if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true>), grid, dim3(512), lds, s, a);
+    if (a.plain) {
+      if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true>), grid, dim3(512), lds, s, a);
+      else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, false, true>), grid, dim3(512), lds, s, a);
+    } else if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, false>), grid, dim3(512), lds, s, a);
+  } else if (a.plain) {
+    if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, true, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, false, true>), grid, dim3(512), lds, s, a);
   } else if (rows) {
     if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, false>), grid, dim3(512), lds, s, a);
@@ -2318,10 +2356,12 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
     a.c1_x32 = d->c1_x32; a.c1_spec64 = d->c1_spec64; a.c1_denom = d->c1_spec64 ? d->c1_denom : nullptr;
     a.c1_w = d->c1_w; a.c1_scale = d->c1_scale; a.c1_shift = d->c1_shift;
   }
-  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
+  if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
   if (d->w_layout < 0 || d->w_layout > 2) return MFPA_EINVAL;
-  if (d->w_layout != 0 && (d->mode != 0 || d->precision != 1)) return MFPA_EINVAL;
+  if (d->w_layout != 0 && (d->mode != 0 || d->precision < 1)) return MFPA_EINVAL;
+  if (d->precision == 2 && d->w_layout != 2) return MFPA_EINVAL;         // plain bf16: conv_wd16_kernel only (it reads the hi halves of the same image)
   a.w_frag = d->w_layout;
+  a.plain = d->precision == 2;
   if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision == 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
   if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
   if (d->y_bf16 != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;
@@ -2333,9 +2373,10 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->bwd_z != nullptr && (!d->stats_part || !d->bwd_scale || !d->bwd_shift || !d->bwd_mean || !d->bwd_invstd)) return MFPA_EINVAL;
   a.bz = d->bwd_z; a.bz_scale = d->bwd_scale; a.bz_shift = d->bwd_shift; a.bz_mean = d->bwd_mean; a.bz_invstd = d->bwd_invstd;
   hipStream_t s = mfpa_stream(stream);
-  if (d->mode == 0) return dispatch_conv<0>(a, s, d->precision);
-  if (d->mode == 1) return dispatch_conv<1>(a, s, d->precision);
-  return dispatch_conv<2>(a, s, d->precision);
+  const int prec = d->precision ? 1 : 0;                                 // kernel family: fp32 MFMA or the bf16 matrix cores
+  if (d->mode == 0) return dispatch_conv<0>(a, s, prec);
+  if (d->mode == 1) return dispatch_conv<1>(a, s, prec);
+  return dispatch_conv<2>(a, s, prec);
 }
 
 #ifdef MFPA_EXPERIMENTS

@@ -67,11 +67,11 @@ def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, 
             w = (w.flip(0) if taps == 9 else w).transpose(1, 2)[:, row0:row0 + nrows].contiguous()
         else:
             w = w[:, row0:row0 + nrows].contiguous()
-        if precision != 1:
+        if precision < 1:
             return w
         return K.split_bf16x3_frag(w, layout) if layout else K.split_bf16x3(w)
     out = torch.empty((taps, nrows, Co if flip_transpose else Ci), dtype=torch.float32, device=w.device)
-    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, (1 + layout) if precision == 1 else precision,
+    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, (1 + layout) if precision >= 1 else precision,
                                        ptr(out), stream()), "mfpa_pack_conv_weights")
     return out
 
@@ -79,7 +79,7 @@ def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, 
 def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int = 0) -> int:
     """Which bf16x3 image the fastest kernel for this convolution reads (mfpa_conv_weight_layout): 0 = the row image, 1 / 2 = the
     fragment-ordered images of the weights-direct kernels."""
-    if precision != 1 or mode != 0 or not K.USE_WEIGHTS_DIRECT:
+    if precision < 1 or mode != 0 or not K.USE_WEIGHTS_DIRECT:
         return 0
     return int(lib().mfpa_conv_weight_layout(H, W, cin, cout, 0, 1))
 
@@ -102,6 +102,9 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
         H, W = x0.shape[1], x0.shape[2]
     C0 = x0.shape[3]
     C1 = 0 if x1 is None else x1.shape[3]
+    # precision 2 = plain bf16 products where conv_wd16_kernel serves the shape (it reads the hi halves of the bf16x3 image); every
+    # other kernel of the family (transposed convolutions, the fall-back shapes) stays on bf16x3
+    plain, precision = precision == 2, min(precision, 1)
     if precision == 1 and not packed:
         w_layout = weight_layout(H, W, C0 + C1, Cout, precision, mode)
         if DEVICE_PACK and w.is_contiguous() and w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0:
@@ -136,7 +139,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2], precision=precision, w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part),
+                 drop_scale=_drop(in_affine)[2], precision=2 if (plain and w_layout == 2 and mode == 0) else precision, w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part),
                  bwd_z=ptr(bwd_of[0]) if (bwd_of and part is not None) else 0,
                  bwd_scale=ptr(bwd_of[1].scale) if (bwd_of and part is not None) else 0,
                  bwd_shift=ptr(bwd_of[1].shift) if (bwd_of and part is not None) else 0,

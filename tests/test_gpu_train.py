@@ -511,3 +511,65 @@ def test_device_weight_pack_equals_the_host_packing():
                     want = T.pack_weights(w, 1, ft, row0, nrows, layout=lay)
                     T.DEVICE_PACK = True
                     assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), (taps, co, ci, "frag", lay, ft)
+
+
+def test_plain_bf16_convolutions_are_the_hi_halves_of_the_bf16x3_products():
+    """mfpa_conv_desc.precision 2 (conv_wd16_kernel<.., PLAIN>): one bf16 MFMA per product on the hi halves of the operands the bf16x3
+    form splits -- the training step's "bf16 MFMA" arithmetic (BASELINE config 4).  Equal to a float64 convolution of the
+    bf16-rounded operands to fp32 accumulation error, ~2^-9 relative per product against the fp32 kernel; same side outputs
+    (bf16 copies, BatchNorm partials of the STORED output) as the bf16x3 form; 64- and 128-channel tiles, two sources, ragged edges,
+    the 16 x 16 patches, dropout + on-load affine."""
+    from musicfpaugment_amd import ops_train as T
+    from musicfpaugment_amd import ops_unet as K
+    g = torch.Generator().manual_seed(21)
+    for (B, H, W, C0, C1, Cout, drop) in [(2, 9, 37, 64, 0, 64, 0.0), (3, 33, 31, 64, 64, 128, 0.0), (70, 64, 62, 64, 0, 64, 0.25),
+                                          (2, 16, 15, 128, 0, 256, 0.0), (1, 40, 70, 128, 0, 128, 0.3), (2, 33, 31, 512, 0, 128, 0.0)]:
+        x0 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x1 = torch.randn(B, H - 1, W - 1, C1, generator=g).cuda() if C1 else None
+        w = K.pack_conv3x3(torch.randn(Cout, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))).cuda()
+        st = T.Stats(C0, "cuda")
+        st.scale.copy_(torch.rand(C0, generator=g) + 0.5); st.shift.copy_(torch.randn(C0, generator=g) * 0.3)
+        st.drop = T.dropout_spec(77, drop)
+        assert T.weight_layout(H, W, C0 + C1, Cout, 2) == 2
+        z32 = T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=0)
+        xb, sp, yb = [], [], []
+        z = T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=2, x0_bf16_out=xb, stats_out=sp, y_bf16_out=yb)
+        assert torch.equal(z, T.conv_mfma(x0, w, Cout, in_affine=st, x1=x1, precision=2))             # side outputs do not change it; deterministic
+        r = rel(z, z32)
+        assert 1e-4 < r < 6e-3, (B, H, W, C0, C1, Cout, r)                                             # really one bf16 product, and no worse
+        assert torch.equal(xb[0].view(torch.int16), T.act_to_bf16(x0, st).view(torch.int16))
+        assert torch.equal(yb[0].view(torch.int16), T.act_to_bf16(z).view(torch.int16))
+        if B <= 3:
+            # float64 convolution of the bf16-rounded operands (activation applied first, like the loader)
+            a0 = T.act_to_bf16(x0, st).float().cpu().double().permute(0, 3, 1, 2)
+            xin = a0 if x1 is None else torch.cat([a0, F.pad(x1.bfloat16().float().cpu().double().permute(0, 3, 1, 2), [0, 1, 0, 1])], dim=1)
+            wt = w.bfloat16().float().cpu().double().view(3, 3, Cout, C0 + C1).permute(2, 3, 0, 1)
+            want = F.conv2d(xin, wt, padding=1)
+            assert rel(z.permute(0, 3, 1, 2), want) < 2e-6, (B, H, W, C0, C1, Cout)
+
+
+def test_train_step_in_plain_bf16_tracks_the_fp32_step():
+    """UNetTrainEngine(precision=2, wgrad_precision=2): forward and input-gradient convolutions with plain bf16 products wherever
+    conv_wd16_kernel serves the layer (the transposed convolutions and the 1-channel first layer keep their arithmetic), bf16 weight
+    gradients -- config 4's "bf16 MFMA".  Against the fp32 engine on the same batch: loss within 1 %, per-parameter gradients within a
+    few % (relative L1, median), and it trains (the loss falls like the fp32 run's)."""
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    am, aug_den, clean_spec = _g7_inputs()
+    runs = {}
+    for prec, wprec in ((0, 0), (2, 2)):
+        net = UNet(1, 1, rate=0.0)
+        net.load_state_dict(formula_state_dict(2))
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec, wgrad_precision=wprec)
+        pred = eng.forward(spec64=am, denom=aug_den)
+        loss, dpred = eng.l1_loss(pred, clean_spec)
+        eng.backward(dpred)
+        grads = {k: v.clone() for k, v in eng.named_grads().items()}
+        eng.optimizer_step()
+        losses = [float(loss)] + [float(eng.train_step(am, aug_den, clean_spec)) for _ in range(6)]
+        runs[prec] = (pred.clone(), grads, losses)
+    assert rel(runs[2][0], runs[0][0]) < 5e-2                 # 23 layers of 2^-9 products, batch statistics of a 2-clip batch, no output activation
+    errs = sorted(rel(runs[2][1][k], runs[0][1][k]) for k in runs[0][1])
+    assert errs[len(errs) // 2] < 5e-2 and errs[-1] < 0.3, (errs[len(errs) // 2], errs[-1])
+    l0, l2 = runs[0][2], runs[2][2]
+    assert abs(l2[0] - l0[0]) < 1e-2 * l0[0] and l2[-1] < l2[0] and abs(l2[-1] - l0[-1]) < 0.1 * l0[0], (l0, l2)
