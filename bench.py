@@ -220,14 +220,16 @@ def device_sample(local_rank: int = 0):
     out = {}
     for k, v in card.items():
         kl = k.lower()
-        if "sclk" in kl and "level" not in kl or kl.startswith("sclk"):
-            out["sclk"] = v
-        elif "mclk" in kl:
-            out["mclk"] = v
+        if kl.startswith("sclk clock speed"):
+            out["sclk_mhz"] = v.strip("()").replace("Mhz", "").replace("MHz", "")
+        elif kl.startswith("mclk clock speed"):
+            out["mclk_mhz"] = v.strip("()").replace("Mhz", "").replace("MHz", "")
         elif "power" in kl and "(w)" in kl:
             out["power_w"] = v
-        elif "temperature" in kl and ("hotspot" in kl or "junction" in kl):
-            out["temp_hotspot_c"] = v
+        elif "temperature" in kl and ("junction" in kl or "hotspot" in kl):
+            out["temp_junction_c"] = v
+        elif "temperature" in kl and "memory" in kl:
+            out["temp_memory_c"] = v
     return out or {"raw_keys": sorted(card)[:12]}
 
 
@@ -653,6 +655,13 @@ def bench_infer(args, rank, world, dev, dist):
         net.precision = 1 - net.precision
         other = (dt_o, timer_o)
 
+    load_sample = None
+    if rank == 0 and net is not None and not args.sub_config:
+        # clock / power UNDER LOAD, outside the timed region: a burst of the same steps is queued, rocm-smi is read while it runs
+        for _ in range(max(8, int(0.6 / max(dt / args.steps, 1e-3)))):
+            hot(wav)
+        load_sample = device_sample(dev.index or 0)
+        torch.cuda.synchronize()
     parity = None
     if net is not None and args.picker == "audfprint":
         # every line certifies the arithmetic it was measured in (outside the timed region, device only): the first 8 clips of this
@@ -738,6 +747,8 @@ def bench_infer(args, rank, world, dev, dist):
         out["roofline"] = roofline(timer, args.precision)
     if parity is not None:
         out["parity_in_run"] = parity
+    if load_sample is not None:
+        out["device_sample_under_load"] = load_sample
     if net is None and args.picker == "audfprint":
         # per-stage figures of the chain (outside the timed region; HIP events on the launch stream, 5 repetitions each): bytes the
         # stage moves per clip / its time.

@@ -1054,7 +1054,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // PLAIN: plain bf16 products -- one MFMA per product on the hi halves only (the lo planes, their fragment reads, the lo weight
   // fragments and two of the three MFMA terms are gone): the training step's "bf16 MFMA" arithmetic (BASELINE config 4), relative
   // error ~2^-9 per product instead of bf16x3's 2^-17.  Never used by the inference chain (its 1e-4 gate needs bf16x3).
-  static_assert(!(PLAIN && ROWS), "the plain-bf16 form uses the tap-by-tap loops");
+  // (PLAIN halves the MFMA work per fragment read to a third: the tap-by-tap loop's 8 ds_read_b128 per 16 MFMAs saturate the CU's LDS
+  //  pipe exactly -- the ROWS form, which reads every halo row once per column offset, is the one that suits it at every depth)
   // SIDE: the training step's side outputs (x0_bf16 / x1_bf16 / y_bf16 / stats_part) -- their own instantiations, so that the inference
   // kernels carry none of their code (it cost the 128-channel form 9 registers and 18 spills)
   // WMW = 2: 2 x 4 waves of 128 px x 32 ch (128-channel output tiles); WMW = 4: 4 x 2 waves of 64 px x 32 ch (the 64-channel layers)
@@ -1435,9 +1436,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       const char* wb = reinterpret_cast<const char*>(a.w) +
                        ((((size_t)(dy * 3 + dx) * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
       wr[par][dy][0][0] = *reinterpret_cast<const bf16x8*>(wb);
-      wr[par][dy][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+      if constexpr (!PLAIN) wr[par][dy][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
       wr[par][dy][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
-      wr[par][dy][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+      if constexpr (!PLAIN) wr[par][dy][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
     }
   };
   // pixel fragments: one "unit" = 16 pixels of one halo row (hi and lo); a ring of NB units, read NB - 1 units ahead of their MFMAs (a
@@ -1449,22 +1450,22 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     const char* wb = reinterpret_cast<const char*>(a.w) +
                      ((((size_t)(dy * 3 + dx) * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
     wr[par][dy][0][0] = *reinterpret_cast<const bf16x8*>(wb);
-    wr[par][dy][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+    if constexpr (!PLAIN) wr[par][dy][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
     wr[par][dy][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
-    wr[par][dy][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+    if constexpr (!PLAIN) wr[par][dy][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
   };
   struct XUnit { bf16x8 h, l; };
   XUnit xu[NB];
   auto read_unit = [&](XUnit& f, const char* stage, int u, int dx) __attribute__((always_inline)) {
     const char* r = stage + xbase + ((u / HV) * HPW + (u % HV) * 16 + dx) * 16;
-    f.l = *reinterpret_cast<const bf16x8*>(r + HLS);
+    if constexpr (!PLAIN) f.l = *reinterpret_cast<const bf16x8*>(r + HLS);
     f.h = *reinterpret_cast<const bf16x8*>(r);
   };
   // unit u = (halo row h, half hv): every (dy, r = h - dy) pair it serves, term-major (an accumulator is touched once per term)
   auto mfma_unit = [&](auto U, const XUnit& f, auto PAR) __attribute__((always_inline)) {
     constexpr int h = decltype(U)::value / HV, hv = decltype(U)::value % HV, par = decltype(PAR)::value;
 #pragma unroll
-    for (int term = 0; term < 3; ++term)
+    for (int term = PLAIN ? 2 : 0; term < 3; ++term)                    // PLAIN: the hi x hi term only
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         if (h - dy < 0 || h - dy >= R) continue;
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         }
       }
   };
-  auto unit_mfmas = [](int u) { const int h = u / HV; int n = 0; for (int dy = 0; dy < 3; ++dy) n += (h - dy >= 0 && h - dy < R) ? 1 : 0; return n * 6; };
+  auto unit_mfmas = [](int u) { const int h = u / HV; int n = 0; for (int dy = 0; dy < 3; ++dy) n += (h - dy >= 0 && h - dy < R) ? 1 : 0; return n * (PLAIN ? 2 : 6); };
   constexpr int BARU = NU - NB + 1;                                    // first unit whose prefetch reads the next period
   constexpr int SA = NU / 2, SB = BARU - AHALF;                        // first split units of periods 1 and 2
   static_assert(SA + AHALF < NU && SB >= 0, "staging schedule");
@@ -1505,8 +1506,19 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     }
     if constexpr (do_split) split_slot(std::integral_constant<int, do_split ? split_it : 0>{}, chunk_n, nxs);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    if constexpr (do_split) {
+    __builtin_amdgcn_sched_group_barrier(0x100, PLAIN ? 1 : 2, 0);
+    if constexpr (do_split && PLAIN) {
+      // a unit carries 2 .. 6 MFMAs here: the split's vector work goes between them in equal parts
+#pragma unroll
+      for (int i = 1; i < n_m; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, (24 + n_m - 2) / (n_m - 1), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    } else if constexpr (PLAIN && u >= 1 && u <= 3) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      if constexpr (n_m - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, n_m - 1, 0);
+    } else if constexpr (do_split) {
       __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1857,7 +1869,11 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
     } else if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, false>), grid, dim3(512), lds, s, a);
   } else if (a.plain) {
-    if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, true, true>), grid, dim3(512), lds, s, a);
+    static const int plain_rows = MFPA_EXP_ENV("MFPA_CONV_PLAIN_ROWS", 1);      // experiments: 0 = the tap-by-tap loop
+    if (plain_rows && cin % 64 == 0) {
+      if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true, true>), grid, dim3(512), lds, s, a);
+      else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, false, true>), grid, dim3(512), lds, s, a);
+    } else if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, true, true>), grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 2, false, true>), grid, dim3(512), lds, s, a);
   } else if (rows) {
     if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true>), grid, dim3(512), lds, s, a);
