@@ -14,6 +14,12 @@
 #include <cstdlib>
 #define MFPA_EXP_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
 #define MFPA_EXP_FLAG(word, bit) (((word) & (bit)) != 0)
+#elif defined(MFPA_SKIP_BITS)
+// timing-only variants of the PRODUCT code (tools/: `build(extra_flags=["-DMFPA_SKIP_BITS=<bits>"], out=...)`): the skip switches of the
+// experiments build as compile-time constants, so that the variant differs from the shipped kernel by the skipped work only (the
+// run-time switches cost conv_wd16_kernel's 64-channel form 12 % by themselves).  Wrong results by design; never loaded by the package.
+#define MFPA_EXP_ENV(name, dflt) (dflt)
+#define MFPA_EXP_FLAG(word, bit) (((MFPA_SKIP_BITS) & (bit)) != 0)
 #else
 #define MFPA_EXP_ENV(name, dflt) (dflt)
 #define MFPA_EXP_FLAG(word, bit) false
