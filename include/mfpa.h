@@ -266,6 +266,9 @@ typedef struct mfpa_conv_desc {
    * (sum g, sum g * xhat) with g = dy where bwd_z * scale + shift > 0 else 0: after mfpa_conv_stats_reduce the `local_sums` of
    * mfpa_bn_relu_bwd_finish, without the reduction pass over (dy, z). */
   const float* bwd_z; const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
+  /* precision 2, one source, no on-load affine: x0 is a BFLOAT16 tensor (B,H,W,C0), C0 % 64 == 0 -- the bf16 copy of dz written by
+   * mfpa_bn_relu_bwd: the loader stages it without any split arithmetic and moves half the bytes. */
+  int x0_is_bf16;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 /* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */
@@ -316,7 +319,10 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
 int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma,
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, float* coef, double* workspace,
-                     unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, void* stream);
+                     unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32,
+                     void* stream);
+/* write_f32 = 0 (needs dz_bf16): only the bf16 copy of dz is written -- every consumer reads it (the plain-bf16 train step: the
+ * input-gradient convolution takes it through mfpa_conv_desc.x0_is_bf16, the weight gradient as its bf16 operand) and dy is left as it was. */
 
 /* The same two operations split for synchronised BatchNorm under data parallelism (statistics over the GLOBAL batch, as the
  * single-GPU reference computes them): *_sums reduces this rank's per-channel pairs into sums[2C] float64 -- (sum z, sum z^2)
@@ -333,7 +339,8 @@ int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C
 int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
-                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, void* stream);
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32,
+                            void* stream);
 
 /* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
 int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 class MfpaError(RuntimeError):
@@ -120,7 +120,7 @@ _SIGNATURES = {
     "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_int, c_void_p], c_int),
     "mfpa_conv_stats_rows": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "mfpa_conv_stats_reduce": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_stats_sums": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
@@ -130,7 +130,7 @@ _SIGNATURES = {
                                c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
     "mfpa_bn_relu_bwd_finish": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
-                                 c_void_p, c_void_p], c_int),
+                                 c_void_p, c_int, c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
                            c_void_p], c_int),
@@ -162,7 +162,8 @@ class ConvDesc(ctypes.Structure):
                 ("c1_x32", c_void_p), ("c1_spec64", c_void_p), ("c1_denom", c_void_p),
                 ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int),
                 ("x0_bf16", c_void_p), ("x1_bf16", c_void_p), ("y_bf16", c_void_p), ("stats_part", c_void_p),
-                ("bwd_z", c_void_p), ("bwd_scale", c_void_p), ("bwd_shift", c_void_p), ("bwd_mean", c_void_p), ("bwd_invstd", c_void_p)]
+                ("bwd_z", c_void_p), ("bwd_scale", c_void_p), ("bwd_shift", c_void_p), ("bwd_mean", c_void_p), ("bwd_invstd", c_void_p),
+                ("x0_is_bf16", c_int)]
 
 
 class GemmDesc(ctypes.Structure):

@@ -143,6 +143,7 @@ struct ConvArgs {
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
   int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
+  int in16;                          // conv_wd16_kernel (plain): source 0 is a bfloat16 tensor (mfpa_conv_desc.x0_is_bf16)
   int plain;                         // conv_wd16_kernel: plain bf16 products (hi halves only: mfpa_conv_desc.precision 2, the training step)
   __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
   __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)
@@ -1049,11 +1050,17 @@ __device__ __forceinline__ float dpp_row_add(float v) {               // v + (v 
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false, bool PLAIN = false>
+template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false, bool PLAIN = false, bool IN16 = false>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // PLAIN: plain bf16 products -- one MFMA per product on the hi halves only (the lo planes, their fragment reads, the lo weight
   // fragments and two of the three MFMA terms are gone): the training step's "bf16 MFMA" arithmetic (BASELINE config 4), relative
   // error ~2^-9 per product instead of bf16x3's 2^-17.  Never used by the inference chain (its 1e-4 gate needs bf16x3).
+  // IN16 (with PLAIN, one source, no on-load affine): source 0 is a bfloat16 tensor -- the bf16 copy of dz the BatchNorm backward writes --
+  // so a staging slot is 8 channels, goes into its (hi, k-group) plane as one 16-byte store without any split arithmetic, and the
+  // loader moves half the bytes (the fp32 dz is then never written: mfpa_bn_relu_bwd(write_f32 = 0)).
+  static_assert(!IN16 || PLAIN, "a bf16 source feeds the plain-bf16 products");
+  constexpr int SPP = IN16 ? KC / 8 : KC / 4;                          // staging slots per pixel and 32-channel chunk
+  constexpr int ESZ = IN16 ? 2 : 4;                                    // bytes per source element
   // (PLAIN halves the MFMA work per fragment read to a third: the tap-by-tap loop's 8 ds_read_b128 per 16 MFMAs saturate the CU's LDS
   //  pipe exactly -- the ROWS form, which reads every halo row once per column offset, is the one that suits it at every depth)
   // SIDE: the training step's side outputs (x0_bf16 / x1_bf16 / y_bf16 / stats_part) -- their own instantiations, so that the inference
@@ -1063,8 +1070,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   static_assert((WMW == 2 || WMW == 4) && (!ROWS || WMW == 2), "wave grid");
   constexpr int HPW = PW + 2, HPH = PH + 2, HP = HPW * HPH, BM = PH * PW;
   static_assert(BM == 256 && (PW == 32 || PW == 16), "two waves of 128 pixels: eight 16-pixel tiles each");
-  constexpr int A_F4 = (HP * (KC / 4) + THREADS - 1) / THREADS;
-  constexpr int HPS = A_F4 * (THREADS / (KC / 4));                     // staged pixels (>= HP): every staging slot has a row
+  constexpr int A_F4 = (HP * SPP + THREADS - 1) / THREADS;
+  constexpr int HPS = A_F4 * (THREADS / SPP);                     // staged pixels (>= HP): every staging slot has a row
   constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;                // bytes of one (hi|lo, k-group) plane, a multiple of 256
   constexpr int HLS = 4 * PLANE + 256;                                 // hi -> lo distance (planes 2, 3 sit 128 B further: room for that)
   constexpr int STAGE = 2 * HLS;
@@ -1095,18 +1102,18 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // recomputed per tile from the slot's (row, column) and the tile's uniform bounds -- a few compares, no table).  Round 3 rebuilt a
   // clamped absolute table per tile (12 x (two divisions, four clamps, an LDS store) per thread): 3.7 k cycles per tile in front of the
   // first tap of every tile of the persistent form (profiles/r04_c64_timeline.txt).
-  const int aq = tid % (KC / 4);
+  const int aq = tid % SPP;
   constexpr int TBL = 2 * A_F4 * THREADS;                              // the offset table: [2][A_F4][THREADS]
   unsigned* const aoffs0 = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
 #pragma unroll
   for (int it = 0; it < A_F4; ++it) {
-    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const int pix = tid / SPP + it * (THREADS / SPP);
     const int py = pix / HPW - 1, px = pix % HPW - 1;
-    aoffs0[it * THREADS + tid] = (unsigned)((py * a.W + px) * a.C0 + 4 * aq) * 4u;                    // may be "negative": wraps, see above
-    aoffs0[(A_F4 + it) * THREADS + tid] = (unsigned)(((py - a.oy1) * a.W1 + (px - a.ox1)) * a.C1 + 4 * aq) * 4u;
+    aoffs0[it * THREADS + tid] = (unsigned)((py * a.W + px) * a.C0 + (KC / SPP) * aq) * (unsigned)ESZ;    // may be "negative": wraps, see above
+    aoffs0[(A_F4 + it) * THREADS + tid] = (unsigned)(((py - a.oy1) * a.W1 + (px - a.ox1)) * a.C1 + (KC / SPP) * aq) * (unsigned)ESZ;
   }
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
-  const unsigned clip0 = (unsigned)a.H * (unsigned)a.W * (unsigned)a.C0 * 4u, clip1 = (unsigned)a.H1 * (unsigned)a.W1 * (unsigned)a.C1 * 4u;
+  const unsigned clip0 = (unsigned)a.H * (unsigned)a.W * (unsigned)a.C0 * (unsigned)ESZ, clip1 = (unsigned)a.H1 * (unsigned)a.W1 * (unsigned)a.C1 * (unsigned)ESZ;
   struct Tile { int b, y0, x0p; unsigned ain; unsigned t0, t1; };      // t0 / t1: byte offset of the tile's origin pixel in source 0 / 1
   // decode tile t (workgroup-uniform scalars) and its inside flags (ain bit it: slot inside source 0's image; bit 8 + it: source 1)
   auto make_tile = [&](int t) __attribute__((always_inline)) {
@@ -1115,11 +1122,11 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty = bx % a.tiles_y; bx /= a.tiles_y;
     T.b = bx; T.y0 = ty * PH; T.x0p = tx * PW; T.ain = 0;
-    T.t0 = (unsigned)((T.y0 * a.W + T.x0p) * a.C0) * 4u;
-    T.t1 = (unsigned)((T.y0 * a.W1 + T.x0p) * a.C1) * 4u;
+    T.t0 = (unsigned)((T.y0 * a.W + T.x0p) * a.C0) * (unsigned)ESZ;
+    T.t1 = (unsigned)((T.y0 * a.W1 + T.x0p) * a.C1) * (unsigned)ESZ;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) {
-      const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+      const int pix = tid / SPP + it * (THREADS / SPP);
       const int gy = T.y0 + pix / HPW - 1, gx = T.x0p + pix % HPW - 1;
       const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int y1 = gy - a.oy1, x1 = gx - a.ox1;
@@ -1180,7 +1187,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;                                      // workgroup-uniform: scalar selects, no branch
     const auto rs = clip_rsrc(from0 ? a.x0 : a.x1, S.b, from0 ? clip0 : clip1);
-    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * 4u : S.t1 + (unsigned)(c0 - a.C0) * 4u;
+    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * (unsigned)ESZ : S.t1 + (unsigned)(c0 - a.C0) * (unsigned)ESZ;
     const unsigned* ao = aoffs0 + (from0 ? 0 : A_F4 * THREADS) + tid;
 #pragma unroll
     for (int it = first; it < first + count && it < A_F4; ++it)
@@ -1203,7 +1210,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     const int c0 = chunk * KC;
     const bool from0 = c0 < a.C0;
     const auto rs = clip_rsrc(from0 ? a.x0 : a.x1, S.b, from0 ? clip0 : clip1);
-    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * 4u : S.t1 + (unsigned)(c0 - a.C0) * 4u;
+    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * (unsigned)ESZ : S.t1 + (unsigned)(c0 - a.C0) * (unsigned)ESZ;
 #pragma unroll
     for (int it = 0; it < A_F4; ++it)
       areg[it % AREGS] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(__float_as_uint(areg[it % AREGS][0]) + toff), 0, 0));
@@ -1212,11 +1219,15 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // into the (hi, k-group) and (lo, k-group) planes (a thread's channel quad is half of k-group aq >> 1)
   auto split_slot = [&](auto IT, int chunk, char* stage) __attribute__((always_inline)) {
     constexpr int it = decltype(IT)::value;
-    const int pix = tid / (KC / 4) + it * (THREADS / (KC / 4));
+    const int pix = tid / SPP + it * (THREADS / SPP);
     const int c0 = chunk * KC;
     const bool inside = (S.ain >> ((c0 < a.C0 ? 0 : 8) + it)) & 1u;
     f32x4 v = areg[it % AREGS];
     if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (IN16) {                                              // eight bf16 channels = the lane's whole (hi, k-group aq) piece
+      *reinterpret_cast<f32x4*>(stage + plane_off(0, aq) + pix * 16) = v;
+      return;
+    }
     if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {
       // from the LDS copy: a global load here is followed by s_waitcnt vmcnt(0), which also waits for every weight load in flight
       const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + c0 + 4 * aq);
@@ -1564,14 +1575,16 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     for (int i = 0; i < AREGS; ++i) keep[i] = areg[i];
     load_a_range(0, std::integral_constant<int, 0>{}, std::integral_constant<int, AHALF>{});
     load_wr(0, S0{}, S0{});
+    // slots [0, AHALF) sit in the staging registers, slots [AHALF, A_F4) in `keep` (AHALF = 3 for float32 sources, 2 for bf16 ones)
     split_slot(std::integral_constant<int, 0>{}, 0, smem);
-    if constexpr (A_F4 > 1) split_slot(std::integral_constant<int, 1>{}, 0, smem);
-    if constexpr (A_F4 > 2) split_slot(std::integral_constant<int, 2>{}, 0, smem);
+    if constexpr (AHALF > 1) split_slot(std::integral_constant<int, 1>{}, 0, smem);
+    if constexpr (AHALF > 2) split_slot(std::integral_constant<int, 2>{}, 0, smem);
 #pragma unroll
     for (int i = 0; i < AREGS; ++i) areg[i] = keep[i];
-    if constexpr (A_F4 > 3) split_slot(std::integral_constant<int, 3>{}, 0, smem);
-    if constexpr (A_F4 > 4) split_slot(std::integral_constant<int, 4>{}, 0, smem);
-    if constexpr (A_F4 > 5) split_slot(std::integral_constant<int, 5>{}, 0, smem);
+    if constexpr (A_F4 > AHALF) split_slot(std::integral_constant<int, AHALF>{}, 0, smem);
+    if constexpr (A_F4 > AHALF + 1) split_slot(std::integral_constant<int, AHALF + 1 < A_F4 ? AHALF + 1 : 0>{}, 0, smem);
+    if constexpr (A_F4 > AHALF + 2) split_slot(std::integral_constant<int, AHALF + 2 < A_F4 ? AHALF + 2 : 0>{}, 0, smem);
+    static_assert(A_F4 <= 2 * AHALF && AHALF <= 3, "two halves of at most three staging slots");
   } else {
     load_a(0);
     load_w(0, 0, S0{});
@@ -1861,6 +1874,18 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   const int cin = a.C0 + a.C1;
   const bool side = a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part;
   const bool rows = WMW == 2 && rows_min > 0 && cin % 64 == 0 && cin >= rows_min;
+  if (a.in16) {                                                        // bf16 source: the plain-bf16 input-gradient convolutions
+    if (!a.plain || a.C1 != 0 || a.in_scale0 || a.x0_bf16 || a.x1_bf16 || cin % 64) return MFPA_EINVAL;
+    if constexpr (WMW == 4) {
+      if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true, true>), grid, dim3(512), lds, s, a);
+      else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, false, true, true>), grid, dim3(512), lds, s, a);
+    } else {
+      if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true, true, true>), grid, dim3(512), lds, s, a);
+      else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, false, true, true>), grid, dim3(512), lds, s, a);
+    }
+    MFPA_CHECK_LAUNCH();
+    return MFPA_OK;
+  }
   if constexpr (WMW == 4) {
     if (cin % 64) return MFPA_EINVAL;
     if (a.plain) {
@@ -2378,6 +2403,8 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->precision == 2 && d->w_layout != 2) return MFPA_EINVAL;         // plain bf16: conv_wd16_kernel only (it reads the hi halves of the same image)
   a.w_frag = d->w_layout;
   a.plain = d->precision == 2;
+  if (d->x0_is_bf16 && (d->precision != 2 || d->C1 != 0 || d->in_scale0 || d->x0_bf16 || (d->C0 % 64) != 0 || d->c1_x32 || d->c1_spec64)) return MFPA_EINVAL;
+  a.in16 = d->x0_is_bf16 ? 1 : 0;
   if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision == 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
   if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
   if (d->y_bf16 != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;

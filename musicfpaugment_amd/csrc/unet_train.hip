@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, unsigned drop_seed,
-                                                           unsigned drop_thresh, float drop_scale, __bf16* __restrict__ dz16) {
+                                                           unsigned drop_thresh, float drop_scale, __bf16* __restrict__ dz16,
+                                                           int write_f32) {
   const int C4 = C / 4;                      // a power of two (checked on the host): no 64-bit division per element
   const long long total = npix * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
       const float xh = (zz[k] - mu[k]) * is[k];
       o[k] = ka[k] * gg - kb[k] - kc[k] * xh;
     }
-    *reinterpret_cast<f32x4*>(dy + e * 4) = o;
+    if (write_f32) *reinterpret_cast<f32x4*>(dy + e * 4) = o;   // (0: every consumer of dz reads the bf16 copy -- the plain-bf16 train step)
     if (dz16) {                              // the bf16 copy the weight-gradient kernel reads (wgrad precision 3)
       wg_bf16x4_t h;
 #pragma unroll
@@ -1323,8 +1324,9 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
 int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                      const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                      float* coef, double* workspace, unsigned drop_seed, unsigned drop_thresh, float drop_scale,
-                     void* dz_bf16, void* stream) {
+                     void* dz_bf16, int write_f32, void* stream) {
   if (npix == 0) return MFPA_OK;
+  if (!write_f32 && !dz_bf16) return MFPA_EINVAL;
   if (!dy || !z || !gamma || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace) return MFPA_EINVAL;
   if (C & (C - 1)) return MFPA_EINVAL;   // channel counts of this UNet are powers of two (64 ... 1024)
   if (npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
@@ -1338,7 +1340,7 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
-                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16));
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1403,8 +1405,9 @@ int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C
 int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
-                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, void* stream) {
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32, void* stream) {
   if (!gamma || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !dgamma || !dbeta || !coef) return MFPA_EINVAL;
+  if (!write_f32 && !dz_bf16) return MFPA_EINVAL;
   if (!bn_shape_ok(npix, C) || (C & (C - 1)) || !(global_count >= 1.0) || (npix > 0 && (!dy || !z))) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   hipLaunchKernelGGL(bn_bwd_finish_sync_kernel, dim3((C + 255) / 256), dim3(256), 0, s, local_sums, global_sums, C, global_count,
@@ -1412,7 +1415,7 @@ int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, co
   MFPA_CHECK_LAUNCH();
   if (npix == 0) return MFPA_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
-                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16));
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

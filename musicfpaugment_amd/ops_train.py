@@ -105,6 +105,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     # precision 2 = plain bf16 products where conv_wd16_kernel serves the shape (it reads the hi halves of the bf16x3 image); every
     # other kernel of the family (transposed convolutions, the fall-back shapes) stays on bf16x3
     plain, precision = precision == 2, min(precision, 1)
+    in16 = x0.dtype == torch.bfloat16                              # the bf16 copy of dz as the input-gradient convolution's source (plain bf16 only)
     if precision == 1 and not packed:
         w_layout = weight_layout(H, W, C0 + C1, Cout, precision, mode)
         if DEVICE_PACK and w.is_contiguous() and w.shape[1] % 32 == 0 and w.shape[2] % 32 == 0:
@@ -144,7 +145,9 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  bwd_scale=ptr(bwd_of[1].scale) if (bwd_of and part is not None) else 0,
                  bwd_shift=ptr(bwd_of[1].shift) if (bwd_of and part is not None) else 0,
                  bwd_mean=ptr(bwd_of[1].mean) if (bwd_of and part is not None) else 0,
-                 bwd_invstd=ptr(bwd_of[1].invstd) if (bwd_of and part is not None) else 0)
+                 bwd_invstd=ptr(bwd_of[1].invstd) if (bwd_of and part is not None) else 0, x0_is_bf16=int(in16))
+    if in16 and not (plain and w_layout == 2 and mode == 0 and x1 is None and in_affine is None):
+        raise ValueError("a bfloat16 source needs the plain-bf16 conv_wd16_kernel (precision 2, w_layout 2, one source, no on-load affine)")
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -152,6 +155,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
+USE_BF16_DZ = True          # plain-bf16 step: input-gradient convolutions read the bf16 copy of dz (False: the float32 dz, A/B runs)
 BF16_WGRAD_MIN_CH = 128     # plain-bf16 weight gradients: layers with at least this many channels on both sides read bf16 copies
 
 
@@ -424,9 +428,11 @@ class UNetTrainEngine:
                                   ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
         return st
 
-    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False, part=None):
+    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False, part=None, write_f32: bool = True):
         """dy <- gradient w.r.t. z, in place; with bf16_copy also its bf16 copy, written by the same pass (the weight-gradient
-        kernel's operand).  Returns (dz, dz_bf16 or None)."""
+        kernel's operand).  `write_f32=False` (needs bf16_copy): ONLY the bf16 copy is written -- every consumer reads it (plain-bf16
+        step) -- and None is returned for dz.  Returns (dz, dz_bf16 or None)."""
+        write_f32 = write_f32 or not bf16_copy
         C = z.shape[-1]
         coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
         dz16 = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device) if bf16_copy else None
@@ -444,14 +450,14 @@ class UNetTrainEngine:
                 st.count_host = float(_npix(z))
             check(lib().mfpa_bn_relu_bwd_finish(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                                 ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
-                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), stream()),
+                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), stream()),
                   "mfpa_bn_relu_bwd_finish")
-            return dy, dz16
+            return (dy if write_f32 else None), dz16
         check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                      ptr(st.mean), ptr(st.invstd), ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
-                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), stream()),
+                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), stream()),
               "mfpa_bn_relu_bwd")
-        return dy, dz16
+        return (dy if write_f32 else None), dz16
 
     # ------------------------------------------------------------------ forward (train mode)
     def _dconv_fwd(self, prefix, src0, aff0: Optional[Stats], src1=None, first_input=None, drop_id=None):
@@ -518,21 +524,29 @@ class UNetTrainEngine:
         """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1)."""
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
-        dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b",
-                                      bf16_copy=bf16_wgrad(cout, cout, self.wgrad_precision, r["xb3"] is not None))
+        H_, W_ = r["z3"].shape[1], r["z3"].shape[2]
+        lay = weight_layout(H_, W_, cout, cout, self.precision)
+        wg16 = bf16_wgrad(cout, cout, self.wgrad_precision, r["xb3"] is not None)
+        # plain bf16 step: when both consumers of dz (input-gradient convolution on conv_wd16_kernel, weight gradient) read its bf16
+        # copy, the float32 dz is never written (mfpa_bn_relu_bwd(write_f32 = 0)) and the convolution's loader moves half the bytes
+        only16 = USE_BF16_DZ and self.precision == 2 and lay == 2 and wg16
+        dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b", bf16_copy=wg16, write_f32=not only16)
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16,
                    x0_bf16=r["xb3"])
-        del dz16
         r["xb3"] = None
-        lay = weight_layout(dz3.shape[1], dz3.shape[2], cout, cout, self.precision)
         wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True, layout=lay)   # [tap'][ci][co]
         spm = [] if r["st0"].drop[1] == 0 else None      # dmid is dy of relu(bn(z0)): the BatchNorm backward's reductions in the epilogue
-        dmid = conv_mfma(dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay, stats_out=spm, bwd_of=(r["z0"], r["st0"]))
-        del dz3
+        dmid = conv_mfma(dz16 if only16 else dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay, stats_out=spm,
+                         bwd_of=(r["z0"], r["st0"]))
+        del dz3, dz16
         cin0 = 0 if r["first_input"] is not None else r["src0"].shape[-1] + (0 if r["src1"] is None else r["src1"].shape[-1])
-        dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b",
-                                      bf16_copy=cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None),
-                                      part=spm[0] if spm else None)
+        wg16 = cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None)
+        c0_ = 0 if r["first_input"] is not None else r["src0"].shape[-1]
+        c1_ = 0 if (r["first_input"] is not None or r["src1"] is None) else r["src1"].shape[-1]
+        only16 = (USE_BF16_DZ and self.precision == 2 and wg16 and need_input_grad and c0_ > 0
+                  and weight_layout(H_, W_, cout, c0_, self.precision) == 2 and (c1_ == 0 or weight_layout(H_, W_, cout, c1_, self.precision) == 2))
+        dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b", bf16_copy=wg16,
+                                      part=spm[0] if spm else None, write_f32=not only16)
         if r["first_input"] is not None:
             x32, spec64, denom = r["first_input"]
             B, H, W, C = dz0.shape
@@ -541,21 +555,21 @@ class UNetTrainEngine:
             return None, None
         wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"],
                    precision=self.wgrad_precision, dz_bf16=dz16, x0_bf16=r["xb0"], x1_bf16=r["xb1"])
-        del dz16
         r["xb0"] = r["xb1"] = None
         if not need_input_grad:
             return None, None
         w0 = self.P[prefix + ".0.w"]                                                # (9, cout, cin)
         c0 = r["src0"].shape[-1]
-        lay = weight_layout(dz0.shape[1], dz0.shape[2], cout, c0, self.precision)
-        d0 = conv_mfma(dz0, pack_weights(w0, self.precision, True, 0, c0, layout=lay), c0, precision=self.precision, packed=True, w_layout=lay)
+        lay = weight_layout(H_, W_, cout, c0, self.precision)
+        dsrc = dz16 if only16 else dz0
+        d0 = conv_mfma(dsrc, pack_weights(w0, self.precision, True, 0, c0, layout=lay), c0, precision=self.precision, packed=True, w_layout=lay)
         d1 = None
         if r["src1"] is not None:
             c1 = r["src1"].shape[-1]
-            lay = weight_layout(dz0.shape[1], dz0.shape[2], cout, c1, self.precision)
+            lay = weight_layout(H_, W_, cout, c1, self.precision)
             sp = []                          # per-channel sums of d1 (the transposed convolution's bias gradient) from the kernel's epilogue
             yb = [] if self.wgrad_precision == 2 else None       # and its bf16 copy (the transposed convolution's weight gradient reads it)
-            d1 = conv_mfma(dz0, pack_weights(w0, self.precision, True, c0, c1, layout=lay), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
+            d1 = conv_mfma(dsrc, pack_weights(w0, self.precision, True, c0, c1, layout=lay), c1, out_hw=(r["src1"].shape[1], r["src1"].shape[2]),
                            precision=self.precision, packed=True, w_layout=lay, stats_out=sp, y_bf16_out=yb)
             r["d1_sums"] = sp[0] if sp else None
             r["d1_bf16"] = yb[0] if yb else None

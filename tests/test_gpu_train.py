@@ -548,6 +548,34 @@ def test_plain_bf16_convolutions_are_the_hi_halves_of_the_bf16x3_products():
             assert rel(z.permute(0, 3, 1, 2), want) < 2e-6, (B, H, W, C0, C1, Cout)
 
 
+def test_plain_bf16_convolution_from_a_bf16_source_is_bit_identical():
+    """mfpa_conv_desc.x0_is_bf16: the input-gradient convolutions of the plain-bf16 step read the bf16 copy of dz the BatchNorm backward
+    writes (8-channel staging slots, no split arithmetic, half the bytes) -- the same bits as feeding the float32 tensor whose
+    hi halves those are.  64- and 128-channel tiles (tap-by-tap / ROWS loops), ragged edges, 16 x 16 patches, more tiles than CUs, cropped
+    output + BatchNorm-backward partials in the epilogue."""
+    from musicfpaugment_amd import ops_train as T
+    from musicfpaugment_amd import ops_unet as K
+    g = torch.Generator().manual_seed(31)
+    for (B, H, W, C0, Cout, crop) in [(2, 9, 37, 64, 64, None), (3, 33, 31, 128, 128, None), (70, 64, 62, 128, 64, None), (2, 16, 15, 256, 128, None),
+                                      (1, 40, 70, 128, 256, None), (2, 33, 31, 512, 128, (32, 30)), (40, 128, 125, 64, 128, None)]:
+        x32 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x16 = x32.bfloat16()
+        w = K.pack_conv3x3(torch.randn(Cout, C0, 3, 3, generator=g) / np.sqrt(9 * C0)).cuda()
+        lay = T.weight_layout(H, W, C0, Cout, 2)
+        assert lay == 2
+        wp = T.pack_weights(w, 2, layout=lay)
+        kw = dict(precision=2, packed=True, w_layout=lay)
+        if crop:
+            kw["out_hw"] = crop
+        sp_a, sp_b = [], []
+        want = T.conv_mfma(x16.float(), wp, Cout, stats_out=sp_a, **kw)
+        got = T.conv_mfma(x16, wp, Cout, stats_out=sp_b, **kw)
+        assert torch.equal(got, want), (B, H, W, C0, Cout)
+        assert len(sp_a) == len(sp_b) and all(torch.equal(a, b) for a, b in zip(sp_a, sp_b))
+    with pytest.raises(ValueError):                                   # a bf16 source is the plain-bf16 kernel's only
+        T.conv_mfma(x16, wp, Cout, precision=1, packed=True, w_layout=lay)
+
+
 def test_train_step_in_plain_bf16_tracks_the_fp32_step():
     """UNetTrainEngine(precision=2, wgrad_precision=2): forward and input-gradient convolutions with plain bf16 products wherever
     conv_wd16_kernel serves the layer (the transposed convolutions and the 1-channel first layer keep their arithmetic), bf16 weight
