@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
-PMC_TRAFFIC_BF16X3 = "r03_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
+PMC_TRAFFIC_BF16X3 = "r04_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
 PMC_TRAFFIC_DEMUCS = "r02_pmc_traffic_demucs.json"   # the same for the Demucs forward (GEMM family + LSTM launches)
 
 
@@ -647,7 +647,7 @@ def bench_infer(args, rank, world, dev, dist):
     barrier()
     dt, timer, (mask, npeaks) = timed(args.steps)
     other = None
-    if net is not None and world == 1 and not args.sub_config:   # the other arithmetic, same run, for the record (not the headline)
+    if net is not None and world == 1 and not args.sub_config and not args.no_extras:   # the other arithmetic, same run, for the record (not the headline)
         net.precision = 1 - net.precision
         hot(wav)
         barrier()
@@ -656,14 +656,14 @@ def bench_infer(args, rank, world, dev, dist):
         other = (dt_o, timer_o)
 
     load_sample = None
-    if rank == 0 and net is not None and not args.sub_config:
+    if rank == 0 and net is not None and not args.sub_config and not args.no_extras:
         # clock / power UNDER LOAD, outside the timed region: a burst of the same steps is queued, rocm-smi is read while it runs
         for _ in range(max(8, int(0.6 / max(dt / args.steps, 1e-3)))):
             hot(wav)
         load_sample = device_sample(dev.index or 0)
         torch.cuda.synchronize()
     parity = None
-    if net is not None and args.picker == "audfprint":
+    if net is not None and args.picker == "audfprint" and not args.no_extras:
         # every line certifies the arithmetic it was measured in (outside the timed region, device only): the first 8 clips of this
         # very batch through the chain in BOTH arithmetic variants -- relative L1 of the bf16x3 UNet output against the exact-fp32
         # MFMA output (the reference's arithmetic; gate 1e-4) and how many of the 8 peak masks are identical
@@ -947,6 +947,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=None, help="clips per GPU per step (default 256; train / demucs-train 64)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of each CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="infer mode: ONLY the timed chain (no other-precision leg, no parity_in_run pass, no "
+                    "under-load clock sample): counter-collection runs, where every extra launch lands in the per-kernel sums")
     ap.add_argument("--no-configs", action="store_true", help="N = 1 infer mode: skip the `configs` block (the other BASELINE configurations)")
     ap.add_argument("--no-unet", action="store_true", help="STFT + peak-pick only (BASELINE config 2 parity runs)")
     ap.add_argument("--picker", choices=["audfprint", "dejavu"], default="audfprint",
