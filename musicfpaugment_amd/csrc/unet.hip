@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MFPA_HALO_SPREAD
+#define MFPA_HALO_SPREAD 0    // conv_wd16_kernel<.., WMW = 4>: staging slot k of the next chunk's halo requested at tap k (1) instead of all at tap 0 (A/B builds)
+#endif
 #ifndef MFPA_EPI_LDS
 #define MFPA_EPI_LDS 1        // conv_wd16_kernel: the epilogue's per-channel constants from an LDS copy (0: global loads inside the epilogue, A/B builds)
 #endif
@@ -1205,6 +1208,16 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < A_F4; ++it) areg[it % AREGS][0] = __uint_as_float(ao[it * THREADS]);
   };
+  // one staging slot of load_a_pre (MFPA_HALO_SPREAD: slot k is requested at tap k instead of all six at tap 0)
+  auto load_a_one = [&](auto IT, int chunk) __attribute__((always_inline)) {
+    constexpr int it = decltype(IT)::value;
+    if (MFPA_EXP_FLAG(a.dbg, 64)) return;
+    const int c0 = chunk * KC;
+    const bool from0 = c0 < a.C0;
+    const auto rs = clip_rsrc(from0 ? a.x0 : a.x1, S.b, from0 ? clip0 : clip1);
+    const unsigned toff = from0 ? S.t0 + (unsigned)c0 * (unsigned)ESZ : S.t1 + (unsigned)(c0 - a.C0) * (unsigned)ESZ;
+    areg[it % AREGS] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(__float_as_uint(areg[it % AREGS][0]) + toff), 0, 0));
+  };
   auto load_a_pre = [&](int chunk) __attribute__((always_inline)) {
     if (MFPA_EXP_FLAG(a.dbg, 64)) return;
     const int c0 = chunk * KC;
@@ -1387,7 +1400,11 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       stamp(9);
     }
+#if MFPA_HALO_SPREAD
+    if constexpr (tap < A_F4) load_a_one(std::integral_constant<int, tap < A_F4 ? tap : 0>{}, chunk_n);
+#else
     if (tap == 0) load_a_pre(chunk_n);
+#endif
     // what the next tap 0 requests: chunk + 2; from the tile's last-but-one chunk on, the next tile's chunk 0, then its chunk 1
     if (tap == TAPS - 1) preload_offsets(chunk + 2 < nchunks ? chunk + 2 : chunk + 1 < nchunks ? 0 : 1 < nchunks ? 1 : 0);
     read_x(par ? fx0 : fx1, nxt, ntap_off, 0);
