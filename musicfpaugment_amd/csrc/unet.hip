@@ -41,6 +41,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MFPA_WD16_PERSIST_ROWS
+#define MFPA_WD16_PERSIST_ROWS 0   // the same for the ROWS inference form (A/B builds)
+#endif
+#ifndef MFPA_WD16_PERSIST2
+#define MFPA_WD16_PERSIST2 1  // conv_wd16_kernel<.., WMW = 2>, tap-by-tap inference form: persistent tile loop like the 64-channel form (0: one tile per workgroup, A/B builds)
+#endif
 #ifndef MFPA_HALO_SPREAD
 #define MFPA_HALO_SPREAD 0    // conv_wd16_kernel<.., WMW = 4>: staging slot k of the next chunk's halo requested at tap k (1) instead of all at tap 0 (A/B builds)
 #endif
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // PERSIST (WMW = 4): a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the halo of the next tile's first chunk is
   // requested and split under the last chunk of the current one, so a tile's prologue (a global round trip) and most of its epilogue
   // disappear behind the neighbours' MFMAs -- with 2 .. 4 chunks per tile they were a third of a workgroup's life.
-  constexpr bool PERSIST = (WMW == 4);
+  constexpr bool PERSIST = (WMW == 4) || (MFPA_WD16_PERSIST2 != 0 && !ROWS && !SIDE && !PLAIN) || (MFPA_WD16_PERSIST_ROWS != 0 && ROWS && !SIDE && !PLAIN);
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / KC;
@@ -1342,7 +1348,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     constexpr int tap = decltype(TAP)::value;
     constexpr int ntap = (tap + 1) % TAPS;
     constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * 16, ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * 16;
-    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : (PERSIST ? 0 : chunk);
     const char* cur = smem + (chunk & 1) * STAGE;
     const char* nxt = (tap == TAPS - 1) ? smem + ((chunk + 1) & 1) * STAGE : cur;
     read_x(fx1, cur, tap_off, 1);
@@ -1359,7 +1365,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (tap == 0) load_a_pre(chunk_n);
-    if (tap == TAPS - 1) preload_offsets(chunk + 2 < nchunks ? chunk + 2 : chunk + 1 < nchunks ? chunk + 1 : chunk);   // what the next tap 0 requests
+    if (tap == TAPS - 1) preload_offsets(PERSIST ? (chunk + 2 < nchunks ? chunk + 2 : chunk + 1 < nchunks ? 0 : 1 < nchunks ? 1 : 0)
+                                                 : (chunk + 2 < nchunks ? chunk + 2 : chunk + 1 < nchunks ? chunk + 1 : chunk));   // what the next tap 0 requests
     read_x(fx0, nxt, ntap_off, 0);
     mfma_half(fx1, wq[tap % 3], 1);
     if constexpr (tap >= 2 && tap - 2 < A_F4) {
@@ -1511,7 +1518,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   auto unit_step = [&](auto U, auto DX, auto PAR, int chunk) __attribute__((always_inline)) {
     constexpr int u = decltype(U)::value, dx = decltype(DX)::value, par = decltype(PAR)::value;
     constexpr int n_m = unit_mfmas(u);
-    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : (PERSIST ? 0 : chunk);
     const char* cur = smem + (chunk & 1) * STAGE;
     char* nxs = smem + ((chunk + 1) & 1) * STAGE;
     if constexpr (u == BARU && dx == 2) {
@@ -1780,6 +1787,29 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     using D2 = std::integral_constant<int, 2>;
 #pragma unroll
     for (int u = 0; u < NB - 1; ++u) read_unit(xu[u], smem, u, 0);
+    if constexpr (PERSIST) {
+      for (;;) {
+        const int tile_n = tile + (int)gridDim.x;
+        const bool has_next = tile_n < ntiles;
+        const Tile N = make_tile(has_next ? tile_n : tile);
+        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+          period(D0{}, S0{}, chunk);
+          period(D1{}, S1{}, chunk);
+          period(D2{}, S0{}, chunk);
+          if (chunk + 2 >= nchunks) S = N;                               // the tile's last chunk stages the next tile's first
+          period(D0{}, S1{}, chunk + 1);
+          period(D1{}, S0{}, chunk + 1);
+          period(D2{}, S1{}, chunk + 1);
+        }
+        epilogue();
+        if (!has_next) break;
+        tile = tile_n; eb = S.b; ey0 = S.y0; ex0p = S.x0p;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
     for (int chunk = 0; chunk < nchunks; chunk += 2) {                 // nchunks is even (C_in % 64 == 0, checked by the dispatcher)
       period(D0{}, S0{}, chunk);
       period(D1{}, S1{}, chunk);
@@ -1789,6 +1819,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       period(D2{}, S1{}, chunk + 1);
     }
     epilogue();
+    }
   } else if constexpr (WMW == 4) {
     read_x(fx0, smem, 0, 0);
     for (;;) {
@@ -1833,6 +1864,32 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
       mfpa_conv_stamps[0] = stamp_n;
     }
 #endif
+  } else if constexpr (PERSIST) {                                    // WMW = 2, tap-by-tap, persistent (MFPA_WD16_PERSIST2)
+    read_x(fx0, smem, 0, 0);
+    for (;;) {
+      const int tile_n = tile + (int)gridDim.x;
+      const bool has_next = tile_n < ntiles;
+      const Tile N = make_tile(has_next ? tile_n : tile);
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 >= nchunks) S = N;                                 // the tile's last chunk stages the next tile's first
+        tap_body(std::integral_constant<int, 0>{}, chunk);
+        tap_body(std::integral_constant<int, 1>{}, chunk);
+        tap_body(std::integral_constant<int, 2>{}, chunk);
+        tap_body(std::integral_constant<int, 3>{}, chunk);
+        tap_body(std::integral_constant<int, 4>{}, chunk);
+        tap_body(std::integral_constant<int, 5>{}, chunk);
+        tap_body(std::integral_constant<int, 6>{}, chunk);
+        tap_body(std::integral_constant<int, 7>{}, chunk);
+        tap_body(std::integral_constant<int, 8>{}, chunk);
+      }
+      epilogue();
+      if (!has_next) break;
+      tile = tile_n; eb = S.b; ey0 = S.y0; ex0p = S.x0p;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
   } else {
   read_x(fx0, smem, 0, 0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -1879,7 +1936,11 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   const_cast<size_t&>(lds) += 4096;
 #endif
   static const int persist_env = MFPA_EXP_ENV("MFPA_CONV_WD16_PERSIST", 1);      // experiments: 0 = one workgroup per tile
-  if (WMW == 4 && persist_env) {                                       // persistent: one workgroup per CU (and output-channel tile) walks the tiles
+  const bool side_ = a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part;
+  const int cin_ = a.C0 + a.C1;
+  const bool rows_ = WMW == 2 && MFPA_CONV_WD16_ROWS > 0 && cin_ % 64 == 0 && cin_ >= MFPA_CONV_WD16_ROWS;
+  const bool persist2 = WMW == 2 && !side_ && !a.plain && ((MFPA_WD16_PERSIST2 != 0 && !rows_) || (MFPA_WD16_PERSIST_ROWS != 0 && rows_));
+  if ((WMW == 4 && persist_env) || persist2) {                         // persistent: one workgroup per CU (and output-channel tile) walks the tiles
     const int cus = mfpa_current_device_cus();
     const unsigned per = (unsigned)((cus > 0 ? cus : 256) / (int)grid.y);
     if (per >= 1 && grid.x > per) grid.x = per;
