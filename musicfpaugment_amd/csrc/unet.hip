@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MFPA_WD16_PERSIST_PLAIN
+#define MFPA_WD16_PERSIST_PLAIN 1  // the same for the plain-bf16 (training) instantiations, whose MFMA time is a third: prologue / epilogue weigh three times more
+#endif
 #ifndef MFPA_WD16_PERSIST_ROWS
 #define MFPA_WD16_PERSIST_ROWS 0   // the same for the ROWS inference form (A/B builds)
 #endif
@@ -1096,7 +1099,8 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   // PERSIST (WMW = 4): a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the halo of the next tile's first chunk is
   // requested and split under the last chunk of the current one, so a tile's prologue (a global round trip) and most of its epilogue
   // disappear behind the neighbours' MFMAs -- with 2 .. 4 chunks per tile they were a third of a workgroup's life.
-  constexpr bool PERSIST = (WMW == 4) || (MFPA_WD16_PERSIST2 != 0 && !ROWS && !SIDE && !PLAIN) || (MFPA_WD16_PERSIST_ROWS != 0 && ROWS && !SIDE && !PLAIN);
+  constexpr bool PERSIST = (WMW == 4) || (MFPA_WD16_PERSIST2 != 0 && !ROWS && !SIDE && !PLAIN) || (MFPA_WD16_PERSIST_ROWS != 0 && ROWS && !SIDE && !PLAIN) ||
+                           (MFPA_WD16_PERSIST_PLAIN != 0 && PLAIN);
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / KC;
@@ -1939,7 +1943,8 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   const bool side_ = a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part;
   const int cin_ = a.C0 + a.C1;
   const bool rows_ = WMW == 2 && MFPA_CONV_WD16_ROWS > 0 && cin_ % 64 == 0 && cin_ >= MFPA_CONV_WD16_ROWS;
-  const bool persist2 = WMW == 2 && !side_ && !a.plain && ((MFPA_WD16_PERSIST2 != 0 && !rows_) || (MFPA_WD16_PERSIST_ROWS != 0 && rows_));
+  const bool persist2 = WMW == 2 && ((!side_ && !a.plain && ((MFPA_WD16_PERSIST2 != 0 && !rows_) || (MFPA_WD16_PERSIST_ROWS != 0 && rows_))) ||
+                                     (MFPA_WD16_PERSIST_PLAIN != 0 && a.plain));
   if ((WMW == 4 && persist_env) || persist2) {                         // persistent: one workgroup per CU (and output-channel tile) walks the tiles
     const int cus = mfpa_current_device_cus();
     const unsigned per = (unsigned)((cus > 0 ? cus : 256) / (int)grid.y);
