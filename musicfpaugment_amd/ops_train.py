@@ -402,7 +402,14 @@ class UNetTrainEngine:
 
     def _bn_stats(self, z, bn, g, b, part=None) -> Stats:
         """Batch statistics of z.  `part`: the producing convolution's per-wave partial sums (conv_mfma(stats_out=...)) -- then z is not
-        read again."""
+        read again.  Accuracy of that shortcut: the partials are float32 sums over <= 128 pixels, reduced in float64; the variance
+        E[z^2] - mean^2 amplifies their error by 1 + mean^2 / var.  Measured (tests/test_gpu_train.py::
+        test_batchnorm_statistics_from_conv_partials_large_offset_channel): channels 12 standard deviations off zero (amplification 145)
+        read invstd 2e-6 off the float64 pass, channels within 3 standard deviations 1e-8 -- the per-wave rounding errors are ~1e-8 and
+        average out, far below the bound a worst-case analysis gives.
+        Only the bf16 kernels (conv_wd16_kernel: precision 1 / 2) write partials -- their own operand rounding (2^-17 / 2^-9) is
+        amplified by the same factor in z itself -- the fp32 engine (precision 0: the golden step, the autograd default) always takes the
+        float64 pass over z below."""
         C = z.shape[-1]
         st = Stats(C, z.device)
         if self.sync_bn or part is not None:

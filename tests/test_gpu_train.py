@@ -149,6 +149,45 @@ def test_forward_conv_side_outputs_bf16_input_copy_and_batchnorm_partials():
         assert rel(dw, dw_ref) < 2e-2, (B, H, W, C0, C1, Cout, rel(dw, dw_ref))
 
 
+def test_batchnorm_statistics_from_conv_partials_large_offset_channel():
+    """the BatchNorm statistics taken from conv_wd16_kernel's float32 per-wave partials form the variance as E[z^2] - mean^2,
+    which amplifies their ~2e-6 error by 1 + mean^2 / var.  Quantified here on an output whose channels sit 0 ... 12 standard deviations
+    off zero (all-positive inputs x constant-sign weight rows), against the float64 pass over z (mfpa_bn_stats_sums): mean exact to 1e-6,
+    invstd within 2e-5 at the worst channel (measured 2e-6) and within 1e-7 where |mean| < 3 std (measured 1e-8): the per-wave rounding
+    errors average out; and only the bf16 kernels write partials at all (the fp32 engine never uses them)."""
+    from musicfpaugment_amd import ops_train as T
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C0, Cout = 4, 64, 62, 64, 128
+    x0 = (torch.rand(B, H, W, C0, generator=g) + 0.5).cuda()                    # all positive
+    w = torch.randn(Cout, C0, 3, 3, generator=g) / np.sqrt(9 * C0)
+    w += torch.linspace(0.0, 0.25, Cout)[:, None, None, None]                    # channel c: a growing positive offset -> mean / std up to ~30
+    wk = K.pack_conv3x3(w).cuda()
+    sp = []
+    z = T.conv_mfma(x0, wk, Cout, precision=1, stats_out=sp)
+    assert len(sp) == 1
+    ws = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device="cuda")
+    got = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
+    ref = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
+    check(lib().mfpa_conv_stats_reduce(ptr(sp[0]), sp[0].shape[0], Cout, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
+    check(lib().mfpa_bn_stats_sums(ptr(z), B * H * W, Cout, ptr(ref), ptr(ws), stream()), "mfpa_bn_stats_sums")
+    n = float(B * H * W)
+
+    def stats(s):
+        s = s.view(Cout, 2)
+        mean = s[:, 0] / n
+        var = s[:, 1] / n - mean * mean
+        return mean, 1.0 / torch.sqrt(var + 1e-5), var
+    (m_g, i_g, _), (m_r, i_r, v_r) = stats(got), stats(ref)
+    ratio = (m_r.abs() / torch.sqrt(v_r)).cpu()
+    assert float(ratio.max()) > 10.0                                             # the test really has far-off-zero channels (zero padding caps it: border pixels see 6 of 9 taps)
+    assert float(((m_g - m_r).abs() / m_r.abs().clamp_min(1e-3)).max()) < 1e-6
+    rel = ((i_g - i_r).abs() / i_r).cpu()
+    print(f"[bn partials] |mean| / std up to {float(ratio.max()):.1f}; invstd relative error: max {float(rel.max()):.2e}, where |mean| < 3 std {float(rel[ratio < 3].max()):.2e}")
+    assert float(rel.max()) < 2e-5 and float(rel[ratio < 3].max()) < 1e-7
+
+
 def test_train_step_matches_reference_golden(golden):
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
