@@ -842,7 +842,7 @@ def other_configs(args, dev):
         ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True, precision="bf16", wgrad="bf16")),
         ("config4_unet_train_step_bf16x3", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True, precision="bf16x3", wgrad="bf16")),
         ("config4_unet_train_step_bf16x3_premixed", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=False, precision="bf16x3", wgrad="bf16")),
-        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=10, warmup=3, clips=256)),
+        ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=20, warmup=5, clips=256)),
         # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
         # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
         ("config5_peak_metrics", bench_metrics, dict(mode="metrics", queries=10000, denoiser="demucs", steps=1, warmup=1, clips=256)),
