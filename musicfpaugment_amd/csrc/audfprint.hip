@@ -37,6 +37,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
   TIn* heap = reinterpret_cast<TIn*>(tile_out + TT * R);  // [chunks][HEAP]
   __shared__ double red[PREP_THREADS / 64];
   __shared__ double bcast[2];
+  __shared__ double logtab[128][3];                  // the log table in LDS (three dependent-address global loads per logarithm otherwise)
+  for (int i = threadIdx.x; i < 128 * 3; i += PREP_THREADS) (&logtab[0][0])[i] = (&mfpa_log_tab[0][0])[i];
+  __syncthreads();
 
   const int tid = threadIdx.x, b = blockIdx.x;
   const int N = F * T;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
         TIn s = has_den ? (TIn)((double)v[u] / den) : v[u];
         if (do_log) {
           s = s > floor_v ? s : floor_v;
-          s = (TIn)mfpa_log((double)s);
+          s = (TIn)mfpa_log_t((double)s, logtab);
         }
         L[i] = (double)s;
       }
@@ -170,19 +173,16 @@ __global__ __launch_bounds__(PREP_THREADS) void prepare_kernel(const TIn* __rest
   }
 }
 
-// ---------------------------------------------------------------------------------------------- prepare, low-latency split form
-// The same arithmetic as prepare_kernel<double> for the path whose per-clip maximum is already known (log_input bit 1: config 2's
-// STFT -> peak-pick chain), as TWO launches with 16 workgroups per clip instead of one 512-thread workgroup per clip walking three
-// passes with a global round trip of the log-spectrogram (176 us per 256 clips: a latency chain -- one workgroup per CU).
-//   prep_sum_kernel    : workgroup (clip, chunk, half) = one child of the root of one 8192-element chunk of numpy's pairwise tree
-//                        (memory order = mean_order): the log values of its <= 4096 elements go to LDS (read from `spec` along
-//                        the frames, whatever the order) and are summed in numpy's order; one double out.
-//   prep_filter_kernel : workgroup (clip, 16 bins): mean = sum of the chunk roots (left + right, chunk after chunk: numpy's order)
-//                        / N; log values (written by the first launch: a float64 log is ~150 instructions, recomputing them
-//                        doubled the launch pair's time) minus mean into an LDS tile [16 bins][T]; 16 lanes run the 1-pole filter
-//                        along the frames; the tile is written frame-major.
+// ---------------------------------------------------------------------------------------------- log values + np.mean's node sums (mfpa_audfprint_pick)
+// First launch of the fused picker for the path whose per-clip maximum is already known (config 2's STFT -> peak-pick chain); same
+// arithmetic as prepare_kernel<double>.  Workgroup (clip, chunk, half) = one child of the root of one 8192-element chunk of numpy's
+// pairwise tree (memory order = mean_order): the raw values of its <= 4104 elements are gathered into LDS in that order (read from
+// `spec` along the frames, whatever the order), turned into log values there and summed in numpy's order; the log values go out
+// frame-major (fm = 1: coalesced) or bin-major (fm = 0), the node sum beside them.  16 workgroups per clip instead of one: the stage is
+// instruction-bound (a float64 division and a float64 log per element), so what counts is that the whole chip works on it.
+// (A 16-bin-per-workgroup filter kernel completed this into a two-launch replacement of prepare_kernel; it measured 75 us per 256 clips,
+//  the pair 190-230 us against the single kernel's 176 -- the pruner now filters the frames itself, mfpa_audfprint_pick.)
 constexpr int SPLIT_THREADS = 256;
-constexpr int SPLIT_BINS = 16;
 constexpr int SPLIT_MAX_T = 512;
 
 __device__ __forceinline__ double prep_log_value(double v, double den, bool do_log, double floor_v, const double (*tab)[3]) {
@@ -311,77 +311,6 @@ __global__ __launch_bounds__(SPLIT_THREADS) void prep_sum_kernel(const double* _
   if (tid == 0) *out = r;
 }
 
-__global__ __launch_bounds__(SPLIT_THREADS) void prep_filter_kernel(const double* __restrict__ spec, int F, int T,
-                                                                    const double* __restrict__ denom,
-                                                                    const double* __restrict__ sums, double pole,
-                                                                    double* __restrict__ filtered) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int Tp = T | 1;                                        // odd row pitch: the 16 filter lanes hit 16 different bank pairs
-  double* tile = reinterpret_cast<double*>(smem);              // [SPLIT_BINS][Tp]
-  const int tid = threadIdx.x, b = blockIdx.x, r0 = blockIdx.y * SPLIT_BINS;
-  const int R = F - 1, N = F * T;
-  const int nb = min(SPLIT_BINS, R - r0);
-  const bool do_log = denom[b] > 0.0;                          // prepare_kernel: smax = denom / denom = 1 (NaN for an all-zero clip)
-  double mean = 0.0;
-  if (do_log) {                                                // np.mean: acc = 0; acc += pairwise(chunk) for every chunk; / N
-    const int nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
-    double total = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-      const int cn = min(NPY_BUFSIZE, N - c * NPY_BUFSIZE);
-      const double* h = sums + (size_t)b * N + (size_t)(F - 1) * T + 2 * c;
-      total = total + (cn > PW_BLOCK ? h[0] + h[1] : h[0]);
-    }
-    mean = total / (double)N;
-  }
-  const double* x = sums + (size_t)b * N + (size_t)r0 * T;    // the log values of nb rows of T frames, contiguous
-  for (int i0 = tid; i0 < nb * T; i0 += 8 * SPLIT_THREADS) {  // eight independent loads in flight per thread
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * SPLIT_THREADS;
-      v[u] = i < nb * T ? x[i] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * SPLIT_THREADS;
-      if (i < nb * T) {
-        const int r = i / T, t = i - r * T;
-        tile[r * Tp + t] = v[u] - mean;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < nb) {                                              // y[n] = x[n] + z; z = -x[n] - (-pole) * y[n]  (scipy lfilter, DF-II transposed)
-    double* row = tile + tid * Tp;
-    double z = 0.0;
-    const double npole = -pole;
-    int t = 0;
-    for (; t + 8 <= T; t += 8) {
-      double xs[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) xs[u] = row[t + u];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const double yn = xs[u] + z;
-        z = -xs[u] - npole * yn;
-        row[t + u] = yn;
-      }
-    }
-    for (; t < T; ++t) {
-      const double xn = row[t];
-      const double yn = xn + z;
-      z = -xn - npole * yn;
-      row[t] = yn;
-    }
-  }
-  __syncthreads();
-  double* outp = filtered + (size_t)b * T * R + r0;
-  for (int i = tid; i < nb * T; i += SPLIT_THREADS) {
-    const int t = i / nb, r = i - t * nb;
-    outp[(size_t)t * R + r] = tile[r * Tp + t];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------- prune
 constexpr int MAXP = 8;
 
@@ -441,7 +370,7 @@ __device__ __forceinline__ Best wave_best(Best x) {
 //     compares against the previous frame's bins held in registers.
 // FUSED: `filtered` holds the LOG values frame-major with pitch R + 1 (prep_sum_kernel, fm = 1) and the kernel applies
 // "minus mean, 1-pole high-pass along the frames" itself while it walks the frames forward (state in registers, exactly prepare's
-// arithmetic) -- the filtered spectrogram never exists in memory and prep_filter_kernel's launch (75 us per 256 clips) is gone.
+// arithmetic) -- the filtered spectrogram never exists in memory.
 template <bool FUSED>
 __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ filtered, int R, int T,
                                                    const double* __restrict__ gauss, double a_dec, int maxpks,
@@ -460,7 +389,7 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   const int k0 = 4 * lane;
   double mean = 0.0, zf[4] = {0.0, 0.0, 0.0, 0.0}, lastcol[4] = {0.0, 0.0, 0.0, 0.0};
   const double npole = -pole;
-  if (FUSED && denom[b] > 0.0) {                               // np.mean: acc = 0; acc += pairwise(chunk) for every chunk; / N  (prep_filter_kernel)
+  if (FUSED && denom[b] > 0.0) {                               // np.mean: acc = 0; acc += pairwise(chunk) for every chunk; / N
     const int N = (R + 1) * T, nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
     double total = 0.0;
     for (int c = 0; c < nchunks; ++c) {
@@ -725,18 +654,6 @@ int mfpa_audfprint_prepare(const void* spec, int dtype, int B, int F, int T, con
   const int nchunks = (int)((N + NPY_BUFSIZE - 1) / NPY_BUFSIZE);
   const size_t lds = sizeof(double) * ((size_t)R * (TT + 1) + (size_t)TT * R) + sizeof(double) * (size_t)nchunks * HEAP;
   hipStream_t s = mfpa_stream(stream);
-  if (dtype == MFPA_F64 && log_input == 2 && denom != nullptr && T <= SPLIT_MAX_T && T >= 2 * nchunks && F <= 257 && F >= 141) {
-    // the per-clip maximum is known: the low-latency split form (16 workgroups per clip, two launches; `scratch` holds the chunk sums)
-    const size_t lds1 = sizeof(double) * (NPY_BUFSIZE / 2 + 8 + HEAP + 128 * 3);
-    hipLaunchKernelGGL(prep_sum_kernel, dim3(B, 2 * nchunks), dim3(SPLIT_THREADS), lds1, s, (const double*)spec, F, T, denom, mean_order, scratch, 0,
-                       scratch + (size_t)(F - 1) * T, (long long)N);        // row F - 1 of the bin-major log values is never read back: its T >= 2 * nchunks doubles hold the node sums
-    MFPA_CHECK_LAUNCH();
-    const size_t lds2 = sizeof(double) * (size_t)SPLIT_BINS * (T | 1);
-    hipLaunchKernelGGL(prep_filter_kernel, dim3(B, (R + SPLIT_BINS - 1) / SPLIT_BINS), dim3(SPLIT_THREADS), lds2, s, (const double*)spec, F, T, denom,
-                       scratch, pole, filtered);
-    MFPA_CHECK_LAUNCH();
-    return MFPA_OK;
-  }
   if (dtype == MFPA_F64)
     hipLaunchKernelGGL(prepare_kernel<double>, dim3(B), dim3(PREP_THREADS), lds, s, (const double*)spec, F, T, denom,
                        mean_order, log_input, pole, filtered, scratch);

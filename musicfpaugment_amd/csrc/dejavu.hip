@@ -31,6 +31,9 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn*
   TIn* heap = reinterpret_cast<TIn*>(smem);
   __shared__ double red[PREP_THREADS / 64];
   __shared__ double bcast[2];
+  __shared__ double logtab[128][3];                  // the log table in LDS (three dependent-address global loads per logarithm otherwise)
+  for (int i = threadIdx.x; i < 128 * 3; i += PREP_THREADS) (&logtab[0][0])[i] = (&mfpa_log_tab[0][0])[i];
+  __syncthreads();
   const int tid = threadIdx.x, b = blockIdx.x;
   const int N = F * T;
   const TIn* x = psd + (size_t)b * N;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn*
       if (i0 + u * PREP_THREADS < N) {
         TIn s = value(v[u]);
         s = s > floor_v ? s : floor_v;
-        L[i0 + u * PREP_THREADS] = (double)(sc * (TIn)mfpa_log((double)s));   // float32: the float64 log rounded once (as audfprint.hip)
+        L[i0 + u * PREP_THREADS] = (double)(sc * (TIn)mfpa_log_t((double)s, logtab));   // float32: the float64 log rounded once (as audfprint.hip)
       }
   }
   __syncthreads();
