@@ -211,6 +211,11 @@ def device_sample(local_rank: int = 0):
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(exe):
         return None
+    # under rocprofv3 the profiler's preloaded library initialises the GPU in every child as well, and rocm-smi is a `#!/usr/bin/env
+    # python3` script: that second exec, from a process that already holds the GPU, is the hop the boxes refuse -- no sample then
+    env = dict(os.environ)
+    if "rocprof" in env.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in env):
+        return {"skipped": "running under rocprofv3 (no child processes from a profiled run)"}
     try:
         r = subprocess.run([exe, "-d", str(local_rank), "--showclocks", "--showpower", "--showtemp", "--json"],
                            capture_output=True, text=True, timeout=20)

@@ -420,18 +420,20 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
   }
   __syncthreads();
 
+  // Unconditional loads from clamped addresses (frames past the end re-read frame T - 1, lanes without bins read bins 0..3; neither is
+  // ever used): with the loads inside exec-masked branches hipcc could not count them across the loop and put s_waitcnt vmcnt(0)
+  // right behind the NEXT group's loads, in front of the first use of the current one -- every group of four frames paid a full
+  // memory round trip (a third of the forward pass at one wave per CU).
+  const double* Sk = S + (own ? k0 : 0);
   auto load_col = [&](int c, double (&v)[4]) {
-    if (own && c < T) {
-      if (FUSED) {                                             // pitch R + 1 doubles: 8-byte aligned only
-        const double* q = S + (size_t)c * P + k0;
-        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-      } else {
-        const double2 a = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0);
-        const double2 d = *reinterpret_cast<const double2*>(S + (size_t)c * R + k0 + 2);
-        v[0] = a.x; v[1] = a.y; v[2] = d.x; v[3] = d.y;
-      }
+    const int cc = c < T ? c : T - 1;
+    if (FUSED) {                                               // pitch R + 1 doubles: 8-byte aligned only
+      const double* q = Sk + (size_t)cc * P;
+      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
     } else {
-      v[0] = v[1] = v[2] = v[3] = 0.0;
+      const double2 a = *reinterpret_cast<const double2*>(Sk + (size_t)cc * R);
+      const double2 d = *reinterpret_cast<const double2*>(Sk + (size_t)cc * R + 2);
+      v[0] = a.x; v[1] = a.y; v[2] = d.x; v[3] = d.y;
     }
   };
   // locmax flags of a column held 4 bins per lane (peak_extractor.py:61-73)

@@ -52,15 +52,15 @@ __device__ __forceinline__ void dft16(cd (&v)[16]) {
 }
 
 constexpr int FRAMES_PER_BLOCK = 16;
-constexpr int SLOTS = 16 * 17;  // padded 16x16 complex tile per frame
+constexpr int SLOTS = 16 * 17;  // padded 16x16 tile of doubles per frame (>= 257 + 1 slots of the [bin][16 frames] output tile per frame)
 
 // MODE 0: centre/reflect magnitude (hypot).  MODE 1: no padding, one-sided PSD (|X|^2, interior bins x2).
 template <int MODE, typename OutT>
-__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav, int T_w, int nF,
+__global__ __launch_bounds__(256, 4) void stft_kernel(const float* __restrict__ wav, int T_w, int nF,
                                                    const double* __restrict__ tables, OutT* __restrict__ out,
                                                    double* __restrict__ clip_max, double scale_in) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cd* buf = reinterpret_cast<cd*>(smem);
+  double* buf = reinterpret_cast<double*>(smem);
   const int tid = threadIdx.x, l = tid & 15, fs = tid >> 4;
   const int b = blockIdx.y, f0 = blockIdx.x * FRAMES_PER_BLOCK, f = f0 + fs;
   const bool active = f < nF;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
   const double* win = tables;
   const double* tw256 = tables + 512;
   const double* tw512 = tables + 1024;
-  cd* mybuf = buf + fs * SLOTS;
+  double* mybuf = buf + fs * SLOTS;   // this frame's 16 x 17 slots: real parts, then imaginary parts
 
   cd a[16];
   const int start = (MODE == 0) ? 256 * f - 256 : 256 * f;
@@ -103,37 +103,74 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
     }
   }
   dft16(a);  // A[k1] at a[4*(k1&3) + (k1>>2)]
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
-    const int m = (l * k1) & 255;
-    const double2 t = *reinterpret_cast<const double2*>(tw256 + 2 * m);
-    mybuf[k1 * 17 + l] = cmul(a[4 * (k1 & 3) + (k1 >> 2)], cd{t.x, t.y});
-  }
-  __syncthreads();
+  // The 16 lanes of a frame sit in ONE wavefront (4 frames per wave), so the two exchanges need no workgroup barrier: a wave's LDS
+  // operations execute in order, wave_sync() only keeps the compiler from moving them across each other.  Real and imaginary parts
+  // go through the same 8-byte slots one after the other: 34 KB of LDS per workgroup instead of 68 KB -- four resident
+  // workgroups per CU instead of two (the kernel is latency-bound: profiles/r03_prune_sq.md, 1.8 waves per SIMD, 38 % issuing).
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   cd c[16];
+  {
+    double tim[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) c[q] = mybuf[l * 17 + q];
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const int m = (l * k1) & 255;
+      const double2 t = *reinterpret_cast<const double2*>(tw256 + 2 * m);
+      const cd v = cmul(a[4 * (k1 & 3) + (k1 >> 2)], cd{t.x, t.y});
+      mybuf[k1 * 17 + l] = v.re;
+      tim[k1] = v.im;
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c[q].re = mybuf[l * 17 + q];
+    wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) mybuf[k1 * 17 + l] = tim[k1];
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c[q].im = mybuf[l * 17 + q];
+    wave_sync();
+  }
   dft16(c);  // Z[l + 16*k2] at c[4*(k2&3) + (k2>>2)]
-  __syncthreads();
-#pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) mybuf[l + 17 * k2] = c[4 * (k2 & 3) + (k2 >> 2)];  // slot(k) = k + (k >> 4)
-  __syncthreads();
 
-  // real-FFT split: bins k and 256-k from Z[k], Z[256-k]
-  double lo[9], hi[9];
+  // real-FFT split: bins k and 256-k from Z[k], Z[256-k]; slot(k) = k + (k >> 4)
+  double zkr[9], znr[9], zki[9], zni[9];
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) mybuf[l + 17 * k2] = c[4 * (k2 & 3) + (k2 >> 2)].re;
+  wave_sync();
 #pragma unroll
   for (int m = 0; m < 9; ++m) {
     const int k = (m < 8) ? l + 16 * m : 128;
     const int kn = (256 - k) & 255;
-    const cd zk = mybuf[k + (k >> 4)];
-    const cd zn = mybuf[kn + (kn >> 4)];
+    zkr[m] = mybuf[k + (k >> 4)];
+    znr[m] = mybuf[kn + (kn >> 4)];
+  }
+  wave_sync();
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) mybuf[l + 17 * k2] = c[4 * (k2 & 3) + (k2 >> 2)].im;
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    const int k = (m < 8) ? l + 16 * m : 128;
+    const int kn = (256 - k) & 255;
+    zki[m] = mybuf[k + (k >> 4)];
+    zni[m] = mybuf[kn + (kn >> 4)];
+  }
+  double lo[9], hi[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) {
+    const int k = (m < 8) ? l + 16 * m : 128;
+    const cd zk = {zkr[m], zki[m]}, zn = {znr[m], zni[m]};
     const cd e = {0.5 * (zk.re + zn.re), 0.5 * (zk.im - zn.im)};
     const cd o = {0.5 * (zk.im + zn.im), -0.5 * (zk.re - zn.re)};  // -i (zk - conj(zn)) / 2
     const double2 t = *reinterpret_cast<const double2*>(tw512 + 2 * k);
     const cd wo = cmul(cd{t.x, t.y}, o);
     const cd xk = e + wo, xn = e - wo;
     if (MODE == 0) {
-      lo[m] = hypot(xk.re, xk.im);
+      lo[m] = hypot(xk.re, xk.im);          // (sqrt(fma(re, re, im * im)) measured the same time and the same bits on the synthetic clips: kept hypot, numpy's abs)
       hi[m] = hypot(xn.re, xn.im);
     } else {
       lo[m] = (xk.re * xk.re + xk.im * xk.im) * ((k >= 1) ? 2.0 : 1.0);
@@ -233,7 +270,7 @@ int mfpa_stft_mag(const float* wav, int B, int T_w, const double* tables, void* 
   const int nF = mfpa_stft_frames(T_w);
   if (clip_max) MFPA_HIP(hipMemsetAsync(clip_max, 0, sizeof(double) * B, s));
   dim3 grid((nF + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK, B);
-  const size_t lds = sizeof(cd) * SLOTS * FRAMES_PER_BLOCK;
+  const size_t lds = sizeof(double) * SLOTS * FRAMES_PER_BLOCK;
   if (out_dtype == MFPA_F64)
     hipLaunchKernelGGL((stft_kernel<0, double>), grid, dim3(256), lds, s, wav, T_w, nF, tables, (double*)mag, clip_max, 1.0);
   else
@@ -252,7 +289,7 @@ int mfpa_specgram_psd(const float* wav, int B, int T_w, double scale_in, const d
   const int nF = mfpa_specgram_frames(T_w);
   if (clip_max) MFPA_HIP(hipMemsetAsync(clip_max, 0, sizeof(double) * B, s));
   dim3 grid((nF + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK, B);
-  const size_t lds = sizeof(cd) * SLOTS * FRAMES_PER_BLOCK;
+  const size_t lds = sizeof(double) * SLOTS * FRAMES_PER_BLOCK;
   hipLaunchKernelGGL((stft_kernel<1, double>), grid, dim3(256), lds, s, wav, T_w, nF, tables, psd, clip_max, scale_in);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
