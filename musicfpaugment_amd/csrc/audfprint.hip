@@ -257,41 +257,68 @@ __global__ __launch_bounds__(SPLIT_THREADS) void prep_sum_kernel(const double* _
   const double floor_v = smax / 1e6;
   const double* x = spec + (size_t)b * N;
   const int e0 = c * NPY_BUFSIZE + off;                        // first element (memory order) of the node
-  // the log table into LDS (three dependent-address global loads per logarithm would put a memory round trip into every call)
+  // the log table into LDS (three dependent-address global loads per logarithm would put a memory round trip into every call); its loads
+  // are issued here and stored after the gather's, so that the two memory round trips overlap
   double (*tab)[3] = reinterpret_cast<double (*)[3]>(heap + HEAP);
-  for (int i = tid; i < 128 * 3; i += SPLIT_THREADS) (&tab[0][0])[i] = (&mfpa_log_tab[0][0])[i];
+  constexpr int TABN = 128 * 3;
+  double tabv[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) tabv[u] = (&mfpa_log_tab[0][0])[min(tid + u * SPLIT_THREADS, TABN - 1)];
   if (mean_order == 0) {
     // memory order = the layout of `spec`: the node is one contiguous piece; eight independent loads in flight per thread
     for (int i0 = tid; i0 < n; i0 += 8 * SPLIT_THREADS) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = i0 + u * SPLIT_THREADS < n ? x[e0 + i0 + u * SPLIT_THREADS] : 1.0;
+      for (int u = 0; u < 8; ++u) v[u] = x[e0 + min(i0 + u * SPLIT_THREADS, n - 1)];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (i0 + u * SPLIT_THREADS < n) vals[i0 + u * SPLIT_THREADS] = v[u];
     }
   } else {
     // memory order e = t * F + f: the node covers frames t0 .. t1 (the first and the last partly, nt <= 32 of them).  Gather along the
-    // frames of `spec` (rows of nt doubles) into the node's own order in LDS: thread -> (bin f = idx >> 5, frame slot idx & 31), no
-    // division; lanes of one row write LDS with stride F doubles (odd: conflict-free)
+    // frames of `spec` into the node's own order in LDS.  Every load is unconditional (clamped row / frame; only the LDS store is
+    // predicated): loads inside exec-masked branches are waited for one by one.  Three pieces, so that (almost) every lane carries
+    // an element: (a) whole blocks of 16 frames x the rows below Fm = F - F % 16, a 16-lane group per row, 16 rows per pass, eight
+    // passes in flight; (b) the nt % 16 frames left over, a lane per row; (c) the F % 16 rows left over (the Nyquist row at F = 257).
     const int t0 = e0 / F, t1 = (e0 + n - 1) / F, nt = t1 - t0 + 1;
-    const int tt = tid & 31, fs = tid >> 5;
     if (nt > 32) return;                                       // (cannot happen: the launcher takes F >= 141 only)
-    for (int f0 = fs; f0 < F; f0 += 8 * (SPLIT_THREADS / 32)) {
-      double v[8];
+    const int Fm = F & ~15, nb = nt >> 4, rem = nt & 15;
+    const int tt = tid & 15, fr = tid >> 4;
+    auto put = [&](int t, int f, double v) {
+      const int e = t * F + f - e0;
+      if (e >= 0 && e < n) vals[e] = v;
+    };
+    for (int tb = 0; tb < nb; ++tb) {                          // (a)
+      const int t = t0 + 16 * tb + tt;                         // < T: a whole block lies inside the node's frames
+      const double* src = x + t;
+      for (int f0 = fr; f0 < Fm; f0 += 8 * 16) {
+        double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = f0 + u * (SPLIT_THREADS / 32);
-        v[u] = (f < F && tt < nt) ? x[(size_t)f * T + t0 + tt] : 1.0;
-      }
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(f0 + 16 * u, Fm - 1) * T];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int f = f0 + u * (SPLIT_THREADS / 32);
-        const int e = (t0 + tt) * F + f - e0;
-        if (f < F && tt < nt && e >= 0 && e < n) vals[e] = v[u];
+        for (int u = 0; u < 8; ++u)
+          if (f0 + 16 * u < Fm) put(t, f0 + 16 * u, v[u]);
       }
     }
+    for (int r = 0; r < rem; ++r) {                            // (b)
+      const int t = t0 + 16 * nb + r;
+      for (int f0 = tid; f0 < Fm; f0 += 2 * SPLIT_THREADS) {
+        double v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = x[(size_t)min(f0 + u * SPLIT_THREADS, Fm - 1) * T + t];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (f0 + u * SPLIT_THREADS < Fm) put(t, f0 + u * SPLIT_THREADS, v[u]);
+      }
+    }
+    for (int i = tid; i < (F - Fm) * nt; i += SPLIT_THREADS) { // (c)
+      const int f = Fm + i / nt, t = t0 + i % nt;
+      put(t, f, x[(size_t)f * T + t]);
+    }
   }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + u * SPLIT_THREADS < TABN) (&tab[0][0])[tid + u * SPLIT_THREADS] = tabv[u];
   __syncthreads();                                             // raw values in memory order, the table in LDS
   // s = x / max, floor, log: in the node's memory order (what the pairwise sum reads); written out bin-major (fm = 0) or, frame-major,
   // as the contiguous piece of (T, F) the node is (fm = 1: coalesced)
