@@ -50,7 +50,7 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn*
   for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
     TIn v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : (TIn)0;
+    for (int u = 0; u < 8; ++u) v[u] = x[min(i0 + u * PREP_THREADS, N - 1)];      // unconditional (clamped) loads: masked ones are waited for one by one
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u * PREP_THREADS < N) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn*
   for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
     TIn v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? x[i0 + u * PREP_THREADS] : (TIn)1;
+    for (int u = 0; u < 8; ++u) v[u] = x[min(i0 + u * PREP_THREADS, N - 1)];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u * PREP_THREADS < N) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(PREP_THREADS) void dejavu_prepare_kernel(const TIn*
   for (int i0 = tid; i0 < N; i0 += 8 * PREP_THREADS) {
     double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * PREP_THREADS < N) ? L[i0 + u * PREP_THREADS] : 0.0;
+    for (int u = 0; u < 8; ++u) v[u] = L[min(i0 + u * PREP_THREADS, N - 1)];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u * PREP_THREADS < N) L[i0 + u * PREP_THREADS] = (double)((TIn)v[u] - mean);
@@ -106,10 +106,14 @@ __device__ __forceinline__ int reflect_index(int i, int n) {  // scipy.ndimage m
   return i >= n ? period - 1 - i : i;
 }
 
-__global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __restrict__ arr, int F, int T, int r,
+// RR: the radius as a compile-time constant (10 = Dejavu's PEAK_NEIGHBORHOOD_SIZE: the index divisions by the halo width become
+// multiplications and the window loops unroll), 0 = the run-time value `r_`.
+template <int RR>
+__global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __restrict__ arr, int F, int T, int r_,
                                                                 double amp_min, uint8_t* __restrict__ mask,
                                                                 int32_t* __restrict__ npeaks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int r = RR ? RR : r_;
   const int HH = TH + 2 * r, HW = TW + 2 * r;
   double* A = reinterpret_cast<double*>(smem);     // [HH][HW] values, reflected
   double* Hm = A + HH * HW;                        // [HH][TW] row-pass maxima
@@ -120,13 +124,27 @@ __global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __
   const int i0 = blockIdx.y * TH, j0 = blockIdx.x * TW;
   const double* X = arr + (size_t)b * F * T;
 
-  for (int e = tid; e < HH * HW; e += LM_THREADS) {
-    const int hi = e / HW, hj = e % HW;
-    const int gi = i0 - r + hi, gj = j0 - r + hj;
-    const double v = X[(size_t)reflect_index(gi, F) * T + reflect_index(gj, T)];
-    A[e] = v;
-    const bool inside = gi >= 0 && gi < F && gj >= 0 && gj < T;
-    Bg[e] = inside ? (uint8_t)(v == 0.0) : (uint8_t)1;
+  // halo tile: six independent loads in flight per thread (one per trip left every element a full memory round trip: 17 in a row);
+  // slots past the end re-read the last element and are not stored
+  for (int e0 = tid; e0 < HH * HW; e0 += 6 * LM_THREADS) {
+    double v[6];
+    int gi[6], gj[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int e = min(e0 + u * LM_THREADS, HH * HW - 1);
+      const int hi = e / HW, hj = e - hi * HW;
+      gi[u] = i0 - r + hi; gj[u] = j0 - r + hj;
+      v[u] = X[(size_t)reflect_index(gi[u], F) * T + reflect_index(gj[u], T)];
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int e = e0 + u * LM_THREADS;
+      if (e < HH * HW) {
+        A[e] = v[u];
+        const bool inside = gi[u] >= 0 && gi[u] < F && gj[u] >= 0 && gj[u] < T;
+        Bg[e] = inside ? (uint8_t)(v[u] == 0.0) : (uint8_t)1;
+      }
+    }
   }
   __syncthreads();
   // Both passes give every thread FOUR adjacent outputs: the 2r + 4 inputs they share are read from LDS once (6 reads
@@ -248,7 +266,8 @@ int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double a
   const int HH = TH + 2 * radius, HW = TW + 2 * radius;
   const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)HH * TW) + (size_t)HH * HW + (size_t)HH * TW;
   dim3 grid((T + TW - 1) / TW, (F + TH - 1) / TH, B);
-  hipLaunchKernelGGL(localmax2d_kernel, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks);
+  if (radius == 10) hipLaunchKernelGGL(localmax2d_kernel<10>, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks);
+  else hipLaunchKernelGGL(localmax2d_kernel<0>, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -128,6 +128,13 @@ def test_dejavu_golden_and_oracle(ops, golden):
             coords, want = od.get_2d_peaks(a[b], 50)
             np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
             assert int(npk[b]) == len(coords)
+        # other neighbourhood sizes run the kernel's run-time-radius instantiation (10 is compiled in)
+        for radius in (3, 7, 16):
+            mask, npk = ops.localmax2d(torch.from_numpy(a).cuda(), radius, 20.0)
+            for b in range(2):
+                coords, want = od.get_2d_peaks(a[b], 20, radius=radius)
+                np.testing.assert_array_equal(mask[b].cpu().numpy(), want.astype(np.uint8))
+                assert int(npk[b]) == len(coords)
 
 
 def test_dejavu_full_pipeline(ops, golden):
