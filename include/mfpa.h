@@ -152,6 +152,16 @@ int mfpa_dejavu_prepare_f32(const float* x, int B, int F, int T, int square, dou
 int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double amp_min,
                     uint8_t* mask, int32_t* npeaks, void* stream);
 
+/* The un-denoised Dejavu chain after the spectrogram in one call -- fingerprint.py:68,78-79 + get_2D_peaks (:94-171): the PSD and
+ * its per-clip maxima as mfpa_specgram_psd returned them -> peak mask.  Same arithmetic as mfpa_dejavu_prepare(denom = clip_max)
+ * followed by mfpa_localmax2d, as two launches: scale * ln(max(a, 1e-6)) + the node sums of np.mean's pairwise tree (many
+ * workgroups per clip), then the local-maximum kernel, which forms the mean from the node sums and subtracts it while it loads
+ * its tiles -- the mean-subtracted array is never written.  clip_max[b] MUST be the maximum of psd[b] (max(a) = 1 is assumed).
+ *   psd (B, F, T) float64, 141 <= F <= 257, T <= 512;  work: B * mfpa_dejavu_pick_work_doubles(F, T) float64;  mask / npeaks as for mfpa_localmax2d */
+int mfpa_dejavu_pick_work_doubles(int F, int T, long long* per_clip);
+int mfpa_dejavu_pick(const double* psd, const double* clip_max, int B, int F, int T, double scale, int mean_order, int radius,
+                     double amp_min, double* work, uint8_t* mask, int32_t* npeaks, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Peak-mask metrics, testing/metrics.py:10-192.  For 0/1 masks (B, N1, N2), N1,N2 >= 2:
  *   counts (B, 4) int64 = [hits_precision, n_predicted, hits_recall, n_ground_truth] per clip,

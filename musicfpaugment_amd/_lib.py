@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 
 class MfpaError(RuntimeError):
@@ -45,6 +45,9 @@ _SIGNATURES = {
     "mfpa_dejavu_prepare": ([c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p], c_int),
     "mfpa_dejavu_prepare_f32": ([c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p], c_int),
     "mfpa_localmax2d": ([c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_dejavu_pick_work_doubles": ([c_int, c_int, c_void_p], c_int),
+    "mfpa_dejavu_pick": ([c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p,
+                          c_void_p], c_int),
     "mfpa_peak_metrics": ([c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_psnr_stats": ([c_void_p, c_int, c_void_p, c_int, c_longlong, c_void_p, c_void_p], c_int),
     "mfpa_audfprint_landmarks": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

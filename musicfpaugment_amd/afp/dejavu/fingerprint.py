@@ -85,8 +85,9 @@ def get_2D_peaks(arr2D, plot: bool = False, amp_min: int = afp_settings["dejavu"
 
 def fingerprint_peaks_batch(wav: torch.Tensor, amp_min: float = afp_settings["dejavu"]["amp_min"],
                             scale_in: float = 32767.0, denoising: bool = False, denoising_model: str = "unet",
-                            unet=None, demucs=None):
-    """(B, T) float32 on the GPU -> (mask (B,257,nF) uint8, npeaks (B,), specgram (B,257,nF)).
+                            unet=None, demucs=None, want_spec: bool = True):
+    """(B, T) float32 on the GPU -> (mask (B,257,nF) uint8, npeaks (B,), specgram (B,257,nF); None with want_spec=False on the
+    un-denoised path, whose normalised specgram is one more pass over the PSD that the peaks do not need).
 
     ``denoising`` / ``denoising_model`` follow fingerprint.py:34-79 and dejavu.py:85-106: "unet" runs the spectrogram
     denoiser on the max-normalised PSD (cast to float32), squares its output and keeps float32 for the log / mean steps
@@ -107,9 +108,13 @@ def fingerprint_peaks_batch(wav: torch.Tensor, amp_min: float = afp_settings["de
         arr = ops.dejavu_prepare_f32(y, square=True, scale=10.0, mean_order=0)
         mask, npeaks = ops.localmax2d(arr, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
         return mask, npeaks, y * y
-    arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=1)
-    mask, npeaks = ops.localmax2d(arr, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
-    return mask, npeaks, ops.normalize_(psd, cmax, per_clip=True)
+    F, T = psd.shape[1:]
+    if 141 <= F <= 257 and T <= 512:      # the fused pair of launches (mfpa_dejavu_pick); same bits as the two calls below
+        mask, npeaks = ops.dejavu_pick(psd, cmax, 10.0, 1, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
+    else:
+        arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=1)
+        mask, npeaks = ops.localmax2d(arr, PEAK_NEIGHBORHOOD_SIZE, float(amp_min))
+    return mask, npeaks, (ops.normalize_(psd, cmax, per_clip=True) if want_spec else None)
 
 
 def _hashes_to_list(dig: torch.Tensor, t1: torch.Tensor, n: int):

@@ -14,10 +14,12 @@
 #include "mfpa_common.h"
 #include "mfpa_fastlog.h"
 #include "mfpa_npsum.h"
+#include "mfpa_prepsum.h"
 
 namespace {
 
 using namespace mfpa_np;
+using namespace mfpa_prepsum;
 constexpr int PREP_THREADS = 512;
 
 // TIn = double: the un-denoised path (psd / max, float64 throughout).  TIn = float: the UNet path (fingerprint.py:70-79) --
@@ -108,10 +110,13 @@ __device__ __forceinline__ int reflect_index(int i, int n) {  // scipy.ndimage m
 
 // RR: the radius as a compile-time constant (10 = Dejavu's PEAK_NEIGHBORHOOD_SIZE: the index divisions by the halo width become
 // multiplications and the window loops unroll), 0 = the run-time value `r_`.
+// node_sums != nullptr (mfpa_dejavu_pick): `arr` holds the values BEFORE the mean is subtracted and node_sums the sums of the nodes of
+// np.mean's tree (prep_sum_kernel); every workgroup forms the clip's mean from them exactly as dejavu_prepare_kernel does (acc = 0;
+// acc += pairwise(chunk) for every chunk; / N) and subtracts it while the halo tile is loaded -- the mean-subtracted array never exists.
 template <int RR>
 __global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __restrict__ arr, int F, int T, int r_,
                                                                 double amp_min, uint8_t* __restrict__ mask,
-                                                                int32_t* __restrict__ npeaks) {
+                                                                int32_t* __restrict__ npeaks, const double* __restrict__ node_sums) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int r = RR ? RR : r_;
   const int HH = TH + 2 * r, HW = TW + 2 * r;
@@ -123,6 +128,18 @@ __global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __
   const int tid = threadIdx.x, b = blockIdx.z;
   const int i0 = blockIdx.y * TH, j0 = blockIdx.x * TW;
   const double* X = arr + (size_t)b * F * T;
+  double mean = 0.0;
+  const bool sub_mean = node_sums != nullptr;
+  if (sub_mean) {
+    const int N = F * T, nchunks = (N + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
+    double total = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int cn = min(NPY_BUFSIZE, N - c * NPY_BUFSIZE);
+      const double* h = node_sums + ((size_t)b * MAX_CHUNKS + c) * 2;
+      total = total + (cn > PW_BLOCK ? h[0] + h[1] : h[0]);
+    }
+    mean = total / (double)N;
+  }
 
   // halo tile: six independent loads in flight per thread (one per trip left every element a full memory round trip: 17 in a row);
   // slots past the end re-read the last element and are not stored
@@ -135,6 +152,10 @@ __global__ __launch_bounds__(LM_THREADS) void localmax2d_kernel(const double* __
       const int hi = e / HW, hj = e - hi * HW;
       gi[u] = i0 - r + hi; gj[u] = j0 - r + hj;
       v[u] = X[(size_t)reflect_index(gi[u], F) * T + reflect_index(gj[u], T)];
+    }
+    if (sub_mean) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) v[u] = v[u] - mean;
     }
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
@@ -266,8 +287,38 @@ int mfpa_localmax2d(const double* arr, int B, int F, int T, int radius, double a
   const int HH = TH + 2 * radius, HW = TW + 2 * radius;
   const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)HH * TW) + (size_t)HH * HW + (size_t)HH * TW;
   dim3 grid((T + TW - 1) / TW, (F + TH - 1) / TH, B);
-  if (radius == 10) hipLaunchKernelGGL(localmax2d_kernel<10>, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks);
-  else hipLaunchKernelGGL(localmax2d_kernel<0>, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks);
+  if (radius == 10) hipLaunchKernelGGL(localmax2d_kernel<10>, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks, (const double*)nullptr);
+  else hipLaunchKernelGGL(localmax2d_kernel<0>, grid, dim3(LM_THREADS), lds, s, arr, F, T, radius, amp_min, mask, npeaks, (const double*)nullptr);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_dejavu_pick_work_doubles(int F, int T, long long* per_clip) {
+  if (!per_clip || F < 1 || T < 1) return MFPA_EINVAL;
+  *per_clip = (long long)F * T + 2 * MAX_CHUNKS;
+  return MFPA_OK;
+}
+
+int mfpa_dejavu_pick(const double* psd, const double* clip_max, int B, int F, int T, double scale, int mean_order, int radius,
+                     double amp_min, double* work, uint8_t* mask, int32_t* npeaks, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!psd || !clip_max || !work || !mask || !npeaks || B < 0 || B > 65535 || radius < 2 || radius > 16) return MFPA_EINVAL;
+  if (F < 141 || F > 257 || T < 1 || T > SPLIT_MAX_T || (mean_order != 0 && mean_order != 1)) return MFPA_EINVAL;   // (a half-chunk node spans <= 32 frames)
+  const long long N = (long long)F * T;
+  const int nchunks = (int)((N + NPY_BUFSIZE - 1) / NPY_BUFSIZE);
+  if (nchunks > MAX_CHUNKS) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  MFPA_HIP(hipMemsetAsync(npeaks, 0, sizeof(int32_t) * B, s));
+  double* sums = work + (size_t)B * N;
+  const size_t lds1 = sizeof(double) * (NPY_BUFSIZE / 2 + 8 + HEAP + 128 * 3);
+  hipLaunchKernelGGL(prep_sum_kernel, dim3(B, 2 * nchunks), dim3(SPLIT_THREADS), lds1, s, psd, F, T, clip_max, mean_order, work, 0, sums,
+                     (long long)(2 * MAX_CHUNKS), scale, F);
+  MFPA_CHECK_LAUNCH();
+  const int HH = TH + 2 * radius, HW = TW + 2 * radius;
+  const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)HH * TW) + (size_t)HH * HW + (size_t)HH * TW;
+  dim3 grid((T + TW - 1) / TW, (F + TH - 1) / TH, B);
+  if (radius == 10) hipLaunchKernelGGL(localmax2d_kernel<10>, grid, dim3(LM_THREADS), lds, s, (const double*)work, F, T, radius, amp_min, mask, npeaks, (const double*)sums);
+  else hipLaunchKernelGGL(localmax2d_kernel<0>, grid, dim3(LM_THREADS), lds, s, (const double*)work, F, T, radius, amp_min, mask, npeaks, (const double*)sums);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

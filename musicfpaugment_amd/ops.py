@@ -237,6 +237,28 @@ def dejavu_prepare(psd: torch.Tensor, denom: Optional[torch.Tensor], scale: floa
     return arr
 
 
+def dejavu_pick(psd: torch.Tensor, clip_max: torch.Tensor, scale: float = 10.0, mean_order: int = 1, radius: int = DEJAVU_RADIUS,
+                amp_min: float = DEJAVU_AMP_MIN):
+    """The un-denoised Dejavu chain after the spectrogram in one call (mfpa_dejavu_pick): PSD (B, F, T) float64 and its per-clip
+    maxima (what specgram_psd returned) -> (mask (B, F, T) uint8, npeaks (B,) int32).  Same arithmetic as
+    dejavu_prepare(psd, clip_max, scale, mean_order) + localmax2d; the mean-subtracted array is never written."""
+    require_gpu(psd, "psd")
+    if psd.dim() != 3 or psd.dtype != torch.float64:
+        raise ValueError("psd must be (B, F, T) float64")
+    psd = psd.contiguous()
+    B, F, T = psd.shape
+    if clip_max.shape != (B,) or clip_max.dtype != torch.float64:
+        raise ValueError("clip_max must be (B,) float64")
+    per = ctypes.c_longlong(0)
+    check(lib().mfpa_dejavu_pick_work_doubles(F, T, ctypes.byref(per)), "mfpa_dejavu_pick_work_doubles")
+    work = torch.empty(max(B, 1) * per.value, dtype=torch.float64, device=psd.device)
+    mask = torch.empty((B, F, T), dtype=torch.uint8, device=psd.device)
+    npeaks = torch.empty(B, dtype=torch.int32, device=psd.device)
+    check(lib().mfpa_dejavu_pick(ptr(psd), ptr(clip_max), B, F, T, float(scale), int(mean_order), int(radius), float(amp_min),
+                                 ptr(work), ptr(mask), ptr(npeaks), stream()), "mfpa_dejavu_pick")
+    return mask, npeaks
+
+
 def dejavu_prepare_f32(x: torch.Tensor, square: bool = True, scale: float = 10.0, mean_order: int = 0) -> torch.Tensor:
     """The denoised branch of Dejavu's pre-processing (fingerprint.py:70-79): float32 (B, F, T) network output -> x**2 ->
     10*log(max(., max/1e6)) - mean in float32, widened to float64 for the picker."""

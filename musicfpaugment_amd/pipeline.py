@@ -56,7 +56,8 @@ class HotPath:
     def __call__(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if self.picker == "dejavu":
             from .afp.dejavu.fingerprint import fingerprint_peaks_batch
-            mask, npeaks, _ = fingerprint_peaks_batch(wav, denoising=self.unet is not None, denoising_model="unet", unet=self.unet)
+            mask, npeaks, _ = fingerprint_peaks_batch(wav, denoising=self.unet is not None, denoising_model="unet", unet=self.unet,
+                                                      want_spec=False)
             return mask, npeaks
         mask, npeaks, _ = self.extractor.find_peaks_batch(wav, want_spec=False)
         return mask, npeaks

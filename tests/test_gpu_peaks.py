@@ -417,3 +417,27 @@ def test_fused_pick_equals_prepare_plus_prune_bit_for_bit():
         for i in (0, B - 1):
             ref = oa.find_peaks(wav[i])[1]
             np.testing.assert_array_equal(got_mask[i].cpu().numpy(), np.asarray(ref).astype(np.uint8) if np.size(ref) else 0)
+
+
+def test_dejavu_pick_equals_prepare_plus_localmax_bit_for_bit(ops):
+    """mfpa_dejavu_pick (log values + np.mean's node sums by many workgroups per clip, the mean subtracted inside the local-maximum
+    kernel) against the two stand-alone calls it replaces: identical masks and counts, on real clips, a silent clip, both summation
+    orders and a second radius."""
+    from musicfpaugment_amd import synth
+    wav = torch.from_numpy(synth.batch(12, seed=77)).cuda()
+    wav[5] = 0.0                                                     # a silent clip: NaN all the way, no peaks
+    psd, cmax = ops.specgram_psd(wav, scale_in=32767.0)
+    for mean_order in (1, 0):
+        for radius, amp in ((10, 50.0), (10, 10.0), (6, 30.0)):
+            arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=mean_order)
+            want_mask, want_n = ops.localmax2d(arr, radius, amp)
+            mask, n = ops.dejavu_pick(psd, cmax, 10.0, mean_order, radius, amp)
+            assert torch.equal(mask, want_mask)
+            assert torch.equal(n, want_n)
+    assert int(want_n[5]) == 0 and int(want_n.sum()) > 0
+    # a shorter clip (a partial last tile, fewer chunks)
+    psd, cmax = ops.specgram_psd(wav[:3, :20000].contiguous(), scale_in=32767.0)
+    arr = ops.dejavu_prepare(psd, cmax, 10.0, mean_order=1)
+    want_mask, want_n = ops.localmax2d(arr, 10, 20.0)
+    mask, n = ops.dejavu_pick(psd, cmax, 10.0, 1, 10, 20.0)
+    assert torch.equal(mask, want_mask) and torch.equal(n, want_n)
