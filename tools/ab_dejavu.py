@@ -4,6 +4,9 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1:
+    from musicfpaugment_amd import _lib
+    _lib.set_library_path(sys.argv[1])
 from musicfpaugment_amd import ops, synth
 B = 256
 base = synth.batch(32, seed=59)
