@@ -18,7 +18,9 @@ using namespace mfpa_np;
 // instruction-bound (a float64 division and a float64 log per element), so what counts is that the whole chip works on it.
 // (A 16-bin-per-workgroup filter kernel completed this into a two-launch replacement of prepare_kernel; it measured 75 us per 256 clips,
 //  the pair 190-230 us against the single kernel's 176 -- the pruner now filters the frames itself, mfpa_audfprint_pick.)
-constexpr int SPLIT_THREADS = 256;
+// 512 threads: the node's 38 KB of LDS allow four workgroups per CU -- 32 resident waves with 512 threads, 16 with 256 (measured:
+// pick stage 365 -> 354 us per 256 clips; the kernel needs 56 registers, inside the 64 that eight waves per SIMD leave each)
+constexpr int SPLIT_THREADS = 512, SPLIT_RPP = SPLIT_THREADS / 16;   // threads; rows per pass of the 16-lane-per-row mappings
 constexpr int SPLIT_MAX_T = 512;
 
 __device__ __forceinline__ double prep_log_value(double v, double den, bool do_log, double floor_v, const double (*tab)[3]) {
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(SPLIT_THREADS) void prep_sum_kernel(const double* _
     for (int tb = 0; tb < nb; ++tb) {                          // (a)
       const int t = t0 + 16 * tb + tt;                         // < T: a whole block lies inside the node's frames
       const double* src = x + t;
-      for (int f0 = fr; f0 < Fm; f0 += 8 * 16) {
+      for (int f0 = fr; f0 < Fm; f0 += 8 * SPLIT_RPP) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(f0 + 16 * u, Fm - 1) * T];
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(f0 + SPLIT_RPP * u, Fm - 1) * T];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (f0 + 16 * u < Fm) put(t, f0 + 16 * u, v[u]);
+          if (f0 + SPLIT_RPP * u < Fm) put(t, f0 + SPLIT_RPP * u, v[u]);
       }
     }
     for (int r = 0; r < rem; ++r) {                            // (b)
