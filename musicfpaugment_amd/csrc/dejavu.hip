@@ -20,7 +20,7 @@ namespace {
 
 using namespace mfpa_np;
 using namespace mfpa_prepsum;
-constexpr int PREP_THREADS = 512;
+constexpr int PREP_THREADS = 1024;   // one workgroup per clip: as many waves as a workgroup can have (latency-bound streaming passes)
 
 // TIn = double: the un-denoised path (psd / max, float64 throughout).  TIn = float: the UNet path (fingerprint.py:70-79) --
 // the network's float32 output is squared and every later step (max, floor max / 1e6, 10 * log, mean, subtraction) stays in
