@@ -787,8 +787,8 @@ def bench_infer(args, rank, world, dev, dist):
         gbs = per_clip * B * args.steps / dt_max / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(gbs / 8000.0, 5), "traffic": None,
-                           "kernel": "stft_kernel + prepare_kernel + prune_kernel (whole chain, wall clock)" if args.picker == "audfprint"
-                           else "stft_kernel (PSD) + dejavu_prepare_kernel + localmax2d_kernel (whole chain, wall clock)"}
+                           "kernel": "stft_kernel + prep_sum_kernel + prune_kernel<fused filter> (whole chain, wall clock)" if args.picker == "audfprint"
+                           else "stft_kernel (PSD) + prep_sum_kernel + localmax2d_kernel<mean from node sums> (whole chain, wall clock)"}
     if other is not None:
         oname = "fp32" if args.precision == "bf16x3" else "bf16x3"
         out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),

@@ -26,4 +26,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2
 cp $(find $O/kt2 -name "*kernel_stats.csv" | head -1) $O/config2_kernel_stats.csv; rm -rf $O/kt2
 python tools/exp_conv.py --both --reps 5 > $O/conv_layers_lds_vs_direct.txt 2>&1
 python tools/exp_c64.py > $O/c64_layers.txt 2>&1
+python tools/time_small_kernels.py > $O/small_kernels.txt 2>&1
+python tools/ab_pick.py > $O/pick_stage.txt 2>&1
+python tools/ab_dejavu.py > $O/dejavu_stages.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -o p -- python3 bench.py --no-unet --picker dejavu --steps 20 --warmup 3 --cpu-seconds 0 --no-configs > $O/config2_dejavu_bench_under_rocprof.json 2>> $O/bench.err
+cp $(find $O/kt3 -name "*kernel_stats.csv" | head -1) $O/config2_dejavu_kernel_stats.csv; rm -rf $O/kt3
+bash tools/run_config2_sq.sh > $O/config2_sq.log 2>&1
+cp gpurun_out/config2_sq/sq1_256.json $O/config2_sq_pass1.json; cp gpurun_out/config2_sq/sq2_256.json $O/config2_sq_pass2.json
 ls $O; tail -2 $O/pmc_traffic.log
