@@ -47,12 +47,13 @@ struct GemmArgs {
 // with the plain order the n tiles that share an A tile land on 8 different XCDs and every one of them fetches that A tile from
 // memory (PMC: the mid-level launches fetched 2.7x what they wrote).  Here XCD k owns a contiguous range of the (clip, m tile,
 // n tile) order, n fastest, so the workgroups sharing an A tile run back to back on ONE XCD.
-__device__ __forceinline__ bool gemm_tile(const GemmArgs& a, int& bx, int& by, int& bz) {
+__device__ __forceinline__ bool gemm_tile_at(const GemmArgs& a, unsigned vb, int& bx, int& by, int& bz) {
   const unsigned total = (unsigned)a.nx * a.ny * a.nz;
-  unsigned lin = blockIdx.x;
+  unsigned lin = vb;
   if (a.xcd) {
     const unsigned per = (total + 7) / 8;
-    lin = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (vb / 8 >= per) return false;           // past the last virtual id (a persistent workgroup stepping by gridDim.x): NOT the next XCD's range
+    lin = (vb % 8) * per + vb / 8;
   }
   if (lin >= total) return false;              // uniform over the workgroup, before any barrier
   bx = lin % a.nx;
@@ -61,6 +62,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& a, int& bx, int& by, i
   bz = rest / a.ny;
   return true;
 }
+__device__ __forceinline__ bool gemm_tile(const GemmArgs& a, int& bx, int& by, int& bz) { return gemm_tile_at(a, blockIdx.x, bx, by, bz); }
 
 // epilogue shared by all GEMM kernels: D[row = m][col = n]; a lane holds column li of both 32-wide n tiles.
 // The short-K launches are bound by vector-instruction issue, and the first form of this epilogue was most of it (64-bit
@@ -547,31 +549,36 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;
-  int bx, by, b;
-  if (!gemm_tile(a, bx, by, b)) return;
-  const int n0 = bx * WBN, m0 = by * PBM;
   const int nk = a.K / HKC;
   const int q = tid & 7, r0 = tid >> 3;              // staging: column quad, rows r0 + 64 i
-  const float* ap[4];
-  const float* bp[2];
-  {
+  // PERSISTENT over tiles: workgroup w takes the virtual workgroup ids w, w + gridDim.x, ... (gridDim.x is a multiple of 8, so they all map
+  // into the same XCD's range of gemm_tile_at).  One workgroup owns a CU (111 KB of LDS), so as one tile per workgroup nothing overlapped a
+  // tile's first loads (a memory round trip before the first MFMA) and its epilogue (stores, addend loads) with anything: on the K = 192 .. 384
+  // layers those two were as long as the main loop.  Here the first two chunks of the NEXT tile are requested before the epilogue of the
+  // current one (their staging registers are free by then), so the round trip runs under the epilogue.
+  struct TileP { const float* ap[4]; const float* bp[2]; int m0, n0, b; };
+  auto tile_at = [&](unsigned vb, TileP& t) __attribute__((always_inline)) -> bool {
+    int bx, by, b;
+    if (!gemm_tile_at(a, vb, bx, by, b)) return false;
+    t.n0 = bx * WBN; t.m0 = by * PBM; t.b = b;
     const float* Ab = a.A + (size_t)b * a.strideA;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int m = m0 + r0 + 64 * i;
+      int m = t.m0 + r0 + 64 * i;
       m = m < a.M ? m : a.M - 1;
-      ap[i] = Ab + (size_t)m * a.lda + 4 * q;
+      t.ap[i] = Ab + (size_t)m * a.lda + 4 * q;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) bp[i] = a.W + (size_t)(n0 + r0 + 64 * i) * a.K + 4 * q;
-  }
+    for (int i = 0; i < 2; ++i) t.bp[i] = a.W + (size_t)(t.n0 + r0 + 64 * i) * a.K + 4 * q;
+    return true;
+  };
   struct Stage { f32x4 a[4], b[2]; };
   Stage st0, st1;
-  auto load = [&](int kc, Stage& st) __attribute__((always_inline)) {
+  auto load = [&](const TileP& t, int kc, Stage& st) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st.a[i] = *reinterpret_cast<const f32x4*>(ap[i] + (MFPA_EXP_FLAG(a.exp, 1) ? 0 : kc) * HKC);
+    for (int i = 0; i < 4; ++i) st.a[i] = *reinterpret_cast<const f32x4*>(t.ap[i] + (MFPA_EXP_FLAG(a.exp, 1) ? 0 : kc) * HKC);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) st.b[i] = *reinterpret_cast<const f32x4*>(bp[i] + (MFPA_EXP_FLAG(a.exp, 2) ? 0 : kc) * HKC);
+    for (int i = 0; i < 2; ++i) st.b[i] = *reinterpret_cast<const f32x4*>(t.bp[i] + (MFPA_EXP_FLAG(a.exp, 2) ? 0 : kc) * HKC);
   };
   auto split_store = [&](char* row, f32x4 v) __attribute__((always_inline)) {
     g_bf16x4 hi, lo;
@@ -606,12 +613,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
     }
   };
   floatx16 acc[2][2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
   auto mfma12 = [&](const Frags& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
       }
   };
   constexpr int N_DSW = WSPLIT ? 10 : 12;            // LDS stores of one chunk per thread
+  TileP cur;
   // one K chunk; SET = chunk parity = LDS buffer it is computed from; STORE: chunk kc + 1 (register set SET ^ 1) goes to the other
   // buffer; LOAD: that register set is refilled with chunk kc + 3
   auto body = [&](auto SET_, auto STORE_, auto LOAD_, int kc) __attribute__((always_inline)) {
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
     read_frags(fr1, SET, 1);
     mfma12(fr0);
     if constexpr (STORE) store(SET ^ 1, other);
-    if constexpr (LOAD) load(kc + 3, other);
+    if constexpr (LOAD) load(cur, kc + 3, other);
     g_pin_reads<8, 8>();
     if constexpr (STORE) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -661,32 +663,53 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
   using F = std::false_type;
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  unsigned vb = blockIdx.x;
+  if (!tile_at(vb, cur)) return;                         // uniform over the workgroup, before any barrier
   // (the scheduling barriers keep the prologue's loads in the order the loop issues them, so the vmcnt state merged at the loop
   // header is the steady state's and the first stores of a trip do not wait for the newest loads)
-  load(0, st0);
+  load(cur, 0, st0);
   __builtin_amdgcn_sched_barrier(0);
-  load(1, st1);
+  load(cur, 1, st1);
   __builtin_amdgcn_sched_barrier(0);
-  store(0, st0);
-  __builtin_amdgcn_sched_barrier(0);
-  load(2, st0);
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
-  read_frags(fr0, 0, 0);
-  int kc = 0;
-  for (; kc < nk - 4; kc += 2) {
-    body(S0{}, T{}, T{}, kc);
-    body(S1{}, T{}, T{}, kc + 1);
-  }
-  body(S0{}, T{}, T{}, kc);                               // kc = nk - 4: chunk nk - 1 is the last load
-  body(S1{}, T{}, F{}, kc + 1);
-  body(S0{}, T{}, F{}, kc + 2);
-  body(S1{}, F{}, F{}, kc + 3);
-  const bool full = m0 + PBM <= a.M;
+  for (;;) {
+    store(0, st0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(cur, 2, st0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frags(fr0, 0, 0);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    if (full) gemm_epilogue_t<true>(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
-    else gemm_epilogue_t<false>(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    int kc = 0;
+    for (; kc < nk - 4; kc += 2) {
+      body(S0{}, T{}, T{}, kc);
+      body(S1{}, T{}, T{}, kc + 1);
+    }
+    body(S0{}, T{}, T{}, kc);                               // kc = nk - 4: chunk nk - 1 is the last load
+    body(S1{}, T{}, F{}, kc + 1);
+    body(S0{}, T{}, F{}, kc + 2);
+    body(S1{}, F{}, F{}, kc + 3);
+    // the next tile's first two chunks go out now: both staging sets are free, and nobody reads LDS after the barrier inside the last body
+    const int m0 = cur.m0, n0 = cur.n0, b = cur.b;
+    vb += gridDim.x;
+    const bool more = tile_at(vb, cur);
+    if (more) {
+      load(cur, 0, st0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(cur, 1, st1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool full = m0 + PBM <= a.M;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (full) gemm_epilogue_t<true>(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+      else gemm_epilogue_t<false>(a, acc[mt], m0, n0 + wn * 64, b, wm * 2 + mt, li, lh);
+    }
+    if (!more) break;
   }
 }
 
@@ -1779,6 +1802,9 @@ int mfpa_gemm_mfma(const mfpa_gemm_desc* d, void* stream) {
   if (wide_ok && pipe && d->K % (2 * HKC) == 0 && d->M >= MFPA_EXP_ENV("MFPA_GEMM_PIPE_MINM", 192)) {   // (rows past M are clamped when loaded: a 249-row clip fills 97 % of a 256-row tile)
     a.ny = (d->M + PBM - 1) / PBM;
     dim3 gw = grid1d(d->npad / WBN);
+    static const int persist = MFPA_EXP_ENV("MFPA_GEMM_PERSIST", 1);   // 0: one tile per workgroup (experiments)
+    const unsigned cus8 = (unsigned)((mfpa_current_device_cus() + 7) / 8 * 8);
+    if (persist && cus8 >= 8 && gw.x > cus8) gw.x = cus8;    // persistent: one workgroup per CU walks the tiles (a multiple of 8: XCD ranges)
     const size_t lds = (size_t)2 * (PBM + WBN) * HROW;
     if (d->precision == 2) hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel<true>, gw, dim3(512), lds, st, a);
     else hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel<false>, gw, dim3(512), lds, st, a);
