@@ -365,6 +365,14 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
                           const float* shift, const float* dp, float* dy,
                           unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
 
+/* The same pass, which also forms the partial sums of the BatchNorm backward that follows on this layer (training/unet.py:17-20 under
+ * autograd: sum g and sum g * xhat per channel, g = dy * [z*scale+shift > 0] (* dropout), xhat = (z - mean) * invstd) over ALL pixels of
+ * dy -- the pooled windows, the odd last row / column --, one row of `part` (B * (H / 2), 2, C) float per workgroup, to be finished by
+ * mfpa_conv_stats_reduce + mfpa_bn_relu_bwd_finish: the separate reduction pass over dy and z is not needed.  C / 4 must divide 256. */
+int mfpa_maxpool2_bwd_add_sums(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, const float* mean,
+                               const float* invstd, const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh,
+                               float drop_scale, float* part, void* stream);
+
 /* Weight gradient on MFMA, ACCUMULATED into dw (zero it first):
  *   mode 0: dw[tap][co][ci] += sum_p dz[p][co] * xin[p + tap][ci]          (3x3 conv; dw (9,Cout,C0+C1))
  *   mode 1: dw[tap][co][ci] += sum_p dz[2y+dy,2x+dx][co] * xin[y,x][ci]    (transposed conv; dw (4,Cout,C0))

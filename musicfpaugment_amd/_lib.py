@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 
 class MfpaError(RuntimeError):
@@ -139,6 +139,8 @@ _SIGNATURES = {
                            c_void_p], c_int),
     "mfpa_maxpool2_bwd_add": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_uint, c_uint, c_float, c_void_p], c_int),
+    "mfpa_maxpool2_bwd_add_sums": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
     "mfpa_wgrad_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_wgrad_c1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_outconv_fwd": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -299,13 +299,41 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
 
 // dy_full += route(dp): the gradient of a pooled cell goes to the first maximum of its 2x2 window of
 // y = relu(z*scale+shift) (scan order (0,0),(0,1),(1,0),(1,1), strict >), as torch's max_pool2d backward.
+// SUMS: the pass also holds everything the BatchNorm backward of this very layer reduces next -- the finished dy and z of every pixel --
+// so it forms that reduction's per-channel partial sums {sum g, sum g * xhat} (g = dy * [z*scale+shift > 0] (* dropout), xhat =
+// (z - mean) * invstd: chan_reduce_kernel<1>'s terms) for its two rows, the odd last column and (last workgroup of a clip) the odd last
+// row included, and writes them as one row of `part` (rows x 2 x C float, the layout of the convolutions' stats_part, finished in
+// float64 by mfpa_conv_stats_reduce): the separate reduction pass over dy and z (2.1 GB at the first level) is not run.
+template <bool SUMS>
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ z, int B, int H, int W, int C,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ dp, float* __restrict__ dy,
-                                                              unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
+                                                              unsigned drop_seed, unsigned drop_thresh, float drop_scale,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ part) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
+  // SUMS: 256 % C4 == 0 (checked by the launcher), so a thread meets ONE channel quad in all its trips: tid % C4
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, scq = {0.f, 0.f, 0.f, 0.f}, sfq = {0.f, 0.f, 0.f, 0.f};
+  if (SUMS) {
+    const int cqt = threadIdx.x % C4;
+    mu = *reinterpret_cast<const f32x4*>(mean + 4 * cqt);
+    is = *reinterpret_cast<const f32x4*>(invstd + 4 * cqt);
+    scq = *reinterpret_cast<const f32x4*>(scale + 4 * cqt);
+    sfq = *reinterpret_cast<const f32x4*>(shift + 4 * cqt);
+  }
+  // one pixel's four channels into the sums (its finished gradient d, its z)
+  auto add = [&](const f32x4& d, const f32x4& v, size_t elem0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float g = (v[k] * scq[k] + sfq[k] > 0.f) ? d[k] : 0.f;
+      if (drop_thresh) g = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)elem0 + k) ? g * drop_scale : 0.f;
+      s0[k] += g;
+      s1[k] += g * ((v[k] - mu[k]) * is[k]);
+    }
+  };
   for (int e32 = threadIdx.x; e32 < Wo * C4; e32 += 256) {
     const int cq = e32 % C4, xo = e32 / C4;
     const size_t e = ((size_t)blockIdx.x * Wo + xo) * C4 + cq;
@@ -315,9 +343,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     const f32x4 g = *reinterpret_cast<const f32x4*>(dp + e * 4);
     float best[4];
     int arg[4];
+    f32x4 vz[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(z + base + ((size_t)(t >> 1) * W + (t & 1)) * C);
+      vz[t] = v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float y = v[k] * sc[k] + sf[k];
@@ -331,11 +361,47 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      float* d = dy + base + ((size_t)(t >> 1) * W + (t & 1)) * C;
+      const size_t off = base + ((size_t)(t >> 1) * W + (t & 1)) * C;
+      float* d = dy + off;
       f32x4 cur = *reinterpret_cast<f32x4*>(d);
 #pragma unroll
       for (int k = 0; k < 4; ++k) cur[k] += (arg[k] == t) ? g[k] : 0.f;
       *reinterpret_cast<f32x4*>(d) = cur;
+      if (SUMS) add(cur, vz[t], off);
+    }
+  }
+  if (SUMS) {
+    if (W & 1) {                                            // the last column lies in no window: its gradient is the skip path's alone
+      for (int e32 = threadIdx.x; e32 < 2 * C4; e32 += 256) {
+        const int cq = e32 % C4, r = e32 / C4;
+        const size_t off = (((size_t)b * H + 2 * yo + r) * W + (W - 1)) * C + 4 * cq;
+        add(*reinterpret_cast<const f32x4*>(dy + off), *reinterpret_cast<const f32x4*>(z + off), off);
+      }
+    }
+    if ((H & 1) && yo == Ho - 1) {                          // ... and so does the last row: the clip's last workgroup takes it
+      for (int e32 = threadIdx.x; e32 < W * C4; e32 += 256) {
+        const int cq = e32 % C4, x = e32 / C4;
+        const size_t off = (((size_t)b * H + (H - 1)) * W + x) * C + 4 * cq;
+        add(*reinterpret_cast<const f32x4*>(dy + off), *reinterpret_cast<const f32x4*>(z + off), off);
+      }
+    }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[threadIdx.x * 8 + k] = s0[k];
+      red[threadIdx.x * 8 + 4 + k] = s1[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {                            // fixed order: deterministic
+      for (int r = 1; r < 256 / C4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s0[k] += red[(r * C4 + threadIdx.x) * 8 + k];
+          s1[k] += red[(r * C4 + threadIdx.x) * 8 + 4 + k];
+        }
+      float* row = part + (size_t)blockIdx.x * 2 * C;
+      *reinterpret_cast<f32x4*>(row + 4 * threadIdx.x) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+      *reinterpret_cast<f32x4*>(row + C + 4 * threadIdx.x) = f32x4{s1[0], s1[1], s1[2], s1[3]};
     }
   }
 }
@@ -1451,8 +1517,20 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !dp || !dy || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   if ((long long)B * (H / 2) > 0x7fffffffLL) return MFPA_EINVAL;
-  hipLaunchKernelGGL(maxpool_bwd_add_kernel, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
-                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<false>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_maxpool2_bwd_add_sums(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, const float* mean,
+                               const float* invstd, const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh,
+                               float drop_scale, float* part, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!z || !scale || !shift || !mean || !invstd || !dp || !dy || !part || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
+  if ((long long)B * (H / 2) > 0x7fffffffLL || C / 4 > 256 || 256 % (C / 4)) return MFPA_EINVAL;   // a thread keeps ONE channel quad's sums
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<true>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, mean, invstd, part);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -156,6 +156,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
 
 
 USE_BF16_DZ = True          # plain-bf16 step: input-gradient convolutions read the bf16 copy of dz (False: the float32 dz, A/B runs)
+FUSE_POOL_BWD_SUMS = True   # False: mfpa_maxpool2_bwd_add, then the BatchNorm backward's own reduction pass (chan_reduce_kernel<1>)
 BF16_WGRAD_MIN_CH = 128     # plain-bf16 weight gradients: layers with at least this many channels on both sides read bf16 copies
 
 
@@ -527,8 +528,10 @@ class UNetTrainEngine:
         return pred
 
     # ------------------------------------------------------------------ backward
-    def _dconv_bwd(self, r, dy, need_input_grad=True):
-        """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1)."""
+    def _dconv_bwd(self, r, dy, need_input_grad=True, dy_part=None):
+        """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1).
+        dy_part: the partial sums of this block's last BatchNorm backward when the pass that finished dy already formed them
+        (mfpa_maxpool2_bwd_add_sums)."""
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
         H_, W_ = r["z3"].shape[1], r["z3"].shape[2]
@@ -537,7 +540,8 @@ class UNetTrainEngine:
         # plain bf16 step: when both consumers of dz (input-gradient convolution on conv_wd16_kernel, weight gradient) read its bf16
         # copy, the float32 dz is never written (mfpa_bn_relu_bwd(write_f32 = 0)) and the convolution's loader moves half the bytes
         only16 = USE_BF16_DZ and self.precision == 2 and lay == 2 and wg16
-        dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b", bf16_copy=wg16, write_f32=not only16)
+        dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b", bf16_copy=wg16, write_f32=not only16,
+                                      part=dy_part)
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16,
                    x0_bf16=r["xb3"])
         r["xb3"] = None
@@ -616,17 +620,27 @@ class UNetTrainEngine:
             wt = pack_weights(self.P[name + ".up.w"], self.precision, flip_transpose=True)   # (4, cin, cout), taps kept
             dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision, packed=True)
             handles.append(self._reduce_bucket(name))
+        dy_part = None
         for i in range(len(ENC) - 1, -1, -1):                                       # down4 ... inc
             name = ENC[i]
             r = recs[name if i else "inc"]
-            d_p, _ = self._dconv_bwd(r, dy)
+            d_p, _ = self._dconv_bwd(r, dy, dy_part=dy_part)
+            dy_part = None
             if i:
                 below = recs[ENC[i - 1] if i - 1 else "inc"]
                 dy = dskip[ENC[i - 1]]
                 z, st = below["z3"], below["st3"]
                 B, H, W, C = z.shape
-                check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
-                                                  st.drop[0], st.drop[1], st.drop[2], stream()), "mfpa_maxpool2_bwd_add")
+                if FUSE_POOL_BWD_SUMS and 256 % (C // 4) == 0:
+                    # the pass that finishes dy (skip gradient + routed pool gradient) also forms the partial sums of the BatchNorm
+                    # backward the next _dconv_bwd starts with: no separate reduction pass over dy and z
+                    dy_part = torch.empty((B * (H // 2), 2, C), dtype=torch.float32, device=z.device)
+                    check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+                                                           ptr(d_p), ptr(dy), st.drop[0], st.drop[1], st.drop[2], ptr(dy_part), stream()),
+                          "mfpa_maxpool2_bwd_add_sums")
+                else:
+                    check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
+                                                      st.drop[0], st.drop[1], st.drop[2], stream()), "mfpa_maxpool2_bwd_add")
             handles.append(self._reduce_bucket(name))
         ev = None
         if self.comm_wait_events is not None and any(h is not None for h in handles):

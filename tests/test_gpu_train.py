@@ -188,6 +188,40 @@ def test_batchnorm_statistics_from_conv_partials_large_offset_channel():
     assert float(rel.max()) < 2e-5 and float(rel[ratio < 3].max()) < 1e-7
 
 
+def test_maxpool_backward_with_batchnorm_sums_equals_the_two_passes():
+    """mfpa_maxpool2_bwd_add_sums = mfpa_maxpool2_bwd_add followed by the BatchNorm backward's reduction pass (mfpa_bn_relu_bwd_sums) over
+    the finished dy: the same dy bit for bit, the same per-channel sums {sum g, sum g xhat} to float32-partial accuracy -- on odd heights and
+    widths (the last row / column lie in no pooling window but belong to the sums), with and without dropout, 64 and 512 channels."""
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(11)
+    ws = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device="cuda")
+    for (B, H, W, C), drop in (((3, 17, 13, 64), (0, 0, 1.0)), ((2, 9, 8, 512), (7, int(0.3 * 2 ** 32), 1.0 / 0.7)), ((2, 8, 11, 128), (3, int(0.5 * 2 ** 32), 2.0)),
+                               ((1, 257, 251, 64), (0, 0, 1.0))):
+        z = torch.randn(B, H, W, C, generator=g).cuda()
+        scale = (torch.rand(C, generator=g) + 0.5).cuda(); shift = (torch.randn(C, generator=g) * 0.3).cuda()
+        mean = (torch.randn(C, generator=g) * 0.2).cuda(); invstd = (torch.rand(C, generator=g) + 0.5).cuda()
+        dp = torch.randn(B, H // 2, W // 2, C, generator=g).cuda()
+        dy0 = torch.randn(B, H, W, C, generator=g).cuda()
+        a, b = dy0.clone(), dy0.clone()
+        check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(dp), ptr(a), drop[0], drop[1], drop[2], stream()),
+              "mfpa_maxpool2_bwd_add")
+        ref = torch.empty(2 * C, dtype=torch.float64, device="cuda")
+        check(lib().mfpa_bn_relu_bwd_sums(ptr(a), ptr(z), B * H * W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(ref), ptr(ws),
+                                          drop[0], drop[1], drop[2], stream()), "mfpa_bn_relu_bwd_sums")
+        part = torch.full((B * (H // 2), 2, C), float("nan"), dtype=torch.float32, device="cuda")
+        check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dp), ptr(b),
+                                               drop[0], drop[1], drop[2], ptr(part), stream()), "mfpa_maxpool2_bwd_add_sums")
+        assert torch.equal(a, b)
+        got = torch.empty(2 * C, dtype=torch.float64, device="cuda")
+        check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (B, H, W, C, err)
+    # C / 4 must divide 256 (a thread keeps one channel quad's sums)
+    z = torch.zeros(1, 4, 4, 48, device="cuda")
+    v = torch.zeros(48, device="cuda")
+    assert lib().mfpa_maxpool2_bwd_add_sums(ptr(z), 1, 4, 4, 48, ptr(v), ptr(v), ptr(v), ptr(v), ptr(z), ptr(z), 0, 0, 1.0, ptr(z), stream()) != 0
+
+
 def test_train_step_matches_reference_golden(golden):
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
