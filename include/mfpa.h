@@ -409,6 +409,19 @@ int mfpa_outconv_fwd(const float* z, long long npix, int C, const float* scale, 
                      const float* w, const float* bias, float* pred, void* stream);
 int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, const float* scale,
                      const float* shift, const float* w, float* dy, float* dwb, double* workspace, void* stream);
+/* The same backward WITHOUT materialising dy (it is rank 1: dpred[p] * w[c]): the pass forms dwb and, holding z and dy of every element
+ * anyway, the partial sums of the BatchNorm backward that follows on z's layer ({sum g, sum g * xhat}, one row of `part`
+ * (mfpa_outconv_bwd_rows(npix, C), 2, C) float per workgroup, finished by mfpa_conv_stats_reduce); mfpa_bn_relu_bwd_finish_rank1 then
+ * forms dy again from dpred and w while it applies the BatchNorm + ReLU backward: dz to dz_f32 (float32, may be null) and / or
+ * dz_bf16.  No dropout on this layer (training/unet.py: the last DoubleConv feeds OutConv directly). */
+int mfpa_outconv_bwd_rows(long long npix, int C, int* rows);
+int mfpa_outconv_bwd_sums(const float* z, const float* dpred, long long npix, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* w, float* dwb, double* workspace, float* part,
+                          void* stream);
+int mfpa_bn_relu_bwd_finish_rank1(const float* dpred, const float* w1, const float* z, long long npix, int C, const float* gamma,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  const double* local_sums, const double* global_sums, double global_count, float* dgamma,
+                                  float* dbeta, float* coef, float* dz_f32, void* dz_bf16, void* stream);
 
 /* nn.L1Loss(mean) of float32 pred against the float64 target (train.py:280): loss[0] (float64) and,
  * if dpred != NULL, dpred = sign(pred - target) / n. */

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 
 class MfpaError(RuntimeError):
@@ -147,6 +147,11 @@ _SIGNATURES = {
                          c_int),
     "mfpa_outconv_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p], c_int),
+    "mfpa_outconv_bwd_rows": ([c_longlong, c_int, c_void_p], c_int),
+    "mfpa_outconv_bwd_sums": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p], c_int),
+    "mfpa_bn_relu_bwd_finish_rank1": ([c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_l1_loss": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_act_to_bf16": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
     "mfpa_pack_conv_weights": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),

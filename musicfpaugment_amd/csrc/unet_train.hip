@@ -229,6 +229,9 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __rest
 
 // dy <- dz in place (BatchNorm + ReLU backward), all per-channel constants precomputed.
 typedef __bf16 wg_bf16x4_t __attribute__((ext_vector_type(4)));
+// RANK1: the incoming gradient is the OutConv's, dy[p][c] = dpred[p] * w1[c] (training/unet.py:94-96 backward): it is formed here from the
+// (B, H, W) dpred and the 64 weights instead of being written by mfpa_outconv_bwd and read back (2 x 1.06 GB per 64-clip step); dz goes to `dy`.
+template <bool RANK1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ z,
                                                            long long npix, int C, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, unsigned drop_seed,
                                                            unsigned drop_thresh, float drop_scale, __bf16* __restrict__ dz16,
-                                                           int write_f32) {
+                                                           int write_f32, const float* __restrict__ dpred, const float* __restrict__ w1) {
   const int C4 = C / 4;                      // a power of two (checked on the host): no 64-bit division per element
   const long long total = npix * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -248,7 +251,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
     const f32x4 ka = *reinterpret_cast<const f32x4*>(coef + 4 * cq);
     const f32x4 kb = *reinterpret_cast<const f32x4*>(coef + C + 4 * cq);
     const f32x4 kc = *reinterpret_cast<const f32x4*>(coef + 2 * C + 4 * cq);
-    f32x4 g = *reinterpret_cast<const f32x4*>(dy + e * 4);
+    f32x4 g;
+    if (RANK1) {
+      const float gp = dpred[e / C4];                     // (C4 is a power of two)
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + 4 * cq);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = gp * wv[k];
+    } else {
+      g = *reinterpret_cast<const f32x4*>(dy + e * 4);
+    }
     const f32x4 zz = *reinterpret_cast<const f32x4*>(z + e * 4);
     f32x4 o;
 #pragma unroll
@@ -1185,15 +1196,26 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
 }
 
 // dy[p][c] = dpred[p]*w[c];  partial[blk][c] = sum_p dpred[p]*y[p][c] (c < C), partial[blk][C] = sum_p dpred[p]
+// SUMS: dy is not written (the BatchNorm backward forms it again from dpred and w: bn_bwd_apply_kernel<RANK1>); instead the pass, which holds
+// z and dy of every element anyway, also forms the partial sums of that BatchNorm backward -- {sum g, sum g * xhat}, g = dy * [y > 0], xhat =
+// (z - mean) * invstd -- as one row of `part` (blocks x 2 x C float, the convolutions' stats_part layout) per workgroup.
+template <bool SUMS>
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dpred,
                                                           long long npix, int C, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ w,
-                                                          float* __restrict__ dy, double* __restrict__ partial) {
+                                                          float* __restrict__ dy, double* __restrict__ partial,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          float* __restrict__ part) {
   const int lpp = C / 4, sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
   const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * sub);
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * sub);
   const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * sub);
-  double sw[4] = {0, 0, 0, 0}, sb = 0;
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
+  if (SUMS) {
+    mu = *reinterpret_cast<const f32x4*>(mean + 4 * sub);
+    is = *reinterpret_cast<const f32x4*>(invstd + 4 * sub);
+  }
+  double sw[4] = {0, 0, 0, 0}, sb = 0, s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
     const float g = dpred[p];
     const f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * sub);
@@ -1203,9 +1225,34 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
       const float y = v[k] * sc[k] + sf[k];
       sw[k] += (double)g * (double)(y > 0.f ? y : 0.f);
       o[k] = g * wv[k];
+      if (SUMS) {
+        const float gg = y > 0.f ? o[k] : 0.f;
+        s0[k] += (double)gg;
+        s1[k] += (double)gg * (double)((v[k] - mu[k]) * is[k]);
+      }
     }
-    *reinterpret_cast<f32x4*>(dy + (size_t)p * C + 4 * sub) = o;
+    if (!SUMS) *reinterpret_cast<f32x4*>(dy + (size_t)p * C + 4 * sub) = o;
     if (sub == 0) sb += (double)g;
+  }
+  if (SUMS) {
+    __shared__ double sh2[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sh2[threadIdx.x * 8 + k] = s0[k];
+      sh2[threadIdx.x * 8 + 4 + k] = s1[k];
+    }
+    __syncthreads();
+    if (pl == 0) {
+      for (int r = 1; r < ppb; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s0[k] += sh2[(r * lpp + sub) * 8 + k];
+          s1[k] += sh2[(r * lpp + sub) * 8 + 4 + k];
+        }
+      float* row = part + (size_t)blockIdx.x * 2 * C;
+      *reinterpret_cast<f32x4*>(row + 4 * sub) = f32x4{(float)s0[0], (float)s0[1], (float)s0[2], (float)s0[3]};
+      *reinterpret_cast<f32x4*>(row + C + 4 * sub) = f32x4{(float)s1[0], (float)s1[1], (float)s1[2], (float)s1[3]};
+    }
   }
   __shared__ double sh[256 * 5];
 #pragma unroll
@@ -1405,8 +1452,9 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
-                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
+                     (const float*)nullptr, (const float*)nullptr);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1480,8 +1528,27 @@ int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, co
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
   if (npix == 0) return MFPA_OK;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
-                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
+                     (const float*)nullptr, (const float*)nullptr);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_bn_relu_bwd_finish_rank1(const float* dpred, const float* w1, const float* z, long long npix, int C, const float* gamma,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd, const double* local_sums,
+                                  const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
+                                  float* dz_f32, void* dz_bf16, void* stream) {
+  if (!dpred || !w1 || !gamma || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !dgamma || !dbeta || !coef) return MFPA_EINVAL;
+  if (!dz_f32 && !dz_bf16) return MFPA_EINVAL;
+  if (!bn_shape_ok(npix, C) || (C & (C - 1)) || !(global_count >= 1.0) || (npix > 0 && !z)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_finish_sync_kernel, dim3((C + 255) / 256), dim3(256), 0, s, local_sums, global_sums, C, global_count,
+                     gamma, invstd, dgamma, dbeta, coef);
+  MFPA_CHECK_LAUNCH();
+  if (npix == 0) return MFPA_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dz_f32, z, npix, C, scale, shift,
+                     mean, invstd, coef, 0u, 0u, 1.f, reinterpret_cast<__bf16*>(dz_bf16), dz_f32 != nullptr ? 1 : 0, dpred, w1);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1670,9 +1737,32 @@ int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, 
   if (npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   const int nblk = grid_for(npix, (256 / (C / 4)) * 16, RED_BLOCKS);
-  hipLaunchKernelGGL(outconv_bwd_kernel, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, dy, workspace);
+  hipLaunchKernelGGL(outconv_bwd_kernel<false>, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, dy, workspace,
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
   MFPA_CHECK_LAUNCH();
   // finish: column sums of the (nblk, C+1) partial matrix: C weight gradients then the bias gradient
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_outconv_bwd_rows(long long npix, int C, int* rows) {
+  if (!rows || npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
+  *rows = npix == 0 ? 0 : grid_for(npix, (256 / (C / 4)) * 16, RED_BLOCKS);
+  return MFPA_OK;
+}
+
+int mfpa_outconv_bwd_sums(const float* z, const float* dpred, long long npix, int C, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* w, float* dwb, double* workspace, float* part,
+                          void* stream) {
+  if (npix == 0) return MFPA_OK;
+  if (!z || !dpred || !scale || !shift || !mean || !invstd || !w || !dwb || !workspace || !part) return MFPA_EINVAL;
+  if (npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int nblk = grid_for(npix, (256 / (C / 4)) * 16, RED_BLOCKS);
+  hipLaunchKernelGGL(outconv_bwd_kernel<true>, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, (float*)nullptr, workspace,
+                     mean, invstd, part);
+  MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;

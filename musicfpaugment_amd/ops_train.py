@@ -157,6 +157,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
 
 USE_BF16_DZ = True          # plain-bf16 step: input-gradient convolutions read the bf16 copy of dz (False: the float32 dz, A/B runs)
 FUSE_POOL_BWD_SUMS = True   # False: mfpa_maxpool2_bwd_add, then the BatchNorm backward's own reduction pass (chan_reduce_kernel<1>)
+RANK1_OUTCONV_BWD = True    # False: mfpa_outconv_bwd writes dy = dpred x w (1.06 GB per 64 clips), the BatchNorm backward reduces and reads it
 BF16_WGRAD_MIN_CH = 128     # plain-bf16 weight gradients: layers with at least this many channels on both sides read bf16 copies
 
 
@@ -436,14 +437,28 @@ class UNetTrainEngine:
                                   ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
         return st
 
-    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False, part=None, write_f32: bool = True):
+    def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False, part=None, write_f32: bool = True, rank1=None):
         """dy <- gradient w.r.t. z, in place; with bf16_copy also its bf16 copy, written by the same pass (the weight-gradient
         kernel's operand).  `write_f32=False` (needs bf16_copy): ONLY the bf16 copy is written -- every consumer reads it (plain-bf16
         step) -- and None is returned for dz.  Returns (dz, dz_bf16 or None)."""
         write_f32 = write_f32 or not bf16_copy
         C = z.shape[-1]
         coef = torch.empty((3, C), dtype=torch.float32, device=z.device)
-        dz16 = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device) if bf16_copy else None
+        dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if bf16_copy else None
+        if rank1 is not None:
+            # dy is the OutConv's gradient dpred[p] * w[c] and was never written: `part` holds its BatchNorm-backward partial sums
+            # (mfpa_outconv_bwd_sums); the apply pass forms dy again from dpred and w (mfpa_bn_relu_bwd_finish_rank1)
+            dpred, w1 = rank1
+            loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
+            check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(loc), ptr(self.workspace), stream()), "mfpa_conv_stats_reduce")
+            glob = self._all_reduce_sums(loc.clone()) if self.sync_bn else loc
+            if not self.sync_bn:
+                st.count_host = float(_npix(z))
+            dz = torch.empty_like(z) if write_f32 else None
+            check(lib().mfpa_bn_relu_bwd_finish_rank1(ptr(dpred), ptr(w1), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
+                                                      ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
+                                                      ptr(self.G[b]), ptr(coef), ptr(dz), ptr(dz16), stream()), "mfpa_bn_relu_bwd_finish_rank1")
+            return dz, dz16
         if self.sync_bn or part is not None:
             loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
             if part is not None:             # the convolution that produced dy reduced (sum g, sum g * xhat) in its epilogue (conv_mfma(bwd_of=))
@@ -528,10 +543,10 @@ class UNetTrainEngine:
         return pred
 
     # ------------------------------------------------------------------ backward
-    def _dconv_bwd(self, r, dy, need_input_grad=True, dy_part=None):
+    def _dconv_bwd(self, r, dy, need_input_grad=True, dy_part=None, dy_rank1=None):
         """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1).
         dy_part: the partial sums of this block's last BatchNorm backward when the pass that finished dy already formed them
-        (mfpa_maxpool2_bwd_add_sums)."""
+        (mfpa_maxpool2_bwd_add_sums, mfpa_outconv_bwd_sums); dy_rank1 = (dpred, w) with dy None: dy = dpred x w, never written."""
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
         H_, W_ = r["z3"].shape[1], r["z3"].shape[2]
@@ -541,7 +556,7 @@ class UNetTrainEngine:
         # copy, the float32 dz is never written (mfpa_bn_relu_bwd(write_f32 = 0)) and the convolution's loader moves half the bytes
         only16 = USE_BF16_DZ and self.precision == 2 and lay == 2 and wg16
         dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b", bf16_copy=wg16, write_f32=not only16,
-                                      part=dy_part)
+                                      part=dy_part, rank1=dy_rank1)
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16,
                    x0_bf16=r["xb3"])
         r["xb3"] = None
@@ -591,16 +606,27 @@ class UNetTrainEngine:
         self.flat_g.zero_()
         last = recs[DEC[-1]]
         z, st = last["z3"], last["st3"]
-        dy = torch.empty_like(z)
         wb = self.P["outc.wb"]
-        check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(wb), ptr(dy),
-                                     ptr(self.G["outc.wb"]), ptr(self.workspace), stream()), "mfpa_outconv_bwd")
+        dy, dy_part, dy_rank1 = None, None, None
+        if RANK1_OUTCONV_BWD and st.drop[1] == 0:
+            rows = ctypes.c_int(0)
+            check(lib().mfpa_outconv_bwd_rows(_npix(z), 64, ctypes.byref(rows)), "mfpa_outconv_bwd_rows")
+            dy_part = torch.empty((rows.value, 2, 64), dtype=torch.float32, device=z.device)
+            check(lib().mfpa_outconv_bwd_sums(ptr(z), ptr(dpred), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+                                              ptr(wb), ptr(self.G["outc.wb"]), ptr(self.workspace), ptr(dy_part), stream()),
+                  "mfpa_outconv_bwd_sums")
+            dy_rank1 = (dpred, wb)
+        else:
+            dy = torch.empty_like(z)
+            check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(wb), ptr(dy),
+                                         ptr(self.G["outc.wb"]), ptr(self.workspace), stream()), "mfpa_outconv_bwd")
         handles = []
         dskip = {}
         enc_of_dec = {DEC[0]: ENC[3], DEC[1]: ENC[2], DEC[2]: ENC[1], DEC[3]: ENC[0]}
         for name in reversed(DEC):                                                  # up4 ... up1
             r = recs[name]
-            d_skip, d_u = self._dconv_bwd(r, dy)
+            d_skip, d_u = self._dconv_bwd(r, dy, dy_part=dy_part, dy_rank1=dy_rank1)
+            dy_part = dy_rank1 = None
             dskip[enc_of_dec[name]] = d_skip
             # transposed conv: bias, weight and input gradients
             cout = d_u.shape[-1]

@@ -222,6 +222,55 @@ def test_maxpool_backward_with_batchnorm_sums_equals_the_two_passes():
     assert lib().mfpa_maxpool2_bwd_add_sums(ptr(z), 1, 4, 4, 48, ptr(v), ptr(v), ptr(v), ptr(v), ptr(z), ptr(z), 0, 0, 1.0, ptr(z), stream()) != 0
 
 
+def test_rank1_outconv_backward_equals_the_materialised_path():
+    """mfpa_outconv_bwd_sums + mfpa_bn_relu_bwd_finish_rank1 (dy = dpred x w never written) against mfpa_outconv_bwd + mfpa_bn_relu_bwd on the
+    written dy: the same OutConv gradients, the same dz (float32 to 1e-6 of its scale, and its bf16 copy), dgamma / dbeta to 1e-6."""
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    import ctypes
+    g = torch.Generator().manual_seed(21)
+    B, H, W, C = 3, 37, 29, 64
+    npix = B * H * W
+    z = torch.randn(B, H, W, C, generator=g).cuda()
+    dpred = (torch.randn(B, H, W, generator=g) * 1e-3).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    mean = (torch.randn(C, generator=g) * 0.2).cuda(); invstd = (torch.rand(C, generator=g) + 0.5).cuda()
+    scale = gamma * invstd; shift = (torch.randn(C, generator=g) * 0.3).cuda()
+    wb = torch.randn(C + 1, generator=g).cuda()
+    ws = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device="cuda")
+    # the two-pass reference
+    dy = torch.empty_like(z); dwb0 = torch.zeros(C + 1, device="cuda")
+    check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), npix, C, ptr(scale), ptr(shift), ptr(wb), ptr(dy), ptr(dwb0), ptr(ws), stream()), "mfpa_outconv_bwd")
+    dg0 = torch.zeros(C, device="cuda"); db0 = torch.zeros(C, device="cuda"); coef = torch.empty(3, C, device="cuda")
+    dz16_0 = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
+    check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), npix, C, ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dg0), ptr(db0), ptr(coef),
+                                 ptr(ws), 0, 0, 1.0, ptr(dz16_0), 1, stream()), "mfpa_bn_relu_bwd")
+    # rank 1
+    rows = ctypes.c_int(0)
+    check(lib().mfpa_outconv_bwd_rows(npix, C, ctypes.byref(rows)), "mfpa_outconv_bwd_rows")
+    part = torch.full((rows.value, 2, C), float("nan"), dtype=torch.float32, device="cuda")
+    dwb1 = torch.zeros(C + 1, device="cuda")
+    check(lib().mfpa_outconv_bwd_sums(ptr(z), ptr(dpred), npix, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(wb), ptr(dwb1), ptr(ws), ptr(part),
+                                      stream()), "mfpa_outconv_bwd_sums")
+    loc = torch.empty(2 * C, dtype=torch.float64, device="cuda")
+    check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(loc), ptr(ws), stream()), "mfpa_conv_stats_reduce")
+    dg1 = torch.zeros(C, device="cuda"); db1 = torch.zeros(C, device="cuda"); coef1 = torch.empty(3, C, device="cuda")
+    dz1 = torch.empty_like(z); dz16_1 = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
+    check(lib().mfpa_bn_relu_bwd_finish_rank1(ptr(dpred), ptr(wb), ptr(z), npix, C, ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(loc),
+                                              ptr(loc), float(npix), ptr(dg1), ptr(db1), ptr(coef1), ptr(dz1), ptr(dz16_1), stream()),
+          "mfpa_bn_relu_bwd_finish_rank1")
+    assert torch.equal(dwb0, dwb1)
+    s = float(dy.abs().max())                                   # dy now holds the reference dz (in place)
+    assert float((dz1 - dy).abs().max()) < 1e-6 * s
+    assert float((dz16_1.float() - dz16_0.float()).abs().max()) < 1e-2 * s and float((dz16_1.float() - dz16_0.float()).abs().mean()) < 1e-5 * s
+    assert float((dg1 - dg0).abs().max() / dg0.abs().max()) < 1e-6 and float((db1 - db0).abs().max() / db0.abs().max()) < 1e-6
+    # bf16 only (the plain-bf16 step): no float32 dz
+    dz16_2 = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
+    check(lib().mfpa_bn_relu_bwd_finish_rank1(ptr(dpred), ptr(wb), ptr(z), npix, C, ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(loc),
+                                              ptr(loc), float(npix), ptr(dg1), ptr(db1), ptr(coef1), 0, ptr(dz16_2), stream()),
+          "mfpa_bn_relu_bwd_finish_rank1")
+    assert torch.equal(dz16_2, dz16_1)
+
+
 def test_train_step_matches_reference_golden(golden):
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet

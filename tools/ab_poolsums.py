@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""UNet train step with / without the BatchNorm-backward partial sums formed inside the max-pool backward pass (ops_train.FUSE_POOL_BWD_SUMS):
+"""UNet train step with / without the rank-1 OutConv backward (ops_train.RANK1_OUTCONV_BWD; FUSE_POOL_BWD_SUMS likewise, edit `run`):
 time per step and the largest relative difference of the parameter gradients.  64 clips x 8 s, plain bf16."""
 import os, sys, time
 import torch
@@ -14,7 +14,8 @@ x = torch.from_numpy(rng.random((B, 257, 251))).cuda()
 y = torch.from_numpy(rng.random((B, 257, 251))).cuda()
 den = torch.ones(B, dtype=torch.float64, device="cuda")
 def run(flag, precision):
-    T.FUSE_POOL_BWD_SUMS = flag
+    T.FUSE_POOL_BWD_SUMS = True
+    T.RANK1_OUTCONV_BWD = flag
     net = UNet(1, 1); net.load_state_dict(formula_state_dict(0)); net = net.cuda().train()
     eng = T.UNetTrainEngine(net, lr=1e-4, precision=precision, wgrad_precision=2 if precision == 2 else None)
     def step():
@@ -32,5 +33,5 @@ def run(flag, precision):
 for prec in (2, 1):
     t0, g0 = run(False, prec); t1, g1 = run(True, prec); t0b, _ = run(False, prec); t1b, _ = run(True, prec)
     worst = max(float((g0[k] - g1[k]).abs().sum() / (g0[k].abs().sum() + 1e-30)) for k in g0)
-    print(f"precision {prec}: fwd+bwd separate reduction {t0:.2f} / {t0b:.2f} ms, fused into the pool backward {t1:.2f} / {t1b:.2f} ms; "
+    print(f"precision {prec}: fwd+bwd with dy written {t0:.2f} / {t0b:.2f} ms, rank-1 (dy never written) {t1:.2f} / {t1b:.2f} ms; "
           f"largest relative L1 difference of a parameter gradient {worst:.2e}", flush=True)
