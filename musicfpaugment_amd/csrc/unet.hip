@@ -17,6 +17,7 @@
 // Global loads of the next tap's weights (and next chunk's halo) are issued before the MFMA
 // block of the current tap and written to LDS after it, so they overlap the matrix work.
 #include "mfpa_common.h"
+#include "mfpa_unet_args.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -135,50 +136,7 @@ constexpr bool conv_is_pipe(int BN, int PH, int PW, int WM, int WN, int MODE, in
          (WM * WN * MT == 16 || (MFPA_CONV_PIPE4 != 0 && WM * WN == 4 && BN == 64 && PH * PW == 256));
 }
 
-struct ConvArgs {
-  const float* x0;         // source 0: (B,H,W,C0) [mode 2: (B,2H,2W,C0)]
-  const float* in_scale0;  // optional per-channel affine + ReLU applied to source 0 ON LOAD (training: the
-  const float* in_shift0;  //   previous layer's BatchNorm+ReLU is never materialised); null = plain
-  const float* x1;         // source 1: (B,H1,W1,C1) or null, zero-padded to (H,W) at offset (oy1,ox1)
-  const float* w;          // [taps][Cout][Cin], Cin contiguous
-  const float* scale;      // epilogue per-output-channel affine (null = identity)
-  const float* shift;
-  float* y;
-  int C0, C1, H1, W1, oy1, ox1;
-  int B, H, W, Cout, relu;
-  int yH, yW;              // output extent (crop): pixels with gy >= yH or gx >= yW are not stored
-  int tiles_x, tiles_y;
-  unsigned drop_seed, drop_thresh;   // dropout on source 0 after the affine+ReLU (thresh 0 = off)
-  float drop_scale;
-  float* y_pool;                     // optional fused MaxPool2d(2) of the (affine+ReLU) output: (B,H/2,W/2,Cout)
-  const float* w1x1;                 // optional fused OutConv 1x1 to one class (needs the whole Cout in one workgroup):
-  float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
-  float* y1x1;
-  int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
-  int in16;                          // conv_wd16_kernel (plain): source 0 is a bfloat16 tensor (mfpa_conv_desc.x0_is_bf16)
-  int plain;                         // conv_wd16_kernel: plain bf16 products (hi halves only: mfpa_conv_desc.precision 2, the training step)
-  __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
-  __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)
-  __bf16* y_bf16;                    // ... of the stored output, (B,yH,yW,Cout)
-  const float* bz;                   // conv_wd16_kernel + stats_part: the output is a gradient dy w.r.t. relu(bn(bz)), bz (B,yH,yW,Cout): the partials are
-  const float* bz_scale;             //   (sum g, sum g * xhat), g = dy where bz * bz_scale + bz_shift > 0 else 0, xhat = (bz - bz_mean) * bz_invstd --
-  const float* bz_shift;             //   the two reductions of the BatchNorm backward (mfpa_conv_desc.bwd_z ...)
-  const float* bz_mean;
-  const float* bz_invstd;
-  float* stats_part;                 // conv_wd16_kernel: optional per-wave partial (sum, sum of squares) of the stored output per channel:
-                                     //   [tile * WMW + wm][2][Cout] (mfpa_conv_desc.stats_part; rows = mfpa_conv_stats_rows())
-  int dbg_stagger;                   // -DMFPA_EXPERIMENTS builds only: start delay of persistent workgroup k = (k & 7) x this x 4096 cycles
-  int dbg_lds_stamps;                // -DMFPA_EXPERIMENTS builds only: LDS byte offset of the tap-timeline stamps (0 = none)
-  int dbg;                           // -DMFPA_EXPERIMENTS builds only (MFPA_CONV_DBG): 1 skip B staging, 2 skip barriers, 4 skip stores, 8 skip MFMA, 16 skip halo staging
-  // C1SRC: source 0 is not read but COMPUTED while it is staged -- the UNet's first layer (1 -> 64 channels, folded BN,
-  // ReLU) applied to the normalised spectrogram, so its 64-channel output never exists in HBM
-  const float* c1_x32;               // (B,H,W) float32, or
-  const double* c1_spec64;           // (B,H,W) float64 divided by c1_denom[b] (the fused spectrogram normalisation)
-  const double* c1_denom;
-  const float* c1_w;                 // (9, 64)
-  const float* c1_scale;             // (64) folded BatchNorm of the first layer
-  const float* c1_shift;
-};
+using mfpa_unet::ConvArgs;     // csrc/mfpa_unet_args.h (shared with csrc/unet_ws.hip)
 
 // MODE 0: 3x3 conv, pad 1 (9 taps, halo 1).
 // MODE 1: 2x2 stride-2 transposed conv forward: one tap per workgroup column
@@ -1911,6 +1869,13 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   }
 }
 
+#ifndef MFPA_CONV_WS64
+#define MFPA_CONV_WS64 1             // 64-channel inference launches on conv_ws64_kernel (csrc/unet_ws.hip); 0: conv_wd16_kernel<.., WMW = 4> (A/B builds)
+#endif
+#ifndef MFPA_CONV_WS_ALL
+#define MFPA_CONV_WS_ALL 128         // conv_ws64_kernel also for outputs of 128 channels and more with at most this many input channels (0 = never): per layer,
+                                     // 64 clips: 64 -> 128 @ 128 x 125 431 -> 380 us, 128 -> 128 725 -> 704, 128 -> 256 @ 64 x 62 360 -> 345; from 256 input channels on it loses
+#endif
 #ifndef MFPA_CONV_WD16_64
 #define MFPA_CONV_WD16_64 64         // conv_wd16_kernel<.., WMW = 4> for 64-channel layers with at least this many input channels (no fused first layer / OutConv); 0 = off
 #endif
@@ -2364,7 +2329,18 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   if constexpr (MODE == 0 && PREC == 1) {
     if (a.w_frag == 2) {   // the 16 x 16 x 32 weights-direct kernel and its image
       if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || a.c1_x32 || a.c1_spec64 || (a.w1x1 && bn128)) return MFPA_EINVAL;
-      if (!bn128) return launch_wd16<8, 32, 4>(a, s);                   // 64-channel output tiles: 4 x 2 waves of 64 px x 32 ch
+      if (!bn128) {
+        // round 5: the wave-specialised kernel (csrc/unet_ws.hip: 4 compute waves of 128 px x 32 ch + 4 loader waves) takes the inference launches
+        static const int ws64 = MFPA_EXP_ENV("MFPA_CONV_WS64", MFPA_CONV_WS64);
+        if (ws64 && mfpa_unet::conv_ws64_serves(a)) return mfpa_unet::launch_conv_ws64(a, s);
+        return launch_wd16<8, 32, 4>(a, s);                             // 64-channel output tiles: 4 x 2 waves of 64 px x 32 ch
+      }
+      {
+        // the same kernel for 128-channel-multiple outputs (two or more workgroup rows of 64 channels): per-layer A/B, see NOTES.md R5
+        static const int ws_all = MFPA_EXP_ENV("MFPA_CONV_WS_ALL", MFPA_CONV_WS_ALL);
+        const int cin_ = a.C0 + a.C1;
+        if (ws_all && cin_ <= ws_all && mfpa_unet::conv_ws64_serves(a)) return mfpa_unet::launch_conv_ws64(a, s);
+      }
       if (a.W > 16) return launch_wd16<8, 32>(a, s);
       return launch_wd16<16, 16>(a, s);
     }

@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
   // SUMS: 256 % C4 == 0 (checked by the launcher), so a thread meets ONE channel quad in all its trips: tid % C4
-  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  // (float64 like the chan_reduce_kernel<1> pass this replaces and like outconv_bwd_kernel<SUMS>: the two sums cancel heavily, and a float32
+  //  running sum over a row's ~500 pixels would put its rounding, relative to sum |g|, into dgamma / dbeta / dz of every engine precision)
+  double s0[4] = {0., 0., 0., 0.}, s1[4] = {0., 0., 0., 0.};
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, scq = {0.f, 0.f, 0.f, 0.f}, sfq = {0.f, 0.f, 0.f, 0.f};
   if (SUMS) {
     const int cqt = threadIdx.x % C4;
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     for (int k = 0; k < 4; ++k) {
       float g = (v[k] * scq[k] + sfq[k] > 0.f) ? d[k] : 0.f;
       if (drop_thresh) g = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)elem0 + k) ? g * drop_scale : 0.f;
-      s0[k] += g;
-      s1[k] += g * ((v[k] - mu[k]) * is[k]);
+      s0[k] += (double)g;
+      s1[k] += (double)g * (double)((v[k] - mu[k]) * is[k]);
     }
   };
   for (int e32 = threadIdx.x; e32 < Wo * C4; e32 += 256) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
         add(*reinterpret_cast<const f32x4*>(dy + off), *reinterpret_cast<const f32x4*>(z + off), off);
       }
     }
-    __shared__ float red[256 * 8];
+    __shared__ double red[256 * 8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       red[threadIdx.x * 8 + k] = s0[k];
@@ -411,8 +413,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
           s1[k] += red[(r * C4 + threadIdx.x) * 8 + 4 + k];
         }
       float* row = part + (size_t)blockIdx.x * 2 * C;
-      *reinterpret_cast<f32x4*>(row + 4 * threadIdx.x) = f32x4{s0[0], s0[1], s0[2], s0[3]};
-      *reinterpret_cast<f32x4*>(row + C + 4 * threadIdx.x) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+      *reinterpret_cast<f32x4*>(row + 4 * threadIdx.x) = f32x4{(float)s0[0], (float)s0[1], (float)s0[2], (float)s0[3]};
+      *reinterpret_cast<f32x4*>(row + C + 4 * threadIdx.x) = f32x4{(float)s1[0], (float)s1[1], (float)s1[2], (float)s1[3]};
     }
   }
 }

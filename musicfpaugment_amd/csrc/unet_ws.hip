@@ -1,0 +1,636 @@
+// Wave-specialised 3x3 convolution for the UNet's 64-channel full-resolution layers (training/unet.py:8-25 DoubleConv of `inc` and
+// `up4`; inference, bf16x3 products on v_mfma_f32_16x16x32_bf16).  Round 5.
+//
+// Why another kernel.  conv_wd16_kernel<.., WMW = 4> (csrc/unet.hip) gives these layers 8 waves that ALL do everything -- request the halo
+// from HBM, split it into bf16 hi / lo planes in LDS, pull their weight fragments through the L1 and issue the MFMAs -- with the two
+// waves of a SIMD in barrier lock-step.  Vector-memory returns are in order, so a wave's wait for a weight fragment requested behind the
+// chunk's six HBM halo loads is a wait for HBM, and while it waits it issues no MFMA either; its SIMD-mate waits for the same thing.
+// Measured on the shipped code (profiles/r04_c64_skip_variants_product_code.txt): MFMA stream alone 480 us, everything else alone
+// 379 us, together 901 us -- they add.  And four pixel-waves fetch the same 8 KB of weights per tap (texture addresser 59 % busy).
+//
+// Here the 8 waves of a workgroup have two ROLES, one wave of each role per SIMD:
+//   * waves 0..3, COMPUTE: 2 pixel halves x 2 channel halves, a wave owns 128 px x 32 ch (the wave tile of the 128-channel form: half
+//     the weight bytes per MFMA of the 64 px x 32 ch tile).  Their instruction stream is MFMAs, LDS fragment reads and the weight
+//     fragments (L1 / L2 hits, two taps ahead through a ring of three register sets) -- nothing in it ever waits for HBM.
+//   * waves 4..7, LOADERS: request the NEXT chunk's halo (256 threads x 11 staging slots of 16 B), split fp32 -> bf16 hi | lo, write the
+//     planes of the other LDS stage, and request the chunk after that into the freed registers -- a whole chunk period (~3.5 us) ahead
+//     of its use.  Their vector work issues in the gaps a v_mfma_f32_16x16x32_bf16 leaves on the SIMD's issue port.
+// The loaders also take the EPILOGUE's memory work: a compute wave applies the output affine + ReLU and writes its accumulators to a 64 KB
+// LDS tile (XOR-swizzled 16-byte pieces: conflict-free both ways) and goes straight on to the next tile's MFMAs; one barrier later the
+// loaders read the tile and issue the global stores (a CU's store path takes ~10 B/clk: the 64 KB of a tile held the compute waves for
+// ~6 k cycles, a quarter of a two-chunk tile) and, for up4's second layer, the fused OutConv's 64-channel dot product per pixel.
+// One s_barrier per 32-channel chunk hands a finished stage to the compute waves and a read-out stage back to the loaders.  The tile loop
+// is persistent (one workgroup per CU walks tiles b, b + G, ...): the loaders simply run on into the next tile's first chunk.
+// LDS: two stages of eight planes [hi | lo][k-group] of (pixel x 16 B), the layout conv_wd16_kernel reads (conflict-free ds_read_b128).
+// Same products and the same summation inside an instruction as conv_wd16_kernel: bit-identical outputs (tests/test_gpu_unet.py).
+#include "mfpa_common.h"
+#include "mfpa_unet_args.h"
+
+#include <type_traits>
+
+namespace mfpa_unet {
+#if defined(MFPA_EXPERIMENTS) || defined(MFPA_WS_STAMPS)
+__device__ unsigned long long* ws_stamps = nullptr;
+#endif
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#ifndef MFPA_WS_COMPUTE_PRIO
+#define MFPA_WS_COMPUTE_PRIO 0     // s_setprio of the compute waves (A/B builds)
+#endif
+#ifndef MFPA_WS_LOADER_PRIO
+#define MFPA_WS_LOADER_PRIO 0      // s_setprio of the loader waves: their few hundred instructions per chunk go first, then they sleep at the barrier
+                                   // (at equal priority the older compute wave of the SIMD wins every arbitration and a loader turn took
+                                   //  7.7 k cycles of a 9.4 k-cycle chunk: the compute waves waited for it at the barrier)
+#endif
+#ifndef MFPA_WS_EPI_PRIO
+#define MFPA_WS_EPI_PRIO 0         // s_setprio of a compute wave inside its epilogue (its ~200 vector instructions would otherwise queue behind the loader's turn)
+#endif
+#ifndef MFPA_WS_XCD_TILES
+#define MFPA_WS_XCD_TILES 1        // the 32 workgroups of an XCD walk 32 CONSECUTIVE tiles at a time (their shared halo rows meet in that XCD's L2)
+#endif
+
+// timing-only variants (tools/build_ws_variants.py: -DMFPA_SKIP_BITS=<bits>, compile-time, wrong results by design) and the in-kernel
+// timeline (-DMFPA_WS_STAMPS or the experiments build): the product build contains neither
+#ifdef MFPA_SKIP_BITS
+#define WS_FLAG(bit) (((MFPA_SKIP_BITS) & (bit)) != 0)
+#else
+#define WS_FLAG(bit) false
+#endif
+#if defined(MFPA_EXPERIMENTS) && !defined(MFPA_WS_STAMPS)
+#define MFPA_WS_STAMPS 1
+#endif
+#ifdef MFPA_WS_STAMPS
+// In-kernel timeline (experiments build only; tools/exp_ws_timeline.py): wave 0 (compute) and wave 4 (loader) of workgroup 17 stamp s_memtime
+// into LDS (tag in the low 8 bits), dumped to this buffer when the kernel ends: [0] = count of wave 0, [1 ..] its stamps; [2048] = count of
+// wave 4, [2049 ..] its stamps.  No output value depends on a stamp.  (the symbol: mfpa_unet::ws_stamps above)
+constexpr int WS_MAX_STAMPS = 140;
+#endif
+
+constexpr int KC = 32;             // channels per K chunk
+constexpr int PH = 8, PW = 32, HPW = PW + 2, HPH = PH + 2, HP = HPW * HPH;
+constexpr int THREADS = 512, LTHREADS = 256;
+constexpr int SPP = KC / 4;                                            // staging slots (16 B = 4 fp32 channels) per pixel and chunk
+constexpr int PPI = LTHREADS / SPP;                                    // pixels per loader pass
+constexpr int A_F4 = (HP + PPI - 1) / PPI;                             // staging slots per loader thread and chunk (11)
+constexpr int HPS = A_F4 * PPI;                                        // staged pixels (>= HP)
+constexpr int PLANE = ((HPS * 16 + 255) / 256) * 256;                  // bytes of one (hi | lo, k-group) plane, a multiple of 256
+constexpr int HLS = 4 * PLANE + 256;                                   // hi -> lo distance (planes 2, 3 sit 128 B further)
+constexpr int STAGE = 2 * HLS;
+constexpr int TAPS = 9, PT = 8;                                        // 16-pixel tiles per compute wave
+constexpr int OUTBUF = PH * PW * 64 * 4;                                // the epilogue's LDS tile: 256 px x 64 ch fp32, piece (pixel m, channel quad q) at m * 256 + ((q ^ (m & 15)) << 4)
+constexpr int C1R = PH + 4, C1W = PW + 4;                              // C1SRC: the 1-channel source patch with a two-pixel halo
+
+__device__ __forceinline__ constexpr int plane_off(int hl, int kg) { return hl * HLS + kg * PLANE + (kg >> 1) * 128; }
+
+// sched_group_barrier pattern "one MFMA, then k LDS reads" with LEFT reads spread evenly over SLOTS MFMAs
+template <int SLOTS, int LEFT, int I = 0>
+__device__ __forceinline__ void pin_reads() {
+  if constexpr (I < SLOTS && LEFT > 0) {
+    constexpr int k = (LEFT + (SLOTS - I) - 1) / (SLOTS - I);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, k, 0);
+    pin_reads<SLOTS, LEFT - k, I + 1>();
+  }
+}
+constexpr int pin_read_slots(int slots, int left) {
+  int used = 0;
+  for (int i = 0; i < slots && left > 0; ++i) {
+    left -= (left + (slots - i) - 1) / (slots - i);
+    ++used;
+  }
+  return used;
+}
+
+// tile index of workgroup b's i-th tile.  Plain: b + i G.  XCD-aware: workgroups b and b + 8 share an XCD (round-robin dispatch: speed
+// only), so within a round of G tiles XCD x = b % 8 takes the G / 8 consecutive tiles [x G / 8, (x + 1) G / 8).
+__device__ __forceinline__ int tile_of(int b, int i, int G) {
+#if MFPA_WS_XCD_TILES
+  if ((G & 7) == 0) return i * G + (b & 7) * (G >> 3) + (b >> 3);
+#endif
+  return i * G + b;
+}
+
+// C1SRC: the 64 input channels are not read but COMPUTED by the loaders -- the UNet's first layer (1 -> 64 channels, 3x3, folded
+// BatchNorm + ReLU; training/unet.py:16-18) applied to the 1-channel source, so `inc`'s 64-channel intermediate never exists in HBM.
+template <bool C1SRC>
+__global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cin = a.C0 + a.C1;
+  const int nchunks = Cin / KC;
+  const int ntiles = a.tiles_x * a.tiles_y * a.B;
+  const int G = (int)gridDim.x;
+  const int n0 = (int)blockIdx.y * 64;                                 // this workgroup's 64 output channels (Cout / 64 workgroup rows)
+  // tiles this workgroup owns: i = 0 .. owned - 1 (tile_of is increasing in i; the launcher keeps G <= ntiles, so owned >= 1)
+  const int first_tile = tile_of((int)blockIdx.x, 0, G);
+  const int owned = first_tile < ntiles ? (ntiles - first_tile + G - 1) / G : 0;
+
+  // LDS: [stage 0 | stage 1 | epilogue constants: scale 64, shift 64, w1x1 64 | the epilogue's output tile 64 KB | (experiments: stamps)]
+  float* const epi = reinterpret_cast<float*>(smem + 2 * STAGE);
+  char* const outbuf = smem + 2 * STAGE + 192 * sizeof(float);
+  float* const c1s = reinterpret_cast<float*>(outbuf + OUTBUF);
+  for (int i = tid; i < 64; i += THREADS) {
+    epi[i] = a.scale ? a.scale[n0 + i] : 1.f;
+    epi[64 + i] = a.shift ? a.shift[n0 + i] : 0.f;
+    epi[128 + i] = a.w1x1 ? a.w1x1[i] : 0.f;
+  }
+  if constexpr (C1SRC) {
+    float* cw = c1s + 2 * C1R * C1W;
+    for (int i = tid; i < 9 * 64; i += THREADS) cw[i] = a.c1_w[i];
+    for (int i = tid; i < 64; i += THREADS) {
+      cw[9 * 64 + i] = a.c1_scale[i];
+      cw[10 * 64 + i] = a.c1_shift[i];
+    }
+  }
+
+#ifdef MFPA_WS_STAMPS
+  unsigned long long* const tsbuf = reinterpret_cast<unsigned long long*>(smem + a.dbg_lds_stamps) + (wave >= 4 ? WS_MAX_STAMPS : 0);
+  int stamp_n = 0;
+  const bool stamping = ws_stamps != nullptr && a.dbg_lds_stamps != 0 && blockIdx.x == 17 && blockIdx.y == 0 && (tid == 0 || tid == LTHREADS);
+  auto stamp = [&](int tag) __attribute__((always_inline)) {
+    if (stamping && stamp_n < WS_MAX_STAMPS) tsbuf[stamp_n++] = (__builtin_amdgcn_s_memtime() & ~0xffull) | (unsigned)tag;
+  };
+  auto dump_stamps = [&]() __attribute__((always_inline)) {
+    if (stamping) {
+      unsigned long long* out = ws_stamps + (wave >= 4 ? 2048 : 0);
+      for (int i = 0; i < stamp_n; ++i) out[1 + i] = tsbuf[i];
+      out[0] = stamp_n;
+    }
+  };
+#else
+  auto stamp = [](int) {};
+  auto dump_stamps = []() {};
+#endif
+  if (wave >= 4) {
+    // =================================================================================================== LOADER waves
+#if MFPA_WS_LOADER_PRIO
+    __builtin_amdgcn_s_setprio(MFPA_WS_LOADER_PRIO);
+#endif
+    const int lt = tid - LTHREADS;
+    const int aq = lt % SPP;
+    struct Tile { int b, y0, x0; unsigned ain; unsigned t0, t1; bool interior; };   // t0 / t1: byte offset of the tile's HALO origin (pixel (-1, -1)) in source 0 / 1: may wrap
+    // a thread's inside flags when the whole halo lies inside both sources (most tiles): only its padding slots (pix >= HP) are off
+    unsigned ain_full = 0;
+#pragma unroll
+    for (int it = 0; it < A_F4; ++it) ain_full |= ((lt / SPP + it * PPI < HP) ? 1u : 0u) << it;
+    ain_full |= ain_full << 16;
+    auto make_tile = [&](int t) __attribute__((always_inline)) {
+      Tile T;
+      int bx = __builtin_amdgcn_readfirstlane(t);
+      const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+      const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+      T.b = bx; T.y0 = ty * PH; T.x0 = tx * PW;
+      T.t0 = (unsigned)(((T.y0 - 1) * a.W + (T.x0 - 1)) * a.C0) * 4u;
+      T.t1 = (unsigned)(((T.y0 - 1 - a.oy1) * a.W1 + (T.x0 - 1 - a.ox1)) * a.C1) * 4u;
+      // interior: every halo pixel inside source 0 and (if there is one) inside source 1 -- wave-uniform
+      T.interior = T.y0 >= 1 && T.y0 + PH + 1 <= a.H && T.x0 >= 1 && T.x0 + PW + 1 <= a.W &&
+                   (a.C1 == 0 || (T.y0 - 1 - a.oy1 >= 0 && T.y0 + PH - a.oy1 < a.H1 && T.x0 - 1 - a.ox1 >= 0 && T.x0 + PW - a.ox1 < a.W1));
+      T.ain = ain_full;
+      if (!T.interior) {
+        T.ain = 0;
+#pragma unroll
+        for (int it = 0; it < A_F4; ++it) {
+          const int pix = lt / SPP + it * PPI;
+          const int gy = T.y0 + pix / HPW - 1, gx = T.x0 + pix % HPW - 1;
+          const bool in = pix < HP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          const int y1 = gy - a.oy1, x1 = gx - a.ox1;
+          const bool in1 = in && y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1;
+          T.ain |= (in ? 1u : 0u) << it | (in1 ? 1u : 0u) << (16 + it);
+        }
+      }
+      return T;
+    };
+
+    if constexpr (!C1SRC) {
+      // a thread's staging slots map to fixed halo pixels (pix = lt / 8 + 32 it); their byte offsets relative to the tile's HALO ORIGIN do
+      // not depend on the tile (registers: the loader waves have room).  Raw buffer loads through a per-clip descriptor.  Edge tiles: halo
+      // rows above / below the image fall outside the clip and return zero by themselves, a slot left / right of the image (or in a padded
+      // column of the smaller source 1) is requested at an offset beyond the clip instead -- nothing is masked when it is split.
+      unsigned off0[A_F4], off1[A_F4];                               // relative to the tile's halo origin: never negative
+#pragma unroll
+      for (int it = 0; it < A_F4; ++it) {
+        const int pix = lt / SPP + it * PPI;
+        const int py = pix / HPW, px = pix % HPW;
+        off0[it] = (unsigned)((py * a.W + px) * a.C0 + 4 * aq) * 4u;
+        off1[it] = (unsigned)((py * a.W1 + px) * a.C1 + 4 * aq) * 4u;
+      }
+      const unsigned clip0 = (unsigned)a.H * (unsigned)a.W * (unsigned)a.C0 * 4u, clip1 = (unsigned)a.H1 * (unsigned)a.W1 * (unsigned)a.C1 * 4u;
+      f32x4 areg[2][A_F4];                                             // two staging sets: chunk k + 1 is split out of one while chunk k + 2 lands in the other
+      // what a chunk's loads need besides the per-slot offsets: the clip's buffer descriptor, the tile-origin + channel offset, which offset
+      // table (source 0 / 1) and where its inside flags sit -- wave-uniform, formed ONCE per turn
+      struct Src { __amdgpu_buffer_rsrc_t rs; unsigned toff; bool from0; int ainsh; };
+      auto make_src = [&](const Tile& T, int chunk) __attribute__((always_inline)) {
+        Src S;
+        const int c0 = chunk * KC;
+        S.from0 = c0 < a.C0;
+        const char* pb = reinterpret_cast<const char*>(S.from0 ? a.x0 : a.x1) + (size_t)T.b * (S.from0 ? clip0 : clip1);
+        S.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, (int)(S.from0 ? clip0 : clip1), 0x00020000);
+        S.toff = S.from0 ? T.t0 + (unsigned)c0 * 4u : T.t1 + (unsigned)(c0 - a.C0) * 4u;
+        S.ainsh = S.from0 ? 0 : 16;
+        return S;
+      };
+      // a slot outside the image (left / right of it, or a padded column of the smaller source 1) is requested at an offset beyond the
+      // clip: the buffer load returns zeros and the split needs no masking (rows above / below fall outside by themselves)
+      auto issue_slot = [&](const Src& S, unsigned ain, auto SET, auto IT) __attribute__((always_inline)) {
+        constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
+        unsigned o0 = off0[it], o1 = off1[it];
+        asm("" : "+v"(o0), "+v"(o1));                                  // two VALUES, then a select (as `from0 ? off0[it] : off1[it]` hipcc indexed a selected
+                                                                       // array base: both arrays went to scratch, a scratch load in front of every halo load)
+        const bool inside = (ain >> (S.ainsh + it)) & 1u;
+        const unsigned off = inside ? (S.from0 ? o0 : o1) + S.toff : 0xfffffff0u;
+        if (WS_FLAG(1)) return;
+        areg[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.rs, (int)off, 0, 0));
+      };
+      // interior tiles (no slot to zero): the table entry is the vector offset as it stands, the tile / channel offset rides in the
+      // instruction's scalar offset -- no vector instruction at all per request
+      auto issue_slot_interior = [&](const Src& S, auto FROM0, auto SET, auto IT) __attribute__((always_inline)) {
+        constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
+        if (WS_FLAG(1)) return;
+        areg[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.rs, (int)(decltype(FROM0)::value ? off0[it] : off1[it]), (int)S.toff, 0));
+      };
+      // one staging slot: bf16 hi / lo split, two 8-byte stores into the (hi, k-group) and (lo, k-group) planes.  Per channel pair: one
+      // packed conversion, the two hi values back as floats by a shift and a mask, two subtractions, one packed conversion.
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      char* const wbase = smem + plane_off(0, aq >> 1) + (lt / SPP) * 16 + 8 * (aq & 1);
+      auto split_slot = [&](auto SET, auto IT, int stage_off) __attribute__((always_inline)) {
+        constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
+        if (WS_FLAG(1)) return;
+        const f32x4 v = areg[set][it];
+        unsigned hi[2], lo[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 x = {v[2 * h], v[2 * h + 1]};
+          hi[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+          const f32x2 r = {x[0] - __uint_as_float(hi[h] << 16), x[1] - __uint_as_float(hi[h] & 0xffff0000u)};
+          lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+        }
+        char* at = wbase + stage_off + it * PPI * 16;
+        *reinterpret_cast<uint2*>(at) = uint2{hi[0], hi[1]};
+        *reinterpret_cast<uint2*>(at + HLS) = uint2{lo[0], lo[1]};
+      };
+      static_assert(A_F4 == 11, "eleven staging slots per loader thread");
+      auto issue_all = [&](const Src& S, unsigned ain, bool interior, auto SET) __attribute__((always_inline)) {
+        if (interior) {
+          if (S.from0) {
+#define MFPA_WS_ISSUE(I) issue_slot_interior(S, std::true_type{}, SET, std::integral_constant<int, I>{});
+            MFPA_WS_ISSUE(0) MFPA_WS_ISSUE(1) MFPA_WS_ISSUE(2) MFPA_WS_ISSUE(3) MFPA_WS_ISSUE(4) MFPA_WS_ISSUE(5)
+            MFPA_WS_ISSUE(6) MFPA_WS_ISSUE(7) MFPA_WS_ISSUE(8) MFPA_WS_ISSUE(9) MFPA_WS_ISSUE(10)
+#undef MFPA_WS_ISSUE
+          } else {
+#define MFPA_WS_ISSUE(I) issue_slot_interior(S, std::false_type{}, SET, std::integral_constant<int, I>{});
+            MFPA_WS_ISSUE(0) MFPA_WS_ISSUE(1) MFPA_WS_ISSUE(2) MFPA_WS_ISSUE(3) MFPA_WS_ISSUE(4) MFPA_WS_ISSUE(5)
+            MFPA_WS_ISSUE(6) MFPA_WS_ISSUE(7) MFPA_WS_ISSUE(8) MFPA_WS_ISSUE(9) MFPA_WS_ISSUE(10)
+#undef MFPA_WS_ISSUE
+          }
+          return;
+        }
+#define MFPA_WS_ISSUE(I) issue_slot(S, ain, SET, std::integral_constant<int, I>{});
+        MFPA_WS_ISSUE(0) MFPA_WS_ISSUE(1) MFPA_WS_ISSUE(2) MFPA_WS_ISSUE(3) MFPA_WS_ISSUE(4) MFPA_WS_ISSUE(5)
+        MFPA_WS_ISSUE(6) MFPA_WS_ISSUE(7) MFPA_WS_ISSUE(8) MFPA_WS_ISSUE(9) MFPA_WS_ISSUE(10)
+#undef MFPA_WS_ISSUE
+      };
+      auto split_all = [&](auto SET, int stage_off) __attribute__((always_inline)) {
+#define MFPA_WS_SPLIT(I) split_slot(SET, std::integral_constant<int, I>{}, stage_off);
+        MFPA_WS_SPLIT(0) stamp(21); MFPA_WS_SPLIT(1) MFPA_WS_SPLIT(2) MFPA_WS_SPLIT(3) MFPA_WS_SPLIT(4) MFPA_WS_SPLIT(5)
+        MFPA_WS_SPLIT(6) MFPA_WS_SPLIT(7) MFPA_WS_SPLIT(8) MFPA_WS_SPLIT(9) MFPA_WS_SPLIT(10)
+#undef MFPA_WS_SPLIT
+      };
+      // the epilogue's memory work for tile `t` out of the LDS tile the compute waves filled (see the header): the 64-channel rows as
+      // 1 KB-per-wave coalesced stores (16 lanes = the 16 channel quads of a pixel, 4 pixels per wave instruction), then -- fused OutConv
+      // -- one pixel per loader thread: 64 channels x their weights + bias
+      auto duty = [&](int t) __attribute__((always_inline)) {
+        int bx = __builtin_amdgcn_readfirstlane(t);
+        const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+        const int ey0 = ty * PH, ex0 = tx * PW;
+        if (a.y != nullptr) {
+          char* yb = reinterpret_cast<char*>(a.y + (size_t)bx * a.H * a.W * a.Cout + n0);
+          const int q = lt & 15;
+          for (int pass = 0; pass < 16; pass += 4) {                  // four LDS reads in flight, then their four stores
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int m = (pass + u) * 16 + (lt >> 4);
+              v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + ((q ^ (m & 15)) << 4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int m = (pass + u) * 16 + (lt >> 4);
+              const int gy = ey0 + m / PW, gx = ex0 + m % PW;
+              if (gy < a.H && gx < a.W) *reinterpret_cast<f32x4*>(yb + (((unsigned)gy * (unsigned)a.W + (unsigned)gx) * (unsigned)a.Cout + 4u * (unsigned)q) * 4u) = v[u];
+            }
+          }
+        }
+        if (a.w1x1 != nullptr) {
+          const int m = lt;
+          float sum = 0.f;
+#pragma unroll 1
+          for (int q0 = 0; q0 < 16; q0 += 4) {                         // (four pieces at a time: the whole row at once cost the kernel its register budget)
+            f32x4 v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + (((q0 + u) ^ (m & 15)) << 4));
+              w[u] = *reinterpret_cast<const f32x4*>(epi + 128 + 4 * (q0 + u));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) sum = fmaf(v[u][k], w[u][k], sum);
+          }
+          const int gy = ey0 + m / PW, gx = ex0 + m % PW;
+          if (gy < a.H && gx < a.W) a.y1x1[((size_t)bx * a.H + gy) * a.W + gx] = sum + a.b1x1;
+        }
+      };
+
+      // the chunk sequence of this workgroup: (tile i, chunk c), c fastest.  Q = the next chunk to REQUEST.
+      int qi = 0, qc = 0;
+      Tile TQ = make_tile(tile_of((int)blockIdx.x, 0, G));
+      auto issue_next = [&](auto SET) __attribute__((always_inline)) {
+        const Src S = make_src(TQ, qc);
+        issue_all(S, TQ.ain, TQ.interior, SET);
+        if (++qc == nchunks) {
+          qc = 0; ++qi;
+          if (qi < owned) TQ = make_tile(tile_of((int)blockIdx.x, qi, G));
+        }
+      };
+      using SET0 = std::integral_constant<int, 0>;
+      using SET1 = std::integral_constant<int, 1>;
+      issue_next(SET0{});                                              // chunk 0 -> set 0
+      int par = 0;
+      const int total = owned * nchunks;                               // chunks this workgroup computes
+      const bool has_duty = a.y != nullptr || a.w1x1 != nullptr;
+      // iteration k = -1 (prologue: chunk 0 -> stage 0, then the barrier that starts the compute waves), then k = 0 .. total - 1: while
+      // the compute waves work on chunk k the loaders REQUEST chunk k + 2 into set k & 1 and then split chunk k + 1 out of the other set
+      // (requested one iteration ago: a whole chunk period in flight) into the stage the compute waves read next.  The output tile of
+      // tile i (last chunk k_i = (i + 1) nchunks - 1) is written by the compute waves between barriers k_i and k_i + 1, so it is read
+      // here in iteration k_i + 2 -- and once more after the last barrier for the last tile; the compute waves write the next one after
+      // barrier k_i + nchunks >= k_i + 2, which the loaders reach only when that iteration's work is done.
+      auto iteration = [&](int k, auto ISSUE_SET, auto SPLIT_SET) __attribute__((always_inline)) {
+        stamp(20);
+        if (k + 2 < total) issue_next(ISSUE_SET);
+        __builtin_amdgcn_sched_barrier(0);                             // the requests first: hipcc sank them below the split
+        if (k + 1 < total) split_all(SPLIT_SET, par * STAGE);
+        stamp(22);
+        if (has_duty && !WS_FLAG(4) && k >= nchunks + 1 && (k - 1) % nchunks == 0) duty(tile_of((int)blockIdx.x, (k - 1) / nchunks - 1, G));
+        stamp(24);
+        __syncthreads();                                               // k = -1: stage 0 is ready; k >= 0: the compute waves' barrier of chunk k
+        stamp(23);
+        par ^= 1;
+      };
+      for (int k = -1; k < total; k += 2) {
+        iteration(k, SET1{}, SET0{});                                  // odd k (and -1): chunk k + 2 is odd
+        if (k + 1 < total) iteration(k + 1, SET0{}, SET1{});
+      }
+      if (has_duty) {
+        // the last tile's read-out iteration k_i + 2 lies beyond the loop (every other tile's does not: nchunks >= 2)
+        __syncthreads();                                               // the compute waves' final barrier: the last tile's output is in LDS
+        duty(tile_of((int)blockIdx.x, owned - 1, G));
+      }
+    }
+    dump_stamps();
+    return;
+  }
+
+  // ===================================================================================================== COMPUTE waves
+#if MFPA_WS_COMPUTE_PRIO
+  __builtin_amdgcn_s_setprio(MFPA_WS_COMPUTE_PRIO);
+#endif
+  const int wm = wave & 1, wn = wave >> 1;                             // pixel half (rows 4 wm .. 4 wm + 3), channel half
+  const int p = lane & 15, g = lane >> 4;
+
+  bool primed = false;
+  bf16x8 wq[3][2][2];                                                  // weight fragments: ring of three sets, [slot][16-channel tile][hi, lo]
+  auto load_w = [&](int chunk, int tap, auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
+    if (WS_FLAG(16) && primed) return;                    // (timing variants: the ring keeps the prologue's weights)
+    const char* wb = reinterpret_cast<const char*>(a.w) + ((((size_t)tap * nchunks + chunk) * (size_t)(a.Cout / 16) + (size_t)(n0 / 16 + 2 * wn)) << 11) + lane * 16;
+    wq[slot][0][0] = *reinterpret_cast<const bf16x8*>(wb);
+    wq[slot][0][1] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+    wq[slot][1][0] = *reinterpret_cast<const bf16x8*>(wb + 2048);
+    wq[slot][1][1] = *reinterpret_cast<const bf16x8*>(wb + 3072);
+  };
+  struct XFrags { bf16x8 h[4], l[4]; };
+  XFrags fx0, fx1;
+  const int xbase = ((4 * wm) * HPW + p) * 16 + plane_off(0, g);      // the lane's row of pixel tile 0 in plane (hi, g) at tap (0, 0)
+  auto tile_disp = [](int pt) { return ((pt >> 1) * HPW + (pt & 1) * 16) * 16; };
+  auto read_x = [&](XFrags& f, const char* stage, int tap_off, int half) __attribute__((always_inline)) {
+    if (WS_FLAG(8)) return;                               // (timing variants: the fragments of the prologue's read stay in the registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* r = stage + xbase + tile_disp(4 * half + i) + tap_off;
+      f.l[i] = *reinterpret_cast<const bf16x8*>(r + HLS);
+      f.h[i] = *reinterpret_cast<const bf16x8*>(r);
+    }
+  };
+  floatx4 acc[2][PT];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half) __attribute__((always_inline)) {
+    // term-major (lo x hi, hi x lo, hi x hi -- conv_wd16_kernel's order: bit-identical sums): an accumulator is touched every eighth instruction
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][1], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.l[i], acc[ct][4 * half + i], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+  };
+  constexpr int N_R = 8, N_M = 24, N_W = 4;                            // fragment reads / MFMAs of one phase, weight loads of one tap
+  // One tap.  Phase A: MFMA(pixel tiles 0..3 of tap t) || read tiles 4..7 of tap t, request the weights of tap t + 2.  Phase B: MFMA(tiles
+  // 4..7) || read tiles 0..3 of tap t + 1.  The chunk's one barrier sits between the phases of tap 8: behind it the other stage is complete
+  // (the loaders arrived) and this one is read out (every compute wave's fragment reads of it have returned: lgkmcnt(0) in front of it).
+  int kpar = 0;                                                        // parity of the stage the current chunk is read from
+  auto tap_body = [&](auto TAP, int chunk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(TAP)::value;
+    constexpr int ntap = (tap + 1) % TAPS;
+    constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * 16, ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * 16;
+    const int chunk_n = chunk + 1 < nchunks ? chunk + 1 : 0;
+    const char* cur = smem + kpar * STAGE;
+    const char* nxt = (tap == TAPS - 1) ? smem + (kpar ^ 1) * STAGE : cur;
+    stamp(tap);
+    read_x(fx1, cur, tap_off, 1);
+    mfma_half(fx0, wq[tap % 3], 0);
+    load_w((tap + 2 >= TAPS) ? chunk_n : chunk, (tap + 2) % TAPS, std::integral_constant<int, (tap + 2) % 3>{});
+    pin_reads<N_M - 1, N_R>();
+    constexpr int used_a = pin_read_slots(N_M - 1, N_R);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, N_W, 0);
+    if constexpr (N_M - used_a - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - used_a - 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == TAPS - 1) {
+      stamp(9);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(10);
+    }
+    read_x(fx0, nxt, ntap_off, 0);
+    mfma_half(fx1, wq[tap % 3], 1);
+    pin_reads<N_M, N_R>();
+    if constexpr (N_M - pin_read_slots(N_M, N_R) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_R), 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  load_w(0, 0, std::integral_constant<int, 0>{});
+  load_w(0, 1, std::integral_constant<int, 1>{});
+  if (WS_FLAG(16)) { load_w(0, 2, std::integral_constant<int, 2>{}); primed = true; }
+  __syncthreads();                                                     // stage 0 holds chunk 0 of the first tile
+  if (WS_FLAG(8)) {                                       // timing variants: both fragment sets once
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fx0.h[i] = fx1.h[i] = *reinterpret_cast<const bf16x8*>(smem + xbase + tile_disp(i));
+      fx0.l[i] = fx1.l[i] = *reinterpret_cast<const bf16x8*>(smem + xbase + tile_disp(i) + HLS);
+    }
+  }
+  read_x(fx0, smem, 0, 0);
+  for (int ti = 0; ti < owned; ++ti) {
+    int bx = __builtin_amdgcn_readfirstlane(tile_of((int)blockIdx.x, ti, G));
+    const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+    const int eb = bx, ey0 = ty * PH, ex0 = tx * PW;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      tap_body(std::integral_constant<int, 0>{}, chunk);
+      tap_body(std::integral_constant<int, 1>{}, chunk);
+      tap_body(std::integral_constant<int, 2>{}, chunk);
+      tap_body(std::integral_constant<int, 3>{}, chunk);
+      tap_body(std::integral_constant<int, 4>{}, chunk);
+      tap_body(std::integral_constant<int, 5>{}, chunk);
+      tap_body(std::integral_constant<int, 6>{}, chunk);
+      tap_body(std::integral_constant<int, 7>{}, chunk);
+      tap_body(std::integral_constant<int, 8>{}, chunk);
+      kpar ^= 1;
+    }
+    stamp(11);
+#if MFPA_WS_EPI_PRIO
+    __builtin_amdgcn_s_setprio(MFPA_WS_EPI_PRIO);
+#endif
+    bool run_epi = true;
+    if (WS_FLAG(2)) {                                     // timing variants: no epilogue, but every accumulator stays live
+      float t = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) t += acc[ct][pt][0] + acc[ct][pt][1] + acc[ct][pt][2] + acc[ct][pt][3];
+      run_epi = t == 12345.678f;
+    }
+    if (run_epi) {
+    const float floor_ = a.relu ? 0.f : -__builtin_inff();
+    // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int chl = wn * 32 + ct * 16 + 4 * g;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(epi + chl);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(epi + 64 + chl);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[ct][pt][j] = fmaxf(fmaf(acc[ct][pt][j], sc[j], sh[j]), floor_);      // relu: floor 0 (NaN -> 0 like `v > 0 ? v : 0`), else -inf
+        }
+    }
+    if (a.y != nullptr || a.w1x1 != nullptr) {
+      // the tile goes to LDS as 16-byte pieces (pixel m, channel quad q) at m * 256 + ((q ^ (m & 15)) << 4): a wave instruction's 16 pixels
+      // of one quad hit 16 different 16-byte bank groups; the loaders store it (and form the fused OutConv) one barrier from now
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int m = wm * 128 + pt * 16 + p;                          // m & 15 == p
+        char* row = outbuf + m * 256;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int q = wn * 8 + ct * 4 + g;
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
+          *reinterpret_cast<f32x4*>(row + ((q ^ p) << 4)) = o;
+        }
+      }
+    }
+    if (a.y_pool != nullptr) {
+      // MaxPool2d(2) (floor): the window's two rows are two of the wave's pixel tiles, its two columns adjacent lanes (one DPP swap)
+      const int Ho = a.H / 2, Wo = a.W / 2;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          if ((pt >> 1) & 1) continue;                                 // odd patch rows are the windows' second rows
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = fmaxf(acc[ct][pt][j], acc[ct][pt + 2][j]);
+            const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+            v[j] = fmaxf(t, o);
+          }
+          const int py = (ey0 + 4 * wm + (pt >> 1)) / 2, px = (ex0 + (pt & 1) * 16 + p) / 2;
+          if (!(p & 1) && py < Ho && px < Wo)
+            *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)eb * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32 + ct * 16 + 4 * g) = v;
+        }
+    }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#if MFPA_WS_EPI_PRIO
+    __builtin_amdgcn_s_setprio(MFPA_WS_COMPUTE_PRIO);
+#endif
+    stamp(12);
+  }
+  if (a.y != nullptr || a.w1x1 != nullptr) __syncthreads();          // the last tile's output is in LDS: the loaders store it
+  dump_stamps();
+}
+
+}  // namespace
+
+bool conv_ws64_serves(const ConvArgs& a) {
+  const bool c1 = a.c1_x32 != nullptr || a.c1_spec64 != nullptr;
+  if (a.Cout % 64 != 0 || (a.w1x1 != nullptr && a.Cout != 64) || a.w_frag != 2 || a.plain || a.in16 || a.in_scale0 || a.drop_thresh) return false;
+  if (a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part || a.bz) return false;           // the training step's side outputs: conv_wd16_kernel<SIDE>
+  if (a.yH != a.H || a.yW != a.W || a.W <= 16 || a.H < 8) return false;
+  // (a slot outside the image is requested at byte offset 0xfffffff0: it must lie beyond a clip)
+  if (4ull * a.H * a.W * a.C0 >= 0xfffffff0ull || 4ull * a.H1 * a.W1 * a.C1 >= 0xfffffff0ull) return false;
+  if (c1) return false;                                                // (first layer in the loaders: not in this form yet)
+  return a.C0 % KC == 0 && a.C1 % KC == 0 && a.C0 + a.C1 >= 64;
+}
+
+int launch_conv_ws64(ConvArgs& a, hipStream_t s) {
+  if (!conv_ws64_serves(a)) return MFPA_EINVAL;
+  a.tiles_x = (a.W + PW - 1) / PW;
+  a.tiles_y = (a.H + PH - 1) / PH;
+  const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
+  if (ntiles > 0x7fffffffLL / 2) return MFPA_EINVAL;
+  const bool c1 = a.c1_x32 != nullptr || a.c1_spec64 != nullptr;
+  const size_t lds = 2 * (size_t)STAGE + 192 * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)(2 * C1R * C1W + 11 * 64 + 4) * sizeof(float) : 0);
+#ifdef MFPA_WS_STAMPS
+  a.dbg_lds_stamps = (int)lds;
+  const_cast<size_t&>(lds) += 2 * WS_MAX_STAMPS * sizeof(unsigned long long);
+#endif
+  const int cus = mfpa_current_device_cus();
+  const unsigned gy = (unsigned)(a.Cout / 64);
+  unsigned gx = (unsigned)(cus > 0 ? cus : 256) / gy;
+  if (gx < 1) gx = 1;
+  if ((long long)gx > ntiles) gx = (unsigned)ntiles;
+  hipLaunchKernelGGL((conv_ws64_kernel<false>), dim3(gx, gy), dim3(THREADS), lds, s, a);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+}  // namespace mfpa_unet
+
+#if defined(MFPA_EXPERIMENTS) || defined(MFPA_WS_STAMPS)
+extern "C" int mfpa_exp_ws_stamps(unsigned long long* buf) {      // experiments build only (not in include/mfpa.h)
+  return hipMemcpyToSymbol(HIP_SYMBOL(mfpa_unet::ws_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -411,7 +411,10 @@ class UNetTrainEngine:
         average out, far below the bound a worst-case analysis gives.
         Only the bf16 kernels (conv_wd16_kernel: precision 1 / 2) write partials -- their own operand rounding (2^-17 / 2^-9) is
         amplified by the same factor in z itself -- the fp32 engine (precision 0: the golden step, the autograd default) always takes the
-        float64 pass over z below."""
+        float64 pass over z below for these FORWARD statistics.  The BatchNorm-backward sums {sum g, sum g * xhat} that ride in
+        other passes at every precision (mfpa_maxpool2_bwd_add_sums, mfpa_outconv_bwd_sums) accumulate in float64 inside a workgroup
+        and hand float32 row totals to the float64 reduction (tests/test_gpu_train.py::
+        test_pool_backward_sums_match_the_float64_reduction_on_a_large_offset_channel)."""
         C = z.shape[-1]
         st = Stats(C, z.device)
         if self.sync_bn or part is not None:

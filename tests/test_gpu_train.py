@@ -222,6 +222,39 @@ def test_maxpool_backward_with_batchnorm_sums_equals_the_two_passes():
     assert lib().mfpa_maxpool2_bwd_add_sums(ptr(z), 1, 4, 4, 48, ptr(v), ptr(v), ptr(v), ptr(v), ptr(z), ptr(z), 0, 0, 1.0, ptr(z), stream()) != 0
 
 
+def test_pool_backward_sums_match_the_float64_reduction_on_a_large_offset_channel():
+    """The BatchNorm-backward sums of mfpa_maxpool2_bwd_add_sums when they CANCEL across workgroups: a gradient of +-100 whose sign
+    alternates with the pooled row, so that every workgroup's row total is large (~5e4) and the channel total ~1e-4 of sum |g| (a nearly
+    converged BatchNorm layer looks like this).  Reference: a float64 reduction in torch of the very dy the kernel wrote.  Inside a
+    workgroup the sums run in float64 (round 5: they were float32 running sums over a row's ~500 pixels); each row total is handed
+    to the float64 reduction as ONE float32 (the stats_part layout), so the bound is float32's rounding of a row total relative to
+    sum |g|, averaged over the rows -- a few 1e-9; a float32 running sum measured ~3x that."""
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 2, 257, 251, 64
+    z = (torch.randn(B, H, W, C, generator=g) + 4.0).cuda()              # every pixel active (scale 1, shift 0): g = dy
+    scale = torch.ones(C).cuda(); shift = torch.zeros(C).cuda()
+    mean = torch.full((C,), 4.0).cuda(); invstd = torch.ones(C).cuda()
+    dp = torch.zeros(B, H // 2, W // 2, C).cuda()
+    sign = torch.where((torch.arange(H) // 2) % 2 == 0, 1.0, -1.0).view(1, H, 1, 1)
+    dy0 = ((100.0 + torch.randn(B, H, W, C, generator=g) * 1e-2) * sign).cuda()
+    ws = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device="cuda")
+    part = torch.full((B * (H // 2), 2, C), float("nan"), dtype=torch.float32, device="cuda")
+    dy = dy0.clone()
+    check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dp), ptr(dy),
+                                           0, 0, 1.0, ptr(part), stream()), "mfpa_maxpool2_bwd_add_sums")
+    got = torch.empty(2 * C, dtype=torch.float64, device="cuda")
+    check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
+    d64 = (dy * (z * scale + shift > 0)).double().view(-1, C)            # g: the gradient where the ReLU is active (a few z + 4 are negative)
+    xhat = ((z - mean) * invstd).double().view(-1, C)                    # float32 xhat like the kernel, summed in float64
+    want = torch.stack([d64.sum(0), (d64 * xhat).sum(0)], dim=1)         # mfpa_conv_stats_reduce's layout: (C, 2) = per channel (sum g, sum g xhat)
+    mag = torch.stack([d64.abs().sum(0), (d64 * xhat).abs().sum(0)], dim=1)
+    assert float((want[:, 0].abs() / mag[:, 0]).max()) < 1e-2            # the case does cancel
+    err = float(((got.view(C, 2) - want).abs() / mag).max())
+    print(f"pool-backward sums vs float64: {err:.2e} of sum |g|")
+    assert err < 1.5e-8, err
+
+
 def test_rank1_outconv_backward_equals_the_materialised_path():
     """mfpa_outconv_bwd_sums + mfpa_bn_relu_bwd_finish_rank1 (dy = dpred x w never written) against mfpa_outconv_bwd + mfpa_bn_relu_bwd on the
     written dy: the same OutConv gradients, the same dz (float32 to 1e-6 of its scale, and its bf16 copy), dgamma / dbeta to 1e-6."""
@@ -372,6 +405,40 @@ def test_reference_training_lines_run_unchanged_and_reproduce_the_golden_step(go
     g1 = model.outc.conv.weight.grad.clone()
     criterion(model(x), clean).backward()
     assert torch.allclose(model.outc.conv.weight.grad, 2 * g1, rtol=1e-3, atol=1e-7)
+    # ... with two DIFFERENT batches and on every parameter class: BatchNorm weight / bias, the transposed convolutions' bias and the
+    # OutConv are views into the engine's flat gradient buffer inside named_grads() -- handed to autograd un-cloned, param.grad
+    # aliased that buffer and the second backward read 2 * g2 instead of g1 + g2 (round-4 review).  Eval-mode BatchNorm is not
+    # involved: both passes are train-mode forwards of the same weights.
+    watch = ["inc.double_conv.1.weight", "down2.maxpool_conv.1.double_conv.4.bias", "up3.up.bias", "up1.conv.double_conv.0.weight",
+             "outc.conv.weight", "outc.conv.bias"]
+    params = dict(model.named_parameters())
+    x2 = torch.flip(x, dims=[0]) * 0.7 + 0.05
+    clean2 = torch.flip(clean, dims=[0])
+
+    def one_grad(xx, cc):
+        optimizer.zero_grad()                                          # set_to_none=True: .grad is created by the backward
+        criterion(model(xx), cc).backward()
+        return {k: params[k].grad.clone() for k in watch}
+
+    ga, gb = one_grad(x, clean), one_grad(x2, clean2)
+    assert float((ga["outc.conv.weight"] - gb["outc.conv.weight"]).abs().max()) > 0      # the two batches do differ
+    optimizer.zero_grad()
+    criterion(model(x), clean).backward()
+    criterion(model(x2), clean2).backward()
+    for k in watch:
+        tol = 2e-3 * float(ga[k].abs().max() + gb[k].abs().max()) + 1e-9
+        assert float((params[k].grad - (ga[k] + gb[k])).abs().max()) <= tol, k
+    # the gradients held after backward 1 were not rewritten behind autograd's back by the engine's second pass
+    eng_flat = model.train_engine().flat_g
+    lo, hi = eng_flat.data_ptr(), eng_flat.data_ptr() + eng_flat.numel() * eng_flat.element_size()
+    for k in watch:
+        assert not (lo <= params[k].grad.data_ptr() < hi), f"{k}.grad aliases the engine's gradient buffer"
+    # zero_grad(set_to_none=False) then ONE backward gives g, not 2 g
+    optimizer.zero_grad(set_to_none=False)
+    criterion(model(x2), clean2).backward()
+    for k in watch:
+        tol = 2e-3 * float(gb[k].abs().max()) + 1e-9
+        assert float((params[k].grad - gb[k]).abs().max()) <= tol, k
     # two forwards, then backward of the first: refused loudly (the engine keeps one forward's activations)
     p1 = model(x); model(x)
     with pytest.raises(RuntimeError):

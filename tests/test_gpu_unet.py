@@ -238,3 +238,51 @@ def test_weights_direct_kernels_against_the_lds_staged_kernel():
     # shapes the weights-direct kernels do not take keep the row image
     assert lib().mfpa_conv_weight_layout(257, 251, 32, 64, 0, 1) == 0 and lib().mfpa_conv_weight_layout(128, 125, 32, 128, 0, 1) == 0
     assert lib().mfpa_conv_weight_layout(128, 125, 64, 128, 0, 0) == 0 and lib().mfpa_conv_weight_layout(128, 125, 64, 128, 1, 1) == 0
+
+
+def test_wave_specialised_64_channel_kernel_equals_conv_wd16_bit_for_bit():
+    """conv_ws64_kernel (csrc/unet_ws.hip, round 5: 4 compute waves of 128 px x 32 ch + 4 loader waves; serves the inference launches with
+    64 output channels) against conv_wd16_kernel<.., WMW = 4> (all eight waves do everything), which still serves the training step:
+    asking for the bf16 copy of the output (a training side output) keeps a launch on the older kernel.  Same products, same order of
+    the three bf16x3 terms, same 32-channel sums inside an instruction: IDENTICAL bits -- on ragged edges, one and two sources (the
+    decoder's zero-padded concat), two and four chunks, fewer tiles than CUs, a tile count that is not a multiple of the grid, with the
+    fused max-pool and the fused OutConv (stored and not stored)."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_unet as K, ops_train as T
+    from musicfpaugment_amd._lib import lib
+    g = torch.Generator().manual_seed(17)
+    if K.frag_layout() != 2:
+        pytest.skip("the library was built without the 16 x 16 x 32 weights-direct kernels")
+    for (B, H, W, C0, C1, pool, outc) in [(2, 9, 37, 64, 0, False, False), (2, 33, 31, 64, 64, False, False), (3, 40, 70, 64, 64, True, False),
+                                          (1, 257, 251, 64, 0, True, True), (5, 64, 62, 128, 0, True, False), (2, 16, 34, 128, 128, False, True),
+                                          (26, 257, 251, 64, 64, False, False), (26, 257, 251, 64, 0, False, True)]:
+        assert lib().mfpa_conv_weight_layout(H, W, C0 + C1, 64, 0, 1) == 2
+        x0 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x1 = torch.randn(B, H - 1, W - 1, C1, generator=g).cuda() if C1 else None
+        w = torch.randn(64, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))
+        sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+        wk = K.pack_conv3x3(w).cuda()
+        w3, wf = K.split_bf16x3(wk), (2, K.split_bf16x3_frag(wk, 2))
+        o1 = (torch.randn(64, generator=g).cuda(), 0.25) if outc else None
+        got, got_p, got_1 = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1, wf=wf)
+        yb = []
+        ref = T.conv_mfma(x0, wf[1], 64, x1=x1, out_scale=sc, out_shift=sh, relu=True, precision=1, packed=True, w_layout=2, y_bf16_out=yb)
+        assert len(yb) == 1                                  # the side output was written: conv_wd16_kernel<SIDE> ran
+        assert torch.equal(got, ref), (B, H, W, C0, C1)
+        assert torch.equal(yb[0], ref.to(torch.bfloat16))
+        if pool:
+            assert torch.equal(got_p, F.max_pool2d(got.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+        if outc:
+            want = (got.double() * o1[0].double()).sum(-1) + o1[1]
+            assert float((got_1.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+            _, _, only = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, out1x1=o1, store=False, wf=wf)      # up4's form: no 64-channel store
+            assert torch.equal(only, got_1)
+        again, _, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1, wf=wf)
+        assert torch.equal(again, got)                       # run to run
+        if B <= 3:
+            xin = x0.permute(0, 3, 1, 2).cpu()
+            if C1:
+                xin = torch.cat([xin, F.pad(x1.permute(0, 3, 1, 2).cpu(), [0, 1, 0, 1])], dim=1)
+            want = F.relu(F.conv2d(xin, w, padding=1) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
+            from oracle.unet import relative_l1
+            assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-4

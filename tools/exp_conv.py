@@ -72,7 +72,11 @@ if args.both:
         else:
             d = a
         tl += a; td += d
-        print(f"{name:28s} lds {a*1e6:8.1f} us {fl/a/1e12:6.1f} TF/s | direct {d*1e6:8.1f} us {fl/d/1e12:6.1f} TF/s  ({(a/d-1)*100:+.1f} %)", flush=True)
+        ya = K.conv3x3_fused(x, w3, sc, sh, precision=1)[0]
+        yd = K.conv3x3_fused(x, w3, sc, sh, precision=1, wf=wf)[0] if d is not a else ya
+        diff = float((ya - yd).abs().max() / ya.abs().max())
+        print(f"{name:28s} lds {a*1e6:8.1f} us {fl/a/1e12:6.1f} TF/s | direct {d*1e6:8.1f} us {fl/d/1e12:6.1f} TF/s  ({(a/d-1)*100:+.1f} %)  max diff {diff:.1e}", flush=True)
+        del ya, yd
     print(f"sum lds {tl*1e3:.3f} ms direct {td*1e3:.3f} ms")
     sys.exit(0)
 
