@@ -578,30 +578,31 @@ def bench_train(args, rank, world, dev, dist):
             "value": round(world * B * args.steps / dt_max, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": (f"bf16x3 forward and input-gradient convolutions (fp32 operands split into bf16 hi+lo, fp32 accumulate), "
-                      f"{args.wgrad} weight gradients, fp32/fp64 reductions and Adam") if args.precision == "bf16x3"
-                     else (f"bf16 (plain bf16 products, fp32 accumulate: one MFMA per product in the 3x3 forward / input-gradient convolutions and "
-                           f"the {args.wgrad} weight gradients; the four transposed convolutions bf16x3; fp32 activations in HBM, fp32/fp64 reductions and Adam)")
+            "dtype": (f"bf16x3 forward / input-gradient convolutions, {args.wgrad} weight gradients, fp32-fp64 reductions and Adam") if args.precision == "bf16x3"
+                     else (f"bf16 (plain bf16 products, fp32 accumulate; transposed convolutions bf16x3; {args.wgrad} weight gradients; fp32-fp64 reductions and Adam)")
                      if args.precision == "bf16" else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), {args.seconds:g} s clips 257x{1 + nsamp // 256}, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
                        "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "loss_last": float(loss),
                        "allreduce_calls_per_step": ar_calls, "allreduce_bytes_per_step": ar_bytes,
                        "allreduce_exposed_wait_ms_per_step": ar_wait_ms,
-                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
-                                      + ("synchronised (global-batch)" if eng.sync_bn else "per-GPU")
-                                      + " BatchNorm statistics, global-batch spectrogram max (scalar MAX all-reduce)"},
+                       "parallelism": f"dp{world}: bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
+                                      + ("sync" if eng.sync_bn else "per-GPU") + " BatchNorm statistics, scalar MAX all-reduce of the spectrogram maxima"},
             "roofline": ({"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           # forward + input gradients (2/3 of the FLOPs) issue 3 bf16 MFMAs per product, the weight gradients 3 or 1
                           "mfma_flops_issued_per_algorithmic_flop": round(issue_x, 3),
                           "mfma_issue_frac": round(issue_x * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                          "kernel": f"conv_wd16_kernel / conv_mfma_kernel<PREC 1> + wgrad_bf16_kernel / wgrad_bf16x3_kernel ({args.wgrad} products)", "launches": timer.launches(),
-                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)} if args.precision in ("bf16x3", "bf16") else
+                          "kernel": f"conv_wd16_kernel / conv_mfma_kernel<PREC 1> + wgrad_{args.wgrad}_kernel", "launches": timer.launches(),
+                          "kernel_ms_per_step": round(conv_ms / args.steps, 3),
+                          # the same algorithmic FLOPs over the WHOLE step (BatchNorm / pooling / loss / Adam / AugmentFP launches included)
+                          "frac_whole_step": round(mfma_gflop * 1e9 * B * args.steps / dt_max / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+                         if args.precision in ("bf16x3", "bf16") else
                          {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                           "kernel": "conv_mfma_kernel<PREC 0> + wgrad_mfma_kernel", "launches": timer.launches(),
-                          "kernel_ms_per_step": round(conv_ms / args.steps, 3)})})
+                          "kernel_ms_per_step": round(conv_ms / args.steps, 3),
+                          "frac_whole_step": round(mfma_gflop * 1e9 * B * args.steps / dt_max / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)})})
     return result
 
 
@@ -721,7 +722,10 @@ def bench_infer(args, rank, world, dev, dist):
                                "STFT(512/256,f64) -> per-clip normalise -> log/mean/high-pass -> Audfprint forward+backward "
                                "prune (BASELINE configs[1]); 8 s / 8 kHz clips",
                    "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "peaks_last_step_rank0": total_peaks,
-                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
+                   "parallelism": f"clip-sharded x{world}, no data-path collective",
+                   **({"why_256": "BASELINE configs[1]'s batch; the UNet runs in passes of <= 128 clips, so clips/s is the same at configs[2]'s 512 "
+                                  "(configs.config3_unet_forward_fp32_512 is that batch at the reference's fp32 arithmetic)"}
+                      if net is not None and B == 256 and not getattr(args, "sub_config", False) else {})},
     }
 
     def roofline(tm, precision):
@@ -731,7 +735,7 @@ def bench_infer(args, rank, world, dev, dist):
         if precision == "fp32":
             return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (3x3 / transposed 2x2 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                    "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (v_mfma_f32_32x32x2_f32)",
                     "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
         traffic, tsrc = None, None
         pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_BF16X3)
@@ -743,9 +747,7 @@ def bench_infer(args, rank, world, dev, dist):
                 "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                 "mfma_flops_issued_per_algorithmic_flop": 3,
                 "mfma_issue_frac": round(3 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                "kernel": "conv_wd16_kernel (weights-direct, v_mfma_f32_16x16x32_bf16: the >= 128-channel layers) + conv_mfma_kernel<PREC 1> "
-                          "(plain loop, v_mfma_f32_32x32x16_bf16: the 64-channel layers) + convT_mfma_kernel<PREC 1>: 3x3 / transposed 2x2 "
-                          "implicit GEMM, 3 bf16 MFMAs per fp32 product",
+                "kernel": "conv_wd16_kernel + conv_ws64_kernel + conv_mfma_kernel<PREC 1> + convT_mfma_kernel<PREC 1> (DESIGN.md 3.1)",
                 "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
 
     if net is not None and timer.launches():
@@ -817,7 +819,10 @@ def bench_launch_check(args, rank, world, dist):
         # the shape of the N > 1 headline line: the nested train-step entries (dist_configs) with their keys, values unmeasured
         skel = {k: None for k in TRAIN_LINE_KEYS}
         skel.update(ranks_seen=rep["ranks_seen"], per_rank_value=rep["per_rank_value"])
-        out["configs"] = {"config4_unet_train_step": dict(skel, scaling="weak"), "config4_unet_train_step_strong": dict(skel, scaling="strong")}
+        out["configs"] = {}
+        for name, kw, per_rank, skipped in dist_plan(args, world):       # the very plan dist_configs runs on GPUs
+            out["configs"][name] = {"skipped": skipped} if skipped else dict(skel, scaling=kw["scaling"], clips_per_gpu_per_step=per_rank,
+                                                                            clips_per_step_all_gpus=per_rank * world)
     return out
 
 
@@ -847,6 +852,9 @@ def other_configs(args, dev):
         ("config4_unet_train_step", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True, precision="bf16", wgrad="bf16")),
         ("config4_unet_train_step_bf16x3", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=True, precision="bf16x3", wgrad="bf16")),
         ("config4_unet_train_step_bf16x3_premixed", bench_train, dict(mode="train", steps=10, warmup=3, clips=64, seconds=8.0, augment=False, precision="bf16x3", wgrad="bf16")),
+        # the origin of the STRONG-scaling curve the N > 1 lines carry (dist_configs): the same entry name, global batch --dist-strong-global on one GPU
+        ("config4_unet_train_step_strong", bench_train, dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_strong_global,
+                                                             seconds=args.dist_train_seconds, augment=True, scaling="strong", precision="bf16", wgrad="bf16")),
         ("config5_demucs_forward", bench_demucs, dict(mode="demucs", steps=20, warmup=5, clips=256)),
         # config 5, second half: the end-to-end 10k-query peak-metrics experiment (testing/audfprint_exps.py:86-215) with the Demucs
         # denoiser, and the same experiment with the UNet denoiser on 2 000 queries; `result` holds the experiment's means
@@ -862,6 +870,9 @@ def other_configs(args, dev):
         if isinstance(r, dict):
             for k in ("higher_is_better", "vs_baseline", "data", "n_gpus"):
                 r.pop(k, None)
+            if name == "config4_unet_train_step_strong" and "config" in r:       # the keys the N > 1 entry of this name carries at its top level
+                for k in ("allreduce_calls_per_step", "allreduce_bytes_per_step", "allreduce_exposed_wait_ms_per_step", "clips_per_gpu_per_step", "clips_per_step_all_gpus"):
+                    r[k] = r["config"].get(k)
             r["wall_s_including_setup"] = round(time.perf_counter() - t0, 2)
         out[name] = r
         gc.collect()
@@ -876,34 +887,51 @@ TRAIN_LINE_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", 
 MAX_TRAIN_CLIPS_PER_PASS = 128     # largest per-GPU batch of the train engine that is exercised (tests/test_gpu_train.py)
 
 
-def dist_configs(args, rank, world, dev, dist):
-    """N > 1: the one collective of the path -- the RCCL all-reduce of the UNet's 31.0 M gradients (BASELINE config 4) -- rides in the
-    SAME line as the collective-free inference headline, so that one driver command per N yields the 1/2/4/8 curve of both: the
-    train step weak-scaled (--dist-train-clips per GPU, default 64) and strong-scaled (global --dist-strong-global, default 512,
-    split over the ranks).  Every rank runs this; rank 0 returns the entries, each carrying `ranks_seen`, `per_rank_value`,
-    `allreduce_bytes_per_step`, `allreduce_exposed_wait_ms_per_step` at its top level."""
-    import gc
-    out = {}
+def dist_plan(args, world):
+    """The nested train-step entries of an N-rank inference line: [(name, bench_train keyword arguments, clips per GPU, reason if skipped)].
+    Pure host logic (tests/test_dist_gloo.py checks that the defaults skip nothing at N = 1, 2, 4, 8)."""
     plan = [("config4_unet_train_step", dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_train_clips,
                                              seconds=args.dist_train_seconds, augment=True, scaling="weak", precision="bf16", wgrad="bf16")),
             ("config4_unet_train_step_strong", dict(mode="train", steps=args.dist_train_steps, warmup=2, clips=args.dist_strong_global,
                                                     seconds=args.dist_train_seconds, augment=True, scaling="strong", precision="bf16", wgrad="bf16"))]
+    out = []
     for name, kw in plan:
         per_rank = kw["clips"] if kw["scaling"] == "weak" else kw["clips"] // world
+        skipped = None
         if per_rank > MAX_TRAIN_CLIPS_PER_PASS or per_rank < 1:
-            r = {"skipped": f"{per_rank} clips per GPU at N = {world}: outside the train engine's exercised per-pass batch (1..{MAX_TRAIN_CLIPS_PER_PASS})"} if rank == 0 else None
+            skipped = f"{per_rank} clips per GPU at N = {world}: outside the train engine's exercised per-pass batch (1..{MAX_TRAIN_CLIPS_PER_PASS})"
+        elif kw["scaling"] == "strong" and kw["clips"] % world:
+            skipped = f"global batch {kw['clips']} does not divide over {world} ranks"
+        out.append((name, kw, per_rank, skipped))        # (bench_train divides a strong entry's global batch by the world size itself)
+    return out
+
+
+def dist_configs(args, rank, world, dev, dist):
+    """N > 1: the one collective of the path -- the RCCL all-reduce of the UNet's 31.0 M gradients (BASELINE config 4) -- rides in the
+    SAME line as the collective-free inference headline, so that one driver command per N yields the 1/2/4/8 curve of both: the
+    train step weak-scaled (--dist-train-clips per GPU, default 64) and strong-scaled (global --dist-strong-global, default 128 = the
+    reference's BATCH_SIZE, split over the ranks: 64 / 32 / 16 clips per GPU at N = 2 / 4 / 8; the N = 1 line carries the same entry at
+    128 clips, so the curve has its origin).  Every rank runs this; rank 0 returns the entries, each carrying `ranks_seen`, `per_rank_value`,
+    `allreduce_bytes_per_step`, `allreduce_exposed_wait_ms_per_step` at its top level."""
+    import gc
+    out = {}
+    for name, kw, per_rank, skipped in dist_plan(args, world):
+        if skipped:
+            r = {"skipped": skipped} if rank == 0 else None
         else:
             t0 = time.perf_counter()
             err = None
             try:
                 r = bench_train(_sub_args(args, **kw), rank, world, dev, dist)
-            except Exception as e:                                   # never take the headline down; every rank reports its own failure
+            except Exception as e:                                   # every rank reports its own failure
                 r, err = None, f"{type(e).__name__}: {e}"
-            flag = torch.tensor([1.0 if err else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            # NO collective after a local failure: the other ranks may still be inside the step's gradient-bucket all-reduces, and a new
+            # collective of another size would pair up with those (hang or corrupt).  The status goes through the rendezvous store
+            # instead (host side, with a timeout); after the first failure nothing collective is issued any more (`broken`).
+            failed = _exchange_status(dist, name, rank, world, err)
             if rank == 0:
-                if flag.item() > 0 or r is None:
-                    r = {"error": err or f"{int(flag.item())} rank(s) failed"}
+                if failed or r is None:
+                    r = {"error": err or failed}
                 else:
                     for k in ("higher_is_better", "vs_baseline", "data", "n_gpus"):
                         r.pop(k, None)
@@ -916,7 +944,31 @@ def dist_configs(args, rank, world, dev, dist):
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        if isinstance(r, dict) and "error" in r or (rank != 0 and _STATUS.get("broken")):
+            break                                                    # (rank 0 learnt it from the store, the others from _exchange_status)
     return out if rank == 0 else None
+
+
+_STATUS = {}
+
+
+def _exchange_status(dist, name, rank, world, err, timeout_s=180.0):
+    """Host-side all-gather of 'this rank finished config `name` (with / without an error)' through the process group's store: no
+    device collective, bounded wait.  Returns None if every rank finished cleanly, else a description; marks the group `broken`."""
+    import datetime
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"mfpa/{name}/{rank}", err or "ok")
+        keys = [f"mfpa/{name}/{k}" for k in range(world)]
+        store.wait(keys, datetime.timedelta(seconds=timeout_s))
+        bad = {k: store.get(f"mfpa/{name}/{k}").decode() for k in range(world)}
+        bad = {k: v for k, v in bad.items() if v != "ok"}
+    except Exception as e:                                           # a rank never reported (stuck in a collective whose peer failed)
+        bad = {"store": f"{type(e).__name__}: {e}"}
+    if bad:
+        _STATUS["broken"] = True
+        return "; ".join(f"rank {k}: {v}" for k, v in bad.items())
+    return None
 
 
 def _self_launch(n: int, argv) -> int:
@@ -981,7 +1033,7 @@ def main():
     ap.add_argument("--no-weights-direct", action="store_true",
                     help="A/B runs: the UNet's 128-channel-tile layers on the LDS-staged weight tiles instead of the weights-direct kernel")
     ap.add_argument("--dist-train-clips", type=int, default=64, help="N > 1 infer line: clips per GPU of the nested weak-scaled train step")
-    ap.add_argument("--dist-strong-global", type=int, default=512, help="N > 1 infer line: global batch of the nested strong-scaled train step")
+    ap.add_argument("--dist-strong-global", type=int, default=128, help="global batch of the nested strong-scaled train step (the reference's BATCH_SIZE, training/parameters.py:18): 128 / 64 / 32 / 16 clips per GPU at N = 1 / 2 / 4 / 8; carried by the N = 1 line too (the curve's origin)")
     ap.add_argument("--dist-train-steps", type=int, default=8, help="N > 1 infer line: timed steps of each nested train-step entry")
     ap.add_argument("--dist-train-seconds", type=float, default=8.0, help="N > 1 infer line: clip length of the nested train step")
     ap.add_argument("--lib", default=None, help="experiments only: bind another build of the library (e.g. musicfpaugment_amd/libmfpa_exp.so)")
@@ -1043,10 +1095,12 @@ def main():
     if world > 1 or "WORLD_SIZE" in os.environ:                   # under torch.distributed.run even one rank goes through RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=600)               # a rank stuck in a collective whose peer failed is aborted after this, not after the default 10+ min
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)   # RCCL on ROCm
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     fn = {"train": bench_train, "demucs": bench_demucs, "demucs-train": bench_demucs_train, "metrics": bench_metrics,
           "infer": bench_infer}[args.mode]
@@ -1058,6 +1112,8 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
+        if rank == 0:      # the collective-free headline is on record (stderr) BEFORE any nested collective can hang or abort the job
+            print("[bench] headline before the nested train-step configs: " + json.dumps(_sanitised(result), allow_nan=False), file=sys.stderr, flush=True)
         nested = dist_configs(args, rank, world, dev, dist)        # every rank: the gradient all-reduce is a collective
     if rank == 0:
         result["dist_backend"] = ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None

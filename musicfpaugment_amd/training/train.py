@@ -87,6 +87,13 @@ class _pickling_as_reference_class:
         import types
         _PICKLE_LOCK.acquire()
         self.added_modules, self.added_attr = [], None
+        try:
+            return self._enter(sys, types)
+        except BaseException:
+            self.__exit__(None, None, None)          # undo the module additions and release the lock: __exit__ is not called when __enter__ raises
+            raise
+
+    def _enter(self, sys, types):
         mod = sys.modules.get("training.train")
         if mod is not None and hasattr(mod, "EarlyStopping"):
             cls = mod.EarlyStopping
@@ -124,8 +131,15 @@ class _pickling_as_reference_class:
 def _atomic_save(obj, path: str) -> None:
     """torch.save to `<path>.tmp`, then os.replace: a crash mid-write never leaves an unreadable resume file."""
     tmp = path + ".tmp"
-    torch.save(obj, tmp)
-    os.replace(tmp, path)
+    try:
+        torch.save(obj, tmp)
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            os.remove(tmp)                           # a failed write leaves no stray .tmp behind
+        except OSError:
+            pass
+        raise
 
 
 class ReduceLROnPlateau:

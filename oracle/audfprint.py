@@ -227,3 +227,32 @@ def find_peaks(d: np.ndarray):
     sgram = ostft.magnitude(d)
     sgram = sgram / np.max(sgram)
     return find_peaks_from_sgram(sgram)
+
+
+def mask_from_sgram_c(sgram: np.ndarray) -> np.ndarray:
+    """(256, T) uint8 peak mask of a C-contiguous spectrogram as find_peaks leaves the UNet branch (peak_extractor.py:265-311): a
+    picklable one-argument worker for process pools (tests compare whole batches of device masks with it)."""
+    return (np.asarray(find_peaks_from_sgram(np.ascontiguousarray(sgram), order="C")[1]) != 0).astype(np.uint8)
+
+
+def float32_log_variants(sgram32: np.ndarray):
+    """The two logarithms the denoised branch can see (peak_extractor.py:275 takes np.log of a FLOAT32 array after the UNet):
+    numpy's own float32 log (SIMD, not correctly rounded: differs from the correctly rounded value on a few per cent of the arguments,
+    by up to a few ulp, CPU-dependent) and the float64 log rounded once to float32 (what csrc/audfprint.hip computes).  Returns
+    (mask with numpy's log, mask with the rounded float64 log, number of log cells that differ, largest difference in float32 ulp)."""
+    assert sgram32.dtype == np.float32
+    smax = np.max(sgram32)
+    floored = np.maximum(sgram32, smax / 1e6)
+    if not smax > 0.0:
+        m = mask_from_sgram_c(sgram32)
+        return m, m, 0, 0.0
+    la = np.log(floored)                                              # float32 in, float32 out: numpy's SIMD kernel
+    lb = np.log(floored.astype(np.float64)).astype(np.float32)        # correctly rounded (glibc's double log is < 1 ulp of double)
+    ulp = np.abs(la.view(np.int32).astype(np.int64) - lb.view(np.int32).astype(np.int64))
+
+    def rest(lg):                                                     # log_mean_normalise's mean (bin-major order) and everything after it
+        flat = np.ascontiguousarray(lg).reshape(-1)
+        mean = lg.dtype.type(numpy_sum(flat) / lg.dtype.type(lg.size))
+        return (np.asarray(peaks_from_filtered(highpass(lg - mean)[:-1])) != 0).astype(np.uint8)
+    return rest(la), rest(lb), int(np.count_nonzero(ulp)), float(ulp.max())
+

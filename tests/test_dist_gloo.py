@@ -123,7 +123,19 @@ def test_bench_line_verifies_itself_with_eight_ranks():
     # 1/2/4/8 curve needs, in the same line as the inference headline (bench.dist_configs fills the values on GPUs)
     sys.path.insert(0, root)
     import bench
-    for name, scaling in (("config4_unet_train_step", "weak"), ("config4_unet_train_step_strong", "strong")):
+    for name, scaling, per_gpu in (("config4_unet_train_step", "weak", 64), ("config4_unet_train_step_strong", "strong", 16)):
         ent = out["configs"][name]
+        assert "skipped" not in ent, ent
         assert set(bench.TRAIN_LINE_KEYS) <= set(ent) and ent["scaling"] == scaling and ent["ranks_seen"] == 8
         assert len(ent["per_rank_value"]) == 8
+        assert ent["clips_per_gpu_per_step"] == per_gpu and ent["clips_per_step_all_gpus"] == 8 * per_gpu
+    # the default plan skips nothing at any N of the driver's curve: the strong entry is the reference's BATCH_SIZE 128
+    # (training/parameters.py:18) split 128 / 64 / 32 / 16, the weak one 64 clips per GPU; N = 1 carries the strong entry too
+    import argparse
+    dflt = argparse.Namespace(dist_train_steps=8, dist_train_clips=64, dist_strong_global=128, dist_train_seconds=8.0)
+    for n in (1, 2, 4, 8):
+        plan = bench.dist_plan(dflt, n)
+        assert [p[0] for p in plan] == ["config4_unet_train_step", "config4_unet_train_step_strong"]
+        assert all(p[3] is None for p in plan), (n, plan)
+        assert plan[1][2] == 128 // n and plan[0][2] == 64
+    assert bench.dist_plan(argparse.Namespace(dist_train_steps=8, dist_train_clips=64, dist_strong_global=512, dist_train_seconds=8.0), 2)[1][3] is not None

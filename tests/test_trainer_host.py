@@ -2,6 +2,8 @@
 torch's own semantics (training/train.py:582-612, :662-666)."""
 import math
 
+import os
+
 import pytest
 
 import torch
@@ -110,3 +112,31 @@ def test_checkpoints_are_replaced_atomically(tmp_path):
     with pytest.raises(RuntimeError):
         _atomic_save({"epoch": 2, "x": Boom()}, path)
     assert torch.load(path, weights_only=True)["epoch"] == 1
+    assert not os.path.exists(path + ".tmp")                             # ... and no stray temporary
+
+
+def test_pickling_context_releases_its_lock_when_enter_fails():
+    """__exit__ is not called when __enter__ raises: a foreign `training.train.EarlyStopping` whose __new__ fails must not leave the
+    module-level lock held (the next checkpoint save would deadlock) nor stub modules behind."""
+    import sys
+    import types
+    from musicfpaugment_amd.training import train as T
+
+    class Hostile:
+        def __new__(cls, *a, **k):
+            raise TypeError("not constructible")
+    pkg, mod = types.ModuleType("training"), types.ModuleType("training.train")
+    mod.EarlyStopping = Hostile
+    sys.modules["training"], sys.modules["training.train"] = pkg, mod
+    try:
+        with pytest.raises(TypeError):
+            with T._pickling_as_reference_class(EarlyStopping(3, 0.0)):
+                pass
+        assert T._PICKLE_LOCK.acquire(timeout=1.0)                       # released
+        T._PICKLE_LOCK.release()
+        assert sys.modules["training.train"] is mod and mod.EarlyStopping is Hostile
+    finally:
+        sys.modules.pop("training.train", None); sys.modules.pop("training", None)
+    with T._pickling_as_reference_class(EarlyStopping(3, 0.0)) as obj:   # and the context still works afterwards
+        assert type(obj).__name__ == "EarlyStopping"
+    assert "training.train" not in sys.modules
