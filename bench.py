@@ -870,6 +870,19 @@ def other_configs(args, dev):
         if isinstance(r, dict):
             for k in ("higher_is_better", "vs_baseline", "data", "n_gpus"):
                 r.pop(k, None)
+            if name == "config4_unet_train_step" and "error" not in r:
+                # does the benched arithmetic (plain bf16 products) train where fp32 does?  200 optimiser steps at 16 clips of 3 s, lr 1e-4,
+                # same weights / batches / dropout masks in both; outside every timed region (tests/test_gpu_train.py gates the same run at 2 %)
+                try:
+                    from musicfpaugment_amd.training.selfcheck import run_convergence
+                    cv = run_convergence({"fp32": (0, 0), "bf16": (2, 2)}, steps=200, B=16, lr=1e-4, verbose=False)
+                    r["fidelity_in_run"] = {"steps": 200, "clips": 16, "seconds": 3.0, "lr": 1e-4,
+                                            "train_loss_fp32": round(cv["fp32"][0], 6), "train_loss_bf16": round(cv["bf16"][0], 6),
+                                            "heldout_l1_fp32": round(cv["fp32"][1], 6), "heldout_l1_bf16": round(cv["bf16"][1], 6),
+                                            "train_loss_rel_dev": round(abs(cv["bf16"][0] - cv["fp32"][0]) / cv["fp32"][0], 5),
+                                            "heldout_l1_rel_dev": round(abs(cv["bf16"][1] - cv["fp32"][1]) / cv["fp32"][1], 5), "gate": 0.02}
+                except Exception as e:
+                    r["fidelity_in_run"] = {"error": f"{type(e).__name__}: {e}"}
             if name == "config4_unet_train_step_strong" and "config" in r:       # the keys the N > 1 entry of this name carries at its top level
                 for k in ("allreduce_calls_per_step", "allreduce_bytes_per_step", "allreduce_exposed_wait_ms_per_step", "clips_per_gpu_per_step", "clips_per_step_all_gpus"):
                     r[k] = r["config"].get(k)
