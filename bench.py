@@ -525,7 +525,9 @@ def bench_train(args, rank, world, dev, dist):
         irs, noises = synthetic_banks(rank)
         af = AugmentFP(None, 8000, ir_bank=irs, noise_bank=noises, device=dev)
 
-    def step():
+    def prepare():
+        """One batch of the input pipeline: AugmentFP chain -> the two spectrogram() calls of train.py:264-269 (STFT, global maximum,
+        normalised clean target)."""
         cm, cmax = ops.stft_mag(clean, torch.float64)
         a = af.batch_augment(clean[:, None, :])[:, 0] if af is not None else aug
         am, amax = ops.stft_mag(a, torch.float64)
@@ -534,7 +536,35 @@ def bench_train(args, rank, world, dev, dist):
             dist.all_reduce(gmax_c, op=dist.ReduceOp.MAX)
             dist.all_reduce(gmax_a, op=dist.ReduceOp.MAX)
         ops.normalize_(cm, gmax_c.expand(B).contiguous(), per_clip=True)
-        return eng.train_step(am, gmax_a.expand(B).contiguous(), cm)
+        return am, gmax_a.expand(B).contiguous(), cm
+
+    # The reference's loader prepares the NEXT batch (AugmentFP included, training/dataset.py:134-154, tf.data AUTOTUNE prefetch) while the
+    # model works on the current one.  Same here, on the device: batch k + 1 is prepared on a side stream under step k.  Every timed
+    # step still contains exactly one prepare() and one train_step() -- `--no-prefetch` runs them back to back on one stream (round 4's line).
+    prefetch = not getattr(args, "no_prefetch", False) and dist is None       # (with ranks the scalar MAX all-reduces stay on the step's stream)
+    main_stream = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev) if prefetch else None
+    pending = {}
+
+    def prepare_async():
+        side.wait_stream(main_stream)                     # (inputs are constant; orders the side stream behind what was queued so far)
+        with torch.cuda.stream(side):
+            batch = prepare()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t_ in batch:
+            t_.record_stream(main_stream)                 # allocated on the side stream, consumed on the main one
+        pending["b"] = (batch, ev)
+
+    def step():
+        if not prefetch:
+            return eng.train_step(*prepare())
+        if "b" not in pending:
+            prepare_async()
+        batch, ev = pending.pop("b")
+        main_stream.wait_event(ev)
+        prepare_async()                                   # batch k + 1, under step k
+        return eng.train_step(*batch)
 
     def barrier():
         if dist is not None:
@@ -582,7 +612,8 @@ def bench_train(args, rank, world, dev, dist):
                      else (f"bf16 (plain bf16 products, fp32 accumulate; transposed convolutions bf16x3; {args.wgrad} weight gradients; fp32-fp64 reductions and Adam)")
                      if args.precision == "bf16" else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), {args.seconds:g} s clips 257x{1 + nsamp // 256}, {args.precision} MFMA, "
-                                   + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips"),
+                                   + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips")
+                                   + (", next batch prepared on a side stream under the step" if prefetch else ""),
                        "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "loss_last": float(loss),
                        "allreduce_calls_per_step": ar_calls, "allreduce_bytes_per_step": ar_bytes,
                        "allreduce_exposed_wait_ms_per_step": ar_wait_ms,
@@ -1032,6 +1063,8 @@ def main():
                     help="train mode: arithmetic of the weight-gradient kernel (default: bf16 with --precision bf16x3 -- one bf16 MFMA "
                          "per product, the sum over all pixels averages the rounding: relative L1 2e-3 per layer -- else fp32)")
     ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: BatchNorm statistics over the global batch")
+    ap.add_argument("--no-prefetch", action="store_true", help="train mode: prepare each batch (AugmentFP + STFTs) on the step's own stream instead of "
+                    "one step ahead on a side stream")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="train mode: weak = --clips per GPU (default), strong = --clips is the GLOBAL batch, split over the ranks")
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
