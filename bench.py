@@ -1076,6 +1076,7 @@ def main():
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick; launch-check: launcher plumbing only (tests)")
+    ap.add_argument("--no-fold-scale", action="store_true", help="A/B runs: never hand conv_ws64_kernel scale-folded weights (ops_unet.FOLD_SCALE)")
     ap.add_argument("--no-weights-direct", action="store_true",
                     help="A/B runs: the UNet's 128-channel-tile layers on the LDS-staged weight tiles instead of the weights-direct kernel")
     ap.add_argument("--dist-train-clips", type=int, default=64, help="N > 1 infer line: clips per GPU of the nested weak-scaled train step")
@@ -1091,6 +1092,9 @@ def main():
     if args.no_weights_direct:
         from musicfpaugment_amd import ops_unet
         ops_unet.USE_WEIGHTS_DIRECT = False
+    if args.no_fold_scale:
+        from musicfpaugment_amd import ops_unet
+        ops_unet.FOLD_SCALE = False
     if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
         args.precision = "bf16x3"
     if args.precision == "bf16" and args.mode != "train":

@@ -283,6 +283,12 @@ typedef struct mfpa_conv_desc {
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 /* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */
 int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision);
+/* HOST function (round 5): 1 if the INFERENCE launch of this 3x3 shape (precision 1, w_layout 2, no on-load affine, no training side
+ * output) runs on conv_ws64_kernel, whose epilogue is cheapest when the output scale is already IN the weights: pass out_scale = NULL
+ * with weights pre-multiplied by the per-output-channel scale (then split / fragment-ordered as usual) and out_shift as before -- the shift
+ * becomes the accumulators' start value and the epilogue a bare ReLU.  The same call with out_scale given stays valid everywhere.
+ * Reference: the folded eval BatchNorm of DoubleConv, training/unet.py:16-21. */
+int mfpa_conv_scale_folds(int H, int W, int Cin, int Cout);
 /* HOST function: rows of mfpa_conv_desc.stats_part for this shape (0: its kernel does not write them). */
 int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout);
 /* stats_part (rows, 2, C) -> sums[2C] float64 as mfpa_bn_stats_sums produces them; workspace as for mfpa_bn_stats. */

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 
 class MfpaError(RuntimeError):
@@ -64,6 +64,7 @@ _SIGNATURES = {
     "mfpa_conv1x1_out": ([c_void_p, c_longlong, c_int, c_void_p, c_float, c_void_p, c_void_p], c_int),
     "mfpa_conv_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_conv_weight_layout": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int),
+    "mfpa_conv_scale_folds": ([c_int, c_int, c_int, c_int], c_int),
     "mfpa_gemm_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_lowpass_taps": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_fir": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -2487,6 +2487,14 @@ int mfpa_exp_conv_stamps(unsigned long long* buf) {       // experiments build o
 }
 #endif
 
+int mfpa_conv_scale_folds(int H, int W, int Cin, int Cout) {
+  if (H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;
+  if (conv_weight_layout(H, W, Cin, Cout, 0, 1) != 2 || Cout % 64 || Cin % KC || W <= 16 || H < 8) return 0;
+  // the dispatcher's own routing (dispatch_conv_p): 64-channel-multiple outputs that are not 128-multiples always, the others up to MFPA_CONV_WS_ALL input channels
+  if (Cout % 128) return MFPA_CONV_WS64 ? 1 : 0;
+  return (MFPA_CONV_WS_ALL > 0 && Cin <= MFPA_CONV_WS_ALL) ? 1 : 0;
+}
+
 int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int precision) {
   if (H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;
   return conv_weight_layout(H, W, Cin, Cout, mode, precision);

@@ -131,14 +131,15 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
   const int first_tile = tile_of((int)blockIdx.x, 0, G);
   const int owned = first_tile < ntiles ? (ntiles - first_tile + G - 1) / G : 0;
 
-  // LDS: [stage 0 | stage 1 | epilogue constants: scale 64, shift 64, w1x1 64 | the epilogue's output tile 64 KB | (experiments: stamps)]
+  // LDS: [stage 0 | stage 1 | epilogue constants: scale 64, shift 64, w1x1 64, accumulator start values 64 | the epilogue's output tile 64 KB | (stamps)]
   float* const epi = reinterpret_cast<float*>(smem + 2 * STAGE);
-  char* const outbuf = smem + 2 * STAGE + 192 * sizeof(float);
+  char* const outbuf = smem + 2 * STAGE + 256 * sizeof(float);
   float* const c1s = reinterpret_cast<float*>(outbuf + OUTBUF);
   for (int i = tid; i < 64; i += THREADS) {
     epi[i] = a.scale ? a.scale[n0 + i] : 1.f;
     epi[64 + i] = a.shift ? a.shift[n0 + i] : 0.f;
     epi[128 + i] = a.w1x1 ? a.w1x1[i] : 0.f;
+    epi[192 + i] = (a.scale == nullptr && a.shift != nullptr) ? a.shift[n0 + i] : 0.f;      // the accumulators' start values (see `initv`)
   }
   if constexpr (C1SRC) {
     float* cw = c1s + 2 * C1R * C1W;
@@ -429,17 +430,22 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
       f.h[i] = *reinterpret_cast<const bf16x8*>(r);
     }
   };
-  floatx4 acc[2][PT];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  floatx4 acc[2][PT];                                                  // per tile they start as the C operand of their first MFMA (see `initv`); the one
+#pragma unroll                                                         // initialisation here only gives the values a definition (left undefined, their
+  for (int ct = 0; ct < 2; ++ct)                                       // live ranges reached back to the kernel's entry and the prologue spilled)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
-  auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half) __attribute__((always_inline)) {
+  // accumulator start values: zero -- or, when the output scale is folded into the weights (a.scale == nullptr), the per-channel shift, so
+  // that the epilogue is a bare ReLU.  They enter as the C operand of an accumulator's FIRST MFMA of a tile (tap 0 of chunk 0 is its own
+  // code: FIRST), so no accumulator is ever initialised by vector moves.  (Filled behind the first barrier: `epi` is written above.)
+  floatx4 initv[2];
+  auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], int half, auto FIRST) __attribute__((always_inline)) {
     // term-major (lo x hi, hi x lo, hi x hi -- conv_wd16_kernel's order: bit-identical sums): an accumulator is touched every eighth instruction
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][1], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][1], f.h[i], decltype(FIRST)::value ? initv[ct] : acc[ct][4 * half + i], 0, 0, 0);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
   // 4..7) || read tiles 0..3 of tap t + 1.  The chunk's one barrier sits between the phases of tap 8: behind it the other stage is complete
   // (the loaders arrived) and this one is read out (every compute wave's fragment reads of it have returned: lgkmcnt(0) in front of it).
   int kpar = 0;                                                        // parity of the stage the current chunk is read from
-  auto tap_body = [&](auto TAP, int chunk) __attribute__((always_inline)) {
+  auto tap_body = [&](auto TAP, int chunk, auto FIRST) __attribute__((always_inline)) {
     constexpr int tap = decltype(TAP)::value;
     constexpr int ntap = (tap + 1) % TAPS;
     constexpr int tap_off = ((tap / 3) * HPW + (tap % 3)) * 16, ntap_off = ((ntap / 3) * HPW + (ntap % 3)) * 16;
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
     const char* nxt = (tap == TAPS - 1) ? smem + (kpar ^ 1) * STAGE : cur;
     stamp(tap);
     read_x(fx1, cur, tap_off, 1);
-    mfma_half(fx0, wq[tap % 3], 0);
+    mfma_half(fx0, wq[tap % 3], 0, FIRST);
     load_w((tap + 2 >= TAPS) ? chunk_n : chunk, (tap + 2) % TAPS, std::integral_constant<int, (tap + 2) % 3>{});
     pin_reads<N_M - 1, N_R>();
     constexpr int used_a = pin_read_slots(N_M - 1, N_R);
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
       stamp(10);
     }
     read_x(fx0, nxt, ntap_off, 0);
-    mfma_half(fx1, wq[tap % 3], 1);
+    mfma_half(fx1, wq[tap % 3], 1, FIRST);
     pin_reads<N_M, N_R>();
     if constexpr (N_M - pin_read_slots(N_M, N_R) > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - pin_read_slots(N_M, N_R), 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -501,18 +507,27 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty = bx % a.tiles_y; bx /= a.tiles_y;
     const int eb = bx, ey0 = ty * PH, ex0 = tx * PW;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      tap_body(std::integral_constant<int, 0>{}, chunk);
-      tap_body(std::integral_constant<int, 1>{}, chunk);
-      tap_body(std::integral_constant<int, 2>{}, chunk);
-      tap_body(std::integral_constant<int, 3>{}, chunk);
-      tap_body(std::integral_constant<int, 4>{}, chunk);
-      tap_body(std::integral_constant<int, 5>{}, chunk);
-      tap_body(std::integral_constant<int, 6>{}, chunk);
-      tap_body(std::integral_constant<int, 7>{}, chunk);
-      tap_body(std::integral_constant<int, 8>{}, chunk);
-      kpar ^= 1;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {                                   // (per tile, out of LDS: eight registers live for one tap instead of the whole kernel)
+      const f32x4 iv = *reinterpret_cast<const f32x4*>(epi + 192 + wn * 32 + ct * 16 + 4 * g);
+      initv[ct] = floatx4{iv[0], iv[1], iv[2], iv[3]};
     }
+    // chunk 0 is its own copy of the nine taps (its tap 0 starts the accumulators): inside ONE loop body the two forms of tap 0 were a
+    // branch diamond across which hipcc spilled 62 registers
+    auto chunk_body = [&](int chunk, auto FIRST) __attribute__((always_inline)) {
+      tap_body(std::integral_constant<int, 0>{}, chunk, FIRST);
+      tap_body(std::integral_constant<int, 1>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 2>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 3>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 4>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 5>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 6>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 7>{}, chunk, std::false_type{});
+      tap_body(std::integral_constant<int, 8>{}, chunk, std::false_type{});
+      kpar ^= 1;
+    };
+    chunk_body(0, std::true_type{});
+    for (int chunk = 1; chunk < nchunks; ++chunk) chunk_body(chunk, std::false_type{});
     stamp(11);
 #if MFPA_WS_EPI_PRIO
     __builtin_amdgcn_s_setprio(MFPA_WS_EPI_PRIO);
@@ -528,18 +543,27 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
     }
     if (run_epi) {
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
-    // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift), 16-byte stores
+    // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift) -- or relu(acc) when the scale is in
+    // the weights and the shift in the accumulators' start values
+    if (a.scale != nullptr) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int chl = wn * 32 + ct * 16 + 4 * g;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(epi + chl);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(epi + 64 + chl);
+      for (int ct = 0; ct < 2; ++ct) {
+        const int chl = wn * 32 + ct * 16 + 4 * g;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(epi + chl);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(epi + 64 + chl);
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[ct][pt][j] = fmaxf(fmaf(acc[ct][pt][j], sc[j], sh[j]), floor_);      // relu: floor 0 (NaN -> 0 like `v > 0 ? v : 0`), else -inf
-        }
+          for (int j = 0; j < 4; ++j)
+            acc[ct][pt][j] = fmaxf(fmaf(acc[ct][pt][j], sc[j], sh[j]), floor_);      // relu: floor 0 (NaN -> 0 like `v > 0 ? v : 0`), else -inf
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ct][pt][j] = fmaxf(acc[ct][pt][j], floor_);
     }
     if (a.y != nullptr || a.w1x1 != nullptr) {
       // the tile goes to LDS as 16-byte pieces (pixel m, channel quad q) at m * 256 + ((q ^ (m & 15)) << 4): a wave instruction's 16 pixels
@@ -579,10 +603,6 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         }
     }
     }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #if MFPA_WS_EPI_PRIO
     __builtin_amdgcn_s_setprio(MFPA_WS_COMPUTE_PRIO);
 #endif
@@ -612,7 +632,7 @@ int launch_conv_ws64(ConvArgs& a, hipStream_t s) {
   const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
   if (ntiles > 0x7fffffffLL / 2) return MFPA_EINVAL;
   const bool c1 = a.c1_x32 != nullptr || a.c1_spec64 != nullptr;
-  const size_t lds = 2 * (size_t)STAGE + 192 * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)(2 * C1R * C1W + 11 * 64 + 4) * sizeof(float) : 0);
+  const size_t lds = 2 * (size_t)STAGE + 256 * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)(2 * C1R * C1W + 11 * 64 + 4) * sizeof(float) : 0);
 #ifdef MFPA_WS_STAMPS
   a.dbg_lds_stamps = (int)lds;
   const_cast<size_t&>(lds) += 2 * WS_MAX_STAMPS * sizeof(unsigned long long);

@@ -116,6 +116,10 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[s
             pw[k + "3"] = split_bf16x3(pw[k])
             if lay and pw[k].shape[0] == 9 and pw[k].shape[1] % 64 == 0 and pw[k].shape[2] >= 64:
                 pw[k + "f"] = (lay, split_bf16x3_frag(pw[k], lay))
+                # the same image with the folded BatchNorm scale already IN the weights (w * scale[co], then split): where
+                # mfpa_conv_scale_folds says so the launch passes it with out_scale = None and the kernel's epilogue is a bare ReLU
+                if lay == 2 and k.endswith(".w"):
+                    pw[k + "ff"] = (lay, split_bf16x3_frag(pw[k] * pw[k[:-2] + ".scale"][None, :, None], lay))
     return pw
 
 
@@ -179,16 +183,18 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
 
 
 USE_WEIGHTS_DIRECT = True     # False: always the row image / LDS-staged weight tiles (A/B runs)
+FOLD_SCALE = True             # False: never pass scale-folded weights (A/B runs)
 
 
-def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None, wf=None):
+def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None, wf=None, wff=None):
     """3x3 conv + folded BN + ReLU through mfpa_conv_mfma with optional fused epilogues: `pool` also writes
     MaxPool2d(2) of the output, `out1x1 = (w (64,), bias)` also writes the OutConv result (B,H,W); `store=False`
     skips the full-resolution output.  `w` must already be in the layout of `precision` (pre-split for bf16x3).
     `c1 = dict(x32= | spec64=, denom=, w, scale, shift)` (x0 None): the 64 input channels are the UNet's first layer, computed
     from the 1-channel input while the tile is staged (mfpa_conv_desc.c1_*).
     `wf` = (layout, image): a fragment-ordered image of the same weights (split_bf16x3_frag); used instead of `w` where
-    mfpa_conv_weight_layout says the "weights direct" kernel reading that layout serves this shape.
+    mfpa_conv_weight_layout says the "weights direct" kernel reading that layout serves this shape.  `wff`: the same with `scale`
+    folded into the weights, used (with out_scale = None) where mfpa_conv_scale_folds says the serving kernel prefers it.
     Returns (y | None, y_pool | None, y1x1 | None)."""
     if c1 is not None:
         src = c1.get("x32") if c1.get("x32") is not None else c1["spec64"]
@@ -202,6 +208,8 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None and (out1x1 is None or (wf[0] == 2 and Cout == 64))
             and lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == wf[0]):
         layout, w = wf
+        if wff is not None and wff[0] == layout and FOLD_SCALE and lib().mfpa_conv_scale_folds(H, W, C0 + C1, Cout) == 1:
+            w, scale = wff[1], None
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev) if store else None
     yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=dev) if pool else None
     y1 = torch.empty((B, H, W), dtype=torch.float32, device=dev) if out1x1 is not None else None
@@ -271,7 +279,8 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
 
     def c(x, prefix, idx, **kw):
         return conv3x3_fused(x, pw[f"{prefix}.{idx}.w{sfx}"], pw[f"{prefix}.{idx}.scale"], pw[f"{prefix}.{idx}.shift"],
-                             precision=prec, wf=pw.get(f"{prefix}.{idx}.wf") if prec == 1 else None, **kw)
+                             precision=prec, wf=pw.get(f"{prefix}.{idx}.wf") if prec == 1 else None,
+                             wff=pw.get(f"{prefix}.{idx}.wff") if prec == 1 else None, **kw)
 
     p = ENC[0]
     skips = []

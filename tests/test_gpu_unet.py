@@ -279,6 +279,18 @@ def test_wave_specialised_64_channel_kernel_equals_conv_wd16_bit_for_bit():
             assert torch.equal(only, got_1)
         again, _, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1, wf=wf)
         assert torch.equal(again, got)                       # run to run
+        # the scale-folded form the UNet's eval chain uses (mfpa_conv_scale_folds): the scale in the weights (w * scale, then split), the
+        # shift as the accumulators' start value, a bare ReLU in the epilogue -- the same numbers to bf16x3's own rounding
+        assert lib().mfpa_conv_scale_folds(H, W, C0 + C1, 64) == 1
+        wff = (2, K.split_bf16x3_frag(wk * sc[None, :, None], 2))
+        fold, fold_p, fold_1 = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1, wf=wf, wff=wff)
+        scale_ = float(got.abs().max())
+        assert float((fold - got).abs().max()) <= 2e-5 * scale_ and float((fold - got).abs().mean()) <= 2e-6 * scale_, (B, H, W, C0, C1)
+        assert float((fold - got).abs().max()) > 0           # (it really is the other arithmetic)
+        if pool:
+            assert torch.equal(fold_p, F.max_pool2d(fold.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+        if outc:
+            assert float((fold_1 - got_1).abs().max()) <= 2e-5 * float(got_1.abs().max())
         if B <= 3:
             xin = x0.permute(0, 3, 1, 2).cpu()
             if C1:
