@@ -50,6 +50,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef MFPA_WS_EPI_PRIO
 #define MFPA_WS_EPI_PRIO 0         // s_setprio of a compute wave inside its epilogue (its ~200 vector instructions would otherwise queue behind the loader's turn)
 #endif
+#ifndef MFPA_WS_SYNC
+#define MFPA_WS_SYNC 0             // 1: stages and the epilogue's tile are handed over through four LDS counters (no s_barrier in the loop: a wave waits only
+                                   //    for the data it needs, and normally finds it there); 0: one s_barrier per chunk for all eight waves (A/B builds)
+#endif
 #ifndef MFPA_WS_XCD_TILES
 #define MFPA_WS_XCD_TILES 1        // the 32 workgroups of an XCD walk 32 CONSECUTIVE tiles at a time (their shared halo rows meet in that XCD's L2)
 #endif
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
 
   // LDS: [stage 0 | stage 1 | epilogue constants: scale 64, shift 64, w1x1 64, accumulator start values 64 | the epilogue's output tile 64 KB | (stamps)]
   float* const epi = reinterpret_cast<float*>(smem + 2 * STAGE);
-  char* const outbuf = smem + 2 * STAGE + 256 * sizeof(float);
+  unsigned* const syncw = reinterpret_cast<unsigned*>(epi + 256);      // 4 x 4 progress words (MFPA_WS_SYNC)
+  char* const outbuf = smem + 2 * STAGE + (256 + 16) * sizeof(float);
   float* const c1s = reinterpret_cast<float*>(outbuf + OUTBUF);
   for (int i = tid; i < 64; i += THREADS) {
     epi[i] = a.scale ? a.scale[n0 + i] : 1.f;
@@ -167,6 +172,35 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
 #else
   auto stamp = [](int) {};
   auto dump_stamps = []() {};
+#endif
+#if MFPA_WS_SYNC
+  // Hand-offs through LDS words, four per kind: [READY | FREED | OUT_READY | OUT_FREE][wave of the role].  A wave publishes ITS OWN progress
+  // (how many chunks it has staged / left, how many output tiles it has written / stored) with a plain store into its word; a waiter reads
+  // the four words of a kind as one 16-byte piece and takes the minimum -- every wave of the other role must have got there (a summed
+  // counter is not enough: without the barrier the waves of a role drift up to a chunk apart, and three waves a chunk ahead would
+  // outvote a late one).  A wave's DS instructions execute in issue order, so "my accesses, then my word" needs no wait on the
+  // publishing side and "my poll has returned, then my accesses" none on the waiting side; hipcc must keep that program order (the empty
+  // asm statements).  Every spin is bounded: a protocol error must end in wrong numbers that a test catches, never in a hung GPU.
+  if (tid < 16) syncw[tid] = 0;
+  __syncthreads();                                                     // the kernel's only barrier: constants and progress words are in LDS
+  constexpr int READY = 0, FREED = 1, OUT_READY = 2, OUT_FREE = 3;
+  const int role_wave = wave & 3;
+  auto publish = [&](int which, unsigned count) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(syncw + 4 * which + role_wave, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto peek = [&](int which) __attribute__((always_inline)) {        // the slowest wave's progress
+    const u32x4 v = *reinterpret_cast<volatile u32x4*>(syncw + 4 * which);
+    return min(min(v[0], v[1]), min(v[2], v[3]));
+  };
+  auto wait_for = [&](int which, unsigned target) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    int spins = 0;
+    while ((unsigned)__builtin_amdgcn_readfirstlane((int)peek(which)) < target && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
 #endif
   if (wave >= 4) {
     // =================================================================================================== LOADER waves
@@ -377,12 +411,31 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         stamp(20);
         if (k + 2 < total) issue_next(ISSUE_SET);
         __builtin_amdgcn_sched_barrier(0);                             // the requests first: hipcc sank them below the split
+#if MFPA_WS_SYNC
+        // counters: chunk k + 1 goes into the stage chunk k - 1 was read from -- when all four compute waves have left it
+        if (k + 1 < total) {
+          if (k >= 1) wait_for(FREED, (unsigned)k);                    // every compute wave has left chunk k - 1
+          split_all(SPLIT_SET, par * STAGE);
+          publish(READY, (unsigned)(k + 2));                           // this wave's part of chunks 0 .. k + 1 is staged
+        }
+        stamp(22);
+        // the output tile of tile i (last chunk k_i = (i + 1) nchunks - 1) is written by the compute waves right behind that chunk:
+        // stored here in iteration k_i + 1, behind this iteration's own chunk
+        if (has_duty && !WS_FLAG(4) && k >= nchunks && k % nchunks == 0) {
+          wait_for(OUT_READY, (unsigned)(k / nchunks));
+          duty(tile_of((int)blockIdx.x, k / nchunks - 1, G));
+          publish(OUT_FREE, (unsigned)(k / nchunks));                  // this wave has read its part of tiles 0 .. k / nchunks - 1
+        }
+        stamp(24);
+        stamp(23);
+#else
         if (k + 1 < total) split_all(SPLIT_SET, par * STAGE);
         stamp(22);
         if (has_duty && !WS_FLAG(4) && k >= nchunks + 1 && (k - 1) % nchunks == 0) duty(tile_of((int)blockIdx.x, (k - 1) / nchunks - 1, G));
         stamp(24);
         __syncthreads();                                               // k = -1: stage 0 is ready; k >= 0: the compute waves' barrier of chunk k
         stamp(23);
+#endif
         par ^= 1;
       };
       for (int k = -1; k < total; k += 2) {
@@ -390,8 +443,12 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         if (k + 1 < total) iteration(k + 1, SET0{}, SET1{});
       }
       if (has_duty) {
-        // the last tile's read-out iteration k_i + 2 lies beyond the loop (every other tile's does not: nchunks >= 2)
+        // the last tile's read-out iteration lies beyond the loop (every other tile's does not: nchunks >= 2)
+#if MFPA_WS_SYNC
+        wait_for(OUT_READY, (unsigned)owned);
+#else
         __syncthreads();                                               // the compute waves' final barrier: the last tile's output is in LDS
+#endif
         duty(tile_of((int)blockIdx.x, owned - 1, G));
       }
     }
@@ -460,6 +517,10 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
   // 4..7) || read tiles 0..3 of tap t + 1.  The chunk's one barrier sits between the phases of tap 8: behind it the other stage is complete
   // (the loaders arrived) and this one is read out (every compute wave's fragment reads of it have returned: lgkmcnt(0) in front of it).
   int kpar = 0;                                                        // parity of the stage the current chunk is read from
+#if MFPA_WS_SYNC
+  unsigned gck = 0, rdy_early = 0;                                     // this workgroup's chunk counter; the READY count peeked at tap 7
+  const unsigned total_c = (unsigned)(owned * nchunks);
+#endif
   auto tap_body = [&](auto TAP, int chunk, auto FIRST) __attribute__((always_inline)) {
     constexpr int tap = decltype(TAP)::value;
     constexpr int ntap = (tap + 1) % TAPS;
@@ -477,9 +538,20 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x020, N_W, 0);
     if constexpr (N_M - used_a - 1 > 0) __builtin_amdgcn_sched_group_barrier(0x008, N_M - used_a - 1, 0);
     __builtin_amdgcn_sched_barrier(0);
+#if MFPA_WS_SYNC
+    if (tap == TAPS - 2) rdy_early = peek(READY);                      // the count the next tap checks, requested a tap ahead of its use
+#endif
     if (tap == TAPS - 1) {
       stamp(9);
+#if MFPA_WS_SYNC
+      // this wave has issued its last read of the current stage: free it (the loaders wait for all four), then make sure the next stage
+      // is there -- the count read a tap ago normally says so already
+      publish(FREED, gck + 1u);
+      if (gck + 1u < total_c && (unsigned)__builtin_amdgcn_readfirstlane((int)rdy_early) < gck + 2u) wait_for(READY, gck + 2u);
+      ++gck;                                                             // (behind the workgroup's last chunk there is nothing to wait for)
+#else
       __syncthreads();
+#endif
       __builtin_amdgcn_sched_barrier(0);
       stamp(10);
     }
@@ -493,7 +565,11 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
   load_w(0, 0, std::integral_constant<int, 0>{});
   load_w(0, 1, std::integral_constant<int, 1>{});
   if (WS_FLAG(16)) { load_w(0, 2, std::integral_constant<int, 2>{}); primed = true; }
+#if MFPA_WS_SYNC
+  wait_for(READY, 1u);                                                 // stage 0 holds chunk 0 of the first tile
+#else
   __syncthreads();                                                     // stage 0 holds chunk 0 of the first tile
+#endif
   if (WS_FLAG(8)) {                                       // timing variants: both fragment sets once
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -566,6 +642,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
           for (int j = 0; j < 4; ++j) acc[ct][pt][j] = fmaxf(acc[ct][pt][j], floor_);
     }
     if (a.y != nullptr || a.w1x1 != nullptr) {
+#if MFPA_WS_SYNC
+      if (ti >= 1 && !WS_FLAG(4)) wait_for(OUT_FREE, (unsigned)ti);               // the loaders have stored the previous tile
+#endif
       // the tile goes to LDS as 16-byte pieces (pixel m, channel quad q) at m * 256 + ((q ^ (m & 15)) << 4): a wave instruction's 16 pixels
       // of one quad hit 16 different 16-byte bank groups; the loaders store it (and form the fused OutConv) one barrier from now
 #pragma unroll
@@ -581,6 +660,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
           *reinterpret_cast<f32x4*>(row + ((q ^ p) << 4)) = o;
         }
       }
+#if MFPA_WS_SYNC
+      publish(OUT_READY, (unsigned)(ti + 1));
+#endif
     }
     if (a.y_pool != nullptr) {
       // MaxPool2d(2) (floor): the window's two rows are two of the wave's pixel tiles, its two columns adjacent lanes (one DPP swap)
@@ -608,7 +690,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
 #endif
     stamp(12);
   }
+#if !MFPA_WS_SYNC
   if (a.y != nullptr || a.w1x1 != nullptr) __syncthreads();          // the last tile's output is in LDS: the loaders store it
+#endif
   dump_stamps();
 }
 
@@ -632,7 +716,7 @@ int launch_conv_ws64(ConvArgs& a, hipStream_t s) {
   const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
   if (ntiles > 0x7fffffffLL / 2) return MFPA_EINVAL;
   const bool c1 = a.c1_x32 != nullptr || a.c1_spec64 != nullptr;
-  const size_t lds = 2 * (size_t)STAGE + 256 * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)(2 * C1R * C1W + 11 * 64 + 4) * sizeof(float) : 0);
+  const size_t lds = 2 * (size_t)STAGE + (256 + 16) * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)(2 * C1R * C1W + 11 * 64 + 4) * sizeof(float) : 0);
 #ifdef MFPA_WS_STAMPS
   a.dbg_lds_stamps = (int)lds;
   const_cast<size_t&>(lds) += 2 * WS_MAX_STAMPS * sizeof(unsigned long long);
