@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the 5 PF headline figure is 2:1 sparse)
 CLIP_SAMPLES = 64000
-PMC_TRAFFIC_BF16X3 = "r04_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
+PMC_TRAFFIC_BF16X3 = "r05_pmc_traffic_bf16x3.json"   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the conv family
 PMC_TRAFFIC_DEMUCS = "r02_pmc_traffic_demucs.json"   # the same for the Demucs forward (GEMM family + LSTM launches)
 
 
@@ -918,10 +918,30 @@ def other_configs(args, dev):
                 for k in ("allreduce_calls_per_step", "allreduce_bytes_per_step", "allreduce_exposed_wait_ms_per_step", "clips_per_gpu_per_step", "clips_per_step_all_gpus"):
                     r[k] = r["config"].get(k)
             r["wall_s_including_setup"] = round(time.perf_counter() - t0, 2)
-        out[name] = r
+        out[name] = _compact(r) if isinstance(r, dict) else r
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    return out
+
+
+def _compact(r):
+    """A nested N = 1 entry without its prose: the driver keeps the last ~8 KB of the line, and eleven entries with their workload /
+    kernel / parallelism sentences were 13 KB (config 2's figures fell off the record in round 4).  Numbers stay; the sentences are in
+    DESIGN.md section 4 and in the line each mode prints on its own (`python bench.py --mode train ...`)."""
+    if "error" in r:
+        return r
+    out = {k: v for k, v in r.items() if k not in ("metric", "config", "dtype", "scaling", "unit")}
+    out["unit"] = r.get("unit")
+    if isinstance(r.get("dtype"), str):
+        out["dtype"] = r["dtype"].split(" ")[0].rstrip(",")
+    cfg = r.get("config") or {}
+    out.update({k: v for k, v in cfg.items() if not isinstance(v, str) and v is not None and k not in out})
+    if isinstance(r.get("roofline"), dict):
+        out["roofline"] = {k: v for k, v in r["roofline"].items() if k not in ("kernel", "traffic_source") and v is not None}
+    if isinstance(r.get("kernel_breakdown"), dict):
+        out["kernel_breakdown"] = {k.split(" ")[0]: ({kk: vv for kk, vv in v.items() if kk in ("us", "GB_per_s")} if isinstance(v, dict) else None)
+                                   for k, v in r["kernel_breakdown"].items() if k != "note"}
     return out
 
 
