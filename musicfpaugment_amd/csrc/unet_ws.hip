@@ -137,7 +137,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
 
   // LDS: [stage 0 | stage 1 | epilogue constants: scale 64, shift 64, w1x1 64, accumulator start values 64 | the epilogue's output tile 64 KB | (stamps)]
   float* const epi = reinterpret_cast<float*>(smem + 2 * STAGE);
-  unsigned* const syncw = reinterpret_cast<unsigned*>(epi + 256);      // 4 x 4 progress words (MFPA_WS_SYNC)
+#if MFPA_WS_SYNC
+  unsigned* const syncw = reinterpret_cast<unsigned*>(epi + 256);      // 4 x 4 progress words
+#endif
   char* const outbuf = smem + 2 * STAGE + (256 + 16) * sizeof(float);
   float* const c1s = reinterpret_cast<float*>(outbuf + OUTBUF);
   for (int i = tid; i < 64; i += THREADS) {
@@ -618,9 +620,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
       run_epi = t == 12345.678f;
     }
     if (run_epi) {
-    const float floor_ = a.relu ? 0.f : -__builtin_inff();
     // ---- epilogue: D[channel 4 g + j of tile ct][pixel p of tile pt]: out = relu(acc * scale + shift) -- or relu(acc) when the scale is in
-    // the weights and the shift in the accumulators' start values
+    // the weights and the shift in the accumulators' start values.  ReLU as max(v, 0): NaN -> 0 like `v > 0 ? v : 0`; without ReLU nothing
+    // touches the value (a NaN stays a NaN, as in the other kernels).
     if (a.scale != nullptr) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -630,16 +632,16 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[ct][pt][j] = fmaxf(fmaf(acc[ct][pt][j], sc[j], sh[j]), floor_);      // relu: floor 0 (NaN -> 0 like `v > 0 ? v : 0`), else -inf
+          for (int j = 0; j < 4; ++j) acc[ct][pt][j] = fmaf(acc[ct][pt][j], sc[j], sh[j]);
       }
-    } else {
+    }
+    if (a.relu) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ct][pt][j] = fmaxf(acc[ct][pt][j], floor_);
+          for (int j = 0; j < 4; ++j) acc[ct][pt][j] = fmaxf(acc[ct][pt][j], 0.f);
     }
     if (a.y != nullptr || a.w1x1 != nullptr) {
 #if MFPA_WS_SYNC
@@ -706,6 +708,8 @@ bool conv_ws64_serves(const ConvArgs& a) {
   // (a slot outside the image is requested at byte offset 0xfffffff0: it must lie beyond a clip)
   if (4ull * a.H * a.W * a.C0 >= 0xfffffff0ull || 4ull * a.H1 * a.W1 * a.C1 >= 0xfffffff0ull) return false;
   if (c1) return false;                                                // (first layer in the loaders: not in this form yet)
+  const long long ntiles = (long long)((a.W + PW - 1) / PW) * ((a.H + PH - 1) / PH) * a.B;
+  if (ntiles > 0x7fffffffLL / 2) return false;                         // (tile_of's round arithmetic stays inside 31 bits; conv_wd16_kernel takes those)
   return a.C0 % KC == 0 && a.C1 % KC == 0 && a.C0 + a.C1 >= 64;
 }
 

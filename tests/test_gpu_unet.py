@@ -279,6 +279,12 @@ def test_wave_specialised_64_channel_kernel_equals_conv_wd16_bit_for_bit():
             assert torch.equal(only, got_1)
         again, _, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, out1x1=o1, wf=wf)
         assert torch.equal(again, got)                       # run to run
+        if not pool and not outc:
+            # without ReLU (and without a scale): the raw convolution, negative values and all -- the training forward's form of the call
+            raw = T.conv_mfma(x0, wf[1], 64, x1=x1, precision=1, packed=True, w_layout=2)
+            yb2 = []
+            raw_ref = T.conv_mfma(x0, wf[1], 64, x1=x1, precision=1, packed=True, w_layout=2, y_bf16_out=yb2)
+            assert len(yb2) == 1 and float(raw.min()) < 0 and torch.equal(raw, raw_ref)
         # the scale-folded form the UNet's eval chain uses (mfpa_conv_scale_folds): the scale in the weights (w * scale, then split), the
         # shift as the accumulators' start value, a bare ReLU in the epilogue -- the same numbers to bf16x3's own rounding
         assert lib().mfpa_conv_scale_folds(H, W, C0 + C1, 64) == 1
