@@ -718,7 +718,9 @@ def bench_infer(args, rank, world, dev, dist):
         differ = (got[1][0] != got[0][0]).sum()
         parity = {"rel_l1_bf16x3_vs_fp32": float(num / den), "gate": 1e-4, "masks_equal_frac": float(same),
                   "mask_cells_differing": int(differ), "peaks_fp32": int(got[0][0].sum()), "clips": int(got[0][0].shape[0]),
-                  "weights": "formula_state_dict(0); the stressed / trained families are gated in tests/test_gpu_unet.py"}
+                  "weights": "formula_state_dict(0); the stressed / trained families are gated in tests/test_gpu_unet.py",
+                  "note": "masks of the two ARITHMETIC variants (their spectrograms are ~2e-5 apart, so a near-tie may fall either way: a cell or "
+                          "two in 8 clips); on IDENTICAL spectrograms the peak sets are bit-exact (tests/test_gpu_fullsize.py)"}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -1096,6 +1098,7 @@ def main():
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick; launch-check: launcher plumbing only (tests)")
+    ap.add_argument("--no-c1-mfma", action="store_true", help="A/B runs: the fused first layer stays on conv_mfma_kernel<C1SRC> (ops_unet.C1_ON_MFMA)")
     ap.add_argument("--no-fold-scale", action="store_true", help="A/B runs: never hand conv_ws64_kernel scale-folded weights (ops_unet.FOLD_SCALE)")
     ap.add_argument("--no-weights-direct", action="store_true",
                     help="A/B runs: the UNet's 128-channel-tile layers on the LDS-staged weight tiles instead of the weights-direct kernel")
@@ -1115,6 +1118,9 @@ def main():
     if args.no_fold_scale:
         from musicfpaugment_amd import ops_unet
         ops_unet.FOLD_SCALE = False
+    if args.no_c1_mfma:
+        from musicfpaugment_amd import ops_unet
+        ops_unet.C1_ON_MFMA = False
     if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
         args.precision = "bf16x3"
     if args.precision == "bf16" and args.mode != "train":

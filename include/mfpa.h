@@ -289,6 +289,11 @@ int mfpa_conv_weight_layout(int H, int W, int Cin, int Cout, int mode, int preci
  * becomes the accumulators' start value and the epilogue a bare ReLU.  The same call with out_scale given stays valid everywhere.
  * Reference: the folded eval BatchNorm of DoubleConv, training/unet.py:16-21. */
 int mfpa_conv_scale_folds(int H, int W, int Cin, int Cout);
+/* HOST function (round 5): the w_layout the FUSED FIRST-LAYER launch of mfpa_conv_mfma (c1_x32 / c1_spec64 given, 64 -> 64 channels,
+ * precision 1) reads at this image size: 2 = the fragment image (conv_ws64_kernel computes the first layer in its loader waves on the
+ * matrix cores, bf16x3 like every other layer), 0 = the row image (conv_mfma_kernel computes it with exact fp32 FMAs in its loader).
+ * Reference: DoubleConv of `inc`, training/unet.py:16-21, 86. */
+int mfpa_conv_c1_layout(int H, int W);
 /* HOST function: rows of mfpa_conv_desc.stats_part for this shape (0: its kernel does not write them). */
 int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout);
 /* stats_part (rows, 2, C) -> sums[2C] float64 as mfpa_bn_stats_sums produces them; workspace as for mfpa_bn_stats. */

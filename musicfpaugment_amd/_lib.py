@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 
 class MfpaError(RuntimeError):
@@ -65,6 +65,7 @@ _SIGNATURES = {
     "mfpa_conv_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_conv_weight_layout": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int),
     "mfpa_conv_scale_folds": ([c_int, c_int, c_int, c_int], c_int),
+    "mfpa_conv_c1_layout": ([c_int, c_int], c_int),
     "mfpa_gemm_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_lowpass_taps": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_fir": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -1872,6 +1872,9 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
 #ifndef MFPA_CONV_WS64
 #define MFPA_CONV_WS64 1             // 64-channel inference launches on conv_ws64_kernel (csrc/unet_ws.hip); 0: conv_wd16_kernel<.., WMW = 4> (A/B builds)
 #endif
+#ifndef MFPA_CONV_WS_C1
+#define MFPA_CONV_WS_C1 1            // the UNet's first two layers (1 -> 64 computed in the loader waves on the matrix cores, 64 -> 64) on conv_ws64_kernel<C1SRC>
+#endif
 #ifndef MFPA_CONV_WS_ALL
 #define MFPA_CONV_WS_ALL 128         // conv_ws64_kernel also for outputs of 128 channels and more with at most this many input channels (0 = never): per layer,
                                      // 64 clips: 64 -> 128 @ 128 x 125 431 -> 380 us, 128 -> 128 725 -> 704, 128 -> 256 @ 64 x 62 360 -> 345; from 256 input channels on it loses
@@ -2328,7 +2331,10 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
   const bool bn128 = (a.Cout % 128 == 0);
   if constexpr (MODE == 0 && PREC == 1) {
     if (a.w_frag == 2) {   // the 16 x 16 x 32 weights-direct kernel and its image
-      if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || a.c1_x32 || a.c1_spec64 || (a.w1x1 && bn128)) return MFPA_EINVAL;
+      if (conv_weight_layout(a.H, a.W, a.C0 + a.C1, a.Cout, 0, 1) != 2 || (a.w1x1 && bn128)) return MFPA_EINVAL;
+      if (a.c1_x32 || a.c1_spec64) {      // fused first layer + fragment image: conv_ws64_kernel<C1SRC> only (mfpa_conv_c1_layout() says where)
+        return (MFPA_CONV_WS64 && MFPA_CONV_WS_C1 && mfpa_unet::conv_ws64_serves(a)) ? mfpa_unet::launch_conv_ws64(a, s) : MFPA_EINVAL;
+      }
       if (!bn128) {
         // round 5: the wave-specialised kernel (csrc/unet_ws.hip: 4 compute waves of 128 px x 32 ch + 4 loader waves) takes the inference launches
         static const int ws64 = MFPA_EXP_ENV("MFPA_CONV_WS64", MFPA_CONV_WS64);
@@ -2486,6 +2492,12 @@ int mfpa_exp_conv_stamps(unsigned long long* buf) {       // experiments build o
   return hipMemcpyToSymbol(HIP_SYMBOL(mfpa_conv_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+int mfpa_conv_c1_layout(int H, int W) {
+  if (H < 1 || W < 1) return MFPA_EINVAL;
+  // the fused first-layer launch (mfpa_conv_desc.c1_*, 64 -> 64) reads the fragment image 2 exactly where conv_ws64_kernel<C1SRC> takes it
+  return (MFPA_CONV_WS64 && MFPA_CONV_WS_C1 && conv_weight_layout(H, W, 64, 64, 0, 1) == 2 && W > 16 && H >= 8) ? 2 : 0;
+}
 
 int mfpa_conv_scale_folds(int H, int W, int Cin, int Cout) {
   if (H < 1 || W < 1 || Cin < 1 || Cout < 1) return MFPA_EINVAL;

@@ -72,7 +72,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // In-kernel timeline (experiments build only; tools/exp_ws_timeline.py): wave 0 (compute) and wave 4 (loader) of workgroup 17 stamp s_memtime
 // into LDS (tag in the low 8 bits), dumped to this buffer when the kernel ends: [0] = count of wave 0, [1 ..] its stamps; [2048] = count of
 // wave 4, [2049 ..] its stamps.  No output value depends on a stamp.  (the symbol: mfpa_unet::ws_stamps above)
-constexpr int WS_MAX_STAMPS = 140;
+constexpr int WS_MAX_STAMPS = 128;
 #endif
 
 constexpr int KC = 32;             // channels per K chunk
@@ -87,7 +87,8 @@ constexpr int HLS = 4 * PLANE + 256;                                   // hi -> 
 constexpr int STAGE = 2 * HLS;
 constexpr int TAPS = 9, PT = 8;                                        // 16-pixel tiles per compute wave
 constexpr int OUTBUF = PH * PW * 64 * 4;                                // the epilogue's LDS tile: 256 px x 64 ch fp32, piece (pixel m, channel quad q) at m * 256 + ((q ^ (m & 15)) << 4)
-constexpr int C1R = PH + 4, C1W = PW + 4;                              // C1SRC: the 1-channel source patch with a two-pixel halo
+constexpr int C1W = PW + 4, C1PROWS = 6;                               // C1SRC: a loader wave's part of the 1-channel source patch: <= 6 rows of PW + 4 columns
+constexpr int C1LDS = (4 * C1PROWS * C1W + 128) * 4;                   // four wave-private patches + the first layer's (scale 64, shift 64)
 
 __device__ __forceinline__ constexpr int plane_off(int hl, int kg) { return hl * HLS + kg * PLANE + (kg >> 1) * 128; }
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
   unsigned* const syncw = reinterpret_cast<unsigned*>(epi + 256);      // 4 x 4 progress words
 #endif
   char* const outbuf = smem + 2 * STAGE + (256 + 16) * sizeof(float);
-  float* const c1s = reinterpret_cast<float*>(outbuf + OUTBUF);
+  float* const c1s = reinterpret_cast<float*>(outbuf + OUTBUF);        // C1SRC: [4 wave-private patches | scale 64 | shift 64]
   for (int i = tid; i < 64; i += THREADS) {
     epi[i] = a.scale ? a.scale[n0 + i] : 1.f;
     epi[64 + i] = a.shift ? a.shift[n0 + i] : 0.f;
@@ -149,11 +150,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
     epi[192 + i] = (a.scale == nullptr && a.shift != nullptr) ? a.shift[n0 + i] : 0.f;      // the accumulators' start values (see `initv`)
   }
   if constexpr (C1SRC) {
-    float* cw = c1s + 2 * C1R * C1W;
-    for (int i = tid; i < 9 * 64; i += THREADS) cw[i] = a.c1_w[i];
     for (int i = tid; i < 64; i += THREADS) {
-      cw[9 * 64 + i] = a.c1_scale[i];
-      cw[10 * 64 + i] = a.c1_shift[i];
+      c1s[4 * C1PROWS * C1W + i] = a.c1_scale[i];
+      c1s[4 * C1PROWS * C1W + 64 + i] = a.c1_shift[i];
     }
   }
 
@@ -453,6 +452,196 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
 #endif
         duty(tile_of((int)blockIdx.x, owned - 1, G));
       }
+    } else {
+      // ---- C1SRC: the 64 input channels are COMPUTED here -- the UNet's first layer (Conv2d(1, 64, 3, padding 1, bias False) + folded
+      // BatchNorm + ReLU, training/unet.py:16-18) on the matrix cores.  The 340 halo pixels are 22 tiles of 16; loader wave w owns
+      // tiles [6, 6, 5, 5] and keeps its own copy of the <= 6 source rows they need (no hand-off between the loader waves).  Per
+      // (16-channel tile, 16-pixel tile): D[channel][pixel] = W[16 x K] . P[K x 16] with K = the nine taps padded to 16
+      // (v_mfma_f32_16x16x16_bf16, bf16x3: three instructions of 8 cycles), then scale / shift / ReLU, zero outside the image (the second
+      // layer's zero padding), bf16 hi | lo split and the same two 8-byte plane stores as the generic loader.  48 MFMAs per chunk and wave
+      // against ~1300 vector instructions per chunk and thread in conv_mfma_kernel<.., C1SRC>'s loader.
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const int lw = wave - 4;
+      const int pt0 = lw < 2 ? 6 * lw : 12 + 5 * (lw - 2), npt = lw < 2 ? 6 : 5;
+      const int hr0 = (pt0 * 16) / HPW;                                  // first halo row of this wave's pixels = first patch row it keeps
+      float* const patch = c1s + lw * (C1PROWS * C1W);
+      const float* const c1c = c1s + 4 * C1PROWS * C1W;
+      const int g = lane >> 4, p = lane & 15;
+      auto split2 = [&](float x0_, float x1_, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {
+        const f32x2 x = {x0_, x1_};
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        const f32x2 r = {x[0] - __uint_as_float(hi << 16), x[1] - __uint_as_float(hi & 0xffff0000u)};
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+      };
+      // the first layer's weights as the A operand: lane (g, c) = channel 16 t + c, k = 4 g .. 4 g + 3 (tap k, zero from tap 9 on)
+      s16x4 Ahi[4], Alo[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 4 * g + j;
+          w4[j] = k < 9 ? a.c1_w[k * 64 + 16 * t + p] : 0.f;
+        }
+        unsigned h0, l0, h1, l1;
+        split2(w4[0], w4[1], h0, l0);
+        split2(w4[2], w4[3], h1, l1);
+        Ahi[t] = __builtin_bit_cast(s16x4, uint2{h0, h1});
+        Alo[t] = __builtin_bit_cast(s16x4, uint2{l0, l1});
+      }
+      // per lane, tile-independent: where pixel p of pixel tile t sits in the wave's patch (tap (0, 0)), its halo coordinates, and the
+      // patch displacement of the lane's four taps
+      int pbase[6], pyx[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int hp = (pt0 + (t < npt ? t : 0)) * 16 + p;
+        const int py = hp / HPW, px = hp % HPW;
+        pbase[t] = (py - hr0) * C1W + px;
+        pyx[t] = (py << 8) | px | (hp < HP ? 0 : 0x10000);
+      }
+      int koff[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * g + j;
+        koff[j] = k < 9 ? (k / 3) * C1W + (k % 3) : -1;
+      }
+      // the wave's patch elements a lane carries from request to commit: i = lane + 64 j < 6 x 36
+      double pvd[4];
+      float pvf[4];
+      unsigned pin = 0;
+      double pden = 1.0;
+      auto request_patch = [&](int t) __attribute__((always_inline)) {
+        int bx = __builtin_amdgcn_readfirstlane(t);
+        const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+        const int y0 = ty * PH, x0 = tx * PW;
+        pden = a.c1_denom ? a.c1_denom[bx] : 1.0;
+        pin = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = lane + 64 * j;
+          const int gy = y0 - 2 + hr0 + i / C1W, gx = x0 - 2 + i % C1W;
+          const bool in = i < C1PROWS * C1W && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          pin |= (in ? 1u : 0u) << j;
+          const size_t o = ((size_t)bx * a.H + min(max(gy, 0), a.H - 1)) * a.W + min(max(gx, 0), a.W - 1);      // clamped: the load is unconditional
+          if (a.c1_spec64) pvd[j] = a.c1_spec64[o];
+          else pvf[j] = a.c1_x32[o];
+        }
+      };
+      auto commit_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = lane + 64 * j;
+          const float v = a.c1_spec64 ? (float)(pvd[j] / pden) : pvf[j];          // the fused spectrogram normalisation (peak_extractor.py:263-265)
+          if (i < C1PROWS * C1W) patch[i] = ((pin >> j) & 1u) ? v : 0.f;            // zero = the first layer's own padding
+        }
+      };
+      s16x4 Bh[6], Bl[6];
+      unsigned inside = 0;                                             // bit t: pixel p of pixel tile t lies inside the image
+      auto build_b = [&](int t) __attribute__((always_inline)) {
+        int bx = __builtin_amdgcn_readfirstlane(t);
+        const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty = bx % a.tiles_y;
+        const int y0 = ty * PH, x0 = tx * PW;
+        inside = 0;
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+          float v4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v4[j] = koff[j] >= 0 ? patch[pbase[tt] + koff[j]] : 0.f;
+          unsigned h0, l0, h1, l1;
+          split2(v4[0], v4[1], h0, l0);
+          split2(v4[2], v4[3], h1, l1);
+          Bh[tt] = __builtin_bit_cast(s16x4, uint2{h0, h1});
+          Bl[tt] = __builtin_bit_cast(s16x4, uint2{l0, l1});
+          const int gy = y0 - 1 + (pyx[tt] >> 8 & 0xff), gx = x0 - 1 + (pyx[tt] & 0xff);
+          const bool in = !(pyx[tt] & 0x10000) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          inside |= (in ? 1u : 0u) << tt;
+        }
+      };
+      // channels [32 c, 32 c + 32) of the current tile into the stage at `stage_off`
+      auto produce = [&](int c, int stage_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cth = 0; cth < 2; ++cth) {
+          const int ct = 2 * c + cth;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(c1c + 16 * ct + 4 * g);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(c1c + 64 + 16 * ct + 4 * g);
+          const s16x4 ah = c ? (cth ? Ahi[3] : Ahi[2]) : (cth ? Ahi[1] : Ahi[0]);
+          const s16x4 al = c ? (cth ? Alo[3] : Alo[2]) : (cth ? Alo[1] : Alo[0]);
+#pragma unroll
+          for (int tt = 0; tt < 6; ++tt) {
+            if (tt >= npt) continue;
+            floatx4 d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, Bh[tt], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, Bl[tt], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, Bh[tt], d, 0, 0, 0);
+            const bool in = (inside >> tt) & 1u;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = in ? fmaxf(fmaf(d[j], sc[j], sh[j]), 0.f) : 0.f;
+            unsigned h0, l0, h1, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
+            // channels 16 ct + 4 g .. + 3 of pixel hp: k-group (ct & 1) * 2 + (g >> 1) of the chunk, half g & 1 of its 16-byte piece
+            char* at = smem + stage_off + plane_off(0, cth * 2 + (g >> 1)) + ((pt0 + tt) * 16 + p) * 16 + 8 * (g & 1);
+            *reinterpret_cast<uint2*>(at) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(at + HLS) = uint2{l0, l1};
+          }
+        }
+      };
+      const bool has_duty = a.y != nullptr || a.w1x1 != nullptr;
+      // the generic loaders' epilogue duty (stores of the 64-channel rows; the fused OutConv is not combined with a fused first layer)
+      auto duty = [&](int t) __attribute__((always_inline)) {
+        int bx = __builtin_amdgcn_readfirstlane(t);
+        const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+        const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+        const int ey0 = ty * PH, ex0 = tx * PW;
+        if (a.y != nullptr) {
+          char* yb = reinterpret_cast<char*>(a.y + (size_t)bx * a.H * a.W * a.Cout + n0);
+          const int q = lt & 15;
+          for (int pass = 0; pass < 16; pass += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int m = (pass + u) * 16 + (lt >> 4);
+              v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + ((q ^ (m & 15)) << 4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int m = (pass + u) * 16 + (lt >> 4);
+              const int gy = ey0 + m / PW, gx = ex0 + m % PW;
+              if (gy < a.H && gx < a.W) *reinterpret_cast<f32x4*>(yb + (((unsigned)gy * (unsigned)a.W + (unsigned)gx) * (unsigned)a.Cout + 4u * (unsigned)q) * 4u) = v[u];
+            }
+          }
+        }
+      };
+      const int total = owned * 2;                                     // two chunks per tile
+      int par = 0;
+      request_patch(tile_of((int)blockIdx.x, 0, G));
+      for (int k = -1; k < total; ++k) {
+        stamp(20);
+        if (k + 1 < total) {
+          const int i = (k + 1) >> 1, c = (k + 1) & 1;
+          if (c == 0) {
+            commit_patch();                                            // (wave-private copy: the wave's own DS instructions execute in order)
+            build_b(tile_of((int)blockIdx.x, i, G));
+            if (i + 1 < owned) request_patch(tile_of((int)blockIdx.x, i + 1, G));
+          }
+          produce(c, par * STAGE);
+        }
+        stamp(22);
+        if (has_duty && k >= 3 && (k - 1) % 2 == 0) duty(tile_of((int)blockIdx.x, (k - 1) / 2 - 1, G));
+        stamp(24);
+        __syncthreads();
+        stamp(23);
+        par ^= 1;
+      }
+      if (has_duty) {
+        __syncthreads();
+        duty(tile_of((int)blockIdx.x, owned - 1, G));
+      }
     }
     dump_stamps();
     return;
@@ -707,7 +896,7 @@ bool conv_ws64_serves(const ConvArgs& a) {
   if (a.yH != a.H || a.yW != a.W || a.W <= 16 || a.H < 8) return false;
   // (a slot outside the image is requested at byte offset 0xfffffff0: it must lie beyond a clip)
   if (4ull * a.H * a.W * a.C0 >= 0xfffffff0ull || 4ull * a.H1 * a.W1 * a.C1 >= 0xfffffff0ull) return false;
-  if (c1) return false;                                                // (first layer in the loaders: not in this form yet)
+  if (c1 && (a.C0 != 64 || a.C1 != 0 || a.Cout != 64 || a.w1x1 != nullptr || !a.c1_w || !a.c1_scale || !a.c1_shift || MFPA_WS_SYNC)) return false;
   const long long ntiles = (long long)((a.W + PW - 1) / PW) * ((a.H + PH - 1) / PH) * a.B;
   if (ntiles > 0x7fffffffLL / 2) return false;                         // (tile_of's round arithmetic stays inside 31 bits; conv_wd16_kernel takes those)
   return a.C0 % KC == 0 && a.C1 % KC == 0 && a.C0 + a.C1 >= 64;
@@ -720,7 +909,7 @@ int launch_conv_ws64(ConvArgs& a, hipStream_t s) {
   const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
   if (ntiles > 0x7fffffffLL / 2) return MFPA_EINVAL;
   const bool c1 = a.c1_x32 != nullptr || a.c1_spec64 != nullptr;
-  const size_t lds = 2 * (size_t)STAGE + (256 + 16) * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)(2 * C1R * C1W + 11 * 64 + 4) * sizeof(float) : 0);
+  const size_t lds = 2 * (size_t)STAGE + (256 + 16) * sizeof(float) + (size_t)OUTBUF + (c1 ? (size_t)C1LDS : 0);
 #ifdef MFPA_WS_STAMPS
   a.dbg_lds_stamps = (int)lds;
   const_cast<size_t&>(lds) += 2 * WS_MAX_STAMPS * sizeof(unsigned long long);
@@ -730,7 +919,8 @@ int launch_conv_ws64(ConvArgs& a, hipStream_t s) {
   unsigned gx = (unsigned)(cus > 0 ? cus : 256) / gy;
   if (gx < 1) gx = 1;
   if ((long long)gx > ntiles) gx = (unsigned)ntiles;
-  hipLaunchKernelGGL((conv_ws64_kernel<false>), dim3(gx, gy), dim3(THREADS), lds, s, a);
+  if (c1) hipLaunchKernelGGL((conv_ws64_kernel<true>), dim3(gx, gy), dim3(THREADS), lds, s, a);
+  else hipLaunchKernelGGL((conv_ws64_kernel<false>), dim3(gx, gy), dim3(THREADS), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

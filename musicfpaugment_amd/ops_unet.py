@@ -184,6 +184,7 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
 
 USE_WEIGHTS_DIRECT = True     # False: always the row image / LDS-staged weight tiles (A/B runs)
 FOLD_SCALE = True             # False: never pass scale-folded weights (A/B runs)
+C1_ON_MFMA = True             # False: the fused first layer stays on conv_mfma_kernel<C1SRC> (exact fp32 FMAs in its loader; A/B runs)
 
 
 def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None, wf=None, wff=None):
@@ -205,7 +206,8 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     C1 = 0 if x1 is None else x1.shape[3]
     dev = w.device
     layout = 0
-    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1 is None and (out1x1 is None or (wf[0] == 2 and Cout == 64))
+    c1_ok = c1 is None or (C1_ON_MFMA and wf is not None and Cout == 64 and out1x1 is None and lib().mfpa_conv_c1_layout(H, W) == wf[0])
+    if (wf is not None and USE_WEIGHTS_DIRECT and precision == 1 and c1_ok and (out1x1 is None or (wf[0] == 2 and Cout == 64))
             and lib().mfpa_conv_weight_layout(H, W, C0 + C1, Cout, 0, 1) == wf[0]):
         layout, w = wf
         if wff is not None and wff[0] == layout and FOLD_SCALE and lib().mfpa_conv_scale_folds(H, W, C0 + C1, Cout) == 1:

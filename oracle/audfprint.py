@@ -256,3 +256,10 @@ def float32_log_variants(sgram32: np.ndarray):
         return (np.asarray(peaks_from_filtered(highpass(lg - mean)[:-1])) != 0).astype(np.uint8)
     return rest(la), rest(lb), int(np.count_nonzero(ulp)), float(ulp.max())
 
+
+def masks_both_logs(sgram32: np.ndarray):
+    """Picklable worker: (mask with numpy's float32 log -- the reference's arithmetic --, mask with the float64 log rounded once -- the
+    device's) of one float32 spectrogram of the denoised branch."""
+    a, b, _, _ = float32_log_variants(np.ascontiguousarray(sgram32, dtype=np.float32))
+    return a, b
+

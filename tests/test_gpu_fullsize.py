@@ -513,23 +513,29 @@ def test_config5_peak_metrics_experiment_at_size_sampled_queries_vs_oracle(net, 
             assert same(rows[q, 7], psnr(sg_den, sg_clean), 1e-8 if denoiser == "demucs" else 1e-4)
         if denoiser == "unet":
             # EVERY denoised mask of the run, not a sample: the device's peak mask of each of the N queries against the oracle picker on
-            # the device's float32 spectrogram of that query.  On this branch the reference takes np.log of a float32 array
-            # (peak_extractor.py:275) -- numpy's SIMD float32 log, ~5 % of whose values differ from the correctly rounded ones the device
-            # computes (float64 log, rounded once) by up to a few ulp -- so equality here is measured, not guaranteed by construction
-            # (tests/test_oracle_vs_libs.py replays both logs through the oracle: 0 of 2 048 masks change).
+            # the device's float32 spectrogram of that query -- twice.  On this branch the reference takes np.log of a float32 array
+            # (peak_extractor.py:275): numpy's SIMD float32 log, ~5 % of whose values differ from the correctly rounded ones by up to a
+            # few ulp; the device computes the float64 log and rounds once.  So (1) against the oracle WITH THE CORRECTLY ROUNDED LOG the
+            # device must agree on every query (same values in -> same peaks out, by construction), and (2) against the oracle with
+            # numpy's log -- the reference's arithmetic to the last bit -- agreement is statistical: counted, printed, and bounded
+            # (observed 0-1 queries of 2 000 with one differing cell; tests/test_oracle_vs_libs.py replays 2 048 more on the CPU).
             import multiprocessing as mp
             from concurrent.futures import ProcessPoolExecutor
-            differing, cells = 0, 0
+            vs_rounded, vs_numpy, cells_numpy = 0, 0, 0
             with ProcessPoolExecutor(max_workers=min(12, os.cpu_count() or 1), mp_context=mp.get_context("spawn")) as ex:
                 for s0 in range(0, N, 256):
                     mask, _, spec = an_den.find_peaks_batch(aug[s0:s0 + 256].contiguous())
                     mask_np, spec_np = mask.cpu().numpy(), spec.cpu().numpy()
-                    want = list(ex.map(oa.mask_from_sgram_c, list(spec_np), chunksize=8))
-                    for k in range(len(want)):
-                        d = int(np.count_nonzero((mask_np[k] != 0) != (want[k] != 0)))
-                        differing += d > 0
-                        cells += d
-            print(f"[config 5, UNet] denoised masks vs the oracle picker on the device's spectrogram: {differing} of {N} clips differ ({cells} cells)")
-            assert differing == 0, (differing, cells)
+                    both = list(ex.map(oa.masks_both_logs, list(spec_np), chunksize=8))
+                    for k in range(len(both)):
+                        dn = int(np.count_nonzero((mask_np[k] != 0) != (both[k][0] != 0)))
+                        dr = int(np.count_nonzero((mask_np[k] != 0) != (both[k][1] != 0)))
+                        vs_numpy += dn > 0
+                        cells_numpy += dn
+                        vs_rounded += dr > 0
+            print(f"[config 5, UNet] denoised masks vs the oracle picker on the device's spectrogram: {vs_rounded} of {N} queries differ with the correctly "
+                  f"rounded float32 log, {vs_numpy} ({cells_numpy} cells) with numpy's own float32 log")
+            assert vs_rounded == 0, vs_rounded
+            assert vs_numpy <= 4 and cells_numpy <= 8, (vs_numpy, cells_numpy)
     finally:
         net.precision = 0

@@ -304,3 +304,55 @@ def test_wave_specialised_64_channel_kernel_equals_conv_wd16_bit_for_bit():
             want = F.relu(F.conv2d(xin, w, padding=1) * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
             from oracle.unet import relative_l1
             assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-4
+
+
+def test_first_layer_on_the_matrix_cores_inside_the_loader_waves():
+    """conv_ws64_kernel<C1SRC> (round 5): the UNet's first layer (Conv2d(1, 64, 3, padding 1) + folded BatchNorm + ReLU, training/unet.py:16-18)
+    is computed by the LOADER waves of the second layer's kernel on the matrix cores (the nine taps padded to K = 16, bf16x3 like every other
+    layer) instead of ~1300 exact-fp32 vector instructions per chunk and thread in conv_mfma_kernel<.., C1SRC>'s loader.  Against that
+    older launch (ops_unet.C1_ON_MFMA = False): the same output to bf16x3's rounding of ONE more layer (relative L1 < 2e-5, the chain's gate
+    is 1e-4), the fused max-pool = the pool of its own output bit for bit, both source forms (float32 input, float64 spectrogram / per-clip
+    maximum), ragged sizes, fewer tiles than CUs and many more; and against torch on the small shapes."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd._lib import lib
+    from oracle.unet import relative_l1
+    g = torch.Generator().manual_seed(23)
+    if K.frag_layout() != 2:
+        pytest.skip("the library was built without the 16 x 16 x 32 weights-direct kernels")
+    for (B, H, W, use64) in [(2, 9, 37, False), (3, 40, 70, True), (1, 257, 251, True), (20, 257, 251, False), (2, 17, 33, True)]:
+        assert lib().mfpa_conv_c1_layout(H, W) == 2
+        w1 = (torch.randn(64, 1, 3, 3, generator=g) / 3.0)
+        w2 = torch.randn(64, 64, 3, 3, generator=g) / np.sqrt(9 * 64)
+        s1, b1 = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.2).cuda()
+        s2, b2 = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+        w1k = w1.permute(2, 3, 1, 0).reshape(9, 64).contiguous().cuda()
+        wk = K.pack_conv3x3(w2).cuda()
+        w3, wf = K.split_bf16x3(wk), (2, K.split_bf16x3_frag(wk, 2))
+        wff = (2, K.split_bf16x3_frag(wk * s2[None, :, None], 2))
+        x = torch.rand(B, H, W, generator=g)
+        if use64:
+            den = (torch.rand(B, generator=g) + 0.5).double()
+            c1 = dict(spec64=(x.double() * den[:, None, None]).cuda(), denom=den.cuda(), w=w1k, scale=s1, shift=b1)
+            xin = ((x.double() * den[:, None, None]) / den[:, None, None]).float()
+        else:
+            c1 = dict(x32=x.cuda(), w=w1k, scale=s1, shift=b1)
+            xin = x
+        K.C1_ON_MFMA = False
+        try:
+            ref, ref_p, _ = K.conv3x3_fused(None, w3, s2, b2, precision=1, pool=True, wf=wf, c1=c1)
+        finally:
+            K.C1_ON_MFMA = True
+        got, got_p, _ = K.conv3x3_fused(None, w3, s2, b2, precision=1, pool=True, wf=wf, c1=c1)
+        fold, fold_p, _ = K.conv3x3_fused(None, w3, s2, b2, precision=1, pool=True, wf=wf, wff=wff, c1=c1)
+        r = relative_l1(got.cpu(), ref.cpu())
+        assert 0 < r < 2e-5, (B, H, W, r)
+        assert relative_l1(fold.cpu(), ref.cpu()) < 2e-5
+        assert torch.equal(got_p, F.max_pool2d(got.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+        assert torch.equal(fold_p, F.max_pool2d(fold.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+        again, _, _ = K.conv3x3_fused(None, w3, s2, b2, precision=1, pool=True, wf=wf, c1=c1)
+        assert torch.equal(again, got)
+        if B <= 3:
+            m = F.relu(F.conv2d(xin[:, None], w1, padding=1) * s1.cpu()[None, :, None, None] + b1.cpu()[None, :, None, None])
+            want = F.relu(F.conv2d(m, w2, padding=1) * s2.cpu()[None, :, None, None] + b2.cpu()[None, :, None, None])
+            assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-4
