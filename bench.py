@@ -1098,6 +1098,7 @@ def main():
                     help="infer: the headline STFT+UNet+peak-pick chain; train: BASELINE config 4, the UNet train step "
                          "(2x STFT, train-mode forward, L1, backward, Adam, RCCL gradient all-reduce); demucs: BASELINE "
                          "config 5's Demucs waveform denoiser forward + STFT + peak-pick; launch-check: launcher plumbing only (tests)")
+    ap.add_argument("--no-split-edges", action="store_true", help="A/B runs: every tensor between two convolutions stays float32 (ops_unet.SPLIT_EDGES)")
     ap.add_argument("--no-c1-mfma", action="store_true", help="A/B runs: the fused first layer stays on conv_mfma_kernel<C1SRC> (ops_unet.C1_ON_MFMA)")
     ap.add_argument("--no-fold-scale", action="store_true", help="A/B runs: never hand conv_ws64_kernel scale-folded weights (ops_unet.FOLD_SCALE)")
     ap.add_argument("--no-weights-direct", action="store_true",
@@ -1121,6 +1122,9 @@ def main():
     if args.no_c1_mfma:
         from musicfpaugment_amd import ops_unet
         ops_unet.C1_ON_MFMA = False
+    if args.no_split_edges:
+        from musicfpaugment_amd import ops_unet
+        ops_unet.SPLIT_EDGES = False
     if args.precision is None:      # the fastest arithmetic inside the 1e-4 forward gate; --precision fp32 = exact fp32 products
         args.precision = "bf16x3"
     if args.precision == "bf16" and args.mode != "train":

@@ -279,6 +279,12 @@ typedef struct mfpa_conv_desc {
   /* precision 2, one source, no on-load affine: x0 is a BFLOAT16 tensor (B,H,W,C0), C0 % 64 == 0 -- the bf16 copy of dz written by
    * mfpa_bn_relu_bwd: the loader stages it without any split arithmetic and moves half the bytes. */
   int x0_is_bf16;
+  /* round 5, inference launches that conv_ws64_kernel serves only (mfpa_conv_scale_folds() == 1; otherwise MFPA_EINVAL): tensors in the
+   * SPLIT layout -- same shape and byte count as the float32 NHWC tensor, but every 32-channel chunk of a pixel holds [32 bf16 hi | 32
+   * bf16 lo] (x = hi + lo to 2^-17) instead of 32 floats: exactly what a bf16x3 convolution's loader makes of the float32 values, made
+   * ONCE by the producer.  x0_split / x1_split: source 0 / 1 arrives in it (the loader waves copy 16-byte pieces, no arithmetic);
+   * y_split / y_pool_split: `y` / `y_pool` leave in it.  A split tensor can only feed another such launch. */
+  int x0_split, x1_split, y_split, y_pool_split;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 /* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 
 class MfpaError(RuntimeError):
@@ -175,7 +175,7 @@ class ConvDesc(ctypes.Structure):
                 ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int),
                 ("x0_bf16", c_void_p), ("x1_bf16", c_void_p), ("y_bf16", c_void_p), ("stats_part", c_void_p),
                 ("bwd_z", c_void_p), ("bwd_scale", c_void_p), ("bwd_shift", c_void_p), ("bwd_mean", c_void_p), ("bwd_invstd", c_void_p),
-                ("x0_is_bf16", c_int)]
+                ("x0_is_bf16", c_int), ("x0_split", c_int), ("x1_split", c_int), ("y_split", c_int), ("y_pool_split", c_int)]
 
 
 class GemmDesc(ctypes.Structure):

@@ -26,6 +26,7 @@ struct ConvArgs {
   float* y1x1;
   int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
   int in16;                          // conv_wd16_kernel (plain): source 0 is a bfloat16 tensor (mfpa_conv_desc.x0_is_bf16)
+  int x0_split, x1_split, y_split, y_pool_split;   // conv_ws64_kernel: tensors in the split layout ([32 bf16 hi | 32 bf16 lo] per 32-channel chunk; mfpa_conv_desc)
   int plain;                         // conv_wd16_kernel: plain bf16 products (hi halves only: mfpa_conv_desc.precision 2, the training step)
   __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
   __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)

@@ -2470,6 +2470,10 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   a.plain = d->precision == 2;
   if (d->x0_is_bf16 && (d->precision != 2 || d->C1 != 0 || d->in_scale0 || d->x0_bf16 || (d->C0 % 64) != 0 || d->c1_x32 || d->c1_spec64)) return MFPA_EINVAL;
   a.in16 = d->x0_is_bf16 ? 1 : 0;
+  a.x0_split = d->x0_split ? 1 : 0; a.x1_split = d->x1_split ? 1 : 0; a.y_split = d->y_split ? 1 : 0; a.y_pool_split = d->y_pool_split ? 1 : 0;
+  const bool any_split = a.x0_split || a.x1_split || a.y_split || a.y_pool_split;
+  if (any_split && (d->mode != 0 || d->precision != 1 || d->w_layout != 2 || (a.x1_split && d->C1 < 1) || (a.y_split && !d->y) || (a.y_pool_split && !d->y_pool) ||
+                    (a.x0_split && (d->c1_x32 || d->c1_spec64)))) return MFPA_EINVAL;
   if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision == 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
   if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
   if (d->y_bf16 != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;
@@ -2480,6 +2484,9 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   a.stats_part = d->stats_part;
   if (d->bwd_z != nullptr && (!d->stats_part || !d->bwd_scale || !d->bwd_shift || !d->bwd_mean || !d->bwd_invstd)) return MFPA_EINVAL;
   a.bz = d->bwd_z; a.bz_scale = d->bwd_scale; a.bz_shift = d->bwd_shift; a.bz_mean = d->bwd_mean; a.bz_invstd = d->bwd_invstd;
+  if (any_split) {                                                       // only conv_ws64_kernel reads / writes the split layout
+    if (!(MFPA_CONV_WS64 && mfpa_unet::conv_ws64_serves(a)) || (a.Cout % 128 == 0 && !(MFPA_CONV_WS_ALL > 0 && d->C0 + d->C1 <= MFPA_CONV_WS_ALL))) return MFPA_EINVAL;
+  }
   hipStream_t s = mfpa_stream(stream);
   const int prec = d->precision ? 1 : 0;                                 // kernel family: fp32 MFMA or the bf16 matrix cores
   if (d->mode == 0) return dispatch_conv<0>(a, s, prec);

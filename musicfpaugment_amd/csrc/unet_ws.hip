@@ -38,6 +38,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef MFPA_WS_COMPUTE_PRIO
 #define MFPA_WS_COMPUTE_PRIO 0     // s_setprio of the compute waves (A/B builds)
@@ -53,6 +55,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef MFPA_WS_SYNC
 #define MFPA_WS_SYNC 0             // 1: stages and the epilogue's tile are handed over through four LDS counters (no s_barrier in the loop: a wave waits only
                                    //    for the data it needs, and normally finds it there); 0: one s_barrier per chunk for all eight waves (A/B builds)
+#endif
+#ifndef MFPA_WS_PACE
+#define MFPA_WS_PACE 0             // s_sleep units (64 cycles) a loader wave waits behind EACH halo request: the CU's vector-memory path serves all waves
+                                   // in order, so a burst of 44 KB of HBM requests holds up the compute waves' weight fragments (L2 hits) behind it
 #endif
 #ifndef MFPA_WS_XCD_TILES
 #define MFPA_WS_XCD_TILES 1        // the 32 workgroups of an XCD walk 32 CONSECUTIVE tiles at a time (their shared halo rows meet in that XCD's L2)
@@ -243,6 +249,89 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
       return T;
     };
 
+    const bool has_duty = a.y != nullptr || a.w1x1 != nullptr;
+    // the epilogue's memory work for tile `t` out of the LDS tile the compute waves filled (see the header): the 64-channel rows as
+    // 1 KB-per-wave coalesced stores (16 lanes = the 16 channel quads of a pixel, 4 pixels per wave instruction), then -- fused OutConv
+    // -- one pixel per loader thread: 64 channels x their weights + bias
+    auto duty = [&](int t) __attribute__((always_inline)) {
+      int bx = __builtin_amdgcn_readfirstlane(t);
+      const int tx = bx % a.tiles_x; bx /= a.tiles_x;
+      const int ty = bx % a.tiles_y; bx /= a.tiles_y;
+      const int ey0 = ty * PH, ex0 = tx * PW;
+      if (a.y != nullptr && a.y_split) {
+        // the SPLIT layout (mfpa_conv_desc.y_split): per pixel and 32-channel chunk [32 bf16 hi | 32 bf16 lo] -- a thread takes eight
+        // channels (two pieces of the LDS tile), splits them exactly as a consumer's loader would, and stores the 16-byte hi piece and
+        // the 16-byte lo piece: the next convolution's loaders only copy
+        char* yb = reinterpret_cast<char*>(a.y + (size_t)bx * a.H * a.W * a.Cout + n0);
+        const int kg8 = lt & 7;                                      // channels 8 kg8 .. 8 kg8 + 7 of this workgroup's 64
+        for (int pass = 0; pass < 8; pass += 2) {
+          f32x4 v[2][2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int m = (pass + u) * 32 + (lt >> 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[u][h] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + (((2 * kg8 + h) ^ (m & 15)) << 4));
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int m = (pass + u) * 32 + (lt >> 3);
+            const int gy = ey0 + m / PW, gx = ex0 + m % PW;
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const f32x2 x = {v[u][h][2 * e], v[u][h][2 * e + 1]};
+                hi[2 * h + e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+                const f32x2 r = {x[0] - __uint_as_float(hi[2 * h + e] << 16), x[1] - __uint_as_float(hi[2 * h + e] & 0xffff0000u)};
+                lo[2 * h + e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+              }
+            if (gy < a.H && gx < a.W) {
+              char* yp = yb + ((unsigned)gy * (unsigned)a.W + (unsigned)gx) * (unsigned)a.Cout * 4u + (unsigned)(kg8 >> 2) * 128u + (unsigned)(kg8 & 3) * 16u;
+              *reinterpret_cast<uint4*>(yp) = uint4{hi[0], hi[1], hi[2], hi[3]};
+              *reinterpret_cast<uint4*>(yp + 64) = uint4{lo[0], lo[1], lo[2], lo[3]};
+            }
+          }
+        }
+      } else if (a.y != nullptr) {
+        char* yb = reinterpret_cast<char*>(a.y + (size_t)bx * a.H * a.W * a.Cout + n0);
+        const int q = lt & 15;
+        for (int pass = 0; pass < 16; pass += 4) {                  // four LDS reads in flight, then their four stores
+          f32x4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int m = (pass + u) * 16 + (lt >> 4);
+            v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + ((q ^ (m & 15)) << 4));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int m = (pass + u) * 16 + (lt >> 4);
+            const int gy = ey0 + m / PW, gx = ex0 + m % PW;
+            if (gy < a.H && gx < a.W) *reinterpret_cast<f32x4*>(yb + (((unsigned)gy * (unsigned)a.W + (unsigned)gx) * (unsigned)a.Cout + 4u * (unsigned)q) * 4u) = v[u];
+          }
+        }
+      }
+      if (a.w1x1 != nullptr) {
+        const int m = lt;
+        float sum = 0.f;
+#pragma unroll 1
+        for (int q0 = 0; q0 < 16; q0 += 4) {                         // (four pieces at a time: the whole row at once cost the kernel its register budget)
+          f32x4 v[4], w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + (((q0 + u) ^ (m & 15)) << 4));
+            w[u] = *reinterpret_cast<const f32x4*>(epi + 128 + 4 * (q0 + u));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum = fmaf(v[u][k], w[u][k], sum);
+        }
+        const int gy = ey0 + m / PW, gx = ex0 + m % PW;
+        if (gy < a.H && gx < a.W) a.y1x1[((size_t)bx * a.H + gy) * a.W + gx] = sum + a.b1x1;
+      }
+    };
+
     if constexpr (!C1SRC) {
       // a thread's staging slots map to fixed halo pixels (pix = lt / 8 + 32 it); their byte offsets relative to the tile's HALO ORIGIN do
       // not depend on the tile (registers: the loader waves have room).  Raw buffer loads through a per-clip descriptor.  Edge tiles: halo
@@ -257,7 +346,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         off1[it] = (unsigned)((py * a.W1 + px) * a.C1 + 4 * aq) * 4u;
       }
       const unsigned clip0 = (unsigned)a.H * (unsigned)a.W * (unsigned)a.C0 * 4u, clip1 = (unsigned)a.H1 * (unsigned)a.W1 * (unsigned)a.C1 * 4u;
-      f32x4 areg[2][A_F4];                                             // two staging sets: chunk k + 1 is split out of one while chunk k + 2 lands in the other
+      f32x4 areg[2][A_F4] = {};                                        // two staging sets: chunk k + 1 is split out of one while chunk k + 2 lands in the other
       // what a chunk's loads need besides the per-slot offsets: the clip's buffer descriptor, the tile-origin + channel offset, which offset
       // table (source 0 / 1) and where its inside flags sit -- wave-uniform, formed ONCE per turn
       struct Src { __amdgpu_buffer_rsrc_t rs; unsigned toff; bool from0; int ainsh; };
@@ -280,21 +369,29 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
                                                                        // array base: both arrays went to scratch, a scratch load in front of every halo load)
         const bool inside = (ain >> (S.ainsh + it)) & 1u;
         const unsigned off = inside ? (S.from0 ? o0 : o1) + S.toff : 0xfffffff0u;
-        if (WS_FLAG(1)) return;
+        if (WS_FLAG(1) || WS_FLAG(32)) return;
         areg[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.rs, (int)off, 0, 0));
+        if (MFPA_WS_PACE) __builtin_amdgcn_s_sleep(MFPA_WS_PACE);
       };
       // interior tiles (no slot to zero): the table entry is the vector offset as it stands, the tile / channel offset rides in the
       // instruction's scalar offset -- no vector instruction at all per request
       auto issue_slot_interior = [&](const Src& S, auto FROM0, auto SET, auto IT) __attribute__((always_inline)) {
         constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
-        if (WS_FLAG(1)) return;
+        if (WS_FLAG(1) || WS_FLAG(32)) return;
         areg[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.rs, (int)(decltype(FROM0)::value ? off0[it] : off1[it]), (int)S.toff, 0));
+        if (MFPA_WS_PACE) __builtin_amdgcn_s_sleep(MFPA_WS_PACE);
       };
       // one staging slot: bf16 hi / lo split, two 8-byte stores into the (hi, k-group) and (lo, k-group) planes.  Per channel pair: one
       // packed conversion, the two hi values back as floats by a shift and a mask, two subtractions, one packed conversion.
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       char* const wbase = smem + plane_off(0, aq >> 1) + (lt / SPP) * 16 + 8 * (aq & 1);
+      // (a source in the SPLIT layout -- mfpa_conv_desc.x0_split / x1_split -- needs none of this: its 16 bytes at the very same offset ARE
+      //  the (hi | lo, k-group) piece aq = 4 hl + kg of the pixel: one 16-byte store)
+      char* const wbase_split = smem + plane_off(aq >> 2, aq & 3) + (lt / SPP) * 16;
+      auto copy_slot = [&](auto SET, auto IT, int stage_off) __attribute__((always_inline)) {
+        constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
+        if (WS_FLAG(1)) return;
+        *reinterpret_cast<f32x4*>(wbase_split + stage_off + it * PPI * 16) = areg[set][it];
+      };
       auto split_slot = [&](auto SET, auto IT, int stage_off) __attribute__((always_inline)) {
         constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
         if (WS_FLAG(1)) return;
@@ -308,6 +405,10 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
           lo[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
         }
         char* at = wbase + stage_off + it * PPI * 16;
+        if (WS_FLAG(64)) {                                             // (timing variants: the split stays live, nothing is stored)
+          if (hi[0] + hi[1] + lo[0] + lo[1] == 0x12345678u) *reinterpret_cast<uint2*>(at) = uint2{hi[0], hi[1]};
+          return;
+        }
         *reinterpret_cast<uint2*>(at) = uint2{hi[0], hi[1]};
         *reinterpret_cast<uint2*>(at + HLS) = uint2{lo[0], lo[1]};
       };
@@ -332,59 +433,19 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         MFPA_WS_ISSUE(6) MFPA_WS_ISSUE(7) MFPA_WS_ISSUE(8) MFPA_WS_ISSUE(9) MFPA_WS_ISSUE(10)
 #undef MFPA_WS_ISSUE
       };
-      auto split_all = [&](auto SET, int stage_off) __attribute__((always_inline)) {
+      auto split_all = [&](auto SET, int stage_off, bool src_split) __attribute__((always_inline)) {
+        if (src_split) {
+#define MFPA_WS_COPY(I) copy_slot(SET, std::integral_constant<int, I>{}, stage_off);
+          MFPA_WS_COPY(0) stamp(21); MFPA_WS_COPY(1) MFPA_WS_COPY(2) MFPA_WS_COPY(3) MFPA_WS_COPY(4) MFPA_WS_COPY(5)
+          MFPA_WS_COPY(6) MFPA_WS_COPY(7) MFPA_WS_COPY(8) MFPA_WS_COPY(9) MFPA_WS_COPY(10)
+#undef MFPA_WS_COPY
+          return;
+        }
 #define MFPA_WS_SPLIT(I) split_slot(SET, std::integral_constant<int, I>{}, stage_off);
         MFPA_WS_SPLIT(0) stamp(21); MFPA_WS_SPLIT(1) MFPA_WS_SPLIT(2) MFPA_WS_SPLIT(3) MFPA_WS_SPLIT(4) MFPA_WS_SPLIT(5)
         MFPA_WS_SPLIT(6) MFPA_WS_SPLIT(7) MFPA_WS_SPLIT(8) MFPA_WS_SPLIT(9) MFPA_WS_SPLIT(10)
 #undef MFPA_WS_SPLIT
       };
-      // the epilogue's memory work for tile `t` out of the LDS tile the compute waves filled (see the header): the 64-channel rows as
-      // 1 KB-per-wave coalesced stores (16 lanes = the 16 channel quads of a pixel, 4 pixels per wave instruction), then -- fused OutConv
-      // -- one pixel per loader thread: 64 channels x their weights + bias
-      auto duty = [&](int t) __attribute__((always_inline)) {
-        int bx = __builtin_amdgcn_readfirstlane(t);
-        const int tx = bx % a.tiles_x; bx /= a.tiles_x;
-        const int ty = bx % a.tiles_y; bx /= a.tiles_y;
-        const int ey0 = ty * PH, ex0 = tx * PW;
-        if (a.y != nullptr) {
-          char* yb = reinterpret_cast<char*>(a.y + (size_t)bx * a.H * a.W * a.Cout + n0);
-          const int q = lt & 15;
-          for (int pass = 0; pass < 16; pass += 4) {                  // four LDS reads in flight, then their four stores
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int m = (pass + u) * 16 + (lt >> 4);
-              v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + ((q ^ (m & 15)) << 4));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int m = (pass + u) * 16 + (lt >> 4);
-              const int gy = ey0 + m / PW, gx = ex0 + m % PW;
-              if (gy < a.H && gx < a.W) *reinterpret_cast<f32x4*>(yb + (((unsigned)gy * (unsigned)a.W + (unsigned)gx) * (unsigned)a.Cout + 4u * (unsigned)q) * 4u) = v[u];
-            }
-          }
-        }
-        if (a.w1x1 != nullptr) {
-          const int m = lt;
-          float sum = 0.f;
-#pragma unroll 1
-          for (int q0 = 0; q0 < 16; q0 += 4) {                         // (four pieces at a time: the whole row at once cost the kernel its register budget)
-            f32x4 v[4], w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + (((q0 + u) ^ (m & 15)) << 4));
-              w[u] = *reinterpret_cast<const f32x4*>(epi + 128 + 4 * (q0 + u));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int k = 0; k < 4; ++k) sum = fmaf(v[u][k], w[u][k], sum);
-          }
-          const int gy = ey0 + m / PW, gx = ex0 + m % PW;
-          if (gy < a.H && gx < a.W) a.y1x1[((size_t)bx * a.H + gy) * a.W + gx] = sum + a.b1x1;
-        }
-      };
-
       // the chunk sequence of this workgroup: (tile i, chunk c), c fastest.  Q = the next chunk to REQUEST.
       int qi = 0, qc = 0;
       Tile TQ = make_tile(tile_of((int)blockIdx.x, 0, G));
@@ -401,13 +462,17 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
       issue_next(SET0{});                                              // chunk 0 -> set 0
       int par = 0;
       const int total = owned * nchunks;                               // chunks this workgroup computes
-      const bool has_duty = a.y != nullptr || a.w1x1 != nullptr;
       // iteration k = -1 (prologue: chunk 0 -> stage 0, then the barrier that starts the compute waves), then k = 0 .. total - 1: while
       // the compute waves work on chunk k the loaders REQUEST chunk k + 2 into set k & 1 and then split chunk k + 1 out of the other set
       // (requested one iteration ago: a whole chunk period in flight) into the stage the compute waves read next.  The output tile of
       // tile i (last chunk k_i = (i + 1) nchunks - 1) is written by the compute waves between barriers k_i and k_i + 1, so it is read
       // here in iteration k_i + 2 -- and once more after the last barrier for the last tile; the compute waves write the next one after
       // barrier k_i + nchunks >= k_i + 2, which the loaders reach only when that iteration's work is done.
+      // is chunk number kk of this workgroup's sequence read from a source in the split layout?  (wave-uniform)
+      auto src_split_of = [&](int kk) __attribute__((always_inline)) {
+        const int c0 = (kk % nchunks) * KC;
+        return (c0 < a.C0 ? a.x0_split : a.x1_split) != 0;
+      };
       auto iteration = [&](int k, auto ISSUE_SET, auto SPLIT_SET) __attribute__((always_inline)) {
         stamp(20);
         if (k + 2 < total) issue_next(ISSUE_SET);
@@ -416,7 +481,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         // counters: chunk k + 1 goes into the stage chunk k - 1 was read from -- when all four compute waves have left it
         if (k + 1 < total) {
           if (k >= 1) wait_for(FREED, (unsigned)k);                    // every compute wave has left chunk k - 1
-          split_all(SPLIT_SET, par * STAGE);
+          split_all(SPLIT_SET, par * STAGE, src_split_of(k + 1));
           publish(READY, (unsigned)(k + 2));                           // this wave's part of chunks 0 .. k + 1 is staged
         }
         stamp(22);
@@ -430,7 +495,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         stamp(24);
         stamp(23);
 #else
-        if (k + 1 < total) split_all(SPLIT_SET, par * STAGE);
+        if (k + 1 < total) split_all(SPLIT_SET, par * STAGE, src_split_of(k + 1));
         stamp(22);
         if (has_duty && !WS_FLAG(4) && k >= nchunks + 1 && (k - 1) % nchunks == 0) duty(tile_of((int)blockIdx.x, (k - 1) / nchunks - 1, G));
         stamp(24);
@@ -461,8 +526,6 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
       // layer's zero padding), bf16 hi | lo split and the same two 8-byte plane stores as the generic loader.  48 MFMAs per chunk and wave
       // against ~1300 vector instructions per chunk and thread in conv_mfma_kernel<.., C1SRC>'s loader.
       typedef short s16x4 __attribute__((ext_vector_type(4)));
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       const int lw = wave - 4;
       const int pt0 = lw < 2 ? 6 * lw : 12 + 5 * (lw - 2), npt = lw < 2 ? 6 : 5;
       const int hr0 = (pt0 * 16) / HPW;                                  // first halo row of this wave's pixels = first patch row it keeps
@@ -588,32 +651,6 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
             char* at = smem + stage_off + plane_off(0, cth * 2 + (g >> 1)) + ((pt0 + tt) * 16 + p) * 16 + 8 * (g & 1);
             *reinterpret_cast<uint2*>(at) = uint2{h0, h1};
             *reinterpret_cast<uint2*>(at + HLS) = uint2{l0, l1};
-          }
-        }
-      };
-      const bool has_duty = a.y != nullptr || a.w1x1 != nullptr;
-      // the generic loaders' epilogue duty (stores of the 64-channel rows; the fused OutConv is not combined with a fused first layer)
-      auto duty = [&](int t) __attribute__((always_inline)) {
-        int bx = __builtin_amdgcn_readfirstlane(t);
-        const int tx = bx % a.tiles_x; bx /= a.tiles_x;
-        const int ty = bx % a.tiles_y; bx /= a.tiles_y;
-        const int ey0 = ty * PH, ex0 = tx * PW;
-        if (a.y != nullptr) {
-          char* yb = reinterpret_cast<char*>(a.y + (size_t)bx * a.H * a.W * a.Cout + n0);
-          const int q = lt & 15;
-          for (int pass = 0; pass < 16; pass += 4) {
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int m = (pass + u) * 16 + (lt >> 4);
-              v[u] = *reinterpret_cast<const f32x4*>(outbuf + m * 256 + ((q ^ (m & 15)) << 4));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int m = (pass + u) * 16 + (lt >> 4);
-              const int gy = ey0 + m / PW, gx = ex0 + m % PW;
-              if (gy < a.H && gx < a.W) *reinterpret_cast<f32x4*>(yb + (((unsigned)gy * (unsigned)a.W + (unsigned)gx) * (unsigned)a.Cout + 4u * (unsigned)q) * 4u) = v[u];
-            }
           }
         }
       };
@@ -871,8 +908,25 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
             v[j] = fmaxf(t, o);
           }
           const int py = (ey0 + 4 * wm + (pt >> 1)) / 2, px = (ex0 + (pt & 1) * 16 + p) / 2;
-          if (!(p & 1) && py < Ho && px < Wo)
-            *reinterpret_cast<f32x4*>(a.y_pool + (((size_t)eb * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32 + ct * 16 + 4 * g) = v;
+          if (!(p & 1) && py < Ho && px < Wo) {
+            float* pp = a.y_pool + (((size_t)eb * Ho + py) * Wo + px) * a.Cout + n0 + wn * 32;       // this pixel's 32-channel chunk (128 bytes)
+            if (a.y_pool_split) {
+              // split layout: channels 16 ct + 4 g .. + 3 of the chunk = half (g & 1) of k-group 2 ct + (g >> 1): 8 bytes of hi, 8 of lo
+              unsigned hi[2], lo[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const f32x2 x = {v[2 * e], v[2 * e + 1]};
+                hi[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+                const f32x2 r = {x[0] - __uint_as_float(hi[e] << 16), x[1] - __uint_as_float(hi[e] & 0xffff0000u)};
+                lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+              }
+              char* at = reinterpret_cast<char*>(pp) + (2 * ct + (g >> 1)) * 16 + 8 * (g & 1);
+              *reinterpret_cast<uint2*>(at) = uint2{hi[0], hi[1]};
+              *reinterpret_cast<uint2*>(at + 64) = uint2{lo[0], lo[1]};
+            } else {
+              *reinterpret_cast<f32x4*>(pp + ct * 16 + 4 * g) = v;
+            }
+          }
         }
     }
     }

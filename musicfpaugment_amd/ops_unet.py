@@ -185,9 +185,11 @@ def conv3x3_bn_relu(x0, w, scale, shift, x1=None, relu=True, precision=0):
 USE_WEIGHTS_DIRECT = True     # False: always the row image / LDS-staged weight tiles (A/B runs)
 FOLD_SCALE = True             # False: never pass scale-folded weights (A/B runs)
 C1_ON_MFMA = True             # False: the fused first layer stays on conv_mfma_kernel<C1SRC> (exact fp32 FMAs in its loader; A/B runs)
+SPLIT_EDGES = True            # False: every tensor between two convolutions stays float32 (A/B runs)
 
 
-def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None, wf=None, wff=None):
+def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1x1=None, store=True, c1=None, wf=None, wff=None,
+                  x0_split=False, x1_split=False, y_split=False, pool_split=False):
     """3x3 conv + folded BN + ReLU through mfpa_conv_mfma with optional fused epilogues: `pool` also writes
     MaxPool2d(2) of the output, `out1x1 = (w (64,), bias)` also writes the OutConv result (B,H,W); `store=False`
     skips the full-resolution output.  `w` must already be in the layout of `precision` (pre-split for bf16x3).
@@ -196,6 +198,9 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     `wf` = (layout, image): a fragment-ordered image of the same weights (split_bf16x3_frag); used instead of `w` where
     mfpa_conv_weight_layout says the "weights direct" kernel reading that layout serves this shape.  `wff`: the same with `scale`
     folded into the weights, used (with out_scale = None) where mfpa_conv_scale_folds says the serving kernel prefers it.
+    `x0_split` / `x1_split` / `y_split` / `pool_split` (mfpa_conv_desc.*_split): that tensor is / leaves in the SPLIT layout -- same shape
+    and bytes, [32 bf16 hi | 32 bf16 lo] per 32-channel chunk of a pixel -- which only conv_ws64_kernel launches read and write
+    (unet_forward_eval uses it on the edges between two such launches).
     Returns (y | None, y_pool | None, y1x1 | None)."""
     if c1 is not None:
         src = c1.get("x32") if c1.get("x32") is not None else c1["spec64"]
@@ -219,7 +224,8 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
                  y=ptr(y), C0=C0, C1=C1, H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=1, yH=H, yW=W, mode=0, drop_seed=0, drop_thresh=0, drop_scale=1.0,
                  precision=precision, y_pool=ptr(yp), w1x1=ptr(out1x1[0]) if out1x1 is not None else 0,
-                 b1x1=float(out1x1[1]) if out1x1 is not None else 0.0, y1x1=ptr(y1), w_layout=layout)
+                 b1x1=float(out1x1[1]) if out1x1 is not None else 0.0, y1x1=ptr(y1), w_layout=layout,
+                 x0_split=int(x0_split), x1_split=int(x1_split), y_split=int(y_split), y_pool_split=int(pool_split))
     if c1 is not None:
         d.c1_x32, d.c1_spec64, d.c1_denom = ptr(c1.get("x32")), ptr(c1.get("spec64")), ptr(c1.get("denom"))
         d.c1_w, d.c1_scale, d.c1_shift = ptr(c1["w"]), ptr(c1["scale"]), ptr(c1["shift"])
@@ -284,22 +290,44 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
                              precision=prec, wf=pw.get(f"{prefix}.{idx}.wf") if prec == 1 else None,
                              wff=pw.get(f"{prefix}.{idx}.wff") if prec == 1 else None, **kw)
 
+    def on_ws(prefix, idx, H_, W_, cin, cout):
+        """Does this launch run on conv_ws64_kernel (the only reader / writer of the split layout)?"""
+        wf_ = pw.get(f"{prefix}.{idx}.wf") if prec == 1 else None
+        return (SPLIT_EDGES and USE_WEIGHTS_DIRECT and wf_ is not None and wf_[0] == 2
+                and lib().mfpa_conv_weight_layout(H_, W_, cin, cout, 0, 1) == 2 and lib().mfpa_conv_scale_folds(H_, W_, cin, cout) == 1)
+
     p = ENC[0]
     skips = []
     src = x32 if x32 is not None else spec64
-    if FUSE_FIRST_LAYER and src.shape[2] > 16 and src.shape[1] >= 8:
+    H0, W0 = src.shape[1], src.shape[2]
+    # Edges between two conv_ws64_kernel launches carry their tensor in the SPLIT layout (round 5): the producer splits each value once,
+    # the consumer's loader waves only copy.  Every such tensor has exactly one consumer: inc -> up4.0 (the skip), inc's pool -> down1.0,
+    # down1.0 -> down1.3, down1.3's pool -> down2.0, up4.0 -> up4.3.  (down1.3's un-pooled output feeds up3.0 on conv_wd16_kernel: float32.)
+    fused_inc = FUSE_FIRST_LAYER and W0 > 16 and H0 >= 8
+    inc_ws = fused_inc and prec == 1 and C1_ON_MFMA and on_ws(p, 3, H0, W0, 64, 64) and lib().mfpa_conv_c1_layout(H0, W0) == 2
+    up4 = DEC[-1] + ".conv.double_conv"
+    e_skip0 = inc_ws and on_ws(up4, 0, H0, W0, 128, 64)
+    H1_, W1_ = H0 // 2, W0 // 2
+    d1, d2 = ENC[1], ENC[2]
+    e_pool0 = inc_ws and on_ws(d1, 0, H1_, W1_, 64, 128)
+    e_d10 = on_ws(d1, 0, H1_, W1_, 64, 128) and on_ws(d1, 3, H1_, W1_, 128, 128)
+    e_pool1 = on_ws(d1, 3, H1_, W1_, 128, 128) and on_ws(d2, 0, H1_ // 2, W1_ // 2, 128, 256)
+    e_up40 = on_ws(up4, 0, H0, W0, 128, 64) and on_ws(up4, 3, H0, W0, 64, 64)
+    if fused_inc:
         # inc.double_conv: the 1 -> 64 layer is evaluated inside the loader of the 64 -> 64 layer (no 64-channel intermediate)
-        x, xp, _ = c(None, p, 3, pool=True, c1=dict(x32=x32, spec64=spec64, denom=denom, w=pw[p + ".0.w"],
-                                                    scale=pw[p + ".0.scale"], shift=pw[p + ".0.shift"]))
+        x, xp, _ = c(None, p, 3, pool=True, y_split=e_skip0, pool_split=e_pool0,
+                     c1=dict(x32=x32, spec64=spec64, denom=denom, w=pw[p + ".0.w"], scale=pw[p + ".0.scale"], shift=pw[p + ".0.shift"]))
     else:
+        e_skip0 = e_pool0 = False
         m = conv3x3_c1_bn_relu(pw[p + ".0.w"], pw[p + ".0.scale"], pw[p + ".0.shift"], x32=x32, spec64=spec64, denom=denom)
         x, xp, _ = c(m, p, 3, pool=True)
         del m
     skips.append(x)
     for name in ENC[1:]:
-        m, _, _ = c(xp, name, 0)
+        first = name == ENC[1]
+        m, _, _ = c(xp, name, 0, x0_split=(e_pool0 if first else (e_pool1 if name == ENC[2] else False)), y_split=(e_d10 and first))
         last = name == ENC[-1]
-        x, xp, _ = c(m, name, 3, pool=not last)
+        x, xp, _ = c(m, name, 3, pool=not last, x0_split=(e_d10 and first), pool_split=(e_pool1 and first))
         del m
         if not last:
             skips.append(x)
@@ -307,11 +335,12 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
     for name in DEC:
         skip = skips.pop()
         u = convT2x2(y, pw[name + ".up.w" + sfx], pw[name + ".up.b"], precision=prec)
-        m, _, _ = c(skip, name + ".conv.double_conv", 0, x1=u)
+        final = name == DEC[-1]
+        m, _, _ = c(skip, name + ".conv.double_conv", 0, x1=u, x0_split=(e_skip0 and final), y_split=(e_up40 and final))
         del u, skip
-        if name != DEC[-1]:
+        if not final:
             y, _, _ = c(m, name + ".conv.double_conv", 3)
         else:                                               # up4: OutConv fused, the 64-channel tensor is never written
-            _, _, y = c(m, name + ".conv.double_conv", 3, out1x1=(pw["outc.w"], pw["outc.b_host"]), store=False)
+            _, _, y = c(m, name + ".conv.double_conv", 3, out1x1=(pw["outc.w"], pw["outc.b_host"]), store=False, x0_split=e_up40)
         del m
     return y

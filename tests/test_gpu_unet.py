@@ -356,3 +356,83 @@ def test_first_layer_on_the_matrix_cores_inside_the_loader_waves():
             m = F.relu(F.conv2d(xin[:, None], w1, padding=1) * s1.cpu()[None, :, None, None] + b1.cpu()[None, :, None, None])
             want = F.relu(F.conv2d(m, w2, padding=1) * s2.cpu()[None, :, None, None] + b2.cpu()[None, :, None, None])
             assert relative_l1(got.cpu().permute(0, 3, 1, 2), want) < 1e-4
+
+
+def _to_split(x):
+    """float32 NHWC (C % 32 == 0) -> the SPLIT layout of include/mfpa.h (mfpa_conv_desc.x0_split ...): per pixel and 32-channel chunk
+    [32 bf16 hi | 32 bf16 lo], returned as a float32 tensor of the same shape (same bytes)."""
+    B, H, W, C = x.shape
+    x4 = x.reshape(B, H, W, C // 32, 32)
+    hi = x4.to(torch.bfloat16)
+    lo = (x4 - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32).reshape(B, H, W, C)
+
+
+def test_split_layout_between_wave_specialised_convolutions():
+    """Round 5: between two conv_ws64_kernel launches a tensor travels in the SPLIT layout -- [32 bf16 hi | 32 bf16 lo] per 32-channel chunk of a
+    pixel, the very pieces a bf16x3 loader makes of float32 values -- so the producer splits each value ONCE and the consumer's loader waves
+    only copy.  (1) A source handed over in that layout gives the SAME BITS as the float32 tensor it was made from (source 0, source 1, both;
+    two and four chunks; ragged edges and many tiles).  (2) `y_split` / `pool_split` outputs ARE the split of the float32 outputs, bit for
+    bit (64- and 128-channel outputs, with the fused first layer too).  (3) The whole UNet with and without split edges: identical output.
+    (4) A launch conv_ws64_kernel does not serve refuses the flags."""
+    import torch.nn.functional as F
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd._lib import lib
+    g = torch.Generator().manual_seed(29)
+    if K.frag_layout() != 2:
+        pytest.skip("the library was built without the 16 x 16 x 32 weights-direct kernels")
+    for (B, H, W, C0, C1, Cout, pool) in [(2, 9, 37, 64, 0, 64, False), (3, 40, 70, 64, 64, 64, True), (6, 128, 125, 64, 0, 128, True),
+                                          (2, 33, 31, 128, 0, 128, True), (20, 257, 251, 64, 64, 64, False), (2, 64, 62, 128, 0, 256, False)]:
+        assert lib().mfpa_conv_scale_folds(H, W, C0 + C1, Cout) == 1
+        x0 = torch.randn(B, H, W, C0, generator=g).cuda()
+        x1 = torch.randn(B, H - 1, W - 1, C1, generator=g).cuda() if C1 else None
+        w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))
+        sc, sh = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+        wk = K.pack_conv3x3(w).cuda()
+        w3, wf = K.split_bf16x3(wk), (2, K.split_bf16x3_frag(wk, 2))
+        ref, ref_p, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, wf=wf)
+        # (1) split sources
+        a, a_p, _ = K.conv3x3_fused(_to_split(x0), w3, sc, sh, x1=x1, precision=1, pool=pool, wf=wf, x0_split=True)
+        assert torch.equal(a, ref) and (not pool or torch.equal(a_p, ref_p)), (B, H, W, C0, C1, Cout)
+        if C1:
+            b_, _, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=_to_split(x1), precision=1, pool=pool, wf=wf, x1_split=True)
+            c_, _, _ = K.conv3x3_fused(_to_split(x0), w3, sc, sh, x1=_to_split(x1), precision=1, pool=pool, wf=wf, x0_split=True, x1_split=True)
+            assert torch.equal(b_, ref) and torch.equal(c_, ref)
+        # (2) split outputs
+        s_, s_p, _ = K.conv3x3_fused(x0, w3, sc, sh, x1=x1, precision=1, pool=pool, wf=wf, y_split=True, pool_split=pool)
+        assert torch.equal(s_.view(torch.int32), _to_split(ref).view(torch.int32)), (B, H, W, C0, C1, Cout)
+        if pool:
+            assert torch.equal(s_p.view(torch.int32), _to_split(ref_p).view(torch.int32))
+    # the fused first layer as a producer
+    B, H, W = 3, 40, 70
+    w1k = (torch.randn(9, 64, generator=g) / 3.0).cuda()
+    s1, b1 = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.2).cuda()
+    wk = K.pack_conv3x3(torch.randn(64, 64, 3, 3, generator=g) / 24.0).cuda()
+    w3, wf = K.split_bf16x3(wk), (2, K.split_bf16x3_frag(wk, 2))
+    sc, sh = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    c1 = dict(x32=torch.rand(B, H, W, generator=g).cuda(), w=w1k, scale=s1, shift=b1)
+    ref, ref_p, _ = K.conv3x3_fused(None, w3, sc, sh, precision=1, pool=True, wf=wf, c1=c1)
+    s_, s_p, _ = K.conv3x3_fused(None, w3, sc, sh, precision=1, pool=True, wf=wf, c1=c1, y_split=True, pool_split=True)
+    assert torch.equal(s_.view(torch.int32), _to_split(ref).view(torch.int32)) and torch.equal(s_p.view(torch.int32), _to_split(ref_p).view(torch.int32))
+    # (3) the whole network
+    from musicfpaugment_amd.training.unet import UNet
+    m = UNet(1, 1, rate=0.05)
+    m.load_state_dict(formula_state_dict(0))
+    m = m.cuda().eval()
+    m.precision = 1
+    x = torch.from_numpy(synth.batch(3, seed=77)).cuda()
+    from musicfpaugment_amd import ops
+    mag, cmax = ops.stft_mag(x, torch.float64)
+    with torch.no_grad():
+        y_split = m.denoise_spectrogram(mag, cmax, per_clip=True)
+        K.SPLIT_EDGES = False
+        try:
+            y_plain = m.denoise_spectrogram(mag, cmax, per_clip=True)
+        finally:
+            K.SPLIT_EDGES = True
+    assert torch.equal(y_split, y_plain)
+    # (4) refused elsewhere: a 512-input-channel layer runs on conv_wd16_kernel
+    xs = torch.randn(1, 32, 31, 512, generator=g).cuda()
+    wk = K.pack_conv3x3(torch.randn(128, 512, 3, 3, generator=g) / 60.0).cuda()
+    with pytest.raises(ValueError):
+        K.conv3x3_fused(xs, K.split_bf16x3(wk), torch.ones(128).cuda(), torch.zeros(128).cuda(), precision=1, wf=(2, K.split_bf16x3_frag(wk, 2)), x0_split=True)

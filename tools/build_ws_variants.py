@@ -2,7 +2,8 @@
 """Timing-only variants of conv_ws64_kernel (csrc/unet_ws.hip) as compile-time skips of the PRODUCT code: for every <bits> given, compile
 unet_ws.hip with -DMFPA_SKIP_BITS=<bits> and link it with the product build's other objects -> musicfpaugment_amd/libmfpa_ws_<bits>.so
 (never loaded by the package; wrong results by design).  Bits: 1 loaders skip the halo (loads + split), 2 compute waves skip the epilogue,
-4 loaders skip the stores, 8 no fragment reads in the loop, 16 no weight loads in the loop.  Extra -D flags after `--`."""
+4 loaders skip the stores, 8 no fragment reads in the loop, 16 no weight loads in the loop, 32 no halo REQUESTS (split + LDS stores stay),
+64 no LDS stores of the split halo (requests + split stay).  Extra -D flags after `--`."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
