@@ -169,7 +169,14 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
   auto stamp = [&](int tag) __attribute__((always_inline)) {
     if (stamping && stamp_n < WS_MAX_STAMPS) tsbuf[stamp_n++] = (__builtin_amdgcn_s_memtime() & ~0xffull) | (unsigned)tag;
   };
+  // the clock the chip holds inside this kernel (MI355X_MICROARCH.md, DVFS give-back item 6): every workgroup's first compute wave writes
+  // {d s_memtime (shader clock), d s_memrealtime (100 MHz)} over its whole life to ws_stamps[3000 + 2 * workgroup]
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   auto dump_stamps = [&]() __attribute__((always_inline)) {
+    if (ws_stamps != nullptr && tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+      ws_stamps[3000 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+      ws_stamps[3001 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
     if (stamping) {
       unsigned long long* out = ws_stamps + (wave >= 4 ? 2048 : 0);
       for (int i = 0; i < stamp_n; ++i) out[1 + i] = tsbuf[i];
