@@ -654,7 +654,7 @@ def bench_infer(args, rank, world, dev, dist):
         if args.unet_pass > 0:
             net.max_clips_per_pass = args.unet_pass
         net.two_streams = bool(args.two_streams)
-    hot = HotPath(net, device=dev, picker=args.picker)
+    hot = HotPath(net, device=dev, picker=args.picker, streams=max(1, int(getattr(args, "batch_streams", 1) or 1)))
     UNET_MFMA_GFLOP_PER_CLIP = unet_mfma_gflop(257, 251 if args.picker == "audfprint" else 249)
 
     # synthetic clips of SURVEY.md §8d: 32 distinct generated clips per rank, tiled to B with a sign/gain variation
@@ -675,12 +675,14 @@ def bench_infer(args, rank, world, dev, dist):
         t0 = time.perf_counter()
         for _ in range(steps):
             out = hot(wav)
+        hot.join()                                           # (--batch-streams > 1: consecutive batches overlap; every one is complete here)
         barrier()
         ops_unet.set_timer(None)
         return time.perf_counter() - t0, timer, out
 
     for _ in range(args.warmup):
         mask, npeaks = hot(wav)
+    hot.join()
     barrier()
     dt, timer, (mask, npeaks) = timed(args.steps)
     other = None
@@ -755,6 +757,7 @@ def bench_infer(args, rank, world, dev, dist):
                                "STFT(512/256,f64) -> per-clip normalise -> log/mean/high-pass -> Audfprint forward+backward "
                                "prune (BASELINE configs[1]); 8 s / 8 kHz clips",
                    "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "peaks_last_step_rank0": total_peaks,
+                   **({"batch_streams": len(hot._side)} if hot._side else {}),
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
                    **({"why_256": "BASELINE configs[1]'s batch; the UNet runs in passes of <= 128 clips, so clips/s is the same at configs[2]'s 512 "
                                   "(configs.config3_unet_forward_fp32_512 is that batch at the reference's fp32 arithmetic)"}
@@ -874,6 +877,9 @@ def other_configs(args, dev):
     out = {}
     plan = [
         ("config2_stft_peakpick_audfprint", bench_infer, dict(no_unet=True, picker="audfprint", steps=20, warmup=3, clips=256)),
+        # the same 256-clip batches with consecutive batches on three HIP streams in turn (HotPath(streams=3)): the pruner is one wavefront per
+        # clip -- 263 us of a 449 us batch with one wave per CU -- so the next batch's STFT / log launches run beside it
+        ("config2_stft_peakpick_audfprint_3streams", bench_infer, dict(no_unet=True, picker="audfprint", steps=60, warmup=6, clips=256, batch_streams=3)),
         ("config2_stft_peakpick_audfprint_8192", bench_infer, dict(no_unet=True, picker="audfprint", steps=5, warmup=2, clips=8192)),
         ("config2_stft_peakpick_dejavu", bench_infer, dict(no_unet=True, picker="dejavu", steps=20, warmup=3, clips=256)),
         ("config3_unet_forward_fp32_512", bench_infer, dict(precision="fp32", steps=3, warmup=1, clips=512)),
@@ -1092,6 +1098,8 @@ def main():
     ap.add_argument("--queries", type=int, default=10000, help="metrics mode: total number of queries (split over the ranks)")
     ap.add_argument("--denoiser", choices=["demucs", "unet"], default="demucs", help="metrics mode: the denoiser under test")
     ap.add_argument("--unet-pass", type=int, default=0, help="infer mode: clips per UNet pass (0 = the module default)")
+    ap.add_argument("--batch-streams", type=int, default=1,
+                    help="infer mode: consecutive batches (steps) run on this many HIP streams in turn (HotPath(streams=)); 1 = serial")
     ap.add_argument("--two-streams", action="store_true", help="infer mode: alternate the UNet passes of a step on two streams")
     ap.add_argument("--seconds", type=float, default=8.0, help="train / demucs-train modes: clip length (the reference trains on 3 s)")
     ap.add_argument("--mode", choices=["infer", "train", "demucs", "demucs-train", "metrics", "launch-check"], default="infer",

@@ -45,15 +45,23 @@ class HotPath:
     """picker "audfprint": STFT -> /max -> [UNet] -> log / mean / high-pass -> decaying-threshold prune (peak_extractor.py:236-311);
     picker "dejavu": specgram PSD -> /max -> [UNet, squared] -> 10 ln / mean -> 21 x 21 local maxima (fingerprint.py:56-171)."""
 
-    def __init__(self, unet, device="cuda", picker: str = "audfprint"):
+    def __init__(self, unet, device="cuda", picker: str = "audfprint", streams: int = 1):
+        """`streams` > 1: consecutive calls run on `streams` HIP streams in turn, so that batch k + 1's STFT overlaps batch k's pruner
+        (one wavefront per clip: at 256 clips it leaves the card almost empty for 263 us of a 449 us batch).  Every call still waits
+        for the work the caller has queued on the current stream (its input); the RESULTS of such calls are ordered behind the current
+        stream only by `join()` -- call it before reading them.  The kernels and their results are the serial path's (per-call buffers)."""
         if picker not in ("audfprint", "dejavu"):
             raise ValueError("picker must be 'audfprint' or 'dejavu'")
+        if streams < 1:
+            raise ValueError("streams must be >= 1")
         self.picker, self.unet = picker, unet
         self.extractor = Audfprint_peaks(None, denoising=unet is not None, denoising_model="unet" if unet else None,
                                          unet=unet, device=device)
+        self._side = [torch.cuda.Stream(device=device) for _ in range(streams)] if streams > 1 else []
+        self._turn = 0
 
     @torch.no_grad()
-    def __call__(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _run(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if self.picker == "dejavu":
             from .afp.dejavu.fingerprint import fingerprint_peaks_batch
             mask, npeaks, _ = fingerprint_peaks_batch(wav, denoising=self.unet is not None, denoising_model="unet", unet=self.unet,
@@ -61,6 +69,25 @@ class HotPath:
             return mask, npeaks
         mask, npeaks, _ = self.extractor.find_peaks_batch(wav, want_spec=False)
         return mask, npeaks
+
+    def __call__(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if not self._side:
+            return self._run(wav)
+        s = self._side[self._turn % len(self._side)]
+        self._turn += 1
+        cur = torch.cuda.current_stream(wav.device)
+        s.wait_stream(cur)                                     # the input was produced on the caller's stream
+        with torch.cuda.stream(s):
+            mask, npeaks = self._run(wav)
+        for t in (wav, mask, npeaks):                          # the allocator must not hand these blocks out while either stream uses them
+            t.record_stream(s)
+            t.record_stream(cur)
+        return mask, npeaks
+
+    def join(self) -> None:
+        """Order the current stream behind every call made so far (no host wait).  No-op with one stream."""
+        for s in self._side:
+            torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
