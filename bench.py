@@ -498,9 +498,12 @@ def bench_train(args, rank, world, dev, dist):
     "bf16 MFMA"; bf16x3 is its fp32-accurate form) for forward, input-gradient and weight-gradient convolutions;
     --precision fp32 runs the exact-fp32 MFMA path."""
     from musicfpaugment_amd import ops, ops_unet, synth
+    from musicfpaugment_amd import ops_train
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
     from musicfpaugment_amd.training.weights import formula_state_dict
+    if getattr(args, "no_z16", False):
+        ops_train.Z16_ACTIVATIONS = False
 
     B = args.clips if args.scaling == "weak" else max(1, args.clips // world)
     net = UNet(1, 1, rate=0.05)
@@ -1086,6 +1089,7 @@ def main():
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
+    ap.add_argument("--no-z16", action="store_true", help="train mode (plain bf16): keep the activations in HBM as float32 (ops_train.Z16_ACTIVATIONS = False; A/B runs)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
     ap.add_argument("--wgrad", choices=["fp32", "bf16x3", "bf16"], default=None,
                     help="train mode: arithmetic of the weight-gradient kernel (default: bf16 with --precision bf16x3 -- one bf16 MFMA "

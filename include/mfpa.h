@@ -276,8 +276,12 @@ typedef struct mfpa_conv_desc {
    * (sum g, sum g * xhat) with g = dy where bwd_z * scale + shift > 0 else 0: after mfpa_conv_stats_reduce the `local_sums` of
    * mfpa_bn_relu_bwd_finish, without the reduction pass over (dy, z). */
   const float* bwd_z; const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_invstd;
-  /* precision 2, one source, no on-load affine: x0 is a BFLOAT16 tensor (B,H,W,C0), C0 % 64 == 0 -- the bf16 copy of dz written by
-   * mfpa_bn_relu_bwd: the loader stages it without any split arithmetic and moves half the bytes. */
+  /* x0 (and x1, when given) are BFLOAT16 tensors.  precision 2, mode 0, (C0 + C1) % 64 == 0 (conv_wd16_kernel): the bf16 copy of dz
+   * written by mfpa_bn_relu_bwd -- staged without any split arithmetic, half the bytes -- or, round 5, the training step's activations
+   * kept as bfloat16 in HBM: an on-load affine / ReLU / dropout is applied in float32 to the widened values and rounded to bf16 once
+   * (x0_bf16 still receives that copy; x1 is its own copy: x1_bf16 must be null).  mode 1, precision 1: the transposed convolution's
+   * source.  Such a launch may also leave its OUTPUT as bfloat16 only: y null, y_bf16 the (B,yH,yW,Cout) [mode 1: (B,2H,2W,Cout)]
+   * destination (stats_part still describes the float32 accumulators). */
   int x0_is_bf16;
   /* round 5, inference launches that conv_ws64_kernel serves only (mfpa_conv_scale_folds() == 1; otherwise MFPA_EINVAL): tensors in the
    * SPLIT layout -- same shape and byte count as the float32 NHWC tensor, but every 32-channel chunk of a pixel holds [32 bf16 hi | 32
@@ -285,6 +289,8 @@ typedef struct mfpa_conv_desc {
    * ONCE by the producer.  x0_split / x1_split: source 0 / 1 arrives in it (the loader waves copy 16-byte pieces, no arithmetic);
    * y_split / y_pool_split: `y` / `y_pool` leave in it.  A split tensor can only feed another such launch. */
   int x0_split, x1_split, y_split, y_pool_split;
+  /* bwd_z is a BFLOAT16 tensor (the activations of the line above). */
+  int bwd_z_is_bf16;
 } mfpa_conv_desc;
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream);
 /* HOST function: the w_layout (0, 1 or 2) the fastest kernel for a (H, W) convolution of this shape reads. */
@@ -310,7 +316,7 @@ int mfpa_conv_stats_reduce(const float* part, long long rows, int C, double* sum
  *   w (9, Cout), y (B,H,W,Cout). */
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip,
                             int B, int H, int W, const float* w, int Cout,
-                            const float* scale, const float* shift, int relu, float* y, void* stream);
+                            const float* scale, const float* shift, int relu, float* y, int y_is_bf16, void* stream);
 
 /* MaxPool2d(2), floor (unet.py:34).  x (B,H,W,C) -> y (B,H/2,W/2,C). */
 int mfpa_maxpool2(const float* x, int B, int H, int W, int C, float* y, void* stream);
@@ -338,7 +344,7 @@ int mfpa_red_blocks(void);
  * in place when non-NULL. */
 int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, const float* beta, float eps,
                   float momentum, float* mean, float* invstd, float* scale, float* shift,
-                  float* running_mean, float* running_var, double* workspace, void* stream);
+                  float* running_mean, float* running_var, double* workspace, int z_is_bf16, void* stream);
 
 /* BatchNorm+ReLU backward: dy (gradient w.r.t. relu(bn(z))) is overwritten with the gradient w.r.t. z;
  * dgamma, dbeta (C) are produced; coef is a (3, C) scratch.  dz_bf16 (optional, may be NULL): a bf16 copy of the result, written in
@@ -347,7 +353,7 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, float* coef, double* workspace,
                      unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32,
-                     void* stream);
+                     int z_is_bf16, void* stream);
 /* write_f32 = 0 (needs dz_bf16): only the bf16 copy of dz is written -- every consumer reads it (the plain-bf16 train step: the
  * input-gradient convolution takes it through mfpa_conv_desc.x0_is_bf16, the weight gradient as its bf16 operand) and dy is left as it was. */
 
@@ -356,18 +362,18 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
  * forward, (sum g, sum g*xhat) backward, g = the ReLU/dropout-masked incoming gradient -- the caller all-reduces (SUM) them
  * and the pixel count over the ranks, *_finish completes from the global sums.  Backward: dgamma / dbeta come from the LOCAL
  * sums (the gradient all-reduce adds the ranks), the mean terms of the input gradient from the GLOBAL ones. */
-int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, void* stream);
+int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, int z_is_bf16, void* stream);
 int mfpa_bn_stats_finish(const double* sums, double count, int C, const float* gamma, const float* beta, float eps,
                          float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
                          float* running_var, void* stream);
 int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C, const float* scale, const float* shift,
                           const float* mean, const float* invstd, double* sums, double* workspace, unsigned drop_seed,
-                          unsigned drop_thresh, float drop_scale, void* stream);
+                          unsigned drop_thresh, float drop_scale, int z_is_bf16, void* stream);
 int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
                             unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32,
-                            void* stream);
+                            int z_is_bf16, void* stream);
 
 /* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
 int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);
@@ -377,10 +383,10 @@ int mfpa_colsum(const float* x, long long npix, int C, float* out, double* works
  * to relu(bn(z)) with the stateless mask of mfpa_conv_desc (thresh 0 = no dropout); mfpa_bn_relu_bwd applies the
  * same mask to the incoming gradient. */
 int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* scale, const float* shift,
-                      float* p, unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
+                      float* p, unsigned drop_seed, unsigned drop_thresh, float drop_scale, int z_is_bf16, int p_is_bf16, void* stream);
 int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const float* scale,
                           const float* shift, const float* dp, float* dy,
-                          unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream);
+                          unsigned drop_seed, unsigned drop_thresh, float drop_scale, int z_is_bf16, void* stream);
 
 /* The same pass, which also forms the partial sums of the BatchNorm backward that follows on this layer (training/unet.py:17-20 under
  * autograd: sum g and sum g * xhat per channel, g = dy * [z*scale+shift > 0] (* dropout), xhat = (z - mean) * invstd) over ALL pixels of
@@ -388,7 +394,7 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
  * mfpa_conv_stats_reduce + mfpa_bn_relu_bwd_finish: the separate reduction pass over dy and z is not needed.  C / 4 must divide 256. */
 int mfpa_maxpool2_bwd_add_sums(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, const float* mean,
                                const float* invstd, const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh,
-                               float drop_scale, float* part, void* stream);
+                               float drop_scale, float* part, int z_is_bf16, void* stream);
 
 /* Weight gradient on MFMA, ACCUMULATED into dw (zero it first):
  *   mode 0: dw[tap][co][ci] += sum_p dz[p][co] * xin[p + tap][ci]          (3x3 conv; dw (9,Cout,C0+C1))
@@ -423,9 +429,9 @@ int mfpa_wgrad_c1(const float* dz, const float* x32, const double* spec64, const
 /* OutConv in training: pred[p] = sum_c relu(z[p][c]*scale[c]+shift[c]) * w[c] + bias[0];
  * backward: dy[p][c] = dpred[p]*w[c], dwb = [C weight gradients, bias gradient]. */
 int mfpa_outconv_fwd(const float* z, long long npix, int C, const float* scale, const float* shift,
-                     const float* w, const float* bias, float* pred, void* stream);
+                     const float* w, const float* bias, float* pred, int z_is_bf16, void* stream);
 int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, const float* scale,
-                     const float* shift, const float* w, float* dy, float* dwb, double* workspace, void* stream);
+                     const float* shift, const float* w, float* dy, float* dwb, double* workspace, int z_is_bf16, void* stream);
 /* The same backward WITHOUT materialising dy (it is rank 1: dpred[p] * w[c]): the pass forms dwb and, holding z and dy of every element
  * anyway, the partial sums of the BatchNorm backward that follows on z's layer ({sum g, sum g * xhat}, one row of `part`
  * (mfpa_outconv_bwd_rows(npix, C), 2, C) float per workgroup, finished by mfpa_conv_stats_reduce); mfpa_bn_relu_bwd_finish_rank1 then
@@ -434,11 +440,11 @@ int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, 
 int mfpa_outconv_bwd_rows(long long npix, int C, int* rows);
 int mfpa_outconv_bwd_sums(const float* z, const float* dpred, long long npix, int C, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* w, float* dwb, double* workspace, float* part,
-                          void* stream);
+                          int z_is_bf16, void* stream);
 int mfpa_bn_relu_bwd_finish_rank1(const float* dpred, const float* w1, const float* z, long long npix, int C, const float* gamma,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
                                   const double* local_sums, const double* global_sums, double global_count, float* dgamma,
-                                  float* dbeta, float* coef, float* dz_f32, void* dz_bf16, void* stream);
+                                  float* dbeta, float* coef, float* dz_f32, void* dz_bf16, int z_is_bf16, void* stream);
 
 /* nn.L1Loss(mean) of float32 pred against the float64 target (train.py:280): loss[0] (float64) and,
  * if dpred != NULL, dpred = sign(pred - target) / n. */

@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 
 class MfpaError(RuntimeError):
@@ -57,7 +57,7 @@ _SIGNATURES = {
     "mfpa_conv3x3_bn_relu": ([c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_conv3x3_c1_bn_relu": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
+                                 c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
     "mfpa_maxpool2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_convT2x2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                        c_void_p], c_int),
@@ -123,37 +123,37 @@ _SIGNATURES = {
     "mfpa_downsample2_adjoint": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_red_blocks": ([], c_int),
     "mfpa_bn_stats": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
-                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "mfpa_bn_relu_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_int, c_void_p], c_int),
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_int, c_int, c_void_p], c_int),
     "mfpa_conv_stats_rows": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "mfpa_conv_stats_reduce": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
-    "mfpa_bn_stats_sums": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_stats_sums": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "mfpa_bn_stats_finish": ([c_void_p, c_double, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_bwd_sums": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_uint, c_uint, c_float, c_void_p], c_int),
+                               c_void_p, c_uint, c_uint, c_float, c_int, c_void_p], c_int),
     "mfpa_bn_relu_bwd_finish": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
-                                 c_void_p, c_int, c_void_p], c_int),
+                                 c_void_p, c_int, c_int, c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
-                           c_void_p], c_int),
+                           c_int, c_int, c_void_p], c_int),
     "mfpa_maxpool2_bwd_add": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_uint, c_uint, c_float, c_void_p], c_int),
+                               c_uint, c_uint, c_float, c_int, c_void_p], c_int),
     "mfpa_maxpool2_bwd_add_sums": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
+                                    c_uint, c_uint, c_float, c_void_p, c_int, c_void_p], c_int),
     "mfpa_wgrad_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_wgrad_c1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
-    "mfpa_outconv_fwd": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mfpa_outconv_fwd": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
                          c_int),
     "mfpa_outconv_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p], c_int),
+                          c_void_p, c_int, c_void_p], c_int),
     "mfpa_outconv_bwd_rows": ([c_longlong, c_int, c_void_p], c_int),
     "mfpa_outconv_bwd_sums": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p], c_int),
+                               c_void_p, c_int, c_void_p], c_int),
     "mfpa_bn_relu_bwd_finish_rank1": ([c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+                                       c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p], c_int),
     "mfpa_l1_loss": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_act_to_bf16": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
     "mfpa_pack_conv_weights": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
@@ -175,7 +175,7 @@ class ConvDesc(ctypes.Structure):
                 ("c1_w", c_void_p), ("c1_scale", c_void_p), ("c1_shift", c_void_p), ("w_layout", c_int),
                 ("x0_bf16", c_void_p), ("x1_bf16", c_void_p), ("y_bf16", c_void_p), ("stats_part", c_void_p),
                 ("bwd_z", c_void_p), ("bwd_scale", c_void_p), ("bwd_shift", c_void_p), ("bwd_mean", c_void_p), ("bwd_invstd", c_void_p),
-                ("x0_is_bf16", c_int), ("x0_split", c_int), ("x1_split", c_int), ("y_split", c_int), ("y_pool_split", c_int)]
+                ("x0_is_bf16", c_int), ("x0_split", c_int), ("x1_split", c_int), ("y_split", c_int), ("y_pool_split", c_int), ("bwd_z_is_bf16", c_int)]
 
 
 class GemmDesc(ctypes.Structure):

@@ -25,13 +25,14 @@ struct ConvArgs {
   float b1x1;                        //   y1x1[pixel] = sum_c out[pixel][c] * w1x1[c] + b1x1
   float* y1x1;
   int w_frag;                        // 1: `w` is the fragment-ordered bf16x3 image of the BDIR kernels (mfpa_conv_desc.w_layout)
-  int in16;                          // conv_wd16_kernel (plain): source 0 is a bfloat16 tensor (mfpa_conv_desc.x0_is_bf16)
+  int in16;                          // conv_wd16_kernel (plain) / convT_mfma_kernel: the sources are bfloat16 tensors (mfpa_conv_desc.x0_is_bf16)
   int x0_split, x1_split, y_split, y_pool_split;   // conv_ws64_kernel: tensors in the split layout ([32 bf16 hi | 32 bf16 lo] per 32-channel chunk; mfpa_conv_desc)
   int plain;                         // conv_wd16_kernel: plain bf16 products (hi halves only: mfpa_conv_desc.precision 2, the training step)
   __bf16* x0_bf16;                   // conv_wd16_kernel: optional bf16 copy of the activated source 0, (B,H,W,C0) (mfpa_conv_desc.x0_bf16)
   __bf16* x1_bf16;                   // ... of source 1, (B,H1,W1,C1)
   __bf16* y_bf16;                    // ... of the stored output, (B,yH,yW,Cout)
   const float* bz;                   // conv_wd16_kernel + stats_part: the output is a gradient dy w.r.t. relu(bn(bz)), bz (B,yH,yW,Cout): the partials are
+  int bz16;                          //   (bz is a bfloat16 tensor: mfpa_conv_desc.bwd_z_is_bf16)
   const float* bz_scale;             //   (sum g, sum g * xhat), g = dy where bz * bz_scale + bz_shift > 0 else 0, xhat = (bz - bz_mean) * bz_invstd --
   const float* bz_shift;             //   the two reductions of the BatchNorm backward (mfpa_conv_desc.bwd_z ...)
   const float* bz_mean;

@@ -41,6 +41,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef MFPA_WD16_PERSIST_PLAIN
 #define MFPA_WD16_PERSIST_PLAIN 1  // the same for the plain-bf16 (training) instantiations, whose MFMA time is a third: prologue / epilogue weigh three times more
@@ -309,7 +311,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
             // samples in one register pair and selects the odd one with v_pk_fma_f32 ... op_sel:[1,0,0], the operand-selection form
             // the library does not ship (mfpa_common.h; tests/test_isa_scan.py).  One v_mov per sample; scalar FMAs in its place made
             // this kernel 18 % slower (7.0 instead of 5.8 vector instructions per MFMA).
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -1020,8 +1021,10 @@ __device__ __forceinline__ float dpp_row_add(float v) {               // v + (v 
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false, bool PLAIN = false, bool IN16 = false>
+template <int PH, int PW, bool ROWS, int WMW = 2, bool SIDE = false, bool PLAIN = false, bool IN16 = false, bool AFF16 = false>
 __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
+  // AFF16 (with IN16 and SIDE): the bfloat16 source 0 carries an on-load affine + ReLU (+ dropout) and the output may leave as bfloat16 only --
+  // the training FORWARD with its activations kept as bfloat16; the input-gradient launches (IN16 without it) carry none of that code
   // PLAIN: plain bf16 products -- one MFMA per product on the hi halves only (the lo planes, their fragment reads, the lo weight
   // fragments and two of the three MFMA terms are gone): the training step's "bf16 MFMA" arithmetic (BASELINE config 4), relative
   // error ~2^-9 per product instead of bf16x3's 2^-17.  Never used by the inference chain (its 1e-4 gate needs bf16x3).
@@ -1206,7 +1209,47 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
     f32x4 v = areg[it % AREGS];
     if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (IN16) {                                              // eight bf16 channels = the lane's whole (hi, k-group aq) piece
+      if (AFF16 && a.in_scale0 != nullptr && c0 < a.C0 && inside) {
+        // bf16 z (the training step's activations kept as bfloat16 in HBM): widen, the producer's BatchNorm affine + ReLU (+ dropout) in
+        // float32 exactly as the float32 path applies them, round to bf16 once -- the MFMA operand
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned u = __float_as_uint(v[k]);
+          f[2 * k] = __uint_as_float(u << 16);
+          f[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+        const float* scp = aff + c0 + 8 * aq;
+        const float* shp = aff + a.C0 + c0 + 8 * aq;
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scp), sc1 = *reinterpret_cast<const f32x4*>(scp + 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shp), sh1 = *reinterpret_cast<const f32x4*>(shp + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float y = f[k] * (k < 4 ? sc0[k & 3] : sc1[k & 3]) + (k < 4 ? sh0[k & 3] : sh1[k & 3]);
+          f[k] = y > 0.f ? y : 0.f;
+        }
+        if (a.drop_thresh) {
+          const int gy = S.y0 + pix / HPW - 1, gx = S.x0p + pix % HPW - 1;   // inside the image here
+          const unsigned long long e0 = (((unsigned long long)S.b * a.H + gy) * a.W + gx) * a.C0 + c0 + 8 * aq;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] = mfpa_keep(a.drop_seed, a.drop_thresh, e0 + k) ? f[k] * a.drop_scale : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bf16x2 h2;
+          h2[0] = (__bf16)f[2 * k];
+          h2[1] = (__bf16)f[2 * k + 1];
+          v[k] = __builtin_bit_cast(float, h2);
+        }
+      }
       *reinterpret_cast<f32x4*>(stage + plane_off(0, aq) + pix * 16) = v;
+      if constexpr (SIDE && AFF16) {                                   // the activated source 0 as the weight gradient reads it (see below)
+        const int py = pix / HPW, px = pix % HPW;
+        if (a.x0_bf16 != nullptr && c0 < a.C0 && inside && py >= 1 && py <= PH && px >= 1 && px <= PW && blockIdx.y == 0) {
+          const size_t e = (size_t)S.b * a.H * a.W * a.C0 + ((aoffs0[it * THREADS + tid] + S.t0) >> 1) + c0;
+          *reinterpret_cast<f32x4*>(a.x0_bf16 + e) = v;
+        }
+      }
       return;
     }
     if (a.in_scale0 != nullptr && c0 < a.C0 && inside) {
@@ -1618,16 +1661,34 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
   #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         f32x4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
-        if (a.bz != nullptr) {
+        if (!AFF16 && a.bz != nullptr) {                                 // (never in the training forward's AFF16 form)
           // the output is dy of a BatchNorm + ReLU whose input bz has this tensor's shape: (sum g, sum g * xhat) instead (see ConvArgs)
           const int ch = n0 + wn * 32 + ct * 16 + 4 * g;
           const f32x4 bsc = *reinterpret_cast<const f32x4*>(a.bz_scale + ch), bsh = *reinterpret_cast<const f32x4*>(a.bz_shift + ch);
           const f32x4 bmu = *reinterpret_cast<const f32x4*>(a.bz_mean + ch), bis = *reinterpret_cast<const f32x4*>(a.bz_invstd + ch);
-  #pragma unroll
-          for (int pt = 0; pt < PT; ++pt) {
+          // (the dtype branch sits OUTSIDE the pixel loop: inside it, every iteration was branch -> load -> wait, eight dependent round trips)
+          f32x4 zzs[PT];
+          auto zoff = [&](int pt) __attribute__((always_inline)) {
             const int m = wm * WPXW + pt * 16 + p;
             const int gy = min(ey0 + m / PW, a.yH - 1), gx = min(ex0p + m % PW, a.yW - 1);      // clamped; masked by vm
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(a.bz + (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + ch);
+            return (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + ch;
+          };
+          if (a.bz16) {                                                  // bz kept as bfloat16 (mfpa_conv_desc.bwd_z_is_bf16)
+            f32x2 raw[PT];
+  #pragma unroll
+            for (int pt = 0; pt < PT; ++pt) raw[pt] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const __bf16*>(a.bz) + zoff(pt));
+  #pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+              const unsigned u0 = __float_as_uint(raw[pt][0]), u1 = __float_as_uint(raw[pt][1]);
+              zzs[pt] = f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u)};
+            }
+          } else {
+  #pragma unroll
+            for (int pt = 0; pt < PT; ++pt) zzs[pt] = *reinterpret_cast<const f32x4*>(a.bz + zoff(pt));
+          }
+  #pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            const f32x4 zz = zzs[pt];
   #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float gg = (zz[j] * bsc[j] + bsh[j] > 0.f) ? acc[ct][pt][j] * vm[pt] : 0.f;
@@ -1657,7 +1718,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         }
       }
     }
-    if (a.y != nullptr) {
+    if (a.y != nullptr || (SIDE && AFF16 && a.y_bf16 != nullptr)) {     // (y null with y_bf16: the output exists as bfloat16 only)
       char* yb = reinterpret_cast<char*>(a.y + (size_t)eb * a.yH * a.yW * a.Cout);
   #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
@@ -1665,6 +1726,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         const int gy = ey0 + m / PW, gx = ex0p + m % PW;
         if (gy < a.yH && gx < a.yW) {
           char* yp = yb + (((unsigned)gy * (unsigned)a.yW + (unsigned)gx) * (unsigned)a.Cout + (unsigned)(n0 + wn * 32 + 4 * g)) * 4u;
+          if (a.y != nullptr) {
   #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
             f32x4 o;
@@ -1672,6 +1734,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
             for (int j = 0; j < 4; ++j) o[j] = acc[ct][pt][j];
             if (MFPA_EXP_FLAG(a.dbg, 512)) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + ct * 64));
             else if (!(MFPA_EXP_FLAG(a.dbg, 4) && v_never(o[0] + o[3]))) *reinterpret_cast<f32x4*>(yp + ct * 64) = o;
+          }
           }
           if (SIDE && a.y_bf16 != nullptr) {
             __bf16* hp = a.y_bf16 + (((size_t)eb * a.yH + gy) * a.yW + gx) * (size_t)a.Cout + n0 + wn * 32 + 4 * g;
@@ -1926,12 +1989,15 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   const bool side = a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part;
   const bool rows = WMW == 2 && rows_min > 0 && cin % 64 == 0 && cin >= rows_min;
   if (a.in16) {                                                        // bf16 source: the plain-bf16 input-gradient convolutions
-    if (!a.plain || a.C1 != 0 || a.in_scale0 || a.x0_bf16 || a.x1_bf16 || cin % 64) return MFPA_EINVAL;
+    if (!a.plain || a.x1_bf16 || cin % 64) return MFPA_EINVAL;         // (both sources bfloat16; source 1 IS its own bf16 copy)
+    const bool fwd16 = a.in_scale0 != nullptr || a.x0_bf16 != nullptr || a.y == nullptr;      // the training forward's form (AFF16)
     if constexpr (WMW == 4) {
-      if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true, true>), grid, dim3(512), lds, s, a);
+      if (fwd16) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true, true, true>), grid, dim3(512), lds, s, a);
+      else if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true, true>), grid, dim3(512), lds, s, a);
       else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, false, true, true>), grid, dim3(512), lds, s, a);
     } else {
-      if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true, true, true>), grid, dim3(512), lds, s, a);
+      if (fwd16) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true, true, true, true>), grid, dim3(512), lds, s, a);
+      else if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, true, true, true>), grid, dim3(512), lds, s, a);
       else hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, true, 2, false, true, true>), grid, dim3(512), lds, s, a);
     }
     MFPA_CHECK_LAUNCH();
@@ -1967,8 +2033,10 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
 // 4..32-iteration loop.  Here a workgroup keeps FOUR accumulator sets (one per tap) for 128 input pixels x 64 output
 // channels: the input chunk is staged once per 32 channels and its fragments are reused by all four taps; a wave owns
 // 32 pixels x 64 channels x 4 taps (128 accumulator VGPRs).  Two workgroups per CU overlap each other's staging.
-template <int PH, int PW, int PREC>
+template <int PH, int PW, int PREC, bool IO16 = false>
 __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
+  // IO16 (the plain-bf16 training step with its activations kept as bfloat16): the source and / or the output are bfloat16 tensors -- its
+  // own instantiation, the inference kernels carry none of it
   constexpr int BM = PH * PW, BN = 64, NT = 2;
   static_assert(BM == 128, "four waves of 32 pixels");
   constexpr int A_F4 = BM * (KC / 4) / 256;            // 4
@@ -1988,7 +2056,8 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
   const int nchunks = a.C0 / KC;
   const int q = tid % (KC / 4);
   const bool affine = a.in_scale0 != nullptr;
-  const char* xb = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * sizeof(float);   // 32-bit offsets from the clip's base
+  const bool in16 = IO16 && a.in16 != 0;                               // source kept as bfloat16 (the training step's activations): widened on load
+  const char* xb = reinterpret_cast<const char*>(a.x0) + (size_t)b * a.H * a.W * a.C0 * (in16 ? 2 : 4);   // 32-bit offsets from the clip's base
 
   f32x4 areg[A_F4], breg[B_F4];
   auto load = [&](int chunk) __attribute__((always_inline)) {
@@ -1998,7 +2067,14 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
       const int pix = (tid + it * 256) / (KC / 4);
       const int gy = y0 + pix / PW, gx = x0p + pix % PW;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < a.H && gx < a.W) v = *reinterpret_cast<const f32x4*>(xb + ((unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * q)) * 4u);
+      if (gy < a.H && gx < a.W) {
+        const unsigned e = (unsigned)(gy * a.W + gx) * (unsigned)a.C0 + (unsigned)(c0 + 4 * q);
+        if (in16) {
+          const f32x2 r = *reinterpret_cast<const f32x2*>(xb + e * 2u);
+          const unsigned u0 = __float_as_uint(r[0]), u1 = __float_as_uint(r[1]);
+          v = f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u)};
+        } else v = *reinterpret_cast<const f32x4*>(xb + e * 4u);
+      }
       areg[it] = v;
     }
 #pragma unroll
@@ -2120,9 +2196,39 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
     sc[nt] = a.scale ? a.scale[n] : 1.f;
     sh[nt] = a.shift ? a.shift[n] : 0.f;
   }
-  char* yb = reinterpret_cast<char*>(a.y + (size_t)b * (2 * a.H) * (2 * a.W) * a.Cout);
-  const unsigned cout4 = (unsigned)a.Cout * 4u, row4 = 2u * (unsigned)a.W * cout4;
-  const unsigned nb = (unsigned)(n0 + li) * 4u;
+  const bool y16 = IO16 && a.y == nullptr;                             // the output as bfloat16 only (a.y_bf16; checked by mfpa_conv_mfma)
+  const unsigned esz = y16 ? 2u : 4u;
+  char* yb = (y16 ? reinterpret_cast<char*>(a.y_bf16) : reinterpret_cast<char*>(a.y)) + (size_t)b * (2 * a.H) * (2 * a.W) * a.Cout * esz;
+  const unsigned cout4 = (unsigned)a.Cout * esz, row4 = 2u * (unsigned)a.W * cout4;
+  const unsigned nb = (unsigned)(n0 + li) * esz;
+  if (y16) {
+    // bfloat16 output: a lane pair (channels 2k, 2k + 1) swaps one value per two accumulator rows (pixels m, m + 1 -- neighbours in the
+    // same patch row), so that the even lane stores both channels of pixel m and the odd lane both channels of pixel m + 1 as one 4-byte
+    // piece each (2-byte stores per lane made this write-bound kernel 20 % slower than its float32 form)
+    const int odd = li & 1;
+    const unsigned nb2 = (unsigned)(n0 + (li & ~1)) * 2u;
+#pragma unroll
+    for (int rp = 0; rp < 16; rp += 2) {
+      const int m = wave * 32 + (rp & 3) + 8 * (rp >> 2) + 4 * lh + odd;
+      const int gy = y0 + m / PW, gx = x0p + m % PW;
+      const bool live = gy < a.H && gx < a.W;
+      char* yp = yb + ((unsigned)(2 * gy) * row4 + (unsigned)(2 * gx) * cout4 + nb2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v0 = acc[t][nt][rp] * sc[nt] + sh[nt], v1 = acc[t][nt][rp + 1] * sc[nt] + sh[nt];
+          if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+          const float send = odd ? v0 : v1;
+          const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+          bf16x2 h;
+          h[0] = (__bf16)(odd ? recv : v0);
+          h[1] = (__bf16)(odd ? v1 : recv);
+          if (live) *reinterpret_cast<bf16x2*>(yp + ((t >> 1) * row4 + (t & 1) * cout4 + nt * 64u)) = h;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -2148,7 +2254,10 @@ int launch_convT(ConvArgs& a, hipStream_t s) {
   if ((long long)a.tiles_x * a.tiles_y * a.B > 0x7fffffffLL) return MFPA_EINVAL;
   const size_t lds = sizeof(float) * ((size_t)PH * PW * LDK + 4 * (size_t)64 * LDK);
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / 64));
-  hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC>), grid, dim3(256), lds, s, a);
+  if (a.in16 || a.y == nullptr) {
+    if constexpr (PREC == 1) hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC, true>), grid, dim3(256), lds, s, a);
+    else return MFPA_EINVAL;
+  } else hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC>), grid, dim3(256), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -2159,7 +2268,7 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
                                                          const double* __restrict__ denom, int per_clip, int B, int H,
                                                          int W, const float* __restrict__ w, int Cout,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int relu, float* __restrict__ y) {
+                                                         int relu, float* __restrict__ y, int y16) {
   const int lanes_per_pix = Cout / 4;
   const int pix_per_block = 256 / lanes_per_pix;
   const int sub = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
@@ -2229,7 +2338,13 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
       o4.z = fmaxf(o4.z, 0.f);
       o4.w = fmaxf(o4.w, 0.f);
     }
-    if (live) *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
+    if (live) {
+      if (y16) {                                                         // the output kept as bfloat16 (the plain-bf16 training step's activations)
+        bf16x4 h;
+        h[0] = (__bf16)o4.x; h[1] = (__bf16)o4.y; h[2] = (__bf16)o4.z; h[3] = (__bf16)o4.w;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + (size_t)p * Cout + 4 * sub) = h;
+      } else *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
+    }
   }
 }
 
@@ -2434,7 +2549,7 @@ int mfpa_convT2x2(const float* x, int B, int H, int W, int Cin, const float* w, 
 int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (!d) return MFPA_EINVAL;
   if (d->B == 0) return MFPA_OK;
-  if ((!d->x0 && !d->c1_x32 && !d->c1_spec64) || !d->w || (!d->y && !d->w1x1) || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
+  if ((!d->x0 && !d->c1_x32 && !d->c1_spec64) || !d->w || (!d->y && !d->w1x1 && !d->y_bf16) || d->B < 0 || d->H < 1 || d->W < 1) return MFPA_EINVAL;
   if (d->C0 < KC || d->C0 % KC || d->C1 < 0 || d->C1 % KC || d->Cout < 64 || d->Cout % 64) return MFPA_EINVAL;
   if (d->mode < 0 || d->mode > 2) return MFPA_EINVAL;
   if (d->C1 > 0 && (d->mode != 0 || !d->x1 || d->H1 < 1 || d->W1 < 1 || d->H1 > d->H || d->W1 > d->W)) return MFPA_EINVAL;
@@ -2468,7 +2583,11 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->precision == 2 && d->w_layout != 2) return MFPA_EINVAL;         // plain bf16: conv_wd16_kernel only (it reads the hi halves of the same image)
   a.w_frag = d->w_layout;
   a.plain = d->precision == 2;
-  if (d->x0_is_bf16 && (d->precision != 2 || d->C1 != 0 || d->in_scale0 || d->x0_bf16 || (d->C0 % 64) != 0 || d->c1_x32 || d->c1_spec64)) return MFPA_EINVAL;
+  // bfloat16 sources (both of them): the plain-bf16 conv_wd16_kernel (any on-load affine / dropout is applied in float32 and rounded once), or
+  // the transposed convolution (mode 1)
+  if (d->x0_is_bf16 && !((d->precision == 2 && d->mode == 0 && ((d->C0 + d->C1) % 64) == 0 && !d->x1_bf16) || (d->mode == 1 && d->precision == 1)))
+    return MFPA_EINVAL;
+  if (d->x0_is_bf16 && (d->c1_x32 || d->c1_spec64)) return MFPA_EINVAL;
   a.in16 = d->x0_is_bf16 ? 1 : 0;
   a.x0_split = d->x0_split ? 1 : 0; a.x1_split = d->x1_split ? 1 : 0; a.y_split = d->y_split ? 1 : 0; a.y_pool_split = d->y_pool_split ? 1 : 0;
   const bool any_split = a.x0_split || a.x1_split || a.y_split || a.y_pool_split;
@@ -2476,13 +2595,18 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
                     (a.x0_split && (d->c1_x32 || d->c1_spec64)))) return MFPA_EINVAL;
   if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision == 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
   if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
-  if (d->y_bf16 != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;
+  // y_bf16 with y: a bf16 copy beside the float32 output; y_bf16 WITHOUT y: the output exists as bfloat16 only (conv_wd16_kernel, or the
+  // bf16x3 transposed convolution)
+  if (d->y_bf16 != nullptr && !(d->w_layout == 2 || (d->mode == 1 && d->precision == 1 && !d->y))) return MFPA_EINVAL;
+  if (!d->y && d->y_bf16 && (d->y_pool || d->w1x1 || d->precision == 0)) return MFPA_EINVAL;
   a.x0_bf16 = reinterpret_cast<__bf16*>(d->x0_bf16);
   a.x1_bf16 = reinterpret_cast<__bf16*>(d->x1_bf16);
   a.y_bf16 = reinterpret_cast<__bf16*>(d->y_bf16);
-  if (d->stats_part != nullptr && (d->w_layout != 2 || !d->y)) return MFPA_EINVAL;       // only conv_wd16_kernel's epilogue writes them
+  if (d->stats_part != nullptr && (d->w_layout != 2 || (!d->y && !d->y_bf16))) return MFPA_EINVAL;       // only conv_wd16_kernel's epilogue writes them
   a.stats_part = d->stats_part;
   if (d->bwd_z != nullptr && (!d->stats_part || !d->bwd_scale || !d->bwd_shift || !d->bwd_mean || !d->bwd_invstd)) return MFPA_EINVAL;
+  if (d->bwd_z != nullptr && d->x0_is_bf16 && (d->in_scale0 || d->x0_bf16 || !d->y)) return MFPA_EINVAL;   // (the training forward's form of the kernel carries no bwd_z code)
+  a.bz16 = (d->bwd_z != nullptr && d->bwd_z_is_bf16) ? 1 : 0;
   a.bz = d->bwd_z; a.bz_scale = d->bwd_scale; a.bz_shift = d->bwd_shift; a.bz_mean = d->bwd_mean; a.bz_invstd = d->bwd_invstd;
   if (any_split) {                                                       // only conv_ws64_kernel reads / writes the split layout
     if (!(MFPA_CONV_WS64 && mfpa_unet::conv_ws64_serves(a)) || (a.Cout % 128 == 0 && !(MFPA_CONV_WS_ALL > 0 && d->C0 + d->C1 <= MFPA_CONV_WS_ALL))) return MFPA_EINVAL;
@@ -2529,14 +2653,14 @@ int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout) {
 
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,
                             int W, const float* w, int Cout, const float* scale, const float* shift, int relu, float* y,
-                            void* stream) {
+                            int y_is_bf16, void* stream) {
   if (B == 0) return MFPA_OK;
   if ((!x32 && !spec64) || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
   if (Cout % 4 || Cout < 4 || Cout > 1024 || (256 % (Cout / 4)) != 0) return MFPA_EINVAL;
   if ((long long)B * H > 0x7fffffffLL) return MFPA_EINVAL;
   const long long blocks = (long long)B * H;
   hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x32, spec64, denom,
-                     per_clip, B, H, W, w, Cout, scale, shift, relu, y);
+                     per_clip, B, H, W, w, Cout, scale, shift, relu, y, y_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

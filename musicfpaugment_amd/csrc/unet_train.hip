@@ -20,6 +20,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RED_BLOCKS = 1024;
 
+// four consecutive channels of an NHWC activation tensor kept as float32 or (z16, round 5: the plain-bf16 step's activations) as bfloat16;
+// e = element index of the first of the four
+__device__ __forceinline__ f32x4 ld_act4(const float* base, size_t e, int z16) {
+  if (z16) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e);
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+  }
+  return *reinterpret_cast<const f32x4*>(base + e);
+}
+
 // ------------------------------------------------------------------ per-channel sums over pixels
 // partial[(blk*C + c)*NV + v]: NV float64 sums per channel.  MODE 0: {sum z, sum z^2} (BN statistics);
 // MODE 1: {sum g, sum g*xhat} with g = dy*[z*scale+shift > 0], xhat = (z-mean)*invstd (BN backward);
@@ -31,7 +41,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd,
                                                           double* __restrict__ partial, unsigned drop_seed,
-                                                          unsigned drop_thresh, float drop_scale) {
+                                                          unsigned drop_thresh, float drop_scale, int z16) {
+  // z16: the activation tensor (x in MODE 0, z in MODE 1) is bfloat16
   constexpr int NV = (MODE == 2) ? 1 : 2;
   const int C4 = C / 4;
   const int lanes = C4 < 256 ? C4 : 256;          // lanes across channel quads
@@ -48,7 +59,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
       is = *reinterpret_cast<const f32x4*>(invstd + 4 * cq);
     }
     for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)p * C + 4 * cq);
+      const f32x4 v = (MODE == 0) ? ld_act4(x, (size_t)p * C + 4 * cq, z16) : *reinterpret_cast<const f32x4*>(x + (size_t)p * C + 4 * cq);
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -56,7 +67,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
           s1[k] += (double)v[k] * (double)v[k];
         }
       } else if (MODE == 1) {
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * cq);
+        const f32x4 zz = ld_act4(z, (size_t)p * C + 4 * cq, z16);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float g = (zz[k] * sc[k] + sf[k] > 0.f) ? v[k] : 0.f;
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, unsigned drop_seed,
                                                            unsigned drop_thresh, float drop_scale, __bf16* __restrict__ dz16,
-                                                           int write_f32, const float* __restrict__ dpred, const float* __restrict__ w1) {
+                                                           int write_f32, const float* __restrict__ dpred, const float* __restrict__ w1, int z16) {
   const int C4 = C / 4;                      // a power of two (checked on the host): no 64-bit division per element
   const long long total = npix * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
     } else {
       g = *reinterpret_cast<const f32x4*>(dy + e * 4);
     }
-    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + e * 4);
+    const f32x4 zz = ld_act4(z, (size_t)e * 4, z16);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -283,7 +294,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restrict__ z, int B, int H, int W, int C,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ p,
-                                                           unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
+                                                           unsigned drop_seed, unsigned drop_thresh, float drop_scale, int z16, int p16) {
+  // z16: z is bfloat16; p16: the pooled activation leaves as bfloat16 (the next convolution's operand as it is: mfpa_conv_desc.x0_is_bf16)
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
   for (int e32 = threadIdx.x; e32 < Wo * C4; e32 += 256) {
@@ -291,20 +303,25 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
     const size_t e = ((size_t)blockIdx.x * Wo + xo) * C4 + cq;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * cq);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(shift + 4 * cq);
-    const float* base = z + (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * cq;
+    const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + 4 * cq;
     f32x4 m = {0.f, 0.f, 0.f, 0.f};   // relu output is >= 0
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const size_t off = ((size_t)(t >> 1) * W + (t & 1)) * C;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(base + off);
+      const f32x4 v = ld_act4(z, base + off, z16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float y = v[k] * sc[k] + sf[k];
-        if (drop_thresh) y = (y > 0.f && mfpa_keep(drop_seed, drop_thresh, (unsigned long long)(base - z) + off + k)) ? y * drop_scale : 0.f;
+        if (drop_thresh) y = (y > 0.f && mfpa_keep(drop_seed, drop_thresh, (unsigned long long)base + off + k)) ? y * drop_scale : 0.f;
         m[k] = y > m[k] ? y : m[k];
       }
     }
-    *reinterpret_cast<f32x4*>(p + e * 4) = m;
+    if (p16) {
+      wg_bf16x4_t h;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) h[k] = (__bf16)m[k];
+      *reinterpret_cast<wg_bf16x4_t*>(reinterpret_cast<__bf16*>(p) + e * 4) = h;
+    } else *reinterpret_cast<f32x4*>(p + e * 4) = m;
   }
 }
 
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
                                                               const float* __restrict__ dp, float* __restrict__ dy,
                                                               unsigned drop_seed, unsigned drop_thresh, float drop_scale,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, int z16) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
   // SUMS: 256 % C4 == 0 (checked by the launcher), so a thread meets ONE channel quad in all its trips: tid % C4
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     f32x4 vz[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(z + base + ((size_t)(t >> 1) * W + (t & 1)) * C);
+      const f32x4 v = ld_act4(z, base + ((size_t)(t >> 1) * W + (t & 1)) * C, z16);
       vz[t] = v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -388,14 +405,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
       for (int e32 = threadIdx.x; e32 < 2 * C4; e32 += 256) {
         const int cq = e32 % C4, r = e32 / C4;
         const size_t off = (((size_t)b * H + 2 * yo + r) * W + (W - 1)) * C + 4 * cq;
-        add(*reinterpret_cast<const f32x4*>(dy + off), *reinterpret_cast<const f32x4*>(z + off), off);
+        add(*reinterpret_cast<const f32x4*>(dy + off), ld_act4(z, off, z16), off);
       }
     }
     if ((H & 1) && yo == Ho - 1) {                          // ... and so does the last row: the clip's last workgroup takes it
       for (int e32 = threadIdx.x; e32 < W * C4; e32 += 256) {
         const int cq = e32 % C4, x = e32 / C4;
         const size_t off = (((size_t)b * H + (H - 1)) * W + x) * C + 4 * cq;
-        add(*reinterpret_cast<const f32x4*>(dy + off), *reinterpret_cast<const f32x4*>(z + off), off);
+        add(*reinterpret_cast<const f32x4*>(dy + off), ld_act4(z, off, z16), off);
       }
     }
     __shared__ double red[256 * 8];
@@ -1174,7 +1191,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restrict__ z, long long npix, int C,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ pred) {
+                                                          const float* __restrict__ bias, float* __restrict__ pred, int z16) {
   const int lpp = C / 4, sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
   const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * sub);
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * sub);
@@ -1185,7 +1202,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const float* __restric
     const long long p = (it * gridDim.x + blockIdx.x) * ppb + pl;
     float s = 0.f;
     if (p < npix) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * sub);
+      const f32x4 v = ld_act4(z, (size_t)p * C + 4 * sub, z16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float y = v[k] * sc[k] + sf[k];
@@ -1207,7 +1224,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
                                                           const float* __restrict__ shift, const float* __restrict__ w,
                                                           float* __restrict__ dy, double* __restrict__ partial,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, int z16) {
   const int lpp = C / 4, sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
   const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 4 * sub);
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * sub);
@@ -1220,7 +1237,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
   double sw[4] = {0, 0, 0, 0}, sb = 0, s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   for (long long p = (long long)blockIdx.x * ppb + pl; p < npix; p += (long long)gridDim.x * ppb) {
     const float g = dpred[p];
-    const f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + 4 * sub);
+    const f32x4 v = ld_act4(z, (size_t)p * C + 4 * sub, z16);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1420,7 +1437,7 @@ int mfpa_red_blocks(void) { return RED_BLOCKS; }
 
 int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, const float* beta, float eps,
                   float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
-                  float* running_var, double* workspace, void* stream) {
+                  float* running_var, double* workspace, int z_is_bf16, void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!z || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace) return MFPA_EINVAL;
   if (npix < 0 || C < 4 || C % 4 || (C / 4 < 256 && 256 % (C / 4) != 0) || (C / 4 > 256 && (C / 4) % 256 != 0)) return MFPA_EINVAL;
@@ -1428,7 +1445,7 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
-                     nullptr, nullptr, workspace, 0u, 0u, 1.f);
+                     nullptr, nullptr, workspace, 0u, 0u, 1.f, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
@@ -1439,7 +1456,7 @@ int mfpa_bn_stats(const float* z, long long npix, int C, const float* gamma, con
 int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                      const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                      float* coef, double* workspace, unsigned drop_seed, unsigned drop_thresh, float drop_scale,
-                     void* dz_bf16, int write_f32, void* stream) {
+                     void* dz_bf16, int write_f32, int z_is_bf16, void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!write_f32 && !dz_bf16) return MFPA_EINVAL;
   if (!dy || !z || !gamma || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !coef || !workspace) return MFPA_EINVAL;
@@ -1449,14 +1466,14 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, z, npix, C, scale, shift, mean, invstd,
-                     workspace, drop_seed, drop_thresh, drop_scale);
+                     workspace, drop_seed, drop_thresh, drop_scale, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix,
                      gamma, invstd, dgamma, dbeta, coef);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
                      mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
-                     (const float*)nullptr, (const float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1465,14 +1482,14 @@ static bool bn_shape_ok(long long npix, int C) {
   return npix >= 0 && C >= 4 && C % 4 == 0 && !(C / 4 < 256 && 256 % (C / 4) != 0) && !(C / 4 > 256 && (C / 4) % 256 != 0);
 }
 
-int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, void* stream) {
+int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, int z_is_bf16, void* stream) {
   if (!sums || !workspace || !bn_shape_ok(npix, C) || (npix > 0 && !z)) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   if (npix == 0) { MFPA_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s)); return MFPA_OK; }
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(nblk), dim3(256), 0, s, z, nullptr, npix, C, nullptr, nullptr,
-                     nullptr, nullptr, workspace, 0u, 0u, 1.f);
+                     nullptr, nullptr, workspace, 0u, 0u, 1.f, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, sums);
   MFPA_CHECK_LAUNCH();
@@ -1503,7 +1520,7 @@ int mfpa_bn_stats_finish(const double* sums, double count, int C, const float* g
 
 int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C, const float* scale, const float* shift,
                           const float* mean, const float* invstd, double* sums, double* workspace, unsigned drop_seed,
-                          unsigned drop_thresh, float drop_scale, void* stream) {
+                          unsigned drop_thresh, float drop_scale, int z_is_bf16, void* stream) {
   if (!sums || !workspace || !scale || !shift || !mean || !invstd || !bn_shape_ok(npix, C) || (C & (C - 1))) return MFPA_EINVAL;
   if (npix > 0 && (!dy || !z)) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
@@ -1511,7 +1528,7 @@ int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, z, npix, C, scale, shift, mean, invstd,
-                     workspace, drop_seed, drop_thresh, drop_scale);
+                     workspace, drop_seed, drop_thresh, drop_scale, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, sums);
   MFPA_CHECK_LAUNCH();
@@ -1521,7 +1538,7 @@ int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C
 int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
-                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32, void* stream) {
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32, int z_is_bf16, void* stream) {
   if (!gamma || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !dgamma || !dbeta || !coef) return MFPA_EINVAL;
   if (!write_f32 && !dz_bf16) return MFPA_EINVAL;
   if (!bn_shape_ok(npix, C) || (C & (C - 1)) || !(global_count >= 1.0) || (npix > 0 && (!dy || !z))) return MFPA_EINVAL;
@@ -1532,7 +1549,7 @@ int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, co
   if (npix == 0) return MFPA_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
                      mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
-                     (const float*)nullptr, (const float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1540,7 +1557,7 @@ int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, co
 int mfpa_bn_relu_bwd_finish_rank1(const float* dpred, const float* w1, const float* z, long long npix, int C, const float* gamma,
                                   const float* scale, const float* shift, const float* mean, const float* invstd, const double* local_sums,
                                   const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
-                                  float* dz_f32, void* dz_bf16, void* stream) {
+                                  float* dz_f32, void* dz_bf16, int z_is_bf16, void* stream) {
   if (!dpred || !w1 || !gamma || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !dgamma || !dbeta || !coef) return MFPA_EINVAL;
   if (!dz_f32 && !dz_bf16) return MFPA_EINVAL;
   if (!bn_shape_ok(npix, C) || (C & (C - 1)) || !(global_count >= 1.0) || (npix > 0 && !z)) return MFPA_EINVAL;
@@ -1550,7 +1567,7 @@ int mfpa_bn_relu_bwd_finish_rank1(const float* dpred, const float* w1, const flo
   MFPA_CHECK_LAUNCH();
   if (npix == 0) return MFPA_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dz_f32, z, npix, C, scale, shift,
-                     mean, invstd, coef, 0u, 0u, 1.f, reinterpret_cast<__bf16*>(dz_bf16), dz_f32 != nullptr ? 1 : 0, dpred, w1);
+                     mean, invstd, coef, 0u, 0u, 1.f, reinterpret_cast<__bf16*>(dz_bf16), dz_f32 != nullptr ? 1 : 0, dpred, w1, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1562,7 +1579,7 @@ int mfpa_colsum(const float* x, long long npix, int C, float* out, double* works
   const int rows = 256 / (C / 4 < 256 ? C / 4 : 256);
   const int nblk = grid_for(npix, rows * 8, RED_BLOCKS);
   hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(nblk), dim3(256), 0, s, x, nullptr, npix, C, nullptr, nullptr, nullptr,
-                     nullptr, workspace, 0u, 0u, 1.f);
+                     nullptr, workspace, 0u, 0u, 1.f, 0);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, out);
   MFPA_CHECK_LAUNCH();
@@ -1570,36 +1587,36 @@ int mfpa_colsum(const float* x, long long npix, int C, float* out, double* works
 }
 
 int mfpa_bn_relu_pool(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, float* p,
-                      unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* stream) {
+                      unsigned drop_seed, unsigned drop_thresh, float drop_scale, int z_is_bf16, int p_is_bf16, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !p || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   if ((long long)B * (H / 2) > 0x7fffffffLL) return MFPA_EINVAL;
   hipLaunchKernelGGL(bn_relu_pool_kernel, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C, scale,
-                     shift, p, drop_seed, drop_thresh, drop_scale);
+                     shift, p, drop_seed, drop_thresh, drop_scale, z_is_bf16, p_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
 int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const float* scale, const float* shift,
                           const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh, float drop_scale,
-                          void* stream) {
+                          int z_is_bf16, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !dp || !dy || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   if ((long long)B * (H / 2) > 0x7fffffffLL) return MFPA_EINVAL;
   hipLaunchKernelGGL(maxpool_bwd_add_kernel<false>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
-                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
 int mfpa_maxpool2_bwd_add_sums(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, const float* mean,
                                const float* invstd, const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh,
-                               float drop_scale, float* part, void* stream) {
+                               float drop_scale, float* part, int z_is_bf16, void* stream) {
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !mean || !invstd || !dp || !dy || !part || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   if ((long long)B * (H / 2) > 0x7fffffffLL || C / 4 > 256 || 256 % (C / 4)) return MFPA_EINVAL;   // a thread keeps ONE channel quad's sums
   hipLaunchKernelGGL(maxpool_bwd_add_kernel<true>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
-                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, mean, invstd, part);
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, mean, invstd, part, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1723,24 +1740,24 @@ int mfpa_wgrad_c1(const float* dz, const float* x32, const double* spec64, const
 }
 
 int mfpa_outconv_fwd(const float* z, long long npix, int C, const float* scale, const float* shift, const float* w,
-                     const float* bias, float* pred, void* stream) {
+                     const float* bias, float* pred, int z_is_bf16, void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!z || !scale || !shift || !w || !bias || !pred || npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
   hipLaunchKernelGGL(outconv_fwd_kernel, dim3(grid_for(npix, 256 / (C / 4), 256 * 32)), dim3(256), 0,
-                     mfpa_stream(stream), z, npix, C, scale, shift, w, bias, pred);
+                     mfpa_stream(stream), z, npix, C, scale, shift, w, bias, pred, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
 
 int mfpa_outconv_bwd(const float* z, const float* dpred, long long npix, int C, const float* scale, const float* shift,
-                     const float* w, float* dy, float* dwb, double* workspace, void* stream) {
+                     const float* w, float* dy, float* dwb, double* workspace, int z_is_bf16, void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!z || !dpred || !scale || !shift || !w || !dy || !dwb || !workspace) return MFPA_EINVAL;
   if (npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   const int nblk = grid_for(npix, (256 / (C / 4)) * 16, RED_BLOCKS);
   hipLaunchKernelGGL(outconv_bwd_kernel<false>, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, dy, workspace,
-                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, (float*)nullptr, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   // finish: column sums of the (nblk, C+1) partial matrix: C weight gradients then the bias gradient
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
@@ -1756,14 +1773,14 @@ int mfpa_outconv_bwd_rows(long long npix, int C, int* rows) {
 
 int mfpa_outconv_bwd_sums(const float* z, const float* dpred, long long npix, int C, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* w, float* dwb, double* workspace, float* part,
-                          void* stream) {
+                          int z_is_bf16, void* stream) {
   if (npix == 0) return MFPA_OK;
   if (!z || !dpred || !scale || !shift || !mean || !invstd || !w || !dwb || !workspace || !part) return MFPA_EINVAL;
   if (npix < 0 || C < 4 || C > 256 || (C & (C - 1))) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   const int nblk = grid_for(npix, (256 / (C / 4)) * 16, RED_BLOCKS);
   hipLaunchKernelGGL(outconv_bwd_kernel<true>, dim3(nblk), dim3(256), 0, s, z, dpred, npix, C, scale, shift, w, (float*)nullptr, workspace,
-                     mean, invstd, part);
+                     mean, invstd, part, z_is_bf16);
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 1 + 3) / 4), dim3(256), 0, s, workspace, nblk, C + 1, dwb);
   MFPA_CHECK_LAUNCH();

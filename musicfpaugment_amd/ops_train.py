@@ -87,14 +87,16 @@ def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int
 def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None, out_scale=None, out_shift=None,
               relu=False, out_hw: Optional[Tuple[int, int]] = None, precision: int = 0, packed: bool = False, w_layout: int = 0,
               x0_bf16_out: Optional[list] = None, stats_out: Optional[list] = None, x1_bf16_out: Optional[list] = None,
-              y_bf16_out: Optional[list] = None, bwd_of=None):
+              y_bf16_out: Optional[list] = None, bwd_of=None, out_bf16: bool = False):
     """General MFMA convolution (mfpa_conv_mfma).  x0 is NHWC; returns the NHWC output.  precision 1 = bf16x3:
     `w` (fp32, kernel layout) is split into the image the kernel for this shape reads (weight_layout) unless it already is an
     operand image (`packed`, in the layout `w_layout`).  `x0_bf16_out` (a list): when the kernel for this shape can write it
     (w_layout 2), the bf16 copy of the activated source 0 is appended -- the weight gradient's operand, for free.  `stats_out` (a
     list): likewise the kernel's per-wave partial BatchNorm statistics of the output ((rows, 2, Cout) float32, mfpa_conv_stats_reduce).
     `x1_bf16_out` / `y_bf16_out`: likewise bf16 copies of source 1 and of the output.  `bwd_of` = (z, Stats) with `stats_out`: the
-    output is dy of relu(bn(z)) and the partials are the BatchNorm backward's two reductions (mfpa_conv_desc.bwd_z)."""
+    output is dy of relu(bn(z)) and the partials are the BatchNorm backward's two reductions (mfpa_conv_desc.bwd_z).
+    bfloat16 sources (x0 and x1 together: the plain-bf16 step's activations kept as bfloat16, Z16_ACTIVATIONS) go to conv_wd16_kernel
+    (precision 2, w_layout 2) or the transposed convolution; `out_bf16`: the output exists as bfloat16 only (returned)."""
     B = x0.shape[0]
     if mode == 2:
         H, W = x0.shape[1] // 2, x0.shape[2] // 2
@@ -116,16 +118,28 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
         oh, ow = 2 * H, 2 * W
     else:
         oh, ow = out_hw if out_hw is not None else (H, W)
-    y = torch.empty((B, oh, ow, Cout), dtype=torch.float32, device=x0.device)
+    if in16 and x1 is not None and x1.dtype != torch.bfloat16:
+        raise ValueError("bfloat16 sources come together (x0 and x1)")
+    if out_bf16 and not ((plain and w_layout == 2 and mode == 0) or (mode == 1 and precision == 1)):
+        raise ValueError("a bfloat16-only output needs conv_wd16_kernel (precision 2, w_layout 2) or the bf16x3 transposed convolution")
+    y = torch.empty((B, oh, ow, Cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x0.device)
     xb = None
     if x0_bf16_out is not None and ((w_layout == 2 and mode == 0) or (mode == 1 and precision == 1)):
-        xb = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
-        x0_bf16_out.append(xb)
+        if in16 and in_affine is None:
+            x0_bf16_out.append(x0)                                 # a bfloat16 source without an on-load transform IS the weight gradient's operand
+        else:
+            xb = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
+            x0_bf16_out.append(xb)
     x1b = yb16 = None
     if x1_bf16_out is not None and x1 is not None and w_layout == 2 and mode == 0:
-        x1b = torch.empty(x1.shape, dtype=torch.bfloat16, device=x0.device)
-        x1_bf16_out.append(x1b)
-    if y_bf16_out is not None and w_layout == 2 and mode == 0:
+        if in16:
+            x1_bf16_out.append(x1)                                 # (source 1 carries no on-load transform)
+        else:
+            x1b = torch.empty(x1.shape, dtype=torch.bfloat16, device=x0.device)
+            x1_bf16_out.append(x1b)
+    if out_bf16:
+        yb16 = y
+    elif y_bf16_out is not None and w_layout == 2 and mode == 0:
         yb16 = torch.empty(y.shape, dtype=torch.bfloat16, device=x0.device)
         y_bf16_out.append(yb16)
     part = None
@@ -136,7 +150,7 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
             stats_out.append(part)
     d = ConvDesc(x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
                  in_shift0=ptr(in_affine.shift) if in_affine else 0, x1=ptr(x1), w=ptr(w),
-                 out_scale=ptr(out_scale), out_shift=ptr(out_shift), y=ptr(y), C0=C0, C1=C1,
+                 out_scale=ptr(out_scale), out_shift=ptr(out_shift), y=0 if out_bf16 else ptr(y), C0=C0, C1=C1,
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
@@ -145,9 +159,10 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  bwd_scale=ptr(bwd_of[1].scale) if (bwd_of and part is not None) else 0,
                  bwd_shift=ptr(bwd_of[1].shift) if (bwd_of and part is not None) else 0,
                  bwd_mean=ptr(bwd_of[1].mean) if (bwd_of and part is not None) else 0,
-                 bwd_invstd=ptr(bwd_of[1].invstd) if (bwd_of and part is not None) else 0, x0_is_bf16=int(in16))
-    if in16 and not (plain and w_layout == 2 and mode == 0 and x1 is None and in_affine is None):
-        raise ValueError("a bfloat16 source needs the plain-bf16 conv_wd16_kernel (precision 2, w_layout 2, one source, no on-load affine)")
+                 bwd_invstd=ptr(bwd_of[1].invstd) if (bwd_of and part is not None) else 0, x0_is_bf16=int(in16),
+                 bwd_z_is_bf16=int(bool(bwd_of) and part is not None and bwd_of[0].dtype == torch.bfloat16))
+    if in16 and not ((plain and w_layout == 2 and mode == 0) or (mode == 1 and precision == 1)):
+        raise ValueError("bfloat16 sources need the plain-bf16 conv_wd16_kernel (precision 2, w_layout 2) or the bf16x3 transposed convolution")
     t0 = K._TIMER.start() if K._TIMER is not None else None
     check(lib().mfpa_conv_mfma(ctypes.byref(d), stream()), "mfpa_conv_mfma")
     if t0 is not None:
@@ -155,6 +170,8 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
+Z16_ACTIVATIONS = True      # plain-bf16 step (precision 2 with bf16 weight gradients): the convolutions' raw outputs z, the pooled activations and the
+                            # transposed convolutions' outputs live in HBM as bfloat16 only (False: float32, A/B runs) -- see UNetTrainEngine._z16_for
 USE_BF16_DZ = True          # plain-bf16 step: input-gradient convolutions read the bf16 copy of dz (False: the float32 dz, A/B runs)
 FUSE_POOL_BWD_SUMS = True   # False: mfpa_maxpool2_bwd_add, then the BatchNorm backward's own reduction pass (chan_reduce_kernel<1>)
 RANK1_OUTCONV_BWD = True    # False: mfpa_outconv_bwd writes dy = dpred x w (1.06 GB per 64 clips), the BatchNorm backward reduces and reads it
@@ -185,7 +202,9 @@ def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x
         # products as precision 2 (one bf16 MFMA each, fp32 accumulate).  dz's copy comes with the BatchNorm backward (dz_bf16), the
         # activated input's with the forward convolution (x0_bf16); what is missing is cast here.
         dz = dz_bf16 if dz_bf16 is not None else act_to_bf16(dz)
-        x0, in_affine = (x0_bf16 if x0_bf16 is not None else act_to_bf16(x0, in_affine)), None
+        if x0_bf16 is None and x0.dtype == torch.bfloat16 and in_affine is not None:
+            raise ValueError("a bfloat16 activation with a pending on-load transform needs the forward convolution's bf16 copy (x0_bf16)")
+        x0, in_affine = (x0_bf16 if x0_bf16 is not None else (x0 if x0.dtype == torch.bfloat16 else act_to_bf16(x0, in_affine))), None
         x1 = None if x1 is None else (x1_bf16 if x1_bf16 is not None else act_to_bf16(x1))
         precision = 3
     d = WgradDesc(dz=ptr(dz), x0=ptr(x0), in_scale0=ptr(in_affine.scale) if in_affine else 0,
@@ -202,6 +221,10 @@ def wgrad_mfma(dz, x0, dw, Cout, *, mode=0, in_affine: Optional[Stats] = None, x
 
 def _npix(t):
     return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def _is16(t) -> int:
+    return int(t.dtype == torch.bfloat16)
 
 
 def flat_layout():
@@ -274,6 +297,28 @@ class UNetTrainEngine:
         self.load_from_module()
         self.workspace = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._z16, self._z16_cache = False, {}
+
+    def _z16_for(self, H: int, W: int) -> bool:
+        """Do this step's activations live in HBM as bfloat16?  Z16_ACTIVATIONS, the plain-bf16 arithmetic with bf16 weight gradients
+        (precision 2 / 2: every consumer rounds them to bf16 anyway, once, after the BatchNorm affine -- here the raw convolution
+        output is rounded too), and EVERY 3x3 convolution of the net on conv_wd16_kernel at this image size (the only kernel that reads
+        and writes them: w_layout 2).  Decided per forward from the input's (H, W); BatchNorm statistics still come from the float32
+        accumulators (stats_part)."""
+        if not (Z16_ACTIVATIONS and self.precision == 2 and self.wgrad_precision == 2):
+            return False
+        key = (H, W)
+        if key not in self._z16_cache:
+            ok, h, w = True, H, W
+            for cin, cout in ((64, 128), (128, 256), (256, 512), (512, 1024)):
+                h, w = h // 2, w // 2
+                ok = ok and h >= 1 and w >= 1 and weight_layout(h, w, cin, cout, 2) == 2 and weight_layout(h, w, cout, cout, 2) == 2
+            ok = ok and weight_layout(H, W, 64, 64, 2) == 2
+            hs = [(H >> k, W >> k) for k in range(4)]               # the Up blocks' resolutions: H/8 .. H (skip sizes)
+            for (hh, ww), cout in zip(reversed(hs), (512, 256, 128, 64)):
+                ok = ok and weight_layout(hh, ww, 2 * cout, cout, 2) == 2 and weight_layout(hh, ww, cout, cout, 2) == 2
+            self._z16_cache[key] = bool(ok)
+        return self._z16_cache[key]
 
     # ------------------------------------------------------------------ flat layout (backward completion order)
     def _layout(self):
@@ -425,7 +470,7 @@ class UNetTrainEngine:
                 check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(sc), ptr(self.workspace), stream()),
                       "mfpa_conv_stats_reduce")
             else:
-                check(lib().mfpa_bn_stats_sums(ptr(z), _npix(z), C, ptr(sc), ptr(self.workspace), stream()), "mfpa_bn_stats_sums")
+                check(lib().mfpa_bn_stats_sums(ptr(z), _npix(z), C, ptr(sc), ptr(self.workspace), _is16(z), stream()), "mfpa_bn_stats_sums")
             if self.sync_bn:
                 self._all_reduce_sums(sc)
             count = float(_npix(z)) * (self._global_over_local_batch if self.sync_bn else 1.0)   # every rank holds clips of the same H x W
@@ -437,7 +482,7 @@ class UNetTrainEngine:
             return st
         check(lib().mfpa_bn_stats(ptr(z), _npix(z), C, ptr(self.P[g]), ptr(self.P[b]), BN_EPS, BN_MOMENTUM, ptr(st.mean),
                                   ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(self.running[bn + ".running_mean"]),
-                                  ptr(self.running[bn + ".running_var"]), ptr(self.workspace), stream()), "mfpa_bn_stats")
+                                  ptr(self.running[bn + ".running_var"]), ptr(self.workspace), _is16(z), stream()), "mfpa_bn_stats")
         return st
 
     def _bn_relu_bwd(self, dy, z, st: Stats, g, b, bf16_copy: bool = False, part=None, write_f32: bool = True, rank1=None):
@@ -457,10 +502,10 @@ class UNetTrainEngine:
             glob = self._all_reduce_sums(loc.clone()) if self.sync_bn else loc
             if not self.sync_bn:
                 st.count_host = float(_npix(z))
-            dz = torch.empty_like(z) if write_f32 else None
+            dz = torch.empty(z.shape, dtype=torch.float32, device=z.device) if write_f32 else None
             check(lib().mfpa_bn_relu_bwd_finish_rank1(ptr(dpred), ptr(w1), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                                       ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
-                                                      ptr(self.G[b]), ptr(coef), ptr(dz), ptr(dz16), stream()), "mfpa_bn_relu_bwd_finish_rank1")
+                                                      ptr(self.G[b]), ptr(coef), ptr(dz), ptr(dz16), _is16(z), stream()), "mfpa_bn_relu_bwd_finish_rank1")
             return dz, dz16
         if self.sync_bn or part is not None:
             loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
@@ -470,18 +515,18 @@ class UNetTrainEngine:
             else:
                 check(lib().mfpa_bn_relu_bwd_sums(ptr(dy), ptr(z), _npix(z), C, ptr(st.scale), ptr(st.shift), ptr(st.mean),
                                                   ptr(st.invstd), ptr(loc), ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2],
-                                                  stream()), "mfpa_bn_relu_bwd_sums")
+                                                  _is16(z), stream()), "mfpa_bn_relu_bwd_sums")
             glob = self._all_reduce_sums(loc.clone()) if self.sync_bn else loc
             if not self.sync_bn:
                 st.count_host = float(_npix(z))
             check(lib().mfpa_bn_relu_bwd_finish(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                                 ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
-                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), stream()),
+                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), _is16(z), stream()),
                   "mfpa_bn_relu_bwd_finish")
             return (dy if write_f32 else None), dz16
         check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                      ptr(st.mean), ptr(st.invstd), ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
-                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), stream()),
+                                     ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), _is16(z), stream()),
               "mfpa_bn_relu_bwd")
         return (dy if write_f32 else None), dz16
 
@@ -493,15 +538,16 @@ class UNetTrainEngine:
         want = self.wgrad_precision == 2
         xb0, xb3, xb1 = ([] if want else None), ([] if want else None), ([] if want else None)
         sp0, sp3 = [], []                    # the convolutions' partial BatchNorm statistics (where their kernel writes them)
+        z16 = self._z16
         if first_input is not None:
             x32, spec64, denom = first_input
             z0 = K.conv3x3_c1_bn_relu(self.P[prefix + ".0.w"], None, None, x32=x32, spec64=spec64, denom=denom,
-                                      per_clip=True, relu=False)
+                                      per_clip=True, relu=False, out_dtype=torch.bfloat16 if z16 else torch.float32)
         else:
             z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1, precision=self.precision, x0_bf16_out=xb0,
-                           stats_out=sp0, x1_bf16_out=xb1)
+                           stats_out=sp0, x1_bf16_out=xb1, out_bf16=z16)
         st0 = self._bn_stats(z0, prefix + ".1", prefix + ".1.g", prefix + ".1.b", part=sp0[0] if sp0 else None)
-        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0, precision=self.precision, x0_bf16_out=xb3, stats_out=sp3)
+        z3 = conv_mfma(z0, self.P[prefix + ".3.w"], cout, in_affine=st0, precision=self.precision, x0_bf16_out=xb3, stats_out=sp3, out_bf16=z16)
         st3 = self._bn_stats(z3, prefix + ".4", prefix + ".4.g", prefix + ".4.b", part=sp3[0] if sp3 else None)
         if drop_id is not None and self.rate > 0:
             st3.drop = dropout_spec(self.drop_seed + 16 * self.step_count + drop_id, self.rate)
@@ -512,15 +558,17 @@ class UNetTrainEngine:
         """Train-mode forward.  Input (B,F,T): float32 spectrogram, or raw float64 |STFT| + per-clip denominators
         (the divide + .float() of train.py:264-272 is fused into the first conv).  Returns pred (B,F,T) float32."""
         recs = {}
+        src = x32 if x32 is not None else spec64
+        self._z16 = self._z16_for(src.shape[1], src.shape[2])
         r = self._dconv_fwd(ENC[0], None, None, first_input=(x32, spec64, denom))
         recs["inc"] = r
         prev = r
         for i, name in enumerate(ENC[1:]):
             z, st = prev["z3"], prev["st3"]
             B, H, W, C = z.shape
-            p = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=z.device)
+            p = torch.empty((B, H // 2, W // 2, C), dtype=torch.bfloat16 if self._z16 else torch.float32, device=z.device)
             check(lib().mfpa_bn_relu_pool(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(p), st.drop[0], st.drop[1],
-                                          st.drop[2], stream()), "mfpa_bn_relu_pool")
+                                          st.drop[2], _is16(z), _is16(p), stream()), "mfpa_bn_relu_pool")
             r = self._dconv_fwd(name, p, None, drop_id=i)                 # x2..x5 = dropout(downN(...))
             recs[name] = r
             prev = r
@@ -528,7 +576,7 @@ class UNetTrainEngine:
         for name, skip in zip(DEC, skips):
             xbu = [] if self.wgrad_precision == 2 else None          # bf16 copy of the activated input: the weight gradient's operand
             u = conv_mfma(prev["z3"], self.P[name + ".up.w"], self.P[name + ".up.w"].shape[1], mode=1,
-                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"], precision=self.precision, x0_bf16_out=xbu)
+                          in_affine=prev["st3"], out_shift=self.P[name + ".up.b"], precision=self.precision, x0_bf16_out=xbu, out_bf16=self._z16)
             if skip["z3"].shape[1] - u.shape[1] > 1 or skip["z3"].shape[2] - u.shape[2] > 1:
                 raise NotImplementedError("skip/upsample size difference > 1 (needs top/left padding offsets)")
             r = self._dconv_fwd(name + ".conv.double_conv", skip["z3"], skip["st3"], src1=u,
@@ -541,7 +589,7 @@ class UNetTrainEngine:
         pred = torch.empty(z.shape[:3], dtype=torch.float32, device=z.device)
         wb = self.P["outc.wb"]
         check(lib().mfpa_outconv_fwd(ptr(z), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(wb), ptr(wb[64:]),
-                                     ptr(pred), stream()), "mfpa_outconv_fwd")
+                                     ptr(pred), _is16(z), stream()), "mfpa_outconv_fwd")
         self._recs = recs
         return pred
 
@@ -616,13 +664,13 @@ class UNetTrainEngine:
             check(lib().mfpa_outconv_bwd_rows(_npix(z), 64, ctypes.byref(rows)), "mfpa_outconv_bwd_rows")
             dy_part = torch.empty((rows.value, 2, 64), dtype=torch.float32, device=z.device)
             check(lib().mfpa_outconv_bwd_sums(ptr(z), ptr(dpred), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
-                                              ptr(wb), ptr(self.G["outc.wb"]), ptr(self.workspace), ptr(dy_part), stream()),
+                                              ptr(wb), ptr(self.G["outc.wb"]), ptr(self.workspace), ptr(dy_part), _is16(z), stream()),
                   "mfpa_outconv_bwd_sums")
             dy_rank1 = (dpred, wb)
         else:
-            dy = torch.empty_like(z)
+            dy = torch.empty(z.shape, dtype=torch.float32, device=z.device)
             check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), _npix(z), 64, ptr(st.scale), ptr(st.shift), ptr(wb), ptr(dy),
-                                         ptr(self.G["outc.wb"]), ptr(self.workspace), stream()), "mfpa_outconv_bwd")
+                                         ptr(self.G["outc.wb"]), ptr(self.workspace), _is16(z), stream()), "mfpa_outconv_bwd")
         handles = []
         dskip = {}
         enc_of_dec = {DEC[0]: ENC[3], DEC[1]: ENC[2], DEC[2]: ENC[1], DEC[3]: ENC[0]}
@@ -665,11 +713,11 @@ class UNetTrainEngine:
                     # backward the next _dconv_bwd starts with: no separate reduction pass over dy and z
                     dy_part = torch.empty((B * (H // 2), 2, C), dtype=torch.float32, device=z.device)
                     check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
-                                                           ptr(d_p), ptr(dy), st.drop[0], st.drop[1], st.drop[2], ptr(dy_part), stream()),
+                                                           ptr(d_p), ptr(dy), st.drop[0], st.drop[1], st.drop[2], ptr(dy_part), _is16(z), stream()),
                           "mfpa_maxpool2_bwd_add_sums")
                 else:
                     check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
-                                                      st.drop[0], st.drop[1], st.drop[2], stream()), "mfpa_maxpool2_bwd_add")
+                                                      st.drop[0], st.drop[1], st.drop[2], _is16(z), stream()), "mfpa_maxpool2_bwd_add")
             handles.append(self._reduce_bucket(name))
         ev = None
         if self.comm_wait_events is not None and any(h is not None for h in handles):

@@ -24,22 +24,30 @@ def convergence_data(n_batches=4, B=16, nsamp=24000, seed0=4000):
 
 def run_convergence(precisions, steps=200, B=16, lr=1e-3, verbose=True):
     """Train UNet(1,1,rate=0.05) from the same weights, on the same batches, with the same (stateless, step-keyed) dropout masks, in each
-    arithmetic of `precisions` = {name: (precision, wgrad_precision)}.  Returns {name: (mean training loss of the last 8 steps, held-out
+    arithmetic of `precisions` = {name: (precision, wgrad_precision[, activations kept as bfloat16 in HBM: ops_train.Z16_ACTIVATIONS])}.  Returns {name: (mean training loss of the last 8 steps, held-out
     L1 of the trained weights evaluated by the fp32 inference kernels)}.  Shared with bench.py's config 4 entry."""
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
     train, held = convergence_data(B=B)
     res = {}
-    for name, (prec, wprec) in precisions.items():
+    from musicfpaugment_amd import ops_train
+    for name, spec in precisions.items():
+        prec, wprec = spec[0], spec[1]
         m = UNet(1, 1, rate=0.05)
         m.load_state_dict(formula_state_dict(0))
         m = m.cuda().train()
+        keep_z16 = ops_train.Z16_ACTIVATIONS
+        if len(spec) > 2:                                                # (precision, wgrad_precision, activations kept as bfloat16?)
+            ops_train.Z16_ACTIVATIONS = bool(spec[2])
         eng = UNetTrainEngine(m, lr=lr, precision=prec, wgrad_precision=wprec)
         losses = []
         for k in range(steps):
             am, aden, cm = train[k % len(train)]
             losses.append(eng.train_step(am, aden, cm).clone())          # (the engine returns its persistent loss scalar)
         losses = [float(l) for l in losses]
+        ops_train.Z16_ACTIVATIONS = keep_z16
+        if len(spec) > 2 and bool(spec[2]) != bool(eng._z16):
+            raise RuntimeError(f"{name}: asked for bfloat16 activations = {bool(spec[2])}, the engine ran with {bool(eng._z16)}")
         eng.sync_to_module()
         m.eval()
         m.precision = 0

@@ -123,7 +123,7 @@ def test_forward_conv_side_outputs_bf16_input_copy_and_batchnorm_partials():
         got = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
         ref = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
         check(lib().mfpa_conv_stats_reduce(ptr(sp[0]), sp[0].shape[0], Cout, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
-        check(lib().mfpa_bn_stats_sums(ptr(z), B * H * W, Cout, ptr(ref), ptr(ws), stream()), "mfpa_bn_stats_sums")
+        check(lib().mfpa_bn_stats_sums(ptr(z), B * H * W, Cout, ptr(ref), ptr(ws), 0, stream()), "mfpa_bn_stats_sums")
         zz = z.double().reshape(-1, Cout)
         assert torch.allclose(ref.view(Cout, 2)[:, 0], zz.sum(0), rtol=1e-9, atol=1e-9)
         scale = ref.view(Cout, 2).abs().max(0).values
@@ -138,7 +138,7 @@ def test_forward_conv_side_outputs_bf16_input_copy_and_batchnorm_partials():
         assert torch.equal(z2, z)
         check(lib().mfpa_conv_stats_reduce(ptr(spb[0]), spb[0].shape[0], Cout, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
         check(lib().mfpa_bn_relu_bwd_sums(ptr(z), ptr(zb), B * H * W, Cout, ptr(sb.scale), ptr(sb.shift), ptr(sb.mean), ptr(sb.invstd),
-                                          ptr(ref), ptr(ws), 0, 0, 1.0, stream()), "mfpa_bn_relu_bwd_sums")
+                                          ptr(ref), ptr(ws), 0, 0, 1.0, 0, stream()), "mfpa_bn_relu_bwd_sums")
         scale = ref.view(Cout, 2).abs().max(0).values
         assert ((got - ref).view(Cout, 2).abs() / scale).max().item() < 5e-6, (B, H, W, C0, C1, Cout, "bwd sums")
         # the weight gradient from the two copies (dz's comes from the BatchNorm backward in the engine; cast here)
@@ -171,7 +171,7 @@ def test_batchnorm_statistics_from_conv_partials_large_offset_channel():
     got = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
     ref = torch.empty(2 * Cout, dtype=torch.float64, device="cuda")
     check(lib().mfpa_conv_stats_reduce(ptr(sp[0]), sp[0].shape[0], Cout, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
-    check(lib().mfpa_bn_stats_sums(ptr(z), B * H * W, Cout, ptr(ref), ptr(ws), stream()), "mfpa_bn_stats_sums")
+    check(lib().mfpa_bn_stats_sums(ptr(z), B * H * W, Cout, ptr(ref), ptr(ws), 0, stream()), "mfpa_bn_stats_sums")
     n = float(B * H * W)
 
     def stats(s):
@@ -203,14 +203,14 @@ def test_maxpool_backward_with_batchnorm_sums_equals_the_two_passes():
         dp = torch.randn(B, H // 2, W // 2, C, generator=g).cuda()
         dy0 = torch.randn(B, H, W, C, generator=g).cuda()
         a, b = dy0.clone(), dy0.clone()
-        check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(dp), ptr(a), drop[0], drop[1], drop[2], stream()),
+        check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(dp), ptr(a), drop[0], drop[1], drop[2], 0, stream()),
               "mfpa_maxpool2_bwd_add")
         ref = torch.empty(2 * C, dtype=torch.float64, device="cuda")
         check(lib().mfpa_bn_relu_bwd_sums(ptr(a), ptr(z), B * H * W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(ref), ptr(ws),
-                                          drop[0], drop[1], drop[2], stream()), "mfpa_bn_relu_bwd_sums")
+                                          drop[0], drop[1], drop[2], 0, stream()), "mfpa_bn_relu_bwd_sums")
         part = torch.full((B * (H // 2), 2, C), float("nan"), dtype=torch.float32, device="cuda")
         check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dp), ptr(b),
-                                               drop[0], drop[1], drop[2], ptr(part), stream()), "mfpa_maxpool2_bwd_add_sums")
+                                               drop[0], drop[1], drop[2], ptr(part), 0, stream()), "mfpa_maxpool2_bwd_add_sums")
         assert torch.equal(a, b)
         got = torch.empty(2 * C, dtype=torch.float64, device="cuda")
         check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
@@ -219,7 +219,7 @@ def test_maxpool_backward_with_batchnorm_sums_equals_the_two_passes():
     # C / 4 must divide 256 (a thread keeps one channel quad's sums)
     z = torch.zeros(1, 4, 4, 48, device="cuda")
     v = torch.zeros(48, device="cuda")
-    assert lib().mfpa_maxpool2_bwd_add_sums(ptr(z), 1, 4, 4, 48, ptr(v), ptr(v), ptr(v), ptr(v), ptr(z), ptr(z), 0, 0, 1.0, ptr(z), stream()) != 0
+    assert lib().mfpa_maxpool2_bwd_add_sums(ptr(z), 1, 4, 4, 48, ptr(v), ptr(v), ptr(v), ptr(v), ptr(z), ptr(z), 0, 0, 1.0, ptr(z), 0, stream()) != 0
 
 
 def test_pool_backward_sums_match_the_float64_reduction_on_a_large_offset_channel():
@@ -242,7 +242,7 @@ def test_pool_backward_sums_match_the_float64_reduction_on_a_large_offset_channe
     part = torch.full((B * (H // 2), 2, C), float("nan"), dtype=torch.float32, device="cuda")
     dy = dy0.clone()
     check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dp), ptr(dy),
-                                           0, 0, 1.0, ptr(part), stream()), "mfpa_maxpool2_bwd_add_sums")
+                                           0, 0, 1.0, ptr(part), 0, stream()), "mfpa_maxpool2_bwd_add_sums")
     got = torch.empty(2 * C, dtype=torch.float64, device="cuda")
     check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(got), ptr(ws), stream()), "mfpa_conv_stats_reduce")
     d64 = (dy * (z * scale + shift > 0)).double().view(-1, C)            # g: the gradient where the ReLU is active (a few z + 4 are negative)
@@ -272,24 +272,24 @@ def test_rank1_outconv_backward_equals_the_materialised_path():
     ws = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device="cuda")
     # the two-pass reference
     dy = torch.empty_like(z); dwb0 = torch.zeros(C + 1, device="cuda")
-    check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), npix, C, ptr(scale), ptr(shift), ptr(wb), ptr(dy), ptr(dwb0), ptr(ws), stream()), "mfpa_outconv_bwd")
+    check(lib().mfpa_outconv_bwd(ptr(z), ptr(dpred), npix, C, ptr(scale), ptr(shift), ptr(wb), ptr(dy), ptr(dwb0), ptr(ws), 0, stream()), "mfpa_outconv_bwd")
     dg0 = torch.zeros(C, device="cuda"); db0 = torch.zeros(C, device="cuda"); coef = torch.empty(3, C, device="cuda")
     dz16_0 = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
     check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), npix, C, ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(dg0), ptr(db0), ptr(coef),
-                                 ptr(ws), 0, 0, 1.0, ptr(dz16_0), 1, stream()), "mfpa_bn_relu_bwd")
+                                 ptr(ws), 0, 0, 1.0, ptr(dz16_0), 1, 0, stream()), "mfpa_bn_relu_bwd")
     # rank 1
     rows = ctypes.c_int(0)
     check(lib().mfpa_outconv_bwd_rows(npix, C, ctypes.byref(rows)), "mfpa_outconv_bwd_rows")
     part = torch.full((rows.value, 2, C), float("nan"), dtype=torch.float32, device="cuda")
     dwb1 = torch.zeros(C + 1, device="cuda")
     check(lib().mfpa_outconv_bwd_sums(ptr(z), ptr(dpred), npix, C, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(wb), ptr(dwb1), ptr(ws), ptr(part),
-                                      stream()), "mfpa_outconv_bwd_sums")
+                                      0, stream()), "mfpa_outconv_bwd_sums")
     loc = torch.empty(2 * C, dtype=torch.float64, device="cuda")
     check(lib().mfpa_conv_stats_reduce(ptr(part), part.shape[0], C, ptr(loc), ptr(ws), stream()), "mfpa_conv_stats_reduce")
     dg1 = torch.zeros(C, device="cuda"); db1 = torch.zeros(C, device="cuda"); coef1 = torch.empty(3, C, device="cuda")
     dz1 = torch.empty_like(z); dz16_1 = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
     check(lib().mfpa_bn_relu_bwd_finish_rank1(ptr(dpred), ptr(wb), ptr(z), npix, C, ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(loc),
-                                              ptr(loc), float(npix), ptr(dg1), ptr(db1), ptr(coef1), ptr(dz1), ptr(dz16_1), stream()),
+                                              ptr(loc), float(npix), ptr(dg1), ptr(db1), ptr(coef1), ptr(dz1), ptr(dz16_1), 0, stream()),
           "mfpa_bn_relu_bwd_finish_rank1")
     assert torch.equal(dwb0, dwb1)
     s = float(dy.abs().max())                                   # dy now holds the reference dz (in place)
@@ -299,7 +299,7 @@ def test_rank1_outconv_backward_equals_the_materialised_path():
     # bf16 only (the plain-bf16 step): no float32 dz
     dz16_2 = torch.empty(z.shape, dtype=torch.bfloat16, device="cuda")
     check(lib().mfpa_bn_relu_bwd_finish_rank1(ptr(dpred), ptr(wb), ptr(z), npix, C, ptr(gamma), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(loc),
-                                              ptr(loc), float(npix), ptr(dg1), ptr(db1), ptr(coef1), 0, ptr(dz16_2), stream()),
+                                              ptr(loc), float(npix), ptr(dg1), ptr(db1), ptr(coef1), 0, ptr(dz16_2), 0, stream()),
           "mfpa_bn_relu_bwd_finish_rank1")
     assert torch.equal(dz16_2, dz16_1)
 
@@ -833,6 +833,60 @@ def test_plain_bf16_train_step_converges_where_fp32_does():
         dev3, devb = abs(x3[i] - f[i]) / f[i], abs(b[i] - f[i]) / f[i]
         print(f"[convergence, lr 1e-3] {what}: fp32-vs-fp32 {100 * spread:.2f} %, bf16x3 {100 * dev3:.2f} %, plain bf16 {100 * devb:.2f} % off fp32")
         assert devb <= max(0.15, 2 * spread, 2 * dev3), (what, devb, spread, dev3)
+
+
+def test_bfloat16_activations_in_hbm_same_step_and_same_convergence():
+    """Round 5: the plain-bf16 step keeps the convolutions' raw outputs z, the pooled activations and the transposed convolutions' outputs
+    as bfloat16 ONLY (ops_train.Z16_ACTIVATIONS; every consumer rounded them to bf16 anyway, after the BatchNorm affine -- now z itself is
+    rounded too; BatchNorm statistics still come from the float32 accumulators).  (1) One step on 8 clips of 8 s against the same engine
+    with float32 activations, same output gradient: loss within 0.5 %, prediction within 6 % (plain bf16 is 2.8 % from fp32 on this
+    un-trained network), per-parameter gradient cosine >= 0.98 median.  (2) 200 optimiser steps (lr 1e-4, 16 clips of 3 s): final training loss and held-out L1 within
+    2 % of the FP32 engine's, the same gate the float32-activation variant is held to."""
+    from musicfpaugment_amd import ops, ops_train, synth
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    B = 8
+    clean = synth.batch(B, seed=7100)
+    noisy = (0.7 * clean + 0.3 * synth.batch(B, seed=7600, tonal=False)).astype(np.float32)
+    cm, cmax = ops.stft_mag(torch.from_numpy(clean).cuda(), torch.float64)
+    am, amax = ops.stft_mag(torch.from_numpy(noisy).cuda(), torch.float64)
+    ops.normalize_(cm, cmax.max().expand(B).contiguous(), per_clip=True)
+    aden = amax.max().expand(B).contiguous()
+    out, dpred0 = {}, None
+    keep = ops_train.Z16_ACTIVATIONS
+    try:
+        for z16 in (False, True):
+            ops_train.Z16_ACTIVATIONS = z16
+            net = UNet(1, 1, rate=0.05)
+            net.load_state_dict(formula_state_dict(2))
+            eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=2, wgrad_precision=2)
+            pred = eng.forward(spec64=am, denom=aden)
+            assert eng._z16 == z16
+            if z16:
+                assert all(r["z3"].dtype == torch.bfloat16 and r["z0"].dtype == torch.bfloat16 for r in eng._recs.values())
+            loss, dpred = eng.l1_loss(pred, cm)
+            if dpred0 is None:
+                dpred0 = dpred.clone()
+            eng.backward(dpred0.clone())
+            out[z16] = (pred.clone(), float(loss), {k: v.double().flatten().clone() for k, v in eng.named_grads().items()})
+            del eng, net
+            torch.cuda.empty_cache()
+    finally:
+        ops_train.Z16_ACTIVATIONS = keep
+    (p0, l0, g0), (p1, l1, g1) = out[False], out[True]
+    cos = np.array([float(torch.dot(g0[k], g1[k]) / (g0[k].norm() * g1[k].norm() + 1e-300)) for k in g0])
+    print(f"[bf16 activations vs float32 activations, plain-bf16 step, 8 x 8 s] prediction rel L1 {rel(p1, p0):.3e}, loss {l0:.6f} / {l1:.6f}, "
+          f"gradient cosine per parameter: median {np.median(cos):.4f}, min {cos.min():.4f}")
+    # (the un-trained formula network amplifies any rounding: plain bf16 itself is 2.8e-2 from fp32 on this measure -- test_train_step_in_plain_bf16_tracks_the_fp32_step)
+    assert rel(p1, p0) < 6e-2 and abs(l1 - l0) < 5e-3 * l0
+    assert np.median(cos) >= 0.98 and cos.min() > 0.8, (np.median(cos), cos.min())
+    res = run_convergence({"fp32": (0, 0), "bf16 z32": (2, 2, False), "bf16 z16": (2, 2, True)}, lr=1e-4)
+    f = res["fp32"]
+    for name in ("bf16 z32", "bf16 z16"):
+        for i, what in ((0, "training loss"), (1, "held-out L1")):
+            dev = abs(res[name][i] - f[i]) / f[i]
+            print(f"[convergence, lr 1e-4] {name} {what}: {100 * dev:.2f} % off fp32")
+            assert dev <= 0.02, (name, what, dev)
 
 
 def test_plain_bf16_gradients_at_the_bench_batch_point_where_fp32s_do():
