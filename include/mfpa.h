@@ -373,7 +373,7 @@ int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, co
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
                             unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32,
-                            int z_is_bf16, void* stream);
+                            int z_is_bf16, int dy_is_bf16, void* stream);
 
 /* out[c] = sum over pixels of x[p][c]  (ConvTranspose2d bias gradient). */
 int mfpa_colsum(const float* x, long long npix, int C, float* out, double* workspace, void* stream);

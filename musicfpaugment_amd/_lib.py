@@ -135,7 +135,7 @@ _SIGNATURES = {
                                c_void_p, c_uint, c_uint, c_float, c_int, c_void_p], c_int),
     "mfpa_bn_relu_bwd_finish": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
-                                 c_void_p, c_int, c_int, c_void_p], c_int),
+                                 c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
                            c_int, c_int, c_void_p], c_int),

@@ -1718,7 +1718,7 @@ __global__ __launch_bounds__(512, 1) void conv_wd16_kernel(ConvArgs a) {
         }
       }
     }
-    if (a.y != nullptr || (SIDE && AFF16 && a.y_bf16 != nullptr)) {     // (y null with y_bf16: the output exists as bfloat16 only)
+    if (a.y != nullptr || (SIDE && IN16 && a.y_bf16 != nullptr)) {      // (y null with y_bf16: the output exists as bfloat16 only)
       char* yb = reinterpret_cast<char*>(a.y + (size_t)eb * a.yH * a.yW * a.Cout);
   #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
@@ -1990,7 +1990,7 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
   const bool rows = WMW == 2 && rows_min > 0 && cin % 64 == 0 && cin >= rows_min;
   if (a.in16) {                                                        // bf16 source: the plain-bf16 input-gradient convolutions
     if (!a.plain || a.x1_bf16 || cin % 64) return MFPA_EINVAL;         // (both sources bfloat16; source 1 IS its own bf16 copy)
-    const bool fwd16 = a.in_scale0 != nullptr || a.x0_bf16 != nullptr || a.y == nullptr;      // the training forward's form (AFF16)
+    const bool fwd16 = a.in_scale0 != nullptr || a.x0_bf16 != nullptr || (a.y == nullptr && a.bz == nullptr);   // the training forward's form (AFF16)
     if constexpr (WMW == 4) {
       if (fwd16) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true, true, true>), grid, dim3(512), lds, s, a);
       else if (side) hipLaunchKernelGGL((conv_wd16_kernel<PH, PW, false, 4, true, true, true>), grid, dim3(512), lds, s, a);
@@ -2605,7 +2605,7 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->stats_part != nullptr && (d->w_layout != 2 || (!d->y && !d->y_bf16))) return MFPA_EINVAL;       // only conv_wd16_kernel's epilogue writes them
   a.stats_part = d->stats_part;
   if (d->bwd_z != nullptr && (!d->stats_part || !d->bwd_scale || !d->bwd_shift || !d->bwd_mean || !d->bwd_invstd)) return MFPA_EINVAL;
-  if (d->bwd_z != nullptr && d->x0_is_bf16 && (d->in_scale0 || d->x0_bf16 || !d->y)) return MFPA_EINVAL;   // (the training forward's form of the kernel carries no bwd_z code)
+  if (d->bwd_z != nullptr && d->x0_is_bf16 && (d->in_scale0 || d->x0_bf16)) return MFPA_EINVAL;   // (the training forward's form of the kernel carries no bwd_z code)
   a.bz16 = (d->bwd_z != nullptr && d->bwd_z_is_bf16) ? 1 : 0;
   a.bz = d->bwd_z; a.bz_scale = d->bwd_scale; a.bz_shift = d->bwd_shift; a.bz_mean = d->bwd_mean; a.bz_invstd = d->bwd_invstd;
   if (any_split) {                                                       // only conv_ws64_kernel reads / writes the split layout

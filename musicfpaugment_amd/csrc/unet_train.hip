@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, unsigned drop_seed,
                                                            unsigned drop_thresh, float drop_scale, __bf16* __restrict__ dz16,
-                                                           int write_f32, const float* __restrict__ dpred, const float* __restrict__ w1, int z16) {
+                                                           int write_f32, const float* __restrict__ dpred, const float* __restrict__ w1, int z16, int dy16) {
+  // dy16: the incoming gradient is a bfloat16 tensor (the input-gradient convolution left it so: mfpa_conv_desc.y_bf16 without y); then only dz16 is written
   const int C4 = C / 4;                      // a power of two (checked on the host): no 64-bit division per element
   const long long total = npix * C4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = gp * wv[k];
     } else {
-      g = *reinterpret_cast<const f32x4*>(dy + e * 4);
+      g = ld_act4(dy, (size_t)e * 4, dy16);
     }
     const f32x4 zz = ld_act4(z, (size_t)e * 4, z16);
     f32x4 o;
@@ -1473,7 +1474,7 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
   MFPA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
                      mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
-                     (const float*)nullptr, (const float*)nullptr, z_is_bf16);
+                     (const float*)nullptr, (const float*)nullptr, z_is_bf16, 0);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1538,9 +1539,10 @@ int mfpa_bn_relu_bwd_sums(const float* dy, const float* z, long long npix, int C
 int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
                             const float* shift, const float* mean, const float* invstd, const double* local_sums,
                             const double* global_sums, double global_count, float* dgamma, float* dbeta, float* coef,
-                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32, int z_is_bf16, void* stream) {
+                            unsigned drop_seed, unsigned drop_thresh, float drop_scale, void* dz_bf16, int write_f32, int z_is_bf16, int dy_is_bf16, void* stream) {
   if (!gamma || !scale || !shift || !mean || !invstd || !local_sums || !global_sums || !dgamma || !dbeta || !coef) return MFPA_EINVAL;
   if (!write_f32 && !dz_bf16) return MFPA_EINVAL;
+  if (dy_is_bf16 && write_f32) return MFPA_EINVAL;                    // a bfloat16 dy cannot take the float32 dz in place
   if (!bn_shape_ok(npix, C) || (C & (C - 1)) || !(global_count >= 1.0) || (npix > 0 && (!dy || !z))) return MFPA_EINVAL;
   hipStream_t s = mfpa_stream(stream);
   hipLaunchKernelGGL(bn_bwd_finish_sync_kernel, dim3((C + 255) / 256), dim3(256), 0, s, local_sums, global_sums, C, global_count,
@@ -1549,7 +1551,7 @@ int mfpa_bn_relu_bwd_finish(float* dy, const float* z, long long npix, int C, co
   if (npix == 0) return MFPA_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
                      mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
-                     (const float*)nullptr, (const float*)nullptr, z_is_bf16);
+                     (const float*)nullptr, (const float*)nullptr, z_is_bf16, dy_is_bf16);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1567,7 +1569,7 @@ int mfpa_bn_relu_bwd_finish_rank1(const float* dpred, const float* w1, const flo
   MFPA_CHECK_LAUNCH();
   if (npix == 0) return MFPA_OK;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dz_f32, z, npix, C, scale, shift,
-                     mean, invstd, coef, 0u, 0u, 1.f, reinterpret_cast<__bf16*>(dz_bf16), dz_f32 != nullptr ? 1 : 0, dpred, w1, z_is_bf16);
+                     mean, invstd, coef, 0u, 0u, 1.f, reinterpret_cast<__bf16*>(dz_bf16), dz_f32 != nullptr ? 1 : 0, dpred, w1, z_is_bf16, 0);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

@@ -170,6 +170,8 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
+DY16_MID = False            # True: a DoubleConv's inner gradient (dy of its first BatchNorm) too leaves its convolution as bfloat16 only -- built, tested, measured
+                            # at -0.07 ms of 31.2 (those two kernels are not bound by these bytes): off
 Z16_ACTIVATIONS = True      # plain-bf16 step (precision 2 with bf16 weight gradients): the convolutions' raw outputs z, the pooled activations and the
                             # transposed convolutions' outputs live in HBM as bfloat16 only (False: float32, A/B runs) -- see UNetTrainEngine._z16_for
 USE_BF16_DZ = True          # plain-bf16 step: input-gradient convolutions read the bf16 copy of dz (False: the float32 dz, A/B runs)
@@ -521,7 +523,7 @@ class UNetTrainEngine:
                 st.count_host = float(_npix(z))
             check(lib().mfpa_bn_relu_bwd_finish(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
                                                 ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
-                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), _is16(z), stream()),
+                                                ptr(self.G[b]), ptr(coef), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32), _is16(z), _is16(dy), stream()),
                   "mfpa_bn_relu_bwd_finish")
             return (dy if write_f32 else None), dz16
         check(lib().mfpa_bn_relu_bwd(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift),
@@ -613,15 +615,21 @@ class UNetTrainEngine:
         r["xb3"] = None
         wt3 = pack_weights(self.P[prefix + ".3.w"], self.precision, flip_transpose=True, layout=lay)   # [tap'][ci][co]
         spm = [] if r["st0"].drop[1] == 0 else None      # dmid is dy of relu(bn(z0)): the BatchNorm backward's reductions in the epilogue
-        dmid = conv_mfma(dz16 if only16 else dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay, stats_out=spm,
-                         bwd_of=(r["z0"], r["st0"]))
-        del dz3, dz16
         cin0 = 0 if r["first_input"] is not None else r["src0"].shape[-1] + (0 if r["src1"] is None else r["src1"].shape[-1])
-        wg16 = cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None)
+        wg16_0 = cin0 > 0 and bf16_wgrad(cout, cin0, self.wgrad_precision, r["xb0"] is not None)
         c0_ = 0 if r["first_input"] is not None else r["src0"].shape[-1]
         c1_ = 0 if (r["first_input"] is not None or r["src1"] is None) else r["src1"].shape[-1]
-        only16 = (USE_BF16_DZ and self.precision == 2 and wg16 and need_input_grad and c0_ > 0
-                  and weight_layout(H_, W_, cout, c0_, self.precision) == 2 and (c1_ == 0 or weight_layout(H_, W_, cout, c1_, self.precision) == 2))
+        only16_0 = (USE_BF16_DZ and self.precision == 2 and wg16_0 and need_input_grad and c0_ > 0
+                    and weight_layout(H_, W_, cout, c0_, self.precision) == 2 and (c1_ == 0 or weight_layout(H_, W_, cout, c1_, self.precision) == 2))
+        # activations as bfloat16 (Z16_ACTIVATIONS): dmid too leaves its convolution as bfloat16 only when the BatchNorm backward that reads
+        # it writes nothing but the bf16 dz (and takes its two reductions from that convolution's epilogue)
+        dmid16 = bool(DY16_MID and only16 and only16_0 and spm is not None and r["z0"].dtype == torch.bfloat16)
+        dmid = conv_mfma(dz16 if only16 else dz3, wt3, cout, precision=self.precision, packed=True, w_layout=lay, stats_out=spm,
+                         bwd_of=(r["z0"], r["st0"]), out_bf16=dmid16)
+        del dz3, dz16
+        wg16, only16 = wg16_0, only16_0
+        if dmid16 and not spm:
+            raise RuntimeError("a bfloat16 dmid needs the convolution's BatchNorm-backward partial sums")
         dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b", bf16_copy=wg16,
                                       part=spm[0] if spm else None, write_f32=not only16)
         if r["first_input"] is not None:

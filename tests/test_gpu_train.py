@@ -853,15 +853,15 @@ def test_bfloat16_activations_in_hbm_same_step_and_same_convergence():
     ops.normalize_(cm, cmax.max().expand(B).contiguous(), per_clip=True)
     aden = amax.max().expand(B).contiguous()
     out, dpred0 = {}, None
-    keep = ops_train.Z16_ACTIVATIONS
+    keep, keep_mid = ops_train.Z16_ACTIVATIONS, ops_train.DY16_MID
     try:
-        for z16 in (False, True):
-            ops_train.Z16_ACTIVATIONS = z16
+        for z16 in (False, True, "mid"):                                 # "mid": with DY16_MID (the inner gradient of a DoubleConv as bfloat16 too; off by default)
+            ops_train.Z16_ACTIVATIONS, ops_train.DY16_MID = bool(z16), z16 == "mid"
             net = UNet(1, 1, rate=0.05)
             net.load_state_dict(formula_state_dict(2))
             eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=2, wgrad_precision=2)
             pred = eng.forward(spec64=am, denom=aden)
-            assert eng._z16 == z16
+            assert eng._z16 == bool(z16)
             if z16:
                 assert all(r["z3"].dtype == torch.bfloat16 and r["z0"].dtype == torch.bfloat16 for r in eng._recs.values())
             loss, dpred = eng.l1_loss(pred, cm)
@@ -872,8 +872,12 @@ def test_bfloat16_activations_in_hbm_same_step_and_same_convergence():
             del eng, net
             torch.cuda.empty_cache()
     finally:
-        ops_train.Z16_ACTIVATIONS = keep
+        ops_train.Z16_ACTIVATIONS, ops_train.DY16_MID = keep, keep_mid
     (p0, l0, g0), (p1, l1, g1) = out[False], out[True]
+    gm = out["mid"][2]
+    cos_mid = np.array([float(torch.dot(g1[k], gm[k]) / (g1[k].norm() * gm[k].norm() + 1e-300)) for k in g1])
+    print(f"[DY16_MID on top] gradient cosine against the default: median {np.median(cos_mid):.5f}, min {cos_mid.min():.4f}")
+    assert torch.equal(out["mid"][0], p1) and np.median(cos_mid) > 0.995 and cos_mid.min() > 0.9       # (the forward is the same)
     cos = np.array([float(torch.dot(g0[k], g1[k]) / (g0[k].norm() * g1[k].norm() + 1e-300)) for k in g0])
     print(f"[bf16 activations vs float32 activations, plain-bf16 step, 8 x 8 s] prediction rel L1 {rel(p1, p0):.3e}, loss {l0:.6f} / {l1:.6f}, "
           f"gradient cosine per parameter: median {np.median(cos):.4f}, min {cos.min():.4f}")
