@@ -363,6 +363,16 @@ int mfpa_bn_relu_bwd(float* dy, const float* z, long long npix, int C, const flo
  * and the pixel count over the ranks, *_finish completes from the global sums.  Backward: dgamma / dbeta come from the LOCAL
  * sums (the gradient all-reduce adds the ranks), the mean terms of the input gradient from the GLOBAL ones. */
 int mfpa_bn_stats_sums(const float* z, long long npix, int C, double* sums, double* workspace, int z_is_bf16, void* stream);
+/* round 5, single-GPU statistics (no all-reduce between the halves): mfpa_conv_stats_reduce + mfpa_bn_stats_finish as two launches
+ * instead of three, and mfpa_conv_stats_reduce + mfpa_bn_relu_bwd_finish as three instead of four -- the finish kernels sum the row
+ * blocks' float64 partials themselves, in mfpa_conv_stats_reduce's order: bit-identical results. */
+int mfpa_conv_stats_bn_finish(const float* part, long long rows, int C, double count, const float* gamma, const float* beta, float eps,
+                              float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                              float* running_var, double* workspace, void* stream);
+int mfpa_bn_relu_bwd_from_part(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* part, long long rows,
+                               float* dgamma, float* dbeta, float* coef, double* workspace, unsigned drop_seed, unsigned drop_thresh,
+                               float drop_scale, void* dz_bf16, int write_f32, int z_is_bf16, int dy_is_bf16, void* stream);
 int mfpa_bn_stats_finish(const double* sums, double count, int C, const float* gamma, const float* beta, float eps,
                          float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
                          float* running_var, void* stream);

@@ -137,6 +137,10 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
                                  c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "mfpa_colsum": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_conv_stats_bn_finish": ([c_void_p, c_longlong, c_int, c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_bn_relu_bwd_from_part": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
     "mfpa_bn_relu_pool": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_uint, c_uint, c_float,
                            c_int, c_int, c_void_p], c_int),
     "mfpa_maxpool2_bwd_add": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

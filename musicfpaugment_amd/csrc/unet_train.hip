@@ -1509,6 +1509,50 @@ int mfpa_conv_stats_reduce(const float* part, long long rows, int C, double* sum
   return MFPA_OK;
 }
 
+// mfpa_conv_stats_reduce + mfpa_bn_stats_finish in two launches instead of three (single-GPU statistics: no all-reduce between them): the
+// finish kernel sums the row blocks' partials itself, in the order pair_sums_kernel does -- bit-identical statistics.
+int mfpa_conv_stats_bn_finish(const float* part, long long rows, int C, double count, const float* gamma, const float* beta, float eps,
+                              float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                              float* running_var, double* workspace, void* stream) {
+  if (!part || !workspace || rows < 1 || C < 1 || (C < 256 && 256 % C) || (C > 256 && C % 256)) return MFPA_EINVAL;
+  if (!gamma || !beta || !mean || !invstd || !scale || !shift || !(count >= 1.0)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int groups = 256 / (C < 256 ? C : 256);
+  const int nblk = grid_for(rows, groups * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(conv_stats_rows_kernel, dim3(nblk), dim3(256), 0, s, part, rows, C, workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, count, eps,
+                     momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+// the BatchNorm + ReLU backward from a convolution's (or pool / OutConv backward's) row partials {sum g, sum g * xhat}: rows -> float64
+// block sums -> dgamma / dbeta / coefficients -> apply, three launches (mfpa_conv_stats_reduce + mfpa_bn_relu_bwd_finish: four).  Single-GPU
+// statistics only (with SyncBN the sums are all-reduced between the two halves: use those two calls).
+int mfpa_bn_relu_bwd_from_part(float* dy, const float* z, long long npix, int C, const float* gamma, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* part, long long rows,
+                               float* dgamma, float* dbeta, float* coef, double* workspace, unsigned drop_seed, unsigned drop_thresh,
+                               float drop_scale, void* dz_bf16, int write_f32, int z_is_bf16, int dy_is_bf16, void* stream) {
+  if (!gamma || !scale || !shift || !mean || !invstd || !part || !dgamma || !dbeta || !coef || !workspace || rows < 1) return MFPA_EINVAL;
+  if (!write_f32 && !dz_bf16) return MFPA_EINVAL;
+  if (dy_is_bf16 && write_f32) return MFPA_EINVAL;
+  if (npix < 1 || !bn_shape_ok(npix, C) || (C & (C - 1)) || !dy || !z || (C < 256 && 256 % C) || (C > 256 && C % 256)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const int groups = 256 / (C < 256 ? C : 256);
+  const int nblk = grid_for(rows, groups * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(conv_stats_rows_kernel, dim3(nblk), dim3(256), 0, s, part, rows, C, workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)npix, gamma, invstd, dgamma,
+                     dbeta, coef);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(npix * (C / 4))), dim3(256), 0, s, dy, z, npix, C, scale, shift,
+                     mean, invstd, coef, drop_seed, drop_thresh, drop_scale, reinterpret_cast<__bf16*>(dz_bf16), write_f32,
+                     (const float*)nullptr, (const float*)nullptr, z_is_bf16, dy_is_bf16);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
 int mfpa_bn_stats_finish(const double* sums, double count, int C, const float* gamma, const float* beta, float eps,
                          float momentum, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
                          float* running_var, void* stream) {

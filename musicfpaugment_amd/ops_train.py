@@ -170,6 +170,8 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
+FUSED_FINISH = True         # single-GPU BatchNorm statistics / backward sums from row partials: the finish kernels read the block partials directly
+                            # (mfpa_conv_stats_bn_finish, mfpa_bn_relu_bwd_from_part: 35 launches fewer per step, bit-identical; False: the separate calls)
 DY16_MID = False            # True: a DoubleConv's inner gradient (dy of its first BatchNorm) too leaves its convolution as bfloat16 only -- built, tested, measured
                             # at -0.07 ms of 31.2 (those two kernels are not bound by these bytes): off
 Z16_ACTIVATIONS = True      # plain-bf16 step (precision 2 with bf16 weight gradients): the convolutions' raw outputs z, the pooled activations and the
@@ -464,6 +466,14 @@ class UNetTrainEngine:
         test_pool_backward_sums_match_the_float64_reduction_on_a_large_offset_channel)."""
         C = z.shape[-1]
         st = Stats(C, z.device)
+        if part is not None and not self.sync_bn and FUSED_FINISH:
+            # single-GPU statistics: the finish kernel sums the row blocks' partials itself (two launches instead of three, same sums)
+            check(lib().mfpa_conv_stats_bn_finish(ptr(part), part.shape[0], C, float(_npix(z)), ptr(self.P[g]), ptr(self.P[b]), BN_EPS, BN_MOMENTUM,
+                                                  ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift),
+                                                  ptr(self.running[bn + ".running_mean"]), ptr(self.running[bn + ".running_var"]),
+                                                  ptr(self.workspace), stream()), "mfpa_conv_stats_bn_finish")
+            st.count_host = float(_npix(z))
+            return st
         if self.sync_bn or part is not None:
             # statistics over the GLOBAL batch (the single-GPU reference's semantics): local (sum, sum^2) + pixel count,
             # one small SUM all-reduce, finish from the global sums
@@ -509,6 +519,13 @@ class UNetTrainEngine:
                                                       ptr(st.mean), ptr(st.invstd), ptr(loc), ptr(glob), st.count_host, ptr(self.G[g]),
                                                       ptr(self.G[b]), ptr(coef), ptr(dz), ptr(dz16), _is16(z), stream()), "mfpa_bn_relu_bwd_finish_rank1")
             return dz, dz16
+        if part is not None and not self.sync_bn and FUSED_FINISH:
+            st.count_host = float(_npix(z))
+            check(lib().mfpa_bn_relu_bwd_from_part(ptr(dy), ptr(z), _npix(z), C, ptr(self.P[g]), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+                                                   ptr(st.invstd), ptr(part), part.shape[0], ptr(self.G[g]), ptr(self.G[b]), ptr(coef),
+                                                   ptr(self.workspace), st.drop[0], st.drop[1], st.drop[2], ptr(dz16), int(write_f32),
+                                                   _is16(z), _is16(dy), stream()), "mfpa_bn_relu_bwd_from_part")
+            return (dy if write_f32 else None), dz16
         if self.sync_bn or part is not None:
             loc = torch.empty(2 * C, dtype=torch.float64, device=z.device)
             if part is not None:             # the convolution that produced dy reduced (sum g, sum g * xhat) in its epilogue (conv_mfma(bwd_of=))

@@ -813,18 +813,22 @@ def test_plain_bf16_train_step_converges_where_fp32_does():
 
     (1) lr 1e-4 -- small enough that 200 steps do not amplify a rounding difference into a different trajectory, so what is compared is
         the accumulated EFFECT of the gradients (a biased gradient would drift): plain bf16's final training loss and held-out L1
-        (trained weights through the fp32 inference kernels) within 2 % of fp32's.
+        (trained weights through the fp32 inference kernels) within 2 % of fp32's -- of the mean of two fp32 runs, plus what those two
+        differ by (float atomics: the same fp32 run repeats to 0.3-1.5 % on these numbers).
     (2) lr 1e-3 (the reference's, training/train.py:661) -- here the loss falls 60-fold in 200 steps and the runs are chaotic: two FP32
         runs of the same everything differ by 1.4-6 % (float atomics order the weight-gradient sums differently) and bf16x3, whose
         gradients equal fp32's to 1.5 %, lands 5-14 % away.  Measured and printed; the gate is relative to that spread: plain bf16 no
         further from fp32 than max(15 %, twice what fp32-vs-fp32 and bf16x3-vs-fp32 show)."""
-    res = run_convergence({"fp32": (0, 0), "bf16x3": (1, 2), "bf16": (2, 2)}, lr=1e-4)
-    f, x3, b = res["fp32"], res["bf16x3"], res["bf16"]
+    res = run_convergence({"fp32": (0, 0), "fp32 (b)": (0, 0), "bf16x3": (1, 2), "bf16": (2, 2)}, lr=1e-4)
+    f, fb, x3, b = res["fp32"], res["fp32 (b)"], res["bf16x3"], res["bf16"]
     assert f[0] < 0.7 * f[2] and b[0] < 0.7 * b[2]                       # both really trained
     for i, what in ((0, "training loss"), (1, "held-out L1")):
-        dev3, devb = abs(x3[i] - f[i]) / f[i], abs(b[i] - f[i]) / f[i]
-        print(f"[convergence, lr 1e-4] {what}: bf16x3 {100 * dev3:.2f} %, plain bf16 {100 * devb:.2f} % off fp32")
-        assert devb <= 0.02, (what, devb)
+        # two FP32 runs of the same everything differ too (float atomics order the weight-gradient sums: 0.3-1.5 % on these two numbers
+        # over the round's runs): the reference is their mean, the gate 2 % beyond their own spread
+        ref, spread = 0.5 * (f[i] + fb[i]), abs(f[i] - fb[i]) / (0.5 * (f[i] + fb[i]))
+        dev3, devb = abs(x3[i] - ref) / ref, abs(b[i] - ref) / ref
+        print(f"[convergence, lr 1e-4] {what}: fp32-vs-fp32 {100 * spread:.2f} %, bf16x3 {100 * dev3:.2f} %, plain bf16 {100 * devb:.2f} % off the fp32 mean")
+        assert devb <= 0.02 + spread, (what, devb, spread)
     res = run_convergence({"fp32": (0, 0), "fp32 (b)": (0, 0), "bf16x3": (1, 2), "bf16": (2, 2)}, lr=1e-3)
     f, fb, x3, b = res["fp32"], res["fp32 (b)"], res["bf16x3"], res["bf16"]
     assert f[0] < 0.1 * f[2] and b[0] < 0.1 * b[2]
@@ -884,13 +888,14 @@ def test_bfloat16_activations_in_hbm_same_step_and_same_convergence():
     # (the un-trained formula network amplifies any rounding: plain bf16 itself is 2.8e-2 from fp32 on this measure -- test_train_step_in_plain_bf16_tracks_the_fp32_step)
     assert rel(p1, p0) < 6e-2 and abs(l1 - l0) < 5e-3 * l0
     assert np.median(cos) >= 0.98 and cos.min() > 0.8, (np.median(cos), cos.min())
-    res = run_convergence({"fp32": (0, 0), "bf16 z32": (2, 2, False), "bf16 z16": (2, 2, True)}, lr=1e-4)
-    f = res["fp32"]
+    res = run_convergence({"fp32": (0, 0), "fp32 (b)": (0, 0), "bf16 z32": (2, 2, False), "bf16 z16": (2, 2, True)}, lr=1e-4)
+    f, fb = res["fp32"], res["fp32 (b)"]
     for name in ("bf16 z32", "bf16 z16"):
         for i, what in ((0, "training loss"), (1, "held-out L1")):
-            dev = abs(res[name][i] - f[i]) / f[i]
-            print(f"[convergence, lr 1e-4] {name} {what}: {100 * dev:.2f} % off fp32")
-            assert dev <= 0.02, (name, what, dev)
+            ref, spread = 0.5 * (f[i] + fb[i]), abs(f[i] - fb[i]) / (0.5 * (f[i] + fb[i]))
+            dev = abs(res[name][i] - ref) / ref
+            print(f"[convergence, lr 1e-4] {name} {what}: {100 * dev:.2f} % off the fp32 mean (fp32-vs-fp32 {100 * spread:.2f} %)")
+            assert dev <= 0.02 + spread, (name, what, dev, spread)
 
 
 def test_plain_bf16_gradients_at_the_bench_batch_point_where_fp32s_do():
