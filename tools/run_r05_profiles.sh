@@ -20,10 +20,12 @@ python tools/summarize_sq.py $O/pmc_s2 conv_mfma_kernel,convT_mfma_kernel,conv_w
 python tools/summarize_sq.py $O/pmc_s3 conv_mfma_kernel,convT_mfma_kernel,conv_wd16_kernel,conv_ws64_kernel $O/pmc_sq_pass3.json > $O/pmc_sq3.txt 2>&1
 python tools/sq_table.py $O/pmc_sq_pass1.json $O/pmc_sq_pass2.json > $O/pmc_sq_table.md 2>&1
 rm -rf $O/pmc_s1 $O/pmc_s2 $O/pmc_s3
-timeout -k 10 300 python bench.py --mode train --precision bf16 --steps 20 --warmup 5 > $O/train_step_bf16_bench_line.json 2>> $O/bench.err
-timeout -k 10 300 python bench.py --mode train --precision bf16x3 --steps 20 --warmup 5 > $O/train_step_bf16x3_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --mode train --precision bf16 --wgrad bf16 --augment --steps 20 --warmup 5 > $O/train_step_bf16_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --mode train --precision bf16x3 --wgrad bf16 --augment --steps 20 --warmup 5 > $O/train_step_bf16x3_bench_line.json
+timeout -k 10 300 python bench.py --mode train --precision bf16 --wgrad bf16 --augment --no-z16 --steps 20 --warmup 5 > $O/train_step_bf16_f32act_bench_line.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --mode train --precision bf16 --wgrad bf16 --steps 20 --warmup 5 > $O/train_step_bf16_premixed_bench_line.json 2>> $O/bench.err 2>> $O/bench.err
 timeout -k 10 300 python bench.py --mode demucs --steps 20 --warmup 5 > $O/demucs_bench_line.json 2>> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -o p -- python3 bench.py --mode train --precision bf16 --steps 10 --warmup 3 --cpu-seconds 0 > $O/train_step_bf16_bench_under_rocprof.json 2>> $O/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -o p -- python3 bench.py --mode train --precision bf16 --wgrad bf16 --augment --steps 10 --warmup 3 --cpu-seconds 0 > $O/train_step_bf16_bench_under_rocprof.json 2>> $O/bench.err
 cp $(find $O/ktt -name "*kernel_stats.csv" | head -1) $O/train_step_bf16_kernel_stats.csv; rm -rf $O/ktt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -o p -- python3 bench.py --no-unet --steps 20 --warmup 3 > $O/config2_bench_under_rocprof.json 2>> $O/bench.err
 cp $(find $O/kt2 -name "*kernel_stats.csv" | head -1) $O/config2_kernel_stats.csv; rm -rf $O/kt2
@@ -38,5 +40,7 @@ bash tools/run_config2_sq.sh > $O/config2_sq.log 2>&1
 cp gpurun_out/config2_sq/sq1_256.json $O/config2_sq_pass1.json; cp gpurun_out/config2_sq/sq2_256.json $O/config2_sq_pass2.json
 ls $O; tail -2 $O/pmc_traffic.log
 python tools/exp_ws_timeline.py musicfpaugment_amd/libmfpa_ws_0_MFPA_WS_STAMPS1.so > $O/ws_timeline.txt 2>&1
+for s_ in 1 3; do python bench.py --mode infer --no-unet --clips 256 --steps 60 --warmup 6 --batch-streams $s_ --no-extras --cpu-seconds 0 --no-configs 2>/dev/null; done > $O/config2_batch_streams_lines.txt 2>&1
+cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/ktr -o tr -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --precision bf16 --wgrad bf16 --steps 4 --warmup 2 --no-configs --no-extras --cpu-seconds 0 > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python tools/train_trace.py $O/ktr/tr_kernel_trace.csv > $O/train_step_launches.txt 2>&1; rm -rf $O/ktr
 for v in "" _old; do echo "== libmfpa$v.so"; python tools/exp_c64.py --lib musicfpaugment_amd/libmfpa$v.so 2>&1 | grep -v amdgpu; done > $O/c64_new_vs_old.txt 2>&1
 for f in "" "--lib musicfpaugment_amd/libmfpa_old.so" "" "--lib musicfpaugment_amd/libmfpa_old.so"; do echo "== bench.py $f"; python bench.py --steps 10 --warmup 3 --no-configs --cpu-seconds 0 $f 2>/dev/null; done > $O/bench_new_vs_old.txt 2>&1
