@@ -85,6 +85,9 @@ int mfpa_normalize(void* data, int dtype, int B, long long n, const double* clip
                    int per_clip, void* stream);
 
 /* data (B, n) float64 -> out (B, n) float32 (the `.float()` of training/train.py:272). */
+/* out[b][i] = (float)(in[b][i] / denom[b]), in (B, n) float64: the reference's `spectrogram / max` + `.float()` (training/train.py:264-272)
+ * as one pass -- the same float64 quotient rounded to float32 that mfpa_conv3x3_c1_bn_relu / mfpa_wgrad_c1 form per tap from (spec64, denom). */
+int mfpa_normalize_f32(const double* in, int B, long long n, const double* denom, float* out, void* stream);
 int mfpa_f64_to_f32(const double* in, float* out, long long n, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -434,7 +437,7 @@ int mfpa_act_to_bf16(const float* z, long long n, int C, const float* scale, con
 /* First layer (1 input channel): dw[tap][co] += sum_p dz[p][co] * x[p + tap]; x as in
  * mfpa_conv3x3_c1_bn_relu (per-clip denominators). */
 int mfpa_wgrad_c1(const float* dz, const float* x32, const double* spec64, const double* denom, int B, int H,
-                  int W, int Cout, float* dw, void* stream);
+                  int W, int Cout, float* dw, int dz_is_bf16, void* stream);
 
 /* OutConv in training: pred[p] = sum_c relu(z[p][c]*scale[c]+shift[c]) * w[c] + bias[0];
  * backward: dy[p][c] = dpred[p]*w[c], dwb = [C weight gradients, bias gradient]. */

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "mfpa_specgram_frames": ([c_int], c_int),
     "mfpa_stft_mag": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_specgram_psd": ([c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_normalize_f32": ([c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_normalize": ([c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p], c_int),
     "mfpa_f64_to_f32": ([c_void_p, c_void_p, c_longlong, c_void_p], c_int),
     "mfpa_audfprint_prepare": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_double,
@@ -148,7 +149,7 @@ _SIGNATURES = {
     "mfpa_maxpool2_bwd_add_sums": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_uint, c_uint, c_float, c_void_p, c_int, c_void_p], c_int),
     "mfpa_wgrad_mfma": ([c_void_p, c_void_p], c_int),
-    "mfpa_wgrad_c1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_wgrad_c1": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p], c_int),
     "mfpa_outconv_fwd": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
                          c_int),
     "mfpa_outconv_bwd": ([c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -311,6 +311,25 @@ int mfpa_normalize(void* data, int dtype, int B, long long n, const double* clip
   return MFPA_OK;
 }
 
+// out[b][i] = (float)(in[b][i] / denom[b]): the reference's `spectrogram / max` followed by `.float()` (training/train.py:264-272) as one pass
+__global__ __launch_bounds__(256) void normalize_f32_kernel(const double* __restrict__ in, long long n, const double* __restrict__ denom,
+                                                            float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const double d = denom[b];
+  const double* ib = in + (size_t)b * n;
+  float* ob = out + (size_t)b * n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) ob[i] = (float)(ib[i] / d);
+}
+
+int mfpa_normalize_f32(const double* in, int B, long long n, const double* denom, float* out, void* stream) {
+  if (B == 0 || n == 0) return MFPA_OK;
+  if (!in || !denom || !out || B < 0 || B > 65535 || n < 0) return MFPA_EINVAL;
+  const long long gx = (n + 255) / 256;
+  hipLaunchKernelGGL(normalize_f32_kernel, dim3((unsigned)(gx > 256 ? 256 : gx), (unsigned)B), dim3(256), 0, mfpa_stream(stream), in, n, denom, out);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
 int mfpa_f64_to_f32(const double* in, float* out, long long n, void* stream) {
   if (!in || !out || n < 0) return MFPA_EINVAL;
   if (n == 0) return MFPA_OK;

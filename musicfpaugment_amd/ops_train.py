@@ -170,6 +170,8 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
     return y
 
 
+PRENORMALISE_INPUT = True   # the train step's float64 spectrogram / clip maximum -> float32 once (mfpa_normalize_f32) instead of inside the first layer's two kernels
+C1_WGRAD_BF16 = True        # plain-bf16 step: the 1-channel first layer's weight gradient reads the bf16 copy of dz like every other (False: float32 dz)
 FUSED_FINISH = True         # single-GPU BatchNorm statistics / backward sums from row partials: the finish kernels read the block partials directly
                             # (mfpa_conv_stats_bn_finish, mfpa_bn_relu_bwd_from_part: 35 launches fewer per step, bit-identical; False: the separate calls)
 DY16_MID = False            # True: a DoubleConv's inner gradient (dy of its first BatchNorm) too leaves its convolution as bfloat16 only -- built, tested, measured
@@ -579,6 +581,14 @@ class UNetTrainEngine:
         recs = {}
         src = x32 if x32 is not None else spec64
         self._z16 = self._z16_for(src.shape[1], src.shape[2])
+        if x32 is None and PRENORMALISE_INPUT:
+            # the divide + .float() of train.py:264-272 once, as its own 50 MB pass: the same float64 quotient rounded to float32 that the first
+            # layer's kernels form on the fly -- but those formed it nine times per pixel (forward) and again in the weight gradient, a float64
+            # division each time (conv3x3_c1_kernel 298 -> ... us, wgrad_c1_kernel 459 -> ... us per 64 clips)
+            x32 = torch.empty(spec64.shape, dtype=torch.float32, device=spec64.device)
+            check(lib().mfpa_normalize_f32(ptr(spec64), spec64.shape[0], spec64.shape[1] * spec64.shape[2], ptr(denom), ptr(x32), stream()),
+                  "mfpa_normalize_f32")
+            spec64 = denom = None
         r = self._dconv_fwd(ENC[0], None, None, first_input=(x32, spec64, denom))
         recs["inc"] = r
         prev = r
@@ -645,15 +655,18 @@ class UNetTrainEngine:
                          bwd_of=(r["z0"], r["st0"]), out_bf16=dmid16)
         del dz3, dz16
         wg16, only16 = wg16_0, only16_0
+        if r["first_input"] is not None and C1_WGRAD_BF16 and self.precision == 2 and self.wgrad_precision == 2:
+            wg16 = only16 = True             # the first layer's weight gradient reads the bf16 dz too (plain-bf16 step): no float32 dz anywhere
         if dmid16 and not spm:
             raise RuntimeError("a bfloat16 dmid needs the convolution's BatchNorm-backward partial sums")
         dz0, dz16 = self._bn_relu_bwd(dmid, r["z0"], r["st0"], prefix + ".1.g", prefix + ".1.b", bf16_copy=wg16,
                                       part=spm[0] if spm else None, write_f32=not only16)
         if r["first_input"] is not None:
             x32, spec64, denom = r["first_input"]
-            B, H, W, C = dz0.shape
-            check(lib().mfpa_wgrad_c1(ptr(dz0), ptr(x32), ptr(spec64), ptr(denom), B, H, W, C, ptr(self.G[prefix + ".0.w"]),
-                                      stream()), "mfpa_wgrad_c1")
+            dsrc = dz0 if dz0 is not None else dz16
+            B, H, W, C = dsrc.shape
+            check(lib().mfpa_wgrad_c1(ptr(dsrc), ptr(x32), ptr(spec64), ptr(denom), B, H, W, C, ptr(self.G[prefix + ".0.w"]),
+                                      _is16(dsrc), stream()), "mfpa_wgrad_c1")
             return None, None
         wgrad_mfma(dz0, r["src0"], self.G[prefix + ".0.w"], cout, in_affine=r["aff0"], x1=r["src1"],
                    precision=self.wgrad_precision, dz_bf16=dz16, x0_bf16=r["xb0"], x1_bf16=r["xb1"])
