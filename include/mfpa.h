@@ -319,7 +319,7 @@ int mfpa_conv_stats_reduce(const float* part, long long rows, int C, double* sum
  *   w (9, Cout), y (B,H,W,Cout). */
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip,
                             int B, int H, int W, const float* w, int Cout,
-                            const float* scale, const float* shift, int relu, float* y, int y_is_bf16, void* stream);
+                            const float* scale, const float* shift, int relu, float* y, int y_is_bf16, float* stats_part /* optional: (B * H, 2, Cout) row partials of the output's (sum, sum of squares), see mfpa_conv_desc.stats_part */, void* stream);
 
 /* MaxPool2d(2), floor (unet.py:34).  x (B,H,W,C) -> y (B,H/2,W/2,C). */
 int mfpa_maxpool2(const float* x, int B, int H, int W, int C, float* y, void* stream);

@@ -58,7 +58,7 @@ _SIGNATURES = {
     "mfpa_conv3x3_bn_relu": ([c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_conv3x3_c1_bn_relu": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p], c_int),
+                                 c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_maxpool2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
     "mfpa_convT2x2": ([c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                        c_void_p], c_int),

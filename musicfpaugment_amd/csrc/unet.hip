@@ -2268,8 +2268,12 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
                                                          const double* __restrict__ denom, int per_clip, int B, int H,
                                                          int W, const float* __restrict__ w, int Cout,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int relu, float* __restrict__ y, int y16) {
+                                                         int relu, float* __restrict__ y, int y16, float* __restrict__ stats_part) {
+  // stats_part (training forward): one row [2][Cout] per workgroup = (sum, sum of squares) of this image row's outputs per channel, float64
+  // inside the workgroup -- mfpa_conv_stats_reduce / mfpa_conv_stats_bn_finish turn the B * H rows into the BatchNorm statistics without
+  // the 200 us pass over the output
   const int lanes_per_pix = Cout / 4;
+  double st_s[4] = {0., 0., 0., 0.}, st_q[4] = {0., 0., 0., 0.};
   const int pix_per_block = 256 / lanes_per_pix;
   const int sub = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
   float4 wt[9];
@@ -2338,12 +2342,34 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict
       o4.z = fmaxf(o4.z, 0.f);
       o4.w = fmaxf(o4.w, 0.f);
     }
+    if (live && stats_part != nullptr) {
+      st_s[0] += (double)o4.x; st_s[1] += (double)o4.y; st_s[2] += (double)o4.z; st_s[3] += (double)o4.w;
+      st_q[0] += (double)o4.x * (double)o4.x; st_q[1] += (double)o4.y * (double)o4.y;
+      st_q[2] += (double)o4.z * (double)o4.z; st_q[3] += (double)o4.w * (double)o4.w;
+    }
     if (live) {
       if (y16) {                                                         // the output kept as bfloat16 (the plain-bf16 training step's activations)
         bf16x4 h;
         h[0] = (__bf16)o4.x; h[1] = (__bf16)o4.y; h[2] = (__bf16)o4.z; h[3] = (__bf16)o4.w;
         *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + (size_t)p * Cout + 4 * sub) = h;
       } else *reinterpret_cast<float4*>(y + (size_t)p * Cout + 4 * sub) = o4;
+    }
+  }
+  if (stats_part != nullptr) {                                           // (uniform: a kernel argument)
+    __shared__ double red[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[threadIdx.x * 8 + k] = st_s[k]; red[threadIdx.x * 8 + 4 + k] = st_q[k]; }
+    __syncthreads();
+    if (pl == 0) {                                                       // fixed order over the workgroup's pixel slots: deterministic
+      for (int r = 1; r < pix_per_block; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          st_s[k] += red[(r * lanes_per_pix + sub) * 8 + k];
+          st_q[k] += red[(r * lanes_per_pix + sub) * 8 + 4 + k];
+        }
+      float* row = stats_part + (size_t)blockIdx.x * 2 * Cout;
+      *reinterpret_cast<float4*>(row + 4 * sub) = make_float4((float)st_s[0], (float)st_s[1], (float)st_s[2], (float)st_s[3]);
+      *reinterpret_cast<float4*>(row + Cout + 4 * sub) = make_float4((float)st_q[0], (float)st_q[1], (float)st_q[2], (float)st_q[3]);
     }
   }
 }
@@ -2653,14 +2679,14 @@ int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout) {
 
 int mfpa_conv3x3_c1_bn_relu(const float* x32, const double* spec64, const double* denom, int per_clip, int B, int H,
                             int W, const float* w, int Cout, const float* scale, const float* shift, int relu, float* y,
-                            int y_is_bf16, void* stream) {
+                            int y_is_bf16, float* stats_part, void* stream) {
   if (B == 0) return MFPA_OK;
   if ((!x32 && !spec64) || !w || !y || B < 0 || H < 1 || W < 1) return MFPA_EINVAL;
   if (Cout % 4 || Cout < 4 || Cout > 1024 || (256 % (Cout / 4)) != 0) return MFPA_EINVAL;
   if ((long long)B * H > 0x7fffffffLL) return MFPA_EINVAL;
   const long long blocks = (long long)B * H;
   hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, mfpa_stream(stream), x32, spec64, denom,
-                     per_clip, B, H, W, w, Cout, scale, shift, relu, y, y_is_bf16);
+                     per_clip, B, H, W, w, Cout, scale, shift, relu, y, y_is_bf16, stats_part);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

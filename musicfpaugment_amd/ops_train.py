@@ -171,6 +171,8 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
 
 
 PRENORMALISE_INPUT = True   # the train step's float64 spectrogram / clip maximum -> float32 once (mfpa_normalize_f32) instead of inside the first layer's two kernels
+C1_STATS = True             # bf16 engines: the first layer's kernel writes its output's BatchNorm row partials (no 200 us statistics pass over 1 GB); the
+                            # fp32 engine keeps the float64 pass (see UNetTrainEngine._bn_stats)
 C1_WGRAD_BF16 = True        # plain-bf16 step: the 1-channel first layer's weight gradient reads the bf16 copy of dz like every other (False: float32 dz)
 FUSED_FINISH = True         # single-GPU BatchNorm statistics / backward sums from row partials: the finish kernels read the block partials directly
                             # (mfpa_conv_stats_bn_finish, mfpa_bn_relu_bwd_from_part: 35 launches fewer per step, bit-identical; False: the separate calls)
@@ -563,7 +565,8 @@ class UNetTrainEngine:
         if first_input is not None:
             x32, spec64, denom = first_input
             z0 = K.conv3x3_c1_bn_relu(self.P[prefix + ".0.w"], None, None, x32=x32, spec64=spec64, denom=denom,
-                                      per_clip=True, relu=False, out_dtype=torch.bfloat16 if z16 else torch.float32)
+                                      per_clip=True, relu=False, out_dtype=torch.bfloat16 if z16 else torch.float32,
+                                      stats_out=sp0 if (C1_STATS and self.precision >= 1) else None)
         else:
             z0 = conv_mfma(src0, self.P[prefix + ".0.w"], cout, in_affine=aff0, x1=src1, precision=self.precision, x0_bf16_out=xb0,
                            stats_out=sp0, x1_bf16_out=xb1, out_bf16=z16)

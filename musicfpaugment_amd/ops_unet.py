@@ -236,13 +236,18 @@ def conv3x3_fused(x0, w, scale, shift, *, x1=None, precision=0, pool=False, out1
     return y, yp, y1
 
 
-def conv3x3_c1_bn_relu(w, scale, shift, x32=None, spec64=None, denom=None, per_clip=True, relu=True, out_dtype=torch.float32):
+def conv3x3_c1_bn_relu(w, scale, shift, x32=None, spec64=None, denom=None, per_clip=True, relu=True, out_dtype=torch.float32, stats_out=None):
+    """`stats_out` (a list, training forward): the kernel's per-row partial BatchNorm statistics of the output, (B * H, 2, Cout) float32, are appended."""
     src = x32 if x32 is not None else spec64
     B, H, W = src.shape
     Cout = w.shape[1]
     y = torch.empty((B, H, W, Cout), dtype=out_dtype, device=src.device)
+    part = None
+    if stats_out is not None and (Cout <= 256 and 256 % Cout == 0):
+        part = torch.empty((B * H, 2, Cout), dtype=torch.float32, device=src.device)
+        stats_out.append(part)
     check(lib().mfpa_conv3x3_c1_bn_relu(ptr(x32), ptr(spec64), ptr(denom), int(per_clip), B, H, W, ptr(w), Cout,
-                                        ptr(scale), ptr(shift), int(relu), ptr(y), int(out_dtype == torch.bfloat16), stream()), "mfpa_conv3x3_c1_bn_relu")
+                                        ptr(scale), ptr(shift), int(relu), ptr(y), int(out_dtype == torch.bfloat16), ptr(part), stream()), "mfpa_conv3x3_c1_bn_relu")
     return y
 
 
