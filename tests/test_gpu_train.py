@@ -815,10 +815,10 @@ def test_plain_bf16_train_step_converges_where_fp32_does():
         the accumulated EFFECT of the gradients (a biased gradient would drift): plain bf16's final training loss and held-out L1
         (trained weights through the fp32 inference kernels) within 2 % of fp32's -- of the mean of two fp32 runs, plus what those two
         differ by (float atomics: the same fp32 run repeats to 0.3-1.5 % on these numbers).
-    (2) lr 1e-3 (the reference's, training/train.py:661) -- here the loss falls 60-fold in 200 steps and the runs are chaotic: two FP32
-        runs of the same everything differ by 1.4-6 % (float atomics order the weight-gradient sums differently) and bf16x3, whose
-        gradients equal fp32's to 1.5 %, lands 5-14 % away.  Measured and printed; the gate is relative to that spread: plain bf16 no
-        further from fp32 than max(15 %, twice what fp32-vs-fp32 and bf16x3-vs-fp32 show)."""
+    (2) lr 1e-3 (the reference's, training/train.py:661) -- here the loss falls 60-fold in 200 steps and the runs are chaotic: three FP32
+        runs of the same everything span 5 % in training loss and 13 % in held-out L1 (float atomics order the weight-gradient sums
+        differently), three plain-bf16 runs 12-16 % and 2-13 % (tools/exp_convergence_lr.py), the ranges overlapping.  Three runs of each;
+        the gate is on the MEANS: no further apart than max(10 %, the two ranges added)."""
     res = run_convergence({"fp32": (0, 0), "fp32 (b)": (0, 0), "bf16x3": (1, 2), "bf16": (2, 2)}, lr=1e-4)
     f, fb, x3, b = res["fp32"], res["fp32 (b)"], res["bf16x3"], res["bf16"]
     assert f[0] < 0.7 * f[2] and b[0] < 0.7 * b[2]                       # both really trained
@@ -829,14 +829,17 @@ def test_plain_bf16_train_step_converges_where_fp32_does():
         dev3, devb = (x3[i] - ref) / ref, (b[i] - ref) / ref
         print(f"[convergence, lr 1e-4] {what}: fp32-vs-fp32 {100 * spread:.2f} %, bf16x3 {100 * dev3:+.2f} %, plain bf16 {100 * devb:+.2f} % against the fp32 mean")
         assert -0.05 <= devb <= 0.02 + spread, (what, devb, spread)   # (no worse than 2 % + spread; the better side, where bf16 lands, bounded at 5 %)
-    res = run_convergence({"fp32": (0, 0), "fp32 (b)": (0, 0), "bf16x3": (1, 2), "bf16": (2, 2)}, lr=1e-3)
-    f, fb, x3, b = res["fp32"], res["fp32 (b)"], res["bf16x3"], res["bf16"]
-    assert f[0] < 0.1 * f[2] and b[0] < 0.1 * b[2]
+    # (2): three runs of each arithmetic; the gate is on the MEANS, relative to the ranges the runs themselves show
+    res = run_convergence({"fp32 a": (0, 0), "fp32 b": (0, 0), "fp32 c": (0, 0), "bf16 a": (2, 2), "bf16 b": (2, 2), "bf16 c": (2, 2)}, lr=1e-3)
     for i, what in ((0, "training loss"), (1, "held-out L1")):
-        spread = abs(fb[i] - f[i]) / f[i]
-        dev3, devb = abs(x3[i] - f[i]) / f[i], abs(b[i] - f[i]) / f[i]
-        print(f"[convergence, lr 1e-3] {what}: fp32-vs-fp32 {100 * spread:.2f} %, bf16x3 {100 * dev3:.2f} %, plain bf16 {100 * devb:.2f} % off fp32")
-        assert devb <= max(0.15, 2 * spread, 2 * dev3), (what, devb, spread, dev3)
+        fv = np.array([res[k][i] for k in ("fp32 a", "fp32 b", "fp32 c")])
+        bv = np.array([res[k][i] for k in ("bf16 a", "bf16 b", "bf16 c")])
+        assert (fv < 0.1 * res["fp32 a"][2]).all() and (bv < 0.1 * res["fp32 a"][2]).all() if i == 0 else True      # every run trained (loss falls > 10-fold)
+        dev = abs(bv.mean() - fv.mean()) / fv.mean()
+        allowed = max(0.10, np.ptp(fv) / fv.mean() + np.ptp(bv) / bv.mean())
+        print(f"[convergence, lr 1e-3] {what}: fp32 {fv.min():.5f}..{fv.max():.5f} (mean {fv.mean():.5f}), plain bf16 {bv.min():.5f}..{bv.max():.5f} "
+              f"(mean {bv.mean():.5f}): means {100 * dev:.1f} % apart, allowed {100 * allowed:.1f} %")
+        assert dev <= allowed, (what, dev, allowed)
 
 
 def test_bfloat16_activations_in_hbm_same_step_and_same_convergence():
@@ -898,6 +901,66 @@ def test_bfloat16_activations_in_hbm_same_step_and_same_convergence():
             # no WORSE than fp32 by more than 2 % (+ what two fp32 runs differ by); the bf16 runs land BELOW fp32 on both numbers in every
             # run of the round (-0.1 ... -2.8 %: rounding noise as a regulariser): that side is bounded at 5 %
             assert -0.05 <= dev <= 0.02 + spread, (name, what, dev, spread)
+
+
+def test_late_round5_step_shortcuts_are_exact_where_they_claim_to_be():
+    """ops_train toggles of the plain-bf16 step, each against its long form on the same batch (2 clips of 8 s, no dropout):
+    FUSED_FINISH (BatchNorm finishes that read the row-block partials directly) and PRENORMALISE_INPUT (spectrogram / maximum -> float32 once)
+    leave prediction, BatchNorm statistics, dgamma / dbeta and the loss BIT-IDENTICAL (weight gradients are summed with float atomics: compared
+    to 1e-3); C1_STATS (the first layer's statistics from its own kernel's row partials instead of the float64 pass) moves the first
+    BatchNorm's mean / invstd by < 1e-4 relative; C1_WGRAD_BF16 (its weight gradient from the bf16 dz) keeps that gradient within 2e-3."""
+    from musicfpaugment_amd import ops, ops_train, synth
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    B = 2
+    clean = synth.batch(B, seed=7300)
+    noisy = (0.7 * clean + 0.3 * synth.batch(B, seed=7800, tonal=False)).astype(np.float32)
+    cm, cmax = ops.stft_mag(torch.from_numpy(clean).cuda(), torch.float64)
+    am, amax = ops.stft_mag(torch.from_numpy(noisy).cuda(), torch.float64)
+    ops.normalize_(cm, cmax.max().expand(B).contiguous(), per_clip=True)
+    aden = amax.max().expand(B).contiguous()
+    names = ("FUSED_FINISH", "PRENORMALISE_INPUT", "C1_STATS", "C1_WGRAD_BF16")
+    keep = {n: getattr(ops_train, n) for n in names}
+
+    def run(**flags):
+        for n in names:
+            setattr(ops_train, n, flags.get(n, True))
+        net = UNet(1, 1, rate=0.0)
+        net.load_state_dict(formula_state_dict(2))
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=2, wgrad_precision=2)
+        pred = eng.forward(spec64=am, denom=aden)
+        assert eng._z16
+        st = eng._recs["inc"]["st0"]
+        stats = (st.mean.clone(), st.invstd.clone())
+        loss, dpred = eng.l1_loss(pred, cm)
+        eng.backward(dpred)
+        g = {k: v.clone() for k, v in eng.named_grads().items()}
+        return pred.clone(), float(loss), stats, g
+
+    try:
+        base = run()
+        for flag in ("FUSED_FINISH", "PRENORMALISE_INPUT"):
+            got = run(**{flag: False})
+            assert torch.equal(got[0], base[0]) and got[1] == base[1], flag
+            assert torch.equal(got[2][0], base[2][0]) and torch.equal(got[2][1], base[2][1]), flag
+            for k in base[3]:
+                if "bn" in k or k.endswith(".1.weight") or k.endswith(".1.bias") or k.endswith(".4.weight") or k.endswith(".4.bias"):
+                    assert torch.equal(got[3][k], base[3][k]), (flag, k)
+                else:
+                    assert rel(got[3][k], base[3][k]) < 1e-3, (flag, k, rel(got[3][k], base[3][k]))
+        got = run(C1_STATS=False)
+        # (the pass reads the STORED bfloat16 z, the kernel's partials describe its float32 values -- like every other layer's stats_part:
+        #  6e-6 on the means, 4e-5 on invstd: rounding adds (2^-9)^2 / 3 of E[z^2] to the variance of what is stored)
+        assert rel(got[2][0], base[2][0]) < 1e-4 and rel(got[2][1], base[2][1]) < 1e-4
+        assert rel(got[0], base[0]) < 6e-2          # (any perturbation re-draws the bf16 roundings downstream: this un-trained net turns that into 2.7 %)
+        got = run(C1_WGRAD_BF16=False)
+        assert torch.equal(got[0], base[0])
+        k0 = [k for k in base[3] if k.startswith("inc.double_conv.0")][0]
+        print(f"[first layer's weight gradient, bf16 dz vs float32 dz] relative L1 {rel(base[3][k0], got[3][k0]):.2e}")
+        assert rel(base[3][k0], got[3][k0]) < 2e-3
+    finally:
+        for n, v in keep.items():
+            setattr(ops_train, n, v)
 
 
 def test_plain_bf16_gradients_at_the_bench_batch_point_where_fp32s_do():
