@@ -506,6 +506,8 @@ def bench_train(args, rank, world, dev, dist):
         ops_train.Z16_ACTIVATIONS = False
     if getattr(args, "no_fused_finish", False):
         ops_train.FUSED_FINISH = False
+    if getattr(args, "no_batch_repack", False):
+        ops_train.BATCH_REPACK = False
 
     B = args.clips if args.scaling == "weak" else max(1, args.clips // world)
     net = UNet(1, 1, rate=0.05)
@@ -1093,6 +1095,7 @@ def main():
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
+    ap.add_argument("--no-batch-repack", action="store_true", help="train mode: one weight re-pack launch per convolution and use (ops_train.BATCH_REPACK = False; A/B runs)")
     ap.add_argument("--no-fused-finish", action="store_true", help="train mode: BatchNorm partial-sum finishes as separate launches (ops_train.FUSED_FINISH = False; A/B runs)")
     ap.add_argument("--no-z16", action="store_true", help="train mode (plain bf16): keep the activations in HBM as float32 (ops_train.Z16_ACTIVATIONS = False; A/B runs)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")

@@ -475,6 +475,16 @@ int mfpa_l1_loss(const float* pred, const double* target, long long n, float* dp
  * ConvTranspose2d backward).  Co, Ci, row0, nrows multiples of 32. */
 int mfpa_pack_conv_weights(const float* w, int taps, int Co, int Ci, int flip_transpose, int row0, int nrows, int precision,
                            float* out, void* stream);
+/* Every operand image a training step needs, in ONE launch (round 5): `jobs_dev` = `njobs` of these in DEVICE memory, each the argument set of
+ * one mfpa_pack_conv_weights call (same checks apply; the caller validates) plus tile0 = the number of 32 x 32 tiles of all jobs before it
+ * (a job has (K / 32) * (nrows / 32) * taps tiles, K = flip_transpose ? Co : Ci); total_tiles = their sum.  Pointers and shapes of a
+ * training engine never change, so the table is built once and the launch repeated after every optimiser step. */
+typedef struct mfpa_pack_job {
+  const float* w; float* out;
+  int taps, Co, Ci, flip_transpose, row0, nrows, precision, pad_;
+  long long tile0;
+} mfpa_pack_job;
+int mfpa_pack_conv_weights_batch(const mfpa_pack_job* jobs_dev, int njobs, long long total_tiles, void* stream);
 /* torch.optim.Adam step (train.py:661: lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay) on flat
  * arrays; g is multiplied by grad_scale first (1/world_size after a SUM all-reduce). step >= 1. */
 int mfpa_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,

@@ -162,9 +162,16 @@ _SIGNATURES = {
     "mfpa_l1_loss": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_act_to_bf16": ([c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_uint, c_uint, c_float, c_void_p, c_void_p], c_int),
     "mfpa_pack_conv_weights": ([c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p], c_int),
+    "mfpa_pack_conv_weights_batch": ([c_void_p, c_int, c_longlong, c_void_p], c_int),
     "mfpa_adam_step": ([c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int,
                         c_float, c_void_p], c_int),
 }
+
+
+class PackJob(ctypes.Structure):
+    """mfpa_pack_job (include/mfpa.h)."""
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("taps", c_int), ("Co", c_int), ("Ci", c_int), ("flip_transpose", c_int), ("row0", c_int),
+                ("nrows", c_int), ("precision", c_int), ("pad_", c_int), ("tile0", c_longlong)]
 
 
 class ConvDesc(ctypes.Structure):

@@ -1421,10 +1421,9 @@ inline int grid_for(long long work, int per_block = 256, int cap = 256 * 16) {
 // tap t reads source tap taps-1-t when taps == 9 (the 3x3 kernel flipped; the 2x2 transposed conv keeps its tap), n = ci in
 // [row0, row0 + nrows), k = co.  One workgroup per 32 x 32 (n, k) tile and tap, transposed through LDS so both sides coalesce.
 template <bool TR>
-__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, int taps, int Co, int Ci, int row0,
-                                                                int nrows, int precision, float* __restrict__ out) {
-  __shared__ float tile[32][33];
-  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, t = blockIdx.z;
+__device__ __forceinline__ void pack_conv_weights_tile(float (*tile)[33], const float* __restrict__ w, int taps, int Co, int Ci, int row0,
+                                                       int nrows, int precision, float* __restrict__ out, int kx, int ny, int t) {
+  const int k0 = kx * 32, n0 = ny * 32;
   const int ts = (TR && taps == 9) ? taps - 1 - t : t;
   const int K = TR ? Co : Ci;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
@@ -1470,6 +1469,33 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
       ob[((4 + (tx >> 3)) ^ swz) * 8 + (tx & 7)] = lo;
     }
   }
+}
+
+template <bool TR>
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, int taps, int Co, int Ci, int row0,
+                                                                int nrows, int precision, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  pack_conv_weights_tile<TR>(tile, w, taps, Co, Ci, row0, nrows, precision, out, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Every operand image of a training step in ONE launch (mfpa_pack_conv_weights_batch): workgroup -> (job, tile) through the jobs' tile
+// prefix (tile0; a job's tiles are (K / 32) x (nrows / 32) x taps, k fastest), then the single-launch kernel's tile code.
+__global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const mfpa_pack_job* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = njobs - 1;                                // the last job whose tile0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const mfpa_pack_job jb = jobs[lo];
+  const int K = jb.flip_transpose ? jb.Co : jb.Ci;
+  int r = (int)((long long)blockIdx.x - jb.tile0);
+  const int kx = r % (K / 32); r /= (K / 32);
+  const int ny = r % (jb.nrows / 32);
+  const int t = r / (jb.nrows / 32);
+  if (t >= jb.taps) return;
+  if (jb.flip_transpose) pack_conv_weights_tile<true>(tile, jb.w, jb.taps, jb.Co, jb.Ci, jb.row0, jb.nrows, jb.precision, jb.out, kx, ny, t);
+  else pack_conv_weights_tile<false>(tile, jb.w, jb.taps, jb.Co, jb.Ci, jb.row0, jb.nrows, jb.precision, jb.out, kx, ny, t);
 }
 
 
@@ -1936,6 +1962,14 @@ int mfpa_pack_conv_weights(const float* w, int taps, int Co, int Ci, int flip_tr
   dim3 grid(K / 32, nrows / 32, taps);
   if (flip_transpose) hipLaunchKernelGGL(pack_conv_weights_kernel<true>, grid, dim3(256), 0, mfpa_stream(stream), w, taps, Co, Ci, row0, nrows, precision, out);
   else hipLaunchKernelGGL(pack_conv_weights_kernel<false>, grid, dim3(256), 0, mfpa_stream(stream), w, taps, Co, Ci, row0, nrows, precision, out);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+int mfpa_pack_conv_weights_batch(const mfpa_pack_job* jobs_dev, int njobs, long long total_tiles, void* stream) {
+  if (njobs == 0) return MFPA_OK;
+  if (!jobs_dev || njobs < 0 || total_tiles < 1 || total_tiles > 0x7fffffffLL) return MFPA_EINVAL;
+  hipLaunchKernelGGL(pack_conv_weights_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, mfpa_stream(stream), jobs_dev, njobs);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

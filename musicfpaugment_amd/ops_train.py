@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from ._lib import ConvDesc, WgradDesc, check, lib, ptr, stream
+from ._lib import ConvDesc, PackJob, WgradDesc, check, lib, ptr, stream
 from . import ops_unet as K
 
 BN_EPS = 1e-5
@@ -70,10 +70,77 @@ def pack_weights(w: torch.Tensor, precision: int, flip_transpose: bool = False, 
         if precision < 1:
             return w
         return K.split_bf16x3_frag(w, layout) if layout else K.split_bf16x3(w)
+    code = (1 + layout) if precision >= 1 else precision
+    cache = _PACK_CACHE
+    if cache is not None:
+        # a training engine's operand images: made by ONE batched launch per step (PackCache.refresh, after the optimiser step); a call that
+        # is not in the table yet packs on its own and joins it
+        hit = cache.lookup(w, taps, Co, Ci, flip_transpose, row0, nrows, code)
+        if hit is not None:
+            return hit
     out = torch.empty((taps, nrows, Co if flip_transpose else Ci), dtype=torch.float32, device=w.device)
-    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, (1 + layout) if precision >= 1 else precision,
-                                       ptr(out), stream()), "mfpa_pack_conv_weights")
+    check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip_transpose), row0, nrows, code, ptr(out), stream()), "mfpa_pack_conv_weights")
+    if cache is not None:
+        cache.add(w, taps, Co, Ci, flip_transpose, row0, nrows, code, out)
     return out
+
+
+class PackCache:
+    """The operand images of one training engine (forward and input-gradient forms of every convolution's weights): pointers and shapes never
+    change, so after the first step -- which packs them one by one and records the calls -- a step repacks ALL of them with one
+    mfpa_pack_conv_weights_batch launch (46 launches of 5-7 us before).  `refresh()` runs it (the engine calls it at the start of a step: the
+    weights changed in the optimiser step); `invalidate()` forgets everything (parameters re-loaded from a module)."""
+
+    def __init__(self):
+        self.entries = {}            # key -> (out tensor, index into jobs)
+        self.jobs = []
+        self.table = None            # device copy of the job structs
+        self.total_tiles = 0
+        self.fresh = set()           # keys whose image matches the current weights
+
+    @staticmethod
+    def _key(w, taps, Co, Ci, flip, row0, nrows, code):
+        return (w.data_ptr(), taps, Co, Ci, bool(flip), row0, nrows, code)
+
+    def lookup(self, w, taps, Co, Ci, flip, row0, nrows, code):
+        k = self._key(w, taps, Co, Ci, flip, row0, nrows, code)
+        if k in self.fresh:
+            return self.entries[k][0]
+        return None
+
+    def add(self, w, taps, Co, Ci, flip, row0, nrows, code, out):
+        k = self._key(w, taps, Co, Ci, flip, row0, nrows, code)
+        K = Co if flip else Ci
+        if k in self.entries:                                   # stale image re-made by a single launch into a fresh tensor: point the job at it
+            idx = self.entries[k][1]
+            self.jobs[idx].out = out.data_ptr()
+        else:
+            idx = len(self.jobs)
+            self.jobs.append(PackJob(w=w.data_ptr(), out=out.data_ptr(), taps=taps, Co=Co, Ci=Ci, flip_transpose=int(bool(flip)), row0=row0,
+                                     nrows=nrows, precision=code, pad_=0, tile0=self.total_tiles))
+            self.total_tiles += (K // 32) * (nrows // 32) * taps
+        self.entries[k] = (out, idx)
+        self.fresh.add(k)
+        self.table = None
+
+    def refresh(self, device):
+        """Re-make every recorded image from the current weights (one launch) and mark them fresh."""
+        if not self.jobs:
+            return
+        if self.table is None:
+            raw = b"".join(bytes(j) for j in self.jobs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        check(lib().mfpa_pack_conv_weights_batch(ptr(self.table), len(self.jobs), self.total_tiles, stream()), "mfpa_pack_conv_weights_batch")
+        self.fresh = set(self.entries.keys())
+
+    def stale(self):
+        self.fresh = set()
+
+    def invalidate(self):
+        self.__init__()
+
+
+_PACK_CACHE: Optional[PackCache] = None      # set by UNetTrainEngine around its forward / backward
 
 
 def weight_layout(H: int, W: int, cin: int, cout: int, precision: int, mode: int = 0) -> int:
@@ -174,6 +241,7 @@ PRENORMALISE_INPUT = True   # the train step's float64 spectrogram / clip maximu
 C1_STATS = True             # bf16 engines: the first layer's kernel writes its output's BatchNorm row partials (no 200 us statistics pass over 1 GB); the
                             # fp32 engine keeps the float64 pass (see UNetTrainEngine._bn_stats)
 C1_WGRAD_BF16 = True        # plain-bf16 step: the 1-channel first layer's weight gradient reads the bf16 copy of dz like every other (False: float32 dz)
+BATCH_REPACK = True         # the convolutions' operand images (forward + input-gradient forms) re-made by ONE launch per step (PackCache); False: one launch each
 FUSED_FINISH = True         # single-GPU BatchNorm statistics / backward sums from row partials: the finish kernels read the block partials directly
                             # (mfpa_conv_stats_bn_finish, mfpa_bn_relu_bwd_from_part: 35 launches fewer per step, bit-identical; False: the separate calls)
 DY16_MID = False            # True: a DoubleConv's inner gradient (dy of its first BatchNorm) too leaves its convolution as bfloat16 only -- built, tested, measured
@@ -306,6 +374,7 @@ class UNetTrainEngine:
         self.workspace = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._z16, self._z16_cache = False, {}
+        self._packs = PackCache()            # the convolutions' operand images, re-made by one launch per step (BATCH_REPACK)
 
     def _z16_for(self, H: int, W: int) -> bool:
         """Do this step's activations live in HBM as bfloat16?  Z16_ACTIVATIONS, the plain-bf16 arithmetic with bf16 weight gradients
@@ -581,6 +650,16 @@ class UNetTrainEngine:
     def forward(self, x32=None, spec64=None, denom=None):
         """Train-mode forward.  Input (B,F,T): float32 spectrogram, or raw float64 |STFT| + per-clip denominators
         (the divide + .float() of train.py:264-272 is fused into the first conv).  Returns pred (B,F,T) float32."""
+        global _PACK_CACHE
+        _PACK_CACHE = self._packs if BATCH_REPACK else None
+        if BATCH_REPACK:
+            self._packs.refresh(self.device)         # every image recorded so far, from the CURRENT weights, in one launch
+        try:
+            return self._forward(x32, spec64, denom)
+        finally:
+            _PACK_CACHE = None
+
+    def _forward(self, x32=None, spec64=None, denom=None):
         recs = {}
         src = x32 if x32 is not None else spec64
         self._z16 = self._z16_for(src.shape[1], src.shape[2])
@@ -694,6 +773,14 @@ class UNetTrainEngine:
         return d0, d1
 
     def backward(self, dpred):
+        global _PACK_CACHE
+        _PACK_CACHE = self._packs if BATCH_REPACK else None      # (images made at the start of this step's forward: the weights have not changed since)
+        try:
+            self._backward(dpred)
+        finally:
+            _PACK_CACHE = None
+
+    def _backward(self, dpred):
         recs = self._recs
         self.flat_g.zero_()
         last = recs[DEC[-1]]
@@ -797,6 +884,7 @@ class UNetTrainEngine:
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
         self.step_count += 1
+        self._packs.stale()
         check(lib().mfpa_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), self.n_params,
                                    self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world,
                                    stream()), "mfpa_adam_step")

@@ -702,6 +702,34 @@ def test_device_weight_pack_equals_the_host_packing():
                     assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32)), (taps, co, ci, "frag", lay, ft)
 
 
+def test_batched_weight_repack_equals_the_single_launches():
+    """ops_train.PackCache / mfpa_pack_conv_weights_batch: after a first step has recorded every operand image the engine needs (forward and
+    input-gradient forms, all three layouts), ONE launch re-makes them all from the current weights -- bit-identical to mfpa_pack_conv_weights
+    called per image, also after the weights changed."""
+    from musicfpaugment_amd import ops_train
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    from musicfpaugment_amd.ops_train import UNetTrainEngine
+    from musicfpaugment_amd.training.unet import UNet
+    am, aug_den, clean_spec = _g7_inputs()
+    for prec in (1, 2):
+        net = UNet(1, 1, rate=0.0)
+        net.load_state_dict(formula_state_dict(2))
+        eng = UNetTrainEngine(net.cuda().train(), lr=1e-3, precision=prec, wgrad_precision=2)
+        eng.train_step(am, aug_den, clean_spec)                          # records the jobs; Adam then changes every weight
+        cache = eng._packs
+        assert len(cache.jobs) >= 40 and not cache.fresh                  # stale behind the optimiser step
+        cache.refresh(eng.device)
+        assert ops_train._PACK_CACHE is None
+        by_ptr = {v.data_ptr(): (k, v) for k, v in eng.P.items()}
+        for (wptr, taps, Co, Ci, flip, row0, nrows, code), (out, _) in cache.entries.items():
+            name, w = by_ptr[wptr]
+            want = torch.empty_like(out)
+            check(lib().mfpa_pack_conv_weights(ptr(w), taps, Co, Ci, int(flip), row0, nrows, code, ptr(want), stream()), "mfpa_pack_conv_weights")
+            assert torch.equal(out.view(torch.int32), want.view(torch.int32)), (name, flip, row0, nrows, code)
+        l2 = float(eng.train_step(am, aug_den, clean_spec))              # a step on the batched images
+        assert np.isfinite(l2)
+
+
 def test_plain_bf16_convolutions_are_the_hi_halves_of_the_bf16x3_products():
     """mfpa_conv_desc.precision 2 (conv_wd16_kernel<.., PLAIN>): one bf16 MFMA per product on the hi halves of the operands the bf16x3
     form splits -- the training step's "bf16 MFMA" arithmetic (BASELINE config 4).  Equal to a float64 convolution of the
