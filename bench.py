@@ -553,8 +553,11 @@ def bench_train(args, rank, world, dev, dist):
     side = torch.cuda.Stream(device=dev) if prefetch else None
     pending = {}
 
-    def prepare_async():
-        side.wait_stream(main_stream)                     # (inputs are constant; orders the side stream behind what was queued so far)
+    def prepare_async(after=None):
+        if after is not None:
+            side.wait_event(after)                        # start behind a point INSIDE the running step (--prefetch-at)
+        else:
+            side.wait_stream(main_stream)                 # (inputs are constant; orders the side stream behind what was queued so far)
         with torch.cuda.stream(side):
             batch = prepare()
             ev = torch.cuda.Event()
@@ -570,8 +573,21 @@ def bench_train(args, rank, world, dev, dist):
             prepare_async()
         batch, ev = pending.pop("b")
         main_stream.wait_event(ev)
-        prepare_async()                                   # batch k + 1, under step k
-        return eng.train_step(*batch)
+        where = getattr(args, "prefetch_at", "forward")
+        if where == "start":
+            prepare_async()                               # batch k + 1, under step k
+            return eng.train_step(*batch)
+        # the same step, with the next batch's preparation released at a later point of it (the engine's train_step, spelled out)
+        pred = eng.forward(spec64=batch[0], denom=batch[1])
+        mark = torch.cuda.Event()
+        if where == "forward":
+            mark.record(main_stream); prepare_async(mark)
+        loss_, dpred = eng.l1_loss(pred, batch[2])
+        eng.backward(dpred)
+        if where == "backward":
+            mark.record(main_stream); prepare_async(mark)
+        eng.optimizer_step()
+        return loss_
 
     def barrier():
         if dist is not None:
@@ -1095,6 +1111,9 @@ def main():
                     help="arithmetic of the UNet's MFMA convolutions at inference: bf16x3 = every fp32 product as three "
                          "bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate; relative L1 ~2e-5 vs the fp32 reference, "
                          "gate 1e-4); fp32 = v_mfma_f32_32x32x2_f32 (relative L1 ~1e-6)")
+    ap.add_argument("--prefetch-at", choices=["start", "forward", "backward"], default="forward",
+                    help="train mode with prefetch: where in step k the side stream starts preparing batch k + 1 (start of the step, behind its forward -- the default: "
+                         "the forward's full-resolution layers are the step's memory-bound part, 32.8 -> 32.6 ms same-call -- or behind its backward: too late, 34.1)")
     ap.add_argument("--no-batch-repack", action="store_true", help="train mode: one weight re-pack launch per convolution and use (ops_train.BATCH_REPACK = False; A/B runs)")
     ap.add_argument("--no-fused-finish", action="store_true", help="train mode: BatchNorm partial-sum finishes as separate launches (ops_train.FUSED_FINISH = False; A/B runs)")
     ap.add_argument("--no-z16", action="store_true", help="train mode (plain bf16): keep the activations in HBM as float32 (ops_train.Z16_ACTIVATIONS = False; A/B runs)")
