@@ -249,6 +249,7 @@ __global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x,
                                                     const uint8_t* __restrict__ apply, float* __restrict__ y) {
   __shared__ unsigned hist[4][2048];
   __shared__ unsigned prefix[4], want[4];
+  __shared__ int uniq[4];                     // uniq[r] = the first rank with the same prefix: ranks that share a prefix share ONE histogram
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* xb = x + (size_t)b * T;
   float* yb = y + (size_t)b * T;
@@ -270,17 +271,29 @@ __global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x,
   for (int pass = 0; pass < 3; ++pass) {
     const int nb = 1 << bits[pass];
     for (int i = tid; i < 4 * 2048; i += 1024) (&hist[0][0])[i] = 0;
+    if (tid < 4) {
+      // all four ranks share the (empty) prefix in pass 0, and floor / ceil of one rank usually share it later: counting an element once per
+      // DISTINCT prefix instead of once per rank cuts the LDS atomics of pass 0 -- where most samples of a clip fall into a few exponent
+      // bins and serialise -- by four (352 -> ... us per 64 clips)
+      int u = tid;
+      for (int r = tid - 1; r >= 0; --r) if (prefix[r] == prefix[tid]) u = r;
+      uniq[tid] = u;
+    }
     __syncthreads();
     const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shifts[pass] + bits[pass]));
+    const bool own0 = true, own1 = uniq[1] == 1, own2 = uniq[2] == 2, own3 = uniq[3] == 3;
+    const unsigned p0 = prefix[0], p1 = prefix[1], p2 = prefix[2], p3 = prefix[3];
     for (int row = FLAT ? 0 : b; row < (FLAT ? B : b + 1); ++row) {
       if (FLAT && !apply[row]) continue;
       const float* xr = x + (size_t)row * T;
       for (int i = tid; i < T; i += 1024) {
         const unsigned k = f2key(xr[i]);
         const unsigned digit = (k >> shifts[pass]) & (nb - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if ((k & himask) == prefix[r]) atomicAdd(&hist[r][digit], 1u);
+        const unsigned kh = k & himask;
+        if (own0 && kh == p0) atomicAdd(&hist[0][digit], 1u);
+        if (own1 && kh == p1) atomicAdd(&hist[1][digit], 1u);
+        if (own2 && kh == p2) atomicAdd(&hist[2][digit], 1u);
+        if (own3 && kh == p3) atomicAdd(&hist[3][digit], 1u);
       }
     }
     __syncthreads();
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(1024) void clip_kernel(const float* __restrict__ x,
       unsigned acc = 0, w = want[tid];
       int d = 0;
       for (; d < nb; ++d) {
-        const unsigned c = hist[tid][d];
+        const unsigned c = hist[uniq[tid]][d];
         if (acc + c > w) break;
         acc += c;
       }
