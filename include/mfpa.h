@@ -133,6 +133,10 @@ int mfpa_audfprint_prune(const double* filtered, int B, int R, int T, const doub
  * that applies "- mean, lfilter" to the frames as it walks them -- the filtered spectrogram is never written.
  *   spec (B, F, T) float64, 141 <= F = R + 1 <= 257, R % 4 == 0, T <= 512, R * T % 16 == 0 (the pruner zeroes the 16-byte aligned mask itself);  clip_max (B) float64
  *   work (B * F * T + B * 128) float64 workspace;  gauss / a_dec / maxpks / mask / npeaks as for mfpa_audfprint_prune */
+/* out[i] = v[i] / den[i] by the sequence the pick kernels use per spectrogram cell (one reciprocal per clip there): q0 = v * RN(1 / den), two
+ * residual / correction multiply-adds -- correctly rounded for normal operands with normal residuals (Markstein), i.e. bit-identical to the IEEE
+ * division; exported so that the tests can compare it with the division on arbitrary pairs. */
+int mfpa_div_by_reciprocal(const double* v, const double* den, long long n, double* out, void* stream);
 int mfpa_audfprint_pick(const double* spec, const double* clip_max, int B, int F, int T, double pole,
                         const double* gauss, double a_dec, int maxpks, double* work, uint8_t* mask,
                         int32_t* npeaks, void* stream);

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "mfpa_specgram_frames": ([c_int], c_int),
     "mfpa_stft_mag": ([c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_specgram_psd": ([c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_div_by_reciprocal": ([c_void_p, c_void_p, c_longlong, c_void_p, c_void_p], c_int),
     "mfpa_normalize_f32": ([c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p], c_int),
     "mfpa_normalize": ([c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p], c_int),
     "mfpa_f64_to_f32": ([c_void_p, c_void_p, c_longlong, c_void_p], c_int),

@@ -506,7 +506,26 @@ __global__ __launch_bounds__(64) void prune_kernel(const double* __restrict__ fi
 
 }  // namespace
 
+// test hook for prep_div_fast (csrc/mfpa_prepsum.h): out[i] = v[i] / den[i] by the pick kernels' reciprocal + two-correction sequence
+__global__ __launch_bounds__(256) void div_fast_kernel(const double* __restrict__ v, const double* __restrict__ den, long long n,
+                                                       double* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double d = den[i];
+    out[i] = mfpa_prepsum::prep_div_fast(v[i], d, 1.0 / d);
+  }
+}
+
 extern "C" {
+
+int mfpa_div_by_reciprocal(const double* v, const double* den, long long n, double* out, void* stream) {
+  if (n == 0) return MFPA_OK;
+  if (!v || !den || !out || n < 0) return MFPA_EINVAL;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(div_fast_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, mfpa_stream(stream), v, den, n, out);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
 
 int mfpa_audfprint_prepare(const void* spec, int dtype, int B, int F, int T, const double* denom, int mean_order,
                            int log_input, double pole, double* filtered, double* scratch, void* stream) {

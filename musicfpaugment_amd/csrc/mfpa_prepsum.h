@@ -20,11 +20,27 @@ using namespace mfpa_np;
 //  the pair 190-230 us against the single kernel's 176 -- the pruner now filters the frames itself, mfpa_audfprint_pick.)
 // 512 threads: the node's 38 KB of LDS allow four workgroups per CU -- 32 resident waves with 512 threads, 16 with 256 (measured:
 // pick stage 365 -> 354 us per 256 clips; the kernel needs 56 registers, inside the 64 that eight waves per SIMD leave each)
+#ifndef MFPA_PREP_FASTDIV
+#define MFPA_PREP_FASTDIV 1       // 0: the IEEE division per element (A/B builds)
+#endif
 constexpr int SPLIT_THREADS = 512, SPLIT_RPP = SPLIT_THREADS / 16;   // threads; rows per pass of the 16-lane-per-row mappings
 constexpr int SPLIT_MAX_T = 512;
 
-__device__ __forceinline__ double prep_log_value(double v, double den, bool do_log, double floor_v, const double (*tab)[3]) {
-  double s = v / den;
+// v / den for 0 <= v <= den with y = RN(1 / den) (one true division per workgroup), CORRECTLY ROUNDED like the division it replaces:
+// q0 = RN(v y); two residual / correction steps r = v - den q (exact in an fma), q <- RN(q + r y).  After the first step q is a/b + O(2^-2p)
+// rounded, i.e. within one ulp (faithful); Markstein's theorem (1990; Muller et al., Handbook of Floating-Point Arithmetic, "division
+// by a correctly rounded reciprocal") then makes the second step's result RN(v / den), absent underflow -- the caller takes this path only
+// for 1e-200 < den < 1e300, where every residual of a quotient above the floor (1e-6) is a normal number; quotients below the floor are
+// replaced by it, so their last bit is immaterial.  Five multiply-adds instead of the ~11-instruction division sequence with its
+// quarter-rate v_rcp_f64 (tests/test_gpu_peaks.py compares it with IEEE division on 2^24 pairs, near-ties included).
+__device__ __forceinline__ double prep_div_fast(double v, double den, double y) {
+  const double q0 = v * y;
+  const double q1 = __builtin_fma(__builtin_fma(-q0, den, v), y, q0);
+  return __builtin_fma(__builtin_fma(-q1, den, v), y, q1);
+}
+
+__device__ __forceinline__ double prep_log_value(double v, double den, double rden, bool do_log, double floor_v, const double (*tab)[3]) {
+  double s = rden != 0.0 ? prep_div_fast(v, den, rden) : v / den;      // (rden = 0: the caller asks for the true division; uniform)
   if (do_log) {
     s = s > floor_v ? s : floor_v;
     s = mfpa_log_t(s, tab);
@@ -95,6 +111,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) void prep_sum_kernel(const double* _
   const double smax = den > 0.0 ? 1.0 : (double)NAN;          // prepare_kernel: denom[b] is this clip's own maximum
   const bool do_log = smax > 0.0;
   const double floor_v = smax / 1e6;
+  // the reciprocal for prep_div_fast: only where its premises hold (a positive, finite, not tiny maximum; the values are magnitudes <= it)
+  const double rden = (MFPA_PREP_FASTDIV && do_log && den > 1e-200 && den < 1e300) ? 1.0 / den : 0.0;
   const double* x = spec + (size_t)b * N;
   const int e0 = c * NPY_BUFSIZE + off;                        // first element (memory order) of the node
   // the log table into LDS (three dependent-address global loads per logarithm would put a memory round trip into every call); its loads
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void prep_sum_kernel(const double* _
   // (an element at a time in memory order every lane wrote into a different row of L).
   const bool transposed_store = !fm && mean_order != 0;
   for (int i = tid; i < n; i += SPLIT_THREADS) {
-    double lv = prep_log_value(vals[i], den, do_log, floor_v, tab);
+    double lv = prep_log_value(vals[i], den, rden, do_log, floor_v, tab);
     if (scale != 1.0) lv = scale * lv;                         // (uniform; x * 1.0 would be exact as well)
     vals[i] = lv;
     const int e = e0 + i;

@@ -441,3 +441,40 @@ def test_dejavu_pick_equals_prepare_plus_localmax_bit_for_bit(ops):
     want_mask, want_n = ops.localmax2d(arr, 10, 20.0)
     mask, n = ops.dejavu_pick(psd, cmax, 10.0, 1, 10, 20.0)
     assert torch.equal(mask, want_mask) and torch.equal(n, want_n)
+
+
+def test_division_by_a_correctly_rounded_reciprocal_is_the_ieee_division():
+    """prep_div_fast (csrc/mfpa_prepsum.h): the pick kernels divide every spectrogram cell by the clip maximum as q0 = v * RN(1 / max) plus two
+    residual / correction multiply-adds.  Against numpy's float64 division (IEEE, correctly rounded) on 2^24 random pairs over 600 binades and
+    2^22 constructed NEAR-TIES (v = RN(den * midpoint of two adjacent doubles): the quotient lies within 2^-53 relative of a rounding boundary):
+    bit-identical, every one."""
+    from musicfpaugment_amd._lib import lib, check, ptr, stream
+    rng = np.random.default_rng(20260105)
+    n1, n2 = 1 << 24, 1 << 22
+    den = np.ldexp(1.0 + rng.random(n1 + n2), rng.integers(-300, 300, n1 + n2))
+    v = np.empty(n1 + n2)
+    v[:n1] = den[:n1] * rng.random(n1) * np.ldexp(1.0, rng.integers(-20, 1, n1))          # 0 <= v <= den, down to 1e-6 of it
+    m = rng.integers(1 << 52, 1 << 53, n2).astype(np.float64)                               # a 53-bit significand ...
+    # ... and the midpoint above it, (m + 0.5) 2^-53 (54 bits: not a double), times den, rounded once more: v = RN(den m 2^-53 + den 2^-54)
+    v[n1:] = np.ldexp(den[n1:] * m, -53) + np.ldexp(den[n1:], -54)
+    want = v / den
+    vd, dd = torch.from_numpy(v).cuda(), torch.from_numpy(den).cuda()
+    out = torch.empty_like(vd)
+    check(lib().mfpa_div_by_reciprocal(ptr(vd), ptr(dd), v.size, ptr(out), stream()), "mfpa_div_by_reciprocal")
+    got = out.cpu().numpy()
+    bad = np.nonzero(got.view(np.int64) != want.view(np.int64))[0]
+    assert bad.size == 0, (bad.size, v[bad[:4]], den[bad[:4]], got[bad[:4]], want[bad[:4]])
+
+
+def test_pick_log_values_equal_the_ieee_division_build_bit_for_bit(ops):
+    """The masks-only Audfprint pick on 64 synthetic clips: its per-cell quotients go through prep_div_fast; the (separate) prepare path of the
+    same spectrograms divides with the IEEE division in mfpa_normalize first.  Same masks, bit for bit (the log values themselves are compared
+    by test_fused_pick_equals_prepare_plus_prune_bit_for_bit through the pruner's decisions on every frame)."""
+    wav = torch.from_numpy(np.stack([synth.clip(8800 + i, tonal=(i % 2 == 0)) for i in range(64)])).cuda()
+    mag, cmax = ops.stft_mag(wav, torch.float64)
+    a_dec = ops.audfprint_a_dec()
+    m1, n1_ = ops.audfprint_pick(mag, cmax, a_dec)
+    spec = ops.normalize_(mag.clone(), cmax, per_clip=True)                                # IEEE division per element
+    filt = ops.audfprint_prepare(spec, None, mean_order=1)
+    m2, n2_ = ops.audfprint_prune(filt, a_dec)
+    assert torch.equal(m1, m2) and torch.equal(n1_, n2_)
