@@ -510,6 +510,8 @@ def bench_train(args, rank, world, dev, dist):
         ops_train.FUSED_FINISH = False
     if getattr(args, "no_batch_repack", False):
         ops_train.BATCH_REPACK = False
+    if getattr(args, "no_pool_fused", False):
+        ops_train.POOL_BWD_FUSED = ops_train.SKIP_GRAD_BF16 = False
 
     B = args.clips if args.scaling == "weak" else max(1, args.clips // world)
     net = UNet(1, 1, rate=0.05)
@@ -1129,6 +1131,8 @@ def main():
     ap.add_argument("--prefetch-at", choices=["start", "forward", "backward"], default="forward",
                     help="train mode with prefetch: where in step k the side stream starts preparing batch k + 1 (start of the step, behind its forward -- the default: "
                          "the forward's full-resolution layers are the step's memory-bound part, 32.8 -> 32.6 ms same-call -- or behind its backward: too late, 34.1)")
+    ap.add_argument("--no-pool-fused", action="store_true", help="train mode: the encoder blocks' pool backward as its own pass with a float32 dy, skip gradients as "
+                    "float32 (ops_train.POOL_BWD_FUSED = SKIP_GRAD_BF16 = False; A/B runs)")
     ap.add_argument("--no-batch-repack", action="store_true", help="train mode: one weight re-pack launch per convolution and use (ops_train.BATCH_REPACK = False; A/B runs)")
     ap.add_argument("--no-fused-finish", action="store_true", help="train mode: BatchNorm partial-sum finishes as separate launches (ops_train.FUSED_FINISH = False; A/B runs)")
     ap.add_argument("--no-z16", action="store_true", help="train mode (plain bf16): keep the activations in HBM as float32 (ops_train.Z16_ACTIVATIONS = False; A/B runs)")

@@ -412,6 +412,15 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
 int mfpa_maxpool2_bwd_add_sums(const float* z, int B, int H, int W, int C, const float* scale, const float* shift, const float* mean,
                                const float* invstd, const float* dp, float* dy, unsigned drop_seed, unsigned drop_thresh,
                                float drop_scale, float* part, int z_is_bf16, void* stream);
+/* round 5: an encoder block's last BatchNorm + ReLU backward without its finished input gradient in memory -- dy (the skip path's gradient,
+ * (B,H,W,C) float32, or bfloat16 with dy_is_bf16) is only READ: g = dy + route(dp) is reduced to the BatchNorm-backward sums (`part`:
+ * (B * (H / 2), 2, C) floats of scratch), dgamma / dbeta / coef ([3][C]) are finished, and g -- formed again -- goes through the backward
+ * formula into the bfloat16 dz (B,H,W,C).  Replaces mfpa_maxpool2_bwd_add_sums + mfpa_bn_relu_bwd_from_part (same arithmetic per element;
+ * single-GPU statistics; C a power of two <= 1024 with 256 % (C / 4) == 0). */
+int mfpa_maxpool2_bwd_bn_relu_bwd(const float* z, int B, int H, int W, int C, const float* gamma, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, const float* dp, const void* dy, int dy_is_bf16, unsigned drop_seed,
+                                  unsigned drop_thresh, float drop_scale, float* part, float* dgamma, float* dbeta, float* coef,
+                                  double* workspace, void* dz_bf16, int z_is_bf16, void* stream);
 
 /* Weight gradient on MFMA, ACCUMULATED into dw (zero it first):
  *   mode 0: dw[tap][co][ci] += sum_p dz[p][co] * xin[p + tap][ci]          (3x3 conv; dw (9,Cout,C0+C1))

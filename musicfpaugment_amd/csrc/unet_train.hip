@@ -396,14 +396,20 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(const float* __restri
 // (z - mean) * invstd: chan_reduce_kernel<1>'s terms) for its two rows, the odd last column and (last workgroup of a clip) the odd last
 // row included, and writes them as one row of `part` (rows x 2 x C float, the layout of the convolutions' stats_part, finished in
 // float64 by mfpa_conv_stats_reduce): the separate reduction pass over dy and z (2.1 GB at the first level) is not run.
-template <bool SUMS>
+// MODE 0: dy += route(dp); 1: ... and the BatchNorm-backward partial sums (SUMS); 2 (round 5): NOTHING of dy is written -- the pass forms
+// g = dy + route(dp) again and applies the BatchNorm + ReLU backward to it on the spot (coef = bn_bwd_finish_kernel's [3][C]), writing only the
+// bfloat16 dz: with MODE 1 run as a pure reduction in front (`nowrite`), the finished float32 dy of an encoder block never exists.
+// d16: dy (the skip path's gradient) is a bfloat16 tensor (then nothing can be written back into it: nowrite or MODE 2).
+template <int MODE>
 __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ z, int B, int H, int W, int C,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ dp, float* __restrict__ dy,
                                                               unsigned drop_seed, unsigned drop_thresh, float drop_scale,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                              float* __restrict__ part, int z16) {
+                                                              float* __restrict__ part, int z16, int d16, int nowrite,
+                                                              const float* __restrict__ coef, __bf16* __restrict__ dz16) {
+  constexpr bool SUMS = MODE == 1;
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const int b = blockIdx.x / Ho, yo = blockIdx.x % Ho;     // one workgroup per pooled row: 32-bit index math only
   // SUMS: 256 % C4 == 0 (checked by the launcher), so a thread meets ONE channel quad in all its trips: tid % C4
@@ -411,13 +417,30 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
   //  running sum over a row's ~500 pixels would put its rounding, relative to sum |g|, into dgamma / dbeta / dz of every engine precision)
   double s0[4] = {0., 0., 0., 0.}, s1[4] = {0., 0., 0., 0.};
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, scq = {0.f, 0.f, 0.f, 0.f}, sfq = {0.f, 0.f, 0.f, 0.f};
-  if (SUMS) {
+  f32x4 ka = {0.f, 0.f, 0.f, 0.f}, kb = {0.f, 0.f, 0.f, 0.f}, kc = {0.f, 0.f, 0.f, 0.f};
+  if (MODE >= 1) {
     const int cqt = threadIdx.x % C4;
     mu = *reinterpret_cast<const f32x4*>(mean + 4 * cqt);
     is = *reinterpret_cast<const f32x4*>(invstd + 4 * cqt);
     scq = *reinterpret_cast<const f32x4*>(scale + 4 * cqt);
     sfq = *reinterpret_cast<const f32x4*>(shift + 4 * cqt);
+    if (MODE == 2) {
+      ka = *reinterpret_cast<const f32x4*>(coef + 4 * cqt);
+      kb = *reinterpret_cast<const f32x4*>(coef + C + 4 * cqt);
+      kc = *reinterpret_cast<const f32x4*>(coef + 2 * C + 4 * cqt);
+    }
   }
+  // MODE 2: one pixel's four channels through the BatchNorm + ReLU (+ dropout) backward (bn_bwd_apply_kernel's formula), bf16 dz out
+  auto apply = [&](const f32x4& d, const f32x4& v, size_t elem0) {
+    wg_bf16x4_t h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gg = (v[k] * scq[k] + sfq[k] > 0.f) ? d[k] : 0.f;
+      if (drop_thresh) gg = mfpa_keep(drop_seed, drop_thresh, (unsigned long long)elem0 + k) ? gg * drop_scale : 0.f;
+      h[k] = (__bf16)(ka[k] * gg - kb[k] - kc[k] * ((v[k] - mu[k]) * is[k]));
+    }
+    *reinterpret_cast<wg_bf16x4_t*>(dz16 + elem0) = h;
+  };
   // one pixel's four channels into the sums (its finished gradient d, its z)
   auto add = [&](const f32x4& d, const f32x4& v, size_t elem0) {
 #pragma unroll
@@ -456,29 +479,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const size_t off = base + ((size_t)(t >> 1) * W + (t & 1)) * C;
-      float* d = dy + off;
-      f32x4 cur = *reinterpret_cast<f32x4*>(d);
+      f32x4 cur = ld_act4(dy, off, d16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) cur[k] += (arg[k] == t) ? g[k] : 0.f;
-      *reinterpret_cast<f32x4*>(d) = cur;
+      if (MODE != 2 && !nowrite) *reinterpret_cast<f32x4*>(dy + off) = cur;
       if (SUMS) add(cur, vz[t], off);
+      if (MODE == 2) apply(cur, vz[t], off);
     }
   }
-  if (SUMS) {
+  if (MODE >= 1) {
     if (W & 1) {                                            // the last column lies in no window: its gradient is the skip path's alone
       for (int e32 = threadIdx.x; e32 < 2 * C4; e32 += 256) {
         const int cq = e32 % C4, r = e32 / C4;
         const size_t off = (((size_t)b * H + 2 * yo + r) * W + (W - 1)) * C + 4 * cq;
-        add(*reinterpret_cast<const f32x4*>(dy + off), ld_act4(z, off, z16), off);
+        if (SUMS) add(ld_act4(dy, off, d16), ld_act4(z, off, z16), off);
+        else apply(ld_act4(dy, off, d16), ld_act4(z, off, z16), off);
       }
     }
     if ((H & 1) && yo == Ho - 1) {                          // ... and so does the last row: the clip's last workgroup takes it
       for (int e32 = threadIdx.x; e32 < W * C4; e32 += 256) {
         const int cq = e32 % C4, x = e32 / C4;
         const size_t off = (((size_t)b * H + (H - 1)) * W + x) * C + 4 * cq;
-        add(*reinterpret_cast<const f32x4*>(dy + off), ld_act4(z, off, z16), off);
+        if (SUMS) add(ld_act4(dy, off, d16), ld_act4(z, off, z16), off);
+        else apply(ld_act4(dy, off, d16), ld_act4(z, off, z16), off);
       }
     }
+  }
+  if (SUMS) {
     __shared__ double red[256 * 8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1756,8 +1783,9 @@ int mfpa_maxpool2_bwd_add(const float* z, int B, int H, int W, int C, const floa
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !dp || !dy || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   if ((long long)B * (H / 2) > 0x7fffffffLL) return MFPA_EINVAL;
-  hipLaunchKernelGGL(maxpool_bwd_add_kernel<false>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
-                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, z_is_bf16);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<0>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, z_is_bf16,
+                     0, 0, (const float*)nullptr, (__bf16*)nullptr);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -1768,8 +1796,41 @@ int mfpa_maxpool2_bwd_add_sums(const float* z, int B, int H, int W, int C, const
   if (B == 0) return MFPA_OK;
   if (!z || !scale || !shift || !mean || !invstd || !dp || !dy || !part || B < 0 || H < 2 || W < 2 || C < 4 || C % 4) return MFPA_EINVAL;
   if ((long long)B * (H / 2) > 0x7fffffffLL || C / 4 > 256 || 256 % (C / 4)) return MFPA_EINVAL;   // a thread keeps ONE channel quad's sums
-  hipLaunchKernelGGL(maxpool_bwd_add_kernel<true>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
-                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, mean, invstd, part, z_is_bf16);
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<1>, dim3((unsigned)(B * (H / 2))), dim3(256), 0, mfpa_stream(stream), z, B, H, W, C,
+                     scale, shift, dp, dy, drop_seed, drop_thresh, drop_scale, mean, invstd, part, z_is_bf16, 0, 0, (const float*)nullptr, (__bf16*)nullptr);
+  MFPA_CHECK_LAUNCH();
+  return MFPA_OK;
+}
+
+// An encoder block's last BatchNorm + ReLU backward WITHOUT its finished input gradient in memory (round 5): dy = the skip path's gradient
+// (float32, or bfloat16 with dy_is_bf16) is only read.  Launch 1: g = dy + route(dp) reduced to the BatchNorm-backward row partials (nothing
+// written back); 2 + 3: mfpa_conv_stats_reduce's row kernel and the finish (dgamma, dbeta, coefficients); 4: the same g formed again and pushed
+// through the backward formula, bfloat16 dz out.  Against mfpa_maxpool2_bwd_add_sums + mfpa_bn_relu_bwd_from_part: the float32 dy is neither
+// written nor read back (2 of 4.75 tensor passes at float32 dy, 1.75 of 4.75 more with a bfloat16 dy).  Single-GPU statistics only.
+int mfpa_maxpool2_bwd_bn_relu_bwd(const float* z, int B, int H, int W, int C, const float* gamma, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, const float* dp, const void* dy, int dy_is_bf16, unsigned drop_seed,
+                                  unsigned drop_thresh, float drop_scale, float* part, float* dgamma, float* dbeta, float* coef,
+                                  double* workspace, void* dz_bf16, int z_is_bf16, void* stream) {
+  if (B == 0) return MFPA_OK;
+  if (!z || !gamma || !scale || !shift || !mean || !invstd || !dp || !dy || !part || !dgamma || !dbeta || !coef || !workspace || !dz_bf16) return MFPA_EINVAL;
+  if (B < 0 || H < 2 || W < 2 || C < 4 || C % 4 || (C & (C - 1))) return MFPA_EINVAL;
+  if ((long long)B * (H / 2) > 0x7fffffffLL || C / 4 > 256 || 256 % (C / 4) || (C < 256 && 256 % C)) return MFPA_EINVAL;
+  hipStream_t s = mfpa_stream(stream);
+  const unsigned grid = (unsigned)(B * (H / 2));
+  float* dyf = const_cast<float*>(reinterpret_cast<const float*>(dy));
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<1>, dim3(grid), dim3(256), 0, s, z, B, H, W, C, scale, shift, dp, dyf, drop_seed, drop_thresh,
+                     drop_scale, mean, invstd, part, z_is_bf16, dy_is_bf16, 1, (const float*)nullptr, (__bf16*)nullptr);
+  MFPA_CHECK_LAUNCH();
+  const long long rows = (long long)grid;
+  const int groups = 256 / (C < 256 ? C : 256);
+  const int nblk = grid_for(rows, groups * 8, RED_BLOCKS);
+  hipLaunchKernelGGL(conv_stats_rows_kernel, dim3(nblk), dim3(256), 0, s, part, rows, C, workspace);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, (double)((long long)B * H * W), gamma, invstd,
+                     dgamma, dbeta, coef);
+  MFPA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(maxpool_bwd_add_kernel<2>, dim3(grid), dim3(256), 0, s, z, B, H, W, C, scale, shift, dp, dyf, drop_seed, drop_thresh,
+                     drop_scale, mean, invstd, (float*)nullptr, z_is_bf16, dy_is_bf16, 1, coef, reinterpret_cast<__bf16*>(dz_bf16));
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }

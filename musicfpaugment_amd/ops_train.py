@@ -241,6 +241,8 @@ PRENORMALISE_INPUT = True   # the train step's float64 spectrogram / clip maximu
 C1_STATS = True             # bf16 engines: the first layer's kernel writes its output's BatchNorm row partials (no 200 us statistics pass over 1 GB); the
                             # fp32 engine keeps the float64 pass (see UNetTrainEngine._bn_stats)
 C1_WGRAD_BF16 = True        # plain-bf16 step: the 1-channel first layer's weight gradient reads the bf16 copy of dz like every other (False: float32 dz)
+POOL_BWD_FUSED = True       # an encoder block's pool backward + last BatchNorm backward without the finished dy in memory (mfpa_maxpool2_bwd_bn_relu_bwd)
+SKIP_GRAD_BF16 = True       # plain-bf16 step with bf16 activations: the decoder's gradients w.r.t. the skip tensors wait for the encoder's backward as bfloat16
 BATCH_REPACK = True         # the convolutions' operand images (forward + input-gradient forms) re-made by ONE launch per step (PackCache); False: one launch each
 FUSED_FINISH = True         # single-GPU BatchNorm statistics / backward sums from row partials: the finish kernels read the block partials directly
                             # (mfpa_conv_stats_bn_finish, mfpa_bn_relu_bwd_from_part: 35 launches fewer per step, bit-identical; False: the separate calls)
@@ -705,10 +707,31 @@ class UNetTrainEngine:
         return pred
 
     # ------------------------------------------------------------------ backward
-    def _dconv_bwd(self, r, dy, need_input_grad=True, dy_part=None, dy_rank1=None):
+    def _pool_bwd_add(self, r, dy, d_p):
+        """dy (the skip path's gradient of an encoder block's output) += route(d_p) through the block's MaxPool2d, in place; returns (dy,
+        the BatchNorm-backward row partials the same pass formed, or None)."""
+        z, st = r["z3"], r["st3"]
+        B, H, W, C = z.shape
+        if dy.dtype == torch.bfloat16:
+            dy = dy.float()                                            # (a bfloat16 skip gradient on the un-fused path: widened first)
+        if FUSE_POOL_BWD_SUMS and 256 % (C // 4) == 0:
+            # the pass that finishes dy (skip gradient + routed pool gradient) also forms the partial sums of the BatchNorm
+            # backward the block's _dconv_bwd starts with: no separate reduction pass over dy and z
+            part = torch.empty((B * (H // 2), 2, C), dtype=torch.float32, device=z.device)
+            check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+                                                   ptr(d_p), ptr(dy), st.drop[0], st.drop[1], st.drop[2], ptr(part), _is16(z), stream()),
+                  "mfpa_maxpool2_bwd_add_sums")
+            return dy, part
+        check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
+                                          st.drop[0], st.drop[1], st.drop[2], _is16(z), stream()), "mfpa_maxpool2_bwd_add")
+        return dy, None
+
+    def _dconv_bwd(self, r, dy, need_input_grad=True, dy_part=None, dy_rank1=None, pool_dp=None):
         """dy: gradient w.r.t. the DoubleConv's (lazy BN+ReLU) output.  Returns gradients w.r.t. (src0, src1).
         dy_part: the partial sums of this block's last BatchNorm backward when the pass that finished dy already formed them
-        (mfpa_maxpool2_bwd_add_sums, mfpa_outconv_bwd_sums); dy_rank1 = (dpred, w) with dy None: dy = dpred x w, never written."""
+        (mfpa_maxpool2_bwd_add_sums, mfpa_outconv_bwd_sums); dy_rank1 = (dpred, w) with dy None: dy = dpred x w, never written.
+        pool_dp (an encoder block): dy is only the SKIP path's part; the gradient that comes back through the block's MaxPool2d (pool_dp,
+        w.r.t. the pooled tensor) still has to be routed into it -- here, so that the fused form can skip the finished dy altogether."""
         prefix = r["prefix"]
         cout = r["z3"].shape[-1]
         H_, W_ = r["z3"].shape[1], r["z3"].shape[2]
@@ -717,8 +740,29 @@ class UNetTrainEngine:
         # plain bf16 step: when both consumers of dz (input-gradient convolution on conv_wd16_kernel, weight gradient) read its bf16
         # copy, the float32 dz is never written (mfpa_bn_relu_bwd(write_f32 = 0)) and the convolution's loader moves half the bytes
         only16 = USE_BF16_DZ and self.precision == 2 and lay == 2 and wg16
-        dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b", bf16_copy=wg16, write_f32=not only16,
-                                      part=dy_part, rank1=dy_rank1)
+        fused_pool = False
+        if pool_dp is not None:
+            z3, st3 = r["z3"], r["st3"]
+            fused_pool = bool(POOL_BWD_FUSED and only16 and not self.sync_bn and FUSED_FINISH and 256 % (cout // 4) == 0
+                              and (cout & (cout - 1)) == 0 and cout <= 1024)
+            if fused_pool:
+                # mfpa_maxpool2_bwd_bn_relu_bwd: the finished dy (skip + routed pool gradient) is neither written nor read back
+                Bq = z3.shape[0]
+                part = torch.empty((Bq * (H_ // 2), 2, cout), dtype=torch.float32, device=z3.device)
+                coef = torch.empty((3, cout), dtype=torch.float32, device=z3.device)
+                dz16 = torch.empty(z3.shape, dtype=torch.bfloat16, device=z3.device)
+                st3.count_host = float(_npix(z3))
+                check(lib().mfpa_maxpool2_bwd_bn_relu_bwd(ptr(z3), Bq, H_, W_, cout, ptr(self.P[prefix + ".4.g"]), ptr(st3.scale), ptr(st3.shift),
+                                                          ptr(st3.mean), ptr(st3.invstd), ptr(pool_dp), ptr(dy), _is16(dy), st3.drop[0], st3.drop[1],
+                                                          st3.drop[2], ptr(part), ptr(self.G[prefix + ".4.g"]), ptr(self.G[prefix + ".4.b"]),
+                                                          ptr(coef), ptr(self.workspace), ptr(dz16), _is16(z3), stream()),
+                      "mfpa_maxpool2_bwd_bn_relu_bwd")
+                dz3 = None
+            else:
+                dy, dy_part = self._pool_bwd_add(r, dy, pool_dp)
+        if not fused_pool:
+            dz3, dz16 = self._bn_relu_bwd(dy, r["z3"], r["st3"], prefix + ".4.g", prefix + ".4.b", bf16_copy=wg16, write_f32=not only16,
+                                          part=dy_part, rank1=dy_rank1)
         wgrad_mfma(dz3, r["z0"], self.G[prefix + ".3.w"], cout, in_affine=r["st0"], precision=self.wgrad_precision, dz_bf16=dz16,
                    x0_bf16=r["xb3"])
         r["xb3"] = None
@@ -759,7 +803,11 @@ class UNetTrainEngine:
         c0 = r["src0"].shape[-1]
         lay = weight_layout(H_, W_, cout, c0, self.precision)
         dsrc = dz16 if only16 else dz0
-        d0 = conv_mfma(dsrc, pack_weights(w0, self.precision, True, 0, c0, layout=lay), c0, precision=self.precision, packed=True, w_layout=lay)
+        # a decoder block's gradient w.r.t. its skip source waits for the encoder's backward: as bfloat16 (SKIP_GRAD_BF16) when the kernel can
+        # write that (bf16 dz in, conv_wd16_kernel) -- the pool-backward passes read it as it is
+        d0_16 = bool(SKIP_GRAD_BF16 and self._z16 and only16 and r["src1"] is not None and lay == 2)
+        d0 = conv_mfma(dsrc, pack_weights(w0, self.precision, True, 0, c0, layout=lay), c0, precision=self.precision, packed=True, w_layout=lay,
+                       out_bf16=d0_16)
         d1 = None
         if r["src1"] is not None:
             c1 = r["src1"].shape[-1]
@@ -825,27 +873,13 @@ class UNetTrainEngine:
             wt = pack_weights(self.P[name + ".up.w"], self.precision, flip_transpose=True)   # (4, cin, cout), taps kept
             dy = conv_mfma(d_u, wt, wt.shape[1], mode=2, precision=self.precision, packed=True)
             handles.append(self._reduce_bucket(name))
-        dy_part = None
+        pool_dp = None
         for i in range(len(ENC) - 1, -1, -1):                                       # down4 ... inc
             name = ENC[i]
             r = recs[name if i else "inc"]
-            d_p, _ = self._dconv_bwd(r, dy, dy_part=dy_part)
-            dy_part = None
+            d_p, _ = self._dconv_bwd(r, dy, pool_dp=pool_dp)
             if i:
-                below = recs[ENC[i - 1] if i - 1 else "inc"]
-                dy = dskip[ENC[i - 1]]
-                z, st = below["z3"], below["st3"]
-                B, H, W, C = z.shape
-                if FUSE_POOL_BWD_SUMS and 256 % (C // 4) == 0:
-                    # the pass that finishes dy (skip gradient + routed pool gradient) also forms the partial sums of the BatchNorm
-                    # backward the next _dconv_bwd starts with: no separate reduction pass over dy and z
-                    dy_part = torch.empty((B * (H // 2), 2, C), dtype=torch.float32, device=z.device)
-                    check(lib().mfpa_maxpool2_bwd_add_sums(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
-                                                           ptr(d_p), ptr(dy), st.drop[0], st.drop[1], st.drop[2], ptr(dy_part), _is16(z), stream()),
-                          "mfpa_maxpool2_bwd_add_sums")
-                else:
-                    check(lib().mfpa_maxpool2_bwd_add(ptr(z), B, H, W, C, ptr(st.scale), ptr(st.shift), ptr(d_p), ptr(dy),
-                                                      st.drop[0], st.drop[1], st.drop[2], _is16(z), stream()), "mfpa_maxpool2_bwd_add")
+                dy, pool_dp = dskip[ENC[i - 1]], d_p                   # the block below: its skip gradient, and what comes back through its pool
             handles.append(self._reduce_bucket(name))
         ev = None
         if self.comm_wait_events is not None and any(h is not None for h in handles):
