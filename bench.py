@@ -637,7 +637,9 @@ def bench_train(args, rank, world, dev, dist):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": (f"bf16x3 forward / input-gradient convolutions, {args.wgrad} weight gradients, fp32-fp64 reductions and Adam") if args.precision == "bf16x3"
-                     else (f"bf16 (plain bf16 products, fp32 accumulate; transposed convolutions bf16x3; {args.wgrad} weight gradients; fp32-fp64 reductions and Adam)")
+                     else (f"bf16 (plain bf16 products, fp32 accumulate; transposed convolutions bf16x3; {args.wgrad} weight gradients; "
+                           + ("activations and skip gradients in HBM as bf16; " if (ops_train.Z16_ACTIVATIONS and args.wgrad == "bf16") else "")
+                           + "fp32-fp64 reductions, statistics and Adam)")
                      if args.precision == "bf16" else f"f32 ({args.wgrad} weight gradients)", "data": "synthetic",
             "config": {"workload": f"UNet(1,1,rate=0.05) train step, L1 + Adam(1e-3), {args.seconds:g} s clips 257x{1 + nsamp // 256}, {args.precision} MFMA, "
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips")
