@@ -846,7 +846,7 @@ def test_plain_bf16_train_step_converges_where_fp32_does():
     (2) lr 1e-3 (the reference's, training/train.py:661) -- here the loss falls 60-fold in 200 steps and the runs are chaotic: three FP32
         runs of the same everything span 5 % in training loss and 13 % in held-out L1 (float atomics order the weight-gradient sums
         differently), three plain-bf16 runs 12-16 % and 2-13 % (tools/exp_convergence_lr.py), the ranges overlapping.  Three runs of each;
-        the gate is on the MEANS: no further apart than max(10 %, the two ranges added)."""
+        the gate is on the MEANS: no further apart than max(15 %, the two ranges added) (observed: 2.7-6 %)."""
     res = run_convergence({"fp32": (0, 0), "fp32 (b)": (0, 0), "bf16x3": (1, 2), "bf16": (2, 2)}, lr=1e-4)
     f, fb, x3, b = res["fp32"], res["fp32 (b)"], res["bf16x3"], res["bf16"]
     assert f[0] < 0.7 * f[2] and b[0] < 0.7 * b[2]                       # both really trained
@@ -864,7 +864,7 @@ def test_plain_bf16_train_step_converges_where_fp32_does():
         bv = np.array([res[k][i] for k in ("bf16 a", "bf16 b", "bf16 c")])
         assert (fv < 0.1 * res["fp32 a"][2]).all() and (bv < 0.1 * res["fp32 a"][2]).all() if i == 0 else True      # every run trained (loss falls > 10-fold)
         dev = abs(bv.mean() - fv.mean()) / fv.mean()
-        allowed = max(0.10, np.ptp(fv) / fv.mean() + np.ptp(bv) / bv.mean())
+        allowed = max(0.15, np.ptp(fv) / fv.mean() + np.ptp(bv) / bv.mean())
         print(f"[convergence, lr 1e-3] {what}: fp32 {fv.min():.5f}..{fv.max():.5f} (mean {fv.mean():.5f}), plain bf16 {bv.min():.5f}..{bv.max():.5f} "
               f"(mean {bv.mean():.5f}): means {100 * dev:.1f} % apart, allowed {100 * allowed:.1f} %")
         assert dev <= allowed, (what, dev, allowed)
