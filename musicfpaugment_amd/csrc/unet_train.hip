@@ -719,8 +719,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   constexpr int X_F4 = (HP * (WG_T / 4) + WGB_THREADS - 1) / WGB_THREADS;        // float4 loads per thread for the xin tile
   constexpr int D_F4 = WGB_PIX * (WG_T / 4) / WGB_THREADS;            // ... and for the dz tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ds = smem;                          // [128 px][320 B]  dz tile
-  char* Xs = smem + WGB_PIX * ROW;       // [HP px][320 B]   xin tile with halo
+  // ALLTAPS (the transposed convolution's weight gradient from bf16 operands, round 5): the four taps' strided views of dz are staged TOGETHER
+  // -- four dz tiles in LDS, requested with the next patch's x tile under the current patch's MFMAs -- instead of one after the other, each
+  // behind its own exposed global round trip and two barriers for 8 MFMAs of work (0.085 MFMA-busy, 1.2 ms per train step)
+  constexpr bool ALLTAPS = MODE == 1 && BF16IN;
+  constexpr int DT = ALLTAPS ? 4 : 1;
+  char* Ds = smem;                          // [DT][128 px][ROW]  dz tile(s)
+  char* Xs = smem + DT * WGB_PIX * ROW;  // [HP px][ROW]   xin tile with halo
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -909,6 +914,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
       *reinterpret_cast<wg_u32x4*>(Ds + pix * ROW + 16 * c8) = in ? dr16[it] : wg_u32x4{0u, 0u, 0u, 0u};
     }
   };
+  // ALLTAPS: the four taps' tiles at once
+  wg_u32x4 dr16q[ALLTAPS ? 4 : 1][D_L];
+  auto load_d16_all = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+    const char* base = reinterpret_cast<const char*>(a.dz) + ((size_t)b * 4 * a.H * a.W * a.Cout + co0 + 8 * c8) * 2;
+#pragma unroll
+    for (int tap = 0; tap < (ALLTAPS ? 4 : 1); ++tap)
+#pragma unroll
+      for (int it = 0; it < D_L; ++it) {
+        const int pix = t8 + it * PIX_STEP8;
+        const int gy = min(y0 + pix / PW, a.H - 1), gx = min(x0p + pix % PW, a.W - 1);
+        const int off = ((2 * gy + (tap >> 1)) * (2 * a.W) + 2 * gx + (tap & 1)) * a.Cout;
+        dr16q[tap][it] = *reinterpret_cast<const wg_u32x4*>(base + (size_t)off * 2);
+      }
+    d_y0 = y0; d_x0 = x0p;
+  };
+  auto store_d16_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < (ALLTAPS ? 4 : 1); ++tap)
+#pragma unroll
+      for (int it = 0; it < D_L; ++it) {
+        const int pix = t8 + it * PIX_STEP8;
+        const bool in = d_y0 + pix / PW < a.H && d_x0 + pix % PW < a.W;
+        *reinterpret_cast<wg_u32x4*>(Ds + (tap * WGB_PIX + pix) * ROW + 16 * c8) = in ? dr16q[tap][it] : wg_u32x4{0u, 0u, 0u, 0u};
+      }
+  };
   // one set of names for the patch loop below
   auto LOAD_X = [&](int b, int y0, int x0p) __attribute__((always_inline)) { if constexpr (BF16IN) load_x16(b, y0, x0p); else load_x(b, y0, x0p); };
   auto STORE_X = [&](int b, int y0, int x0p) __attribute__((always_inline)) { if constexpr (BF16IN) store_x16(y0, x0p); else store_x(b, y0, x0p); };
@@ -924,12 +954,44 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
 
   int b = 0, y0 = 0, x0p = 0;
   long long patch = bzi;
+  if constexpr (ALLTAPS) {
+    if (patch < npatch) {
+      decode(patch, b, y0, x0p);
+      LOAD_X(b, y0, x0p);
+      load_d16_all(b, y0, x0p);
+    }
+    for (; patch < npatch; patch += gridDim.z) {
+      __syncthreads();                     // the previous patch's fragment reads are done
+      STORE_X(b, y0, x0p);
+      store_d16_all();
+      __syncthreads();
+      const long long next = patch + gridDim.z;
+      int nb = 0, ny0 = 0, nx0 = 0;
+      if (next < npatch) {                 // the next patch's five tiles: their loads land during the MFMA block below
+        decode(next, nb, ny0, nx0);
+        LOAD_X(nb, ny0, nx0);
+        load_d16_all(nb, ny0, nx0);
+      }
+#pragma unroll 2
+      for (int ks = 0; ks < WG_PIX / 16; ++ks) {
+        const char* bp = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * ROW;
+        const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * ROW);           // the x fragment serves all four taps
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const char* ap = a_lane + (t * WGB_PIX + 16 * ks) * ROW;
+          const wg_bf16x8 ah = wg_tr_frag(ap, ap + 4 * ROW);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        }
+      }
+      b = nb; y0 = ny0; x0p = nx0;
+    }
+  } else
   if (patch < npatch) {
     decode(patch, b, y0, x0p);
     LOAD_X(b, y0, x0p);
     LOAD_D(b, y0, x0p, 0);
   }
-  for (; patch < npatch; patch += gridDim.z) {
+  for (; !ALLTAPS && patch < npatch; patch += gridDim.z) {
     __syncthreads();                       // the previous patch's fragment reads are done
     STORE_X(b, y0, x0p);
     STORE_D();
@@ -1881,7 +1943,7 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
     static const int xcd_env = MFPA_EXP_ENV("MFPA_GEMM_XCD", 1);   // 0: plain order (experiments)
     a.xcd = xcd_env;
     const bool plain = d->precision >= 2;
-    const size_t lds = (size_t)(plain ? 192 : WGB_ROW) * (pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
+    const size_t lds = (size_t)(plain ? 192 : WGB_ROW) * ((d->mode == 1 && d->precision == 3 ? 4 : 1) * pix + (d->mode == 0 ? (phh + 2) * (pw + 2) : pix));
     const dim3 blk(64 * nw);
 #define MFPA_WG_LAUNCH(M, P, N, Q) hipLaunchKernelGGL((wgrad_bf16x3_kernel<M, P, N, Q>), grid, blk, lds, s, a)
 #define MFPA_WG_PICK(N, Q)                                  \
