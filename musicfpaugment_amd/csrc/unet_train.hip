@@ -707,9 +707,15 @@ __device__ __forceinline__ void wg_store_split(char* row, int c4, f32x4 v) {
 // BatchNorm + ReLU + dropout applied, or a plain cast) -- every (co, ci) tile re-reads the patches of both operands, so for layers
 // with many tiles halving the bytes per re-read pays for one cast pass (the kernel was bound by what it pulls from L2: skipping its
 // loads returned 24 %); staging is then a 16-byte copy, no split.
-template <int MODE, int PW, int NW, bool PLAIN, bool BF16IN = false>
+template <int MODE, int PW, int NW, bool PLAIN, bool BF16IN = false, bool CI128 = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(WgradArgs a) {
   static_assert(!BF16IN || PLAIN, "bf16 operands carry only the hi halves");
+  static_assert(!CI128 || (MODE == 1 && BF16IN && NW == 8), "the 128-input-channel tile is a form of ALLTAPS");
+  // CI128 (ALLTAPS only): a workgroup owns 64 output x 128 INPUT channels -- waves 2 (co) x 4 (ci), every wave walks all 128 pixels of the patch --
+  // so the dz tiles, the larger operand (four taps), are re-read C_in / 128 times instead of C_in / 64: the 64 x 64 form moved 1.25 GB through L2
+  // for 64 GFLOP (up1.up) at 5.7 TB/s
+  constexpr int CIW = CI128 ? 128 : WG_T;                              // input channels per workgroup
+  constexpr int ROWX = CI128 ? 320 : (PLAIN ? 192 : WGB_ROW);          // bytes per staged x pixel (256 B + 64 B pad: rows on bank offsets 0 / 64 / 128 / 192)
   constexpr int ROW = PLAIN ? 192 : WGB_ROW;
   constexpr int WGB_THREADS = 64 * NW, WGB_PIX = 16 * NW;
   constexpr int WGB_PH = WGB_PIX / PW;
@@ -725,11 +731,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   constexpr bool ALLTAPS = MODE == 1 && BF16IN;
   constexpr int DT = ALLTAPS ? 4 : 1;
   char* Ds = smem;                          // [DT][128 px][ROW]  dz tile(s)
-  char* Xs = smem + DT * WGB_PIX * ROW;  // [HP px][ROW]   xin tile with halo
+  char* Xs = smem + DT * WGB_PIX * ROW;  // [HP px][ROWX]  xin tile with halo
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int cot = wave & 1, cit = (wave >> 1) & 1, ph = wave >> 2;   // ph: the patch's upper / lower 64 pixels (NW = 8)
+  const int cot = wave & 1, cit = CI128 ? (wave >> 1) : ((wave >> 1) & 1), ph = CI128 ? 0 : (wave >> 2);   // ph: the patch's upper / lower 64 pixels (NW = 8)
   // (co tile, ci tile, patch group) of this workgroup.  Every tile of one patch group reads the same dz / x patches; consecutive
   // workgroup ids are dealt round-robin over the 8 XCDs (one L2 each), so with the plain order every XCD fetched every patch.
   // When the grid size is a multiple of 8, XCD k owns a contiguous range of the (group, tile) order instead, tiles fastest.
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
       bzi = lin / tiles; bxi = tile % gridDim.x; byi = tile / gridDim.x;
     }
   }
-  const int co0 = bxi * WG_T, ci0 = byi * WG_T;
+  const int co0 = bxi * WG_T, ci0 = byi * CIW;
   const int Cin = a.C0 + a.C1;
   const bool from0 = ci0 < a.C0;
   const bool affine = from0 && a.in_scale0 != nullptr;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   // transposing read: lane 4q+p of a 16-lane group addresses row q (pixel), columns 4p..4p+3 (channels) of its block
   const int gl = lane & 15, tq = gl >> 2, tp = gl & 3, gsel = (lane >> 4) & 1;
   const char* a_lane = Ds + (64 * ph + 8 * lh + tq) * ROW + (32 * cot + 16 * gsel + 4 * tp) * 2;
-  const char* b_lane = Xs + ((64 / PW) * ph * HPW + 8 * lh + tq) * ROW + (32 * cit + 16 * gsel + 4 * tp) * 2;
+  const char* b_lane = Xs + ((64 / PW) * ph * HPW + 8 * lh + tq) * ROWX + (32 * cit + 16 * gsel + 4 * tp) * 2;
 
   f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f};
   if (affine) {
@@ -914,6 +920,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
       *reinterpret_cast<wg_u32x4*>(Ds + pix * ROW + 16 * c8) = in ? dr16[it] : wg_u32x4{0u, 0u, 0u, 0u};
     }
   };
+  // CI128: the x tile is 128 pixels x 16 pieces of 16 bytes (no halo in mode 1): four pieces per thread
+  constexpr int X_L2 = CI128 ? WGB_PIX * 16 / WGB_THREADS : 1;
+  const int c16 = tid % 16, t16b = tid / 16;
+  wg_u32x4 xr16w[X_L2];
+  auto load_x16w = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
+    const char* base = reinterpret_cast<const char*>(a.x0) + ((size_t)b * a.H * a.W * a.C0 + ci0 + 8 * c16) * 2;
+#pragma unroll
+    for (int it = 0; it < X_L2; ++it) {
+      const int pix = t16b + it * (WGB_THREADS / 16);
+      const int gy = min(y0 + pix / PW, a.H - 1), gx = min(x0p + pix % PW, a.W - 1);
+      xr16w[it] = *reinterpret_cast<const wg_u32x4*>(base + (size_t)((gy * a.W + gx) * a.C0) * 2);
+    }
+  };
+  auto store_x16w = [&](int y0, int x0p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < X_L2; ++it) {
+      const int pix = t16b + it * (WGB_THREADS / 16);
+      const bool inside = y0 + pix / PW < a.H && x0p + pix % PW < a.W;
+      *reinterpret_cast<wg_u32x4*>(Xs + pix * ROWX + 16 * c16) = inside ? xr16w[it] : wg_u32x4{0u, 0u, 0u, 0u};
+    }
+  };
   // ALLTAPS: the four taps' tiles at once
   wg_u32x4 dr16q[ALLTAPS ? 4 : 1][D_L];
   auto load_d16_all = [&](int b, int y0, int x0p) __attribute__((always_inline)) {
@@ -955,27 +982,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void wgrad_bf16x3_kernel(
   int b = 0, y0 = 0, x0p = 0;
   long long patch = bzi;
   if constexpr (ALLTAPS) {
+    auto LOAD_XA = [&](int b_, int y_, int x_) __attribute__((always_inline)) { if constexpr (CI128) load_x16w(b_, y_, x_); else LOAD_X(b_, y_, x_); };
+    auto STORE_XA = [&](int b_, int y_, int x_) __attribute__((always_inline)) { if constexpr (CI128) store_x16w(y_, x_); else STORE_X(b_, y_, x_); };
     if (patch < npatch) {
       decode(patch, b, y0, x0p);
-      LOAD_X(b, y0, x0p);
+      LOAD_XA(b, y0, x0p);
       load_d16_all(b, y0, x0p);
     }
     for (; patch < npatch; patch += gridDim.z) {
       __syncthreads();                     // the previous patch's fragment reads are done
-      STORE_X(b, y0, x0p);
+      STORE_XA(b, y0, x0p);
       store_d16_all();
       __syncthreads();
       const long long next = patch + gridDim.z;
       int nb = 0, ny0 = 0, nx0 = 0;
       if (next < npatch) {                 // the next patch's five tiles: their loads land during the MFMA block below
         decode(next, nb, ny0, nx0);
-        LOAD_X(nb, ny0, nx0);
+        LOAD_XA(nb, ny0, nx0);
         load_d16_all(nb, ny0, nx0);
       }
 #pragma unroll 2
-      for (int ks = 0; ks < WG_PIX / 16; ++ks) {
-        const char* bp = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * ROW;
-        const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * ROW);           // the x fragment serves all four taps
+      for (int ks = 0; ks < (CI128 ? WGB_PIX : WG_PIX) / 16; ++ks) {
+        const char* bp = b_lane + (((16 * ks) / PW) * HPW + (16 * ks) % PW) * ROWX;
+        const wg_bf16x8 bh = wg_tr_frag(bp, bp + 4 * ROWX);          // the x fragment serves all four taps
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const char* ap = a_lane + (t * WGB_PIX + 16 * ks) * ROW;
@@ -1971,7 +2000,19 @@ int mfpa_wgrad_mfma(const mfpa_wgrad_desc* d, void* stream) {
       else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<32, 2>), grid2, dim3(512), lds2, s, a);
       else hipLaunchKernelGGL((wgrad_bf16_kernel<16, 2>), grid2, dim3(512), lds2, s, a);
     } else if (d->precision == 3) {
-      if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32, 8, true, true>), grid, dim3(512), lds, s, a);
+      static const int ci128_env = MFPA_EXP_ENV("MFPA_WGRAD_T_CI128", 1);
+      if (ci128_env && d->C0 % 128 == 0 && d->C1 == 0) {
+        // 64 output x 128 input channels per workgroup (halves the re-reads of the four dz tap tiles)
+        const int tiles3 = (d->Cout / WG_T) * (d->C0 / 128);
+        long long split3 = (1024 + tiles3 - 1) / tiles3;
+        if (split3 > npatch_b) split3 = npatch_b;
+        if (split3 < 1) split3 = 1;
+        if (split3 > 65535) split3 = 65535;
+        const dim3 grid3(d->Cout / WG_T, d->C0 / 128, (unsigned)split3);
+        const size_t lds3 = (size_t)192 * 4 * pix + (size_t)320 * pix;
+        if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32, 8, true, true, true>), grid3, dim3(512), lds3, s, a);
+        else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 16, 8, true, true, true>), grid3, dim3(512), lds3, s, a);
+      } else if (pw == 32) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 32, 8, true, true>), grid, dim3(512), lds, s, a);
       else hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 16, 8, true, true>), grid, dim3(512), lds, s, a);
     }
     else if (nw == 8 && plain) MFPA_WG_PICK(8, true);
