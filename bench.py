@@ -645,6 +645,7 @@ def bench_train(args, rank, world, dev, dist):
                                    + ("AugmentFP chain on the device inside the step" if af is not None else "pre-mixed noisy clips")
                                    + (", next batch prepared on a side stream under the step" if prefetch else ""),
                        "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "loss_last": float(loss),
+                       "prefetch": bool(prefetch), "timer_every": timer.every,
                        "allreduce_calls_per_step": ar_calls, "allreduce_bytes_per_step": ar_bytes,
                        "allreduce_exposed_wait_ms_per_step": ar_wait_ms,
                        "parallelism": f"dp{world}: bucketed RCCL all-reduce of 31.0 M fp32 gradients, "
@@ -655,6 +656,7 @@ def bench_train(args, rank, world, dev, dist):
                           "mfma_flops_issued_per_algorithmic_flop": round(issue_x, 3),
                           "mfma_issue_frac": round(issue_x * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                           "kernel": f"conv_wd16_kernel / conv_mfma_kernel<PREC 1> + wgrad_{args.wgrad}_kernel", "launches": timer.launches(), "timed_steps": timer.sampled,
+                          "launches_per_step": round(timer.launches() / max(timer.sampled, 1), 2),
                           "kernel_ms_per_step": round(conv_ms / args.steps, 3),
                           # the same algorithmic FLOPs over the WHOLE step (BatchNorm / pooling / loss / Adam / AugmentFP launches included)
                           "frac_whole_step": round(mfma_gflop * 1e9 * B * args.steps / dt_max / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
@@ -863,6 +865,12 @@ def bench_infer(args, rank, world, dev, dist):
         out["other_precision"] = {"precision": oname, "value": round(world * B * args.steps / other[0], 3),
                                   "unit": "clips/s", "ms_per_step": round(1e3 * other[0] / args.steps, 3),
                                   "roofline": roofline(other[1], oname)}
+        # the same chain at the REFERENCE's arithmetic (exact fp32 products: BASELINE config 3's wording) as first-class keys of the line,
+        # whichever leg was the headline: a record that keeps only the top-level scalars still carries it
+        f32 = out["other_precision"] if oname == "fp32" else {"value": out["value"], "ms_per_step": out["ms_per_step"], "roofline": out.get("roofline")}
+        out["value_fp32"], out["ms_per_step_fp32"] = f32["value"], f32["ms_per_step"]
+        r32 = f32.get("roofline") or {}
+        out["roofline_fp32"] = {k: r32.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step")}
     return out
 
 
@@ -1109,7 +1117,7 @@ def _self_launch(n: int, argv) -> int:
     return 0 if line is not None else 1
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -1168,7 +1176,11 @@ def main():
     ap.add_argument("--dist-train-steps", type=int, default=8, help="N > 1 infer line: timed steps of each nested train-step entry")
     ap.add_argument("--dist-train-seconds", type=float, default=8.0, help="N > 1 infer line: clip length of the nested train step")
     ap.add_argument("--lib", default=None, help="experiments only: bind another build of the library (e.g. musicfpaugment_amd/libmfpa_exp.so)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
     args.sub_config = False
     if args.lib:
         from musicfpaugment_amd import _lib
@@ -1280,6 +1292,12 @@ def main():
                 pass
         print(json.dumps(_sanitised(result), allow_nan=False), flush=True)
     if dist is not None:
+        if _STATUS.get("broken"):
+            # a nested config failed on some rank: peers may still sit in a bucket all-reduce -- tearing the communicator down with a
+            # collective pending can block; the line (with its error entry) is out, so leave without it and say so with the exit code
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3)
         dist.destroy_process_group()
 
 

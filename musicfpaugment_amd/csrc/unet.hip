@@ -2480,6 +2480,7 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
         // round 5: the wave-specialised kernel (csrc/unet_ws.hip: 4 compute waves of 128 px x 32 ch + 4 loader waves) takes the inference launches
         static const int ws64 = MFPA_EXP_ENV("MFPA_CONV_WS64", MFPA_CONV_WS64);
         if (ws64 && mfpa_unet::conv_ws64_serves(a)) return mfpa_unet::launch_conv_ws64(a, s);
+        if (a.x0_split || a.x1_split || a.y_split || a.y_pool_split) return MFPA_EINVAL;   // (a run-time A/B switch sent a split-layout launch here: only conv_ws64_kernel knows that layout)
         return launch_wd16<8, 32, 4>(a, s);                             // 64-channel output tiles: 4 x 2 waves of 64 px x 32 ch
       }
       {
@@ -2488,6 +2489,7 @@ int dispatch_conv_p(ConvArgs& a, hipStream_t s) {
         const int cin_ = a.C0 + a.C1;
         if (ws_all && cin_ <= ws_all && mfpa_unet::conv_ws64_serves(a)) return mfpa_unet::launch_conv_ws64(a, s);
       }
+      if (a.x0_split || a.x1_split || a.y_split || a.y_pool_split) return MFPA_EINVAL;     // as above
       if (a.W > 16) return launch_wd16<8, 32>(a, s);
       return launch_wd16<16, 16>(a, s);
     }

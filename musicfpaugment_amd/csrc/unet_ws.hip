@@ -351,6 +351,10 @@ __global__ __launch_bounds__(THREADS, 1) void conv_ws64_kernel(ConvArgs a) {
         const int py = pix / HPW, px = pix % HPW;
         off0[it] = (unsigned)((py * a.W + px) * a.C0 + 4 * aq) * 4u;
         off1[it] = (unsigned)((py * a.W1 + px) * a.C1 + 4 * aq) * 4u;
+        // a PADDING slot (pix >= HP: halo row PH + 2, which an interior tile's clip need not contain) is never inside: its VECTOR offset lies
+        // beyond any clip, so the interior form's request (table entry + scalar tile offset) is out of range whether or not the range
+        // check sees the scalar part; nothing reads what it returns (fragment reads stop at pixel HP - 1)
+        if (pix >= HP) off0[it] = off1[it] = 0xfffffff0u;
       }
       const unsigned clip0 = (unsigned)a.H * (unsigned)a.W * (unsigned)a.C0 * 4u, clip1 = (unsigned)a.H1 * (unsigned)a.W1 * (unsigned)a.C1 * 4u;
       f32x4 areg[2][A_F4] = {};                                        // two staging sets: chunk k + 1 is split out of one while chunk k + 2 lands in the other
@@ -956,7 +960,10 @@ bool conv_ws64_serves(const ConvArgs& a) {
   if (a.x0_bf16 || a.x1_bf16 || a.y_bf16 || a.stats_part || a.bz) return false;           // the training step's side outputs: conv_wd16_kernel<SIDE>
   if (a.yH != a.H || a.yW != a.W || a.W <= 16 || a.H < 8) return false;
   // (a slot outside the image is requested at byte offset 0xfffffff0: it must lie beyond a clip)
-  if (4ull * a.H * a.W * a.C0 >= 0xfffffff0ull || 4ull * a.H1 * a.W1 * a.C1 >= 0xfffffff0ull) return false;
+  // ... and an edge tile's halo origin is a WRAPPED negative offset (up to (W + 1) pixels in front of the clip): with a halo row's span added
+  // it must still lie beyond the clip, never inside it
+  if (4ull * a.H * a.W * a.C0 + 4ull * (a.W + 2) * (unsigned long long)a.C0 * 2ull >= 0xfffffff0ull ||
+      4ull * a.H1 * a.W1 * a.C1 + 4ull * (a.W1 + 2) * (unsigned long long)a.C1 * 2ull >= 0xfffffff0ull) return false;
   if (c1 && (a.C0 != 64 || a.C1 != 0 || a.Cout != 64 || a.w1x1 != nullptr || !a.c1_w || !a.c1_scale || !a.c1_shift || MFPA_WS_SYNC)) return false;
   const long long ntiles = (long long)((a.W + PW - 1) / PW) * ((a.H + PH - 1) / PH) * a.B;
   if (ntiles > 0x7fffffffLL / 2) return false;                         // (tile_of's round arithmetic stays inside 31 bits; conv_wd16_kernel takes those)

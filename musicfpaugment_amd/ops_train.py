@@ -91,7 +91,10 @@ class PackCache:
     mfpa_pack_conv_weights_batch launch (46 launches of 5-7 us before).  `refresh()` runs it (the engine calls it at the start of a step: the
     weights changed in the optimiser step); `invalidate()` forgets everything (parameters re-loaded from a module)."""
 
-    def __init__(self):
+    def __init__(self, owner: Optional[torch.Tensor] = None):
+        # `owner`: the persistent buffer whose views may be cached (the engine's flat parameter buffer).  Keys and jobs hold raw data
+        # pointers that refresh() re-reads every step: a weight tensor that does not live inside `owner` (a temporary) must never enter
+        self.owner_range = None if owner is None else (owner.data_ptr(), owner.data_ptr() + owner.numel() * owner.element_size())
         self.entries = {}            # key -> (out tensor, index into jobs)
         self.jobs = []
         self.table = None            # device copy of the job structs
@@ -102,13 +105,23 @@ class PackCache:
     def _key(w, taps, Co, Ci, flip, row0, nrows, code):
         return (w.data_ptr(), taps, Co, Ci, bool(flip), row0, nrows, code)
 
+    def owns(self, w) -> bool:
+        if self.owner_range is None:
+            return True
+        p = w.data_ptr()
+        return self.owner_range[0] <= p and p + w.numel() * w.element_size() <= self.owner_range[1]
+
     def lookup(self, w, taps, Co, Ci, flip, row0, nrows, code):
+        if not self.owns(w):
+            return None
         k = self._key(w, taps, Co, Ci, flip, row0, nrows, code)
         if k in self.fresh:
             return self.entries[k][0]
         return None
 
     def add(self, w, taps, Co, Ci, flip, row0, nrows, code, out):
+        if not self.owns(w):
+            return
         k = self._key(w, taps, Co, Ci, flip, row0, nrows, code)
         K = Co if flip else Ci
         if k in self.entries:                                   # stale image re-made by a single launch into a fresh tensor: point the job at it
@@ -376,7 +389,7 @@ class UNetTrainEngine:
         self.workspace = torch.empty(lib().mfpa_red_blocks() * 2 * 1024, dtype=torch.float64, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._z16, self._z16_cache = False, {}
-        self._packs = PackCache()            # the convolutions' operand images, re-made by one launch per step (BATCH_REPACK)
+        self._packs = PackCache(self.flat_p) # the convolutions' operand images, re-made by one launch per step (BATCH_REPACK)
 
     def _z16_for(self, H: int, W: int) -> bool:
         """Do this step's activations live in HBM as bfloat16?  Z16_ACTIVATIONS, the plain-bf16 arithmetic with bf16 weight gradients

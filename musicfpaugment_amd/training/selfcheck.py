@@ -39,13 +39,15 @@ def run_convergence(precisions, steps=200, B=16, lr=1e-3, verbose=True):
         keep_z16 = ops_train.Z16_ACTIVATIONS
         if len(spec) > 2:                                                # (precision, wgrad_precision, activations kept as bfloat16?)
             ops_train.Z16_ACTIVATIONS = bool(spec[2])
-        eng = UNetTrainEngine(m, lr=lr, precision=prec, wgrad_precision=wprec)
-        losses = []
-        for k in range(steps):
-            am, aden, cm = train[k % len(train)]
-            losses.append(eng.train_step(am, aden, cm).clone())          # (the engine returns its persistent loss scalar)
-        losses = [float(l) for l in losses]
-        ops_train.Z16_ACTIVATIONS = keep_z16
+        try:
+            eng = UNetTrainEngine(m, lr=lr, precision=prec, wgrad_precision=wprec)
+            losses = []
+            for k in range(steps):
+                am, aden, cm = train[k % len(train)]
+                losses.append(eng.train_step(am, aden, cm).clone())      # (the engine returns its persistent loss scalar)
+            losses = [float(l) for l in losses]
+        finally:
+            ops_train.Z16_ACTIVATIONS = keep_z16                         # the module-level switch goes back whatever happened in between
         if len(spec) > 2 and bool(spec[2]) != bool(eng._z16):
             raise RuntimeError(f"{name}: asked for bfloat16 activations = {bool(spec[2])}, the engine ran with {bool(eng._z16)}")
         eng.sync_to_module()

@@ -1,6 +1,7 @@
 """CPU-side checks of the drop-in boundary: libmfpa.so loads, exports every symbol include/mfpa.h declares,
 host-only entry points work, and the product package refuses to run without a GPU (no CPU fallback)."""
 import ctypes
+import hashlib
 import os
 import re
 
@@ -144,3 +145,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_committed_build_record_matches_the_sources_in_the_tree():
+    """profiles/BUILD_rNN.txt (written by __graft_entry__.build()) must describe THESE sources: `sources_sha256` covers every .hip / .h of
+    csrc/ and include/mfpa.h.  A record committed before the round's last source change fails here (round 5's was one commit stale)."""
+    import json
+    import __graft_entry__ as ge
+    from musicfpaugment_amd.csrc import build as b
+    path = os.path.join(ROOT, "profiles", ge.BUILD_RECORD)
+    assert os.path.exists(path), f"{path}: run __graft_entry__.build() and commit the record"
+    rec = json.load(open(path))
+    h = hashlib.sha256()
+    for f in b._sources() + sorted(x for x in os.listdir(b.HERE) if x.endswith(".h")) + ["../../include/mfpa.h"]:
+        with open(os.path.join(b.HERE, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    assert rec["sources_sha256"] == h.hexdigest(), "profiles/%s is stale: rebuild (python -c 'import __graft_entry__ as g; g.build()') and commit it" % ge.BUILD_RECORD
+    if os.path.exists(b.OUT):                                        # the library in the tree (git-ignored, travels to the GPU box) is the recorded one
+        lib_h = hashlib.sha256(open(b.OUT, "rb").read()).hexdigest()
+        assert rec["sha256"] == lib_h, "libmfpa.so in the tree is not the build the record describes"

@@ -367,10 +367,13 @@ def test_config1_dejavu_picker_256_clips_bit_exact_and_batch_invariant(net):
     for i in (0, 9, 63):
         _, want = od.get_2d_peaks(od.preprocess_denoised(y[i].cpu().numpy())[0], 5)
         np.testing.assert_array_equal(mask_d[i].cpu().numpy(), want.astype(np.uint8))
-    net.max_clips_per_pass = 16
-    mask_s, _, _ = fingerprint_peaks_batch(xd, amp_min=5, denoising=True, denoising_model="unet", unet=net)
-    net.max_clips_per_pass = 64
-    net.precision = 0
+    saved_pass = net.max_clips_per_pass
+    try:
+        net.max_clips_per_pass = 16
+        mask_s, _, _ = fingerprint_peaks_batch(xd, amp_min=5, denoising=True, denoising_model="unet", unet=net)
+    finally:
+        net.max_clips_per_pass = saved_pass                            # the module-scoped fixture goes on at the class default
+        net.precision = 0
     assert torch.equal(mask_s, mask_d)
 
 
@@ -382,7 +385,9 @@ def test_headline_chain_256_clips_end_to_end_as_benched(net):
             spectrogram in -> identical peak set out, BASELINE.json north_star);
       (ii)  the denoised spectrogram of sampled clips vs oracle STFT -> oracle UNet: relative L1 <= 1e-4 (bf16x3) / 1e-5 (fp32);
       (iii) the masks-only path bench.py runs (want_spec=False) == the path that also returns the spectrogram; determinism; a
-            ragged 37-clip sharding of the batch gives the same bits."""
+            ragged 37-clip sharding of the batch gives the same bits;
+      (iv)  the UNet pass size is the one bench.py times (the class default of training/unet.UNet.max_clips_per_pass: bench.py only
+            overrides it under --unet-pass), and 64-clip passes give the same bits as that default."""
     from concurrent.futures import ThreadPoolExecutor
     from musicfpaugment_amd.afp.audfprint.peak_extractor import Audfprint_peaks
     from musicfpaugment_amd.pipeline import HotPath
@@ -401,11 +406,23 @@ def test_headline_chain_256_clips_end_to_end_as_benched(net):
         sg = np.stack([ostft.magnitude(wav_np[i]) for i in picks])
         sg = sg / sg.max(axis=(1, 2), keepdims=True)                   # find_peaks normalises per clip (peak_extractor.py:258)
         want_den = ou.forward(torch.from_numpy(sg).float()[:, None], sd)[:, 0]
+    from musicfpaugment_amd.training.unet import UNet
+    import bench
+    benched_pass = UNet(1, 1).max_clips_per_pass                       # what a fresh module -- bench_infer's -- runs with
+    assert bench.build_parser().get_default("unet_pass") == 0          # ... and bench.py leaves it alone by default
+    assert net.max_clips_per_pass == benched_pass, "an earlier test left the shared module at another pass size"
     try:
         for prec, tol in ((1, 1e-4), (0, 1e-5)):
             net.precision = prec
             hot = HotPath(net)
             mask, npk = hot(wav)                                       # what bench.py times
+            if benched_pass != 64:                                     # (iv) the other pass size: same bits
+                try:
+                    net.max_clips_per_pass = 64
+                    mask64, npk64 = hot(wav)
+                finally:
+                    net.max_clips_per_pass = benched_pass
+                assert torch.equal(mask64, mask) and torch.equal(npk64, npk), prec
             assert mask.shape == (B, 256, 251) and mask.dtype == torch.uint8 and int(npk.min()) > 0
             ext = Audfprint_peaks(None, denoising=True, denoising_model="unet", unet=net, device="cuda")
             mask_s, npk_s, spec = ext.find_peaks_batch(wav)            # the same chain, also returning the denoised spectrogram

@@ -100,9 +100,12 @@ def test_forward_vs_oracle_batch_and_fused_entry(net):
     mag, cmax = ops.stft_mag(torch.from_numpy(wav).cuda(), torch.float64)
     got2 = net.denoise_spectrogram(mag, cmax, per_clip=False).cpu()
     assert ou.relative_l1(got2.unsqueeze(1), want) <= TOL
-    net.max_clips_per_pass = 2                                     # sub-batching must not change results
-    got3 = net(x.cuda()).cpu()
-    net.max_clips_per_pass = 64
+    saved_pass = net.max_clips_per_pass
+    try:
+        net.max_clips_per_pass = 2                                 # sub-batching must not change results
+        got3 = net(x.cuda()).cpu()
+    finally:
+        net.max_clips_per_pass = saved_pass
     assert torch.equal(got3, got)
 
 
