@@ -313,6 +313,31 @@ int mfpa_conv_scale_folds(int H, int W, int Cin, int Cout);
  * matrix cores, bf16x3 like every other layer), 0 = the row image (conv_mfma_kernel computes it with exact fp32 FMAs in its loader).
  * Reference: DoubleConv of `inc`, training/unet.py:16-21, 86. */
 int mfpa_conv_c1_layout(int H, int W);
+/* Round 6: a decoder level's FIRST convolution with the transposed convolution folded into it -- Up.forward of training/unet.py:58-65,
+ *   up = ConvTranspose2d(Cl, Cu, 2, 2)(low); pad to the skip's size; y = relu(bn(conv3x3(cat([skip, up]))))        (eval-mode BatchNorm)
+ * as ONE launch that reads `skip` and `low` and never forms `up`: nothing non-linear sits between the two convolutions, so the up half is,
+ * per output phase (Y & 1, X & 1), a 2 x 2 convolution of `low` with composite weights (exact algebra; float64 check:
+ * tools/exp_phase_composite.py) plus a bias that depends only on the pixel's border class.  bf16x3 products like mfpa_conv_mfma(precision 1).
+ *   mfpa_upconv_pack (one-time, device): w3 [9][Cout][Cs + Cu] (tap = 3 ky + kx: mfpa_conv_mfma's fp32 kernel layout), wt [4][Cu][Cl]
+ *     (mfpa_convT2x2's layout), bt (Cu), scale (Cout, the folded BatchNorm scale, or NULL) -> wc16 [16][Cout][Cl] float32, index
+ *     ((py * 2 + px) * 2 + ty) * 2 + tx = phase (py, px), low-resolution tap (ty - 1 + py, tx - 1 + px), and bias_tab (4, 4, Cout) by
+ *     (row class, column class): 0 first row / column of the up-sampled extent, 1 interior, 2 its last, 3 the padding row / column of an
+ *     odd size; both with `scale` multiplied in, float64 accumulation.
+ *   mfpa_upconv_fused: w_skip = the w_layout-2 fragment image of (w3[:, :, :Cs] * scale) and w_up = that of wc16 (as a 16-tap kernel);
+ *     shift (Cout) the folded BatchNorm shift.  skip (B,H,W,Cs), low (B,Hl,Wl,Cl), y (B,H,W,Cout) float32 NHWC; H - 2 Hl and W - 2 Wl in {0, 1}.
+ *   mfpa_upconv_serves (HOST): 1 if mfpa_upconv_fused takes this shape, else 0 (the caller then runs mfpa_convT2x2 + mfpa_conv_mfma). */
+typedef struct mfpa_upconv_desc {
+  const float* skip; const float* low;
+  const float* w_skip; const float* w_up;
+  const float* shift; const float* bias_tab;
+  float* y;
+  int B, H, W, Cs, Hl, Wl, Cl, Cout, relu;
+} mfpa_upconv_desc;
+int mfpa_upconv_fused(const mfpa_upconv_desc* d, void* stream);
+int mfpa_upconv_pack(const float* w3, const float* wt, const float* bt, const float* scale, int Cout, int Cs, int Cu, int Cl,
+                     float* wc16, float* bias_tab, void* stream);
+int mfpa_upconv_serves(int H, int W, int Hl, int Wl, int Cs, int Cl, int Cout);
+
 /* HOST function: rows of mfpa_conv_desc.stats_part for this shape (0: its kernel does not write them). */
 int mfpa_conv_stats_rows(int B, int H, int W, int Cin, int Cout);
 /* stats_part (rows, 2, C) -> sums[2C] float64 as mfpa_bn_stats_sums produces them; workspace as for mfpa_bn_stats. */

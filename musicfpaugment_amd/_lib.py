@@ -20,7 +20,7 @@ EINVAL = -22
 EHIP = -1000
 F32, F64 = 0, 1
 STFT_TABLE_LEN = 1288
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 
 class MfpaError(RuntimeError):
@@ -68,6 +68,9 @@ _SIGNATURES = {
     "mfpa_conv_weight_layout": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int),
     "mfpa_conv_scale_folds": ([c_int, c_int, c_int, c_int], c_int),
     "mfpa_conv_c1_layout": ([c_int, c_int], c_int),
+    "mfpa_upconv_fused": ([c_void_p, c_void_p], c_int),
+    "mfpa_upconv_pack": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p], c_int),
+    "mfpa_upconv_serves": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int),
     "mfpa_gemm_mfma": ([c_void_p, c_void_p], c_int),
     "mfpa_lowpass_taps": ([c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p], c_int),
     "mfpa_fir": ([c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
@@ -175,6 +178,13 @@ class PackJob(ctypes.Structure):
     """mfpa_pack_job (include/mfpa.h)."""
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("taps", c_int), ("Co", c_int), ("Ci", c_int), ("flip_transpose", c_int), ("row0", c_int),
                 ("nrows", c_int), ("precision", c_int), ("pad_", c_int), ("tile0", c_longlong)]
+
+
+class UpconvDesc(ctypes.Structure):
+    """mfpa_upconv_desc of include/mfpa.h."""
+    _fields_ = [("skip", c_void_p), ("low", c_void_p), ("w_skip", c_void_p), ("w_up", c_void_p), ("shift", c_void_p), ("bias_tab", c_void_p),
+                ("y", c_void_p), ("B", c_int), ("H", c_int), ("W", c_int), ("Cs", c_int), ("Hl", c_int), ("Wl", c_int), ("Cl", c_int),
+                ("Cout", c_int), ("relu", c_int)]
 
 
 class ConvDesc(ctypes.Structure):

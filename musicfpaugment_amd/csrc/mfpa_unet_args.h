@@ -52,6 +52,21 @@ struct ConvArgs {
   const float* c1_shift;
 };
 
+// csrc/unet_up.hip: a decoder level's first convolution with the transposed convolution folded in (mfpa_upconv_desc, include/mfpa.h)
+struct UpArgs {
+  const float* skip;       // (B,H,W,Cs)
+  const float* low;        // (B,Hl,Wl,Cl): the transposed convolution's input
+  const float* w_skip;     // fragment image (w_layout 2) of [9][Cout][Cs], output scale folded in
+  const float* w_up;       // fragment image of the composite weights [16][Cout][Cl]
+  const float* shift;      // (Cout)
+  const float* bias_tab;   // (4, 4, Cout)
+  float* y;                // (B,H,W,Cout)
+  int B, H, W, Cs, Hl, Wl, Cl, Cout, relu;
+  int tiles_x, tiles_y;
+};
+__attribute__((visibility("hidden"))) int launch_conv_up(UpArgs& a, hipStream_t s);
+__attribute__((visibility("hidden"))) bool conv_up_serves(int H, int W, int Hl, int Wl, int Cs, int Cl, int Cout);
+
 // csrc/unet_ws.hip: the wave-specialised 64-channel 3x3 convolution (inference, bf16x3).  Returns MFPA_OK / a negative code.
 __attribute__((visibility("hidden"))) int launch_conv_ws64(ConvArgs& a, hipStream_t s);
 // does conv_ws64_kernel serve this ConvArgs (checked by the dispatcher before it routes a launch there)?

@@ -241,7 +241,7 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restri
 
 extern "C" {
 
-int mfpa_version(void) { return 37; }
+int mfpa_version(void) { return 38; }
 
 int mfpa_stft_frames(int T_w) { return 1 + T_w / MFPA_N_HOP; }
 

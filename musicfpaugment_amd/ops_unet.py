@@ -10,7 +10,7 @@ import torch
 
 import ctypes
 
-from ._lib import ConvDesc, check, lib, ptr, stream
+from ._lib import ConvDesc, UpconvDesc, check, lib, ptr, stream
 
 BN_EPS = 1e-5  # nn.BatchNorm2d default (training/unet.py:17,20)
 
@@ -120,7 +120,50 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[s
                 # mfpa_conv_scale_folds says so the launch passes it with out_scale = None and the kernel's epilogue is a bare ReLU
                 if lay == 2 and k.endswith(".w"):
                     pw[k + "ff"] = (lay, split_bf16x3_frag(pw[k] * pw[k[:-2] + ".scale"][None, :, None], lay))
+        if lay == 2 and FOLD_UP:
+            for name in FOLD_UP_LEVELS:
+                pw.update(pack_upconv(pw, name))
     return pw
+
+
+FOLD_UP = True                # False: never fold a level's transposed convolution into its consumer (A/B runs)
+FOLD_UP_LEVELS = ("up1", "up2", "up3", "up4")   # the decoder levels whose Up block runs as ONE launch (mfpa_upconv_fused); same-call pairs against
+                                                # the two launches it replaces, 64 clips: +6 / +19 / +32 / +40 % (profiles/r06_upconv_levels.txt)
+
+
+def pack_upconv(pw: Dict[str, torch.Tensor], name: str) -> Dict[str, torch.Tensor]:
+    """Operands of mfpa_upconv_fused for decoder level `name` from the fp32 kernel-layout weights already in `pw`: the skip half of the
+    level's first 3x3 convolution with the folded BatchNorm scale multiplied in (fragment image), the composite weights of its up half
+    (ConvTranspose2d folded in: mfpa_upconv_pack on the device, float64 accumulation; fragment image as a 16-tap kernel) and the
+    border-class bias table.  Reference: training/unet.py:41-65."""
+    w3 = pw[name + ".conv.double_conv.0.w"]                        # [9][Cout][Cs + Cu]
+    wt = pw[name + ".up.w"]                                        # [4][Cu][Cl]
+    bt = pw[name + ".up.b"]
+    scale = pw[name + ".conv.double_conv.0.scale"]
+    Cout, Cu, Cl = w3.shape[1], wt.shape[1], wt.shape[2]
+    Cs = w3.shape[2] - Cu
+    if not w3.is_cuda:
+        return {}                                                  # (CPU-side packing: the fused launch is simply not offered)
+    wc = torch.empty((16, Cout, Cl), dtype=torch.float32, device=w3.device)
+    tab = torch.empty((4, 4, Cout), dtype=torch.float32, device=w3.device)
+    check(lib().mfpa_upconv_pack(ptr(w3), ptr(wt), ptr(bt), ptr(scale), Cout, Cs, Cu, Cl, ptr(wc), ptr(tab), stream()), "mfpa_upconv_pack")
+    wsk = (w3[:, :, :Cs] * scale[None, :, None]).contiguous()
+    return {name + ".upc.wsk": split_bf16x3_frag(wsk, 2), name + ".upc.wup": split_bf16x3_frag(wc, 2), name + ".upc.bias": tab,
+            name + ".upc.shape": (Cs, Cl, Cout)}
+
+
+def upconv_fused(skip, low, w_skip, w_up, shift, bias_tab, Cout, relu=True):
+    """One decoder level's up -> pad -> cat -> conv3x3 + BN + ReLU (training/unet.py:58-65) as one launch; see include/mfpa.h."""
+    B, H, W, Cs = skip.shape
+    _, Hl, Wl, Cl = low.shape
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=skip.device)
+    d = UpconvDesc(skip=ptr(skip), low=ptr(low), w_skip=ptr(w_skip), w_up=ptr(w_up), shift=ptr(shift), bias_tab=ptr(bias_tab), y=ptr(y),
+                   B=B, H=H, W=W, Cs=Cs, Hl=Hl, Wl=Wl, Cl=Cl, Cout=Cout, relu=int(relu))
+    t0 = _TIMER.start() if _TIMER is not None else None
+    check(lib().mfpa_upconv_fused(ctypes.byref(d), stream()), "mfpa_upconv_fused")
+    if t0 is not None:
+        _TIMER.stop(t0)
+    return y
 
 
 # ----------------------------------------------------------------------------- kernels
@@ -316,6 +359,13 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
         return (SPLIT_EDGES and USE_WEIGHTS_DIRECT and wf_ is not None and wf_[0] == 2
                 and lib().mfpa_conv_weight_layout(H_, W_, cin, cout, 0, 1) == 2 and lib().mfpa_conv_scale_folds(H_, W_, cin, cout) == 1)
 
+    def folds(name, H_, W_, Hl_, Wl_):
+        """Does decoder level `name` run as mfpa_upconv_fused at this size?"""
+        if not (FOLD_UP and prec == 1 and name in FOLD_UP_LEVELS and (name + ".upc.wup") in pw):
+            return False
+        cs, cl, co = pw[name + ".upc.shape"]
+        return lib().mfpa_upconv_serves(H_, W_, Hl_, Wl_, cs, cl, co) == 1
+
     p = ENC[0]
     skips = []
     src = x32 if x32 is not None else spec64
@@ -326,13 +376,14 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
     fused_inc = FUSE_FIRST_LAYER and W0 > 16 and H0 >= 8
     inc_ws = fused_inc and prec == 1 and C1_ON_MFMA and on_ws(p, 3, H0, W0, 64, 64) and lib().mfpa_conv_c1_layout(H0, W0) == 2
     up4 = DEC[-1] + ".conv.double_conv"
-    e_skip0 = inc_ws and on_ws(up4, 0, H0, W0, 128, 64)
+    up4_folds = folds(DEC[-1], H0, W0, H0 // 2, W0 // 2)   # (the folded launch reads / writes plain float32 tensors)
+    e_skip0 = inc_ws and on_ws(up4, 0, H0, W0, 128, 64) and not up4_folds
     H1_, W1_ = H0 // 2, W0 // 2
     d1, d2 = ENC[1], ENC[2]
     e_pool0 = inc_ws and on_ws(d1, 0, H1_, W1_, 64, 128)
     e_d10 = on_ws(d1, 0, H1_, W1_, 64, 128) and on_ws(d1, 3, H1_, W1_, 128, 128)
     e_pool1 = on_ws(d1, 3, H1_, W1_, 128, 128) and on_ws(d2, 0, H1_ // 2, W1_ // 2, 128, 256)
-    e_up40 = on_ws(up4, 0, H0, W0, 128, 64) and on_ws(up4, 3, H0, W0, 64, 64)
+    e_up40 = on_ws(up4, 0, H0, W0, 128, 64) and on_ws(up4, 3, H0, W0, 64, 64) and not up4_folds
     if fused_inc:
         # inc.double_conv: the 1 -> 64 layer is evaluated inside the loader of the 64 -> 64 layer (no 64-channel intermediate)
         x, xp, _ = c(None, p, 3, pool=True, y_split=e_skip0, pool_split=e_pool0,
@@ -354,10 +405,16 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
     y = x                                                   # x5
     for name in DEC:
         skip = skips.pop()
-        u = convT2x2(y, pw[name + ".up.w" + sfx], pw[name + ".up.b"], precision=prec)
         final = name == DEC[-1]
-        m, _, _ = c(skip, name + ".conv.double_conv", 0, x1=u, x0_split=(e_skip0 and final), y_split=(e_up40 and final))
-        del u, skip
+        if folds(name, skip.shape[1], skip.shape[2], y.shape[1], y.shape[2]):
+            # round 6: the level's transposed convolution folded into its first 3x3 convolution -- one launch, `up` never exists
+            m = upconv_fused(skip, y, pw[name + ".upc.wsk"], pw[name + ".upc.wup"], pw[name + ".conv.double_conv.0.shift"],
+                             pw[name + ".upc.bias"], pw[name + ".upc.shape"][2])
+            del skip
+        else:
+            u = convT2x2(y, pw[name + ".up.w" + sfx], pw[name + ".up.b"], precision=prec)
+            m, _, _ = c(skip, name + ".conv.double_conv", 0, x1=u, x0_split=(e_skip0 and final), y_split=(e_up40 and final))
+            del u, skip
         if not final:
             y, _, _ = c(m, name + ".conv.double_conv", 3)
         else:                                               # up4: OutConv fused, the 64-channel tensor is never written

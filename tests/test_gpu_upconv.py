@@ -1,0 +1,123 @@
+"""GPU parity of mfpa_upconv_fused (csrc/unet_up.hip): a decoder level's ConvTranspose2d folded into the 3x3 convolution that consumes it
+(training/unet.py:41-65) against the reference formulation in float64 on the CPU -- up -> pad -> cat -> conv3x3 -> folded BatchNorm -> ReLU --
+and against the two-launch device path it replaces."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _level(g, B, H, W, Hl, Wl, Cs, Cu, Cl, Cout):
+    skip = torch.randn(B, Cs, H, W, generator=g)
+    low = torch.randn(B, Cl, Hl, Wl, generator=g)
+    wt = torch.randn(Cl, Cu, 2, 2, generator=g) / np.sqrt(Cl)
+    bt = torch.randn(Cu, generator=g) * 0.5
+    w3 = torch.randn(Cout, Cs + Cu, 3, 3, generator=g) / np.sqrt(9 * (Cs + Cu))
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    return skip, low, wt, bt, w3, sc, sh
+
+
+def _reference(skip, low, wt, bt, w3, sc, sh):
+    dd = torch.float64
+    up = F.conv_transpose2d(low.to(dd), wt.to(dd), bt.to(dd), stride=2)
+    dY, dX = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]
+    up = F.pad(up, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])                     # unet.py:60-63
+    z = F.conv2d(torch.cat([skip.to(dd), up], dim=1), w3.to(dd), padding=1)
+    return F.relu(z * sc.to(dd)[None, :, None, None] + sh.to(dd)[None, :, None, None])
+
+
+def _fused(skip, low, wt, bt, w3, sc, sh):
+    from musicfpaugment_amd import ops_unet as K
+    Cs = skip.shape[1]
+    pw = {"L.conv.double_conv.0.w": K.pack_conv3x3(w3).cuda(), "L.up.w": K.pack_convT2x2(wt).cuda(), "L.up.b": bt.cuda(),
+          "L.conv.double_conv.0.scale": sc.cuda(), "L.conv.double_conv.0.shift": sh.cuda()}
+    pk = K.pack_upconv(pw, "L")
+    assert pk["L.upc.shape"] == (Cs, low.shape[1], w3.shape[0])
+    y = K.upconv_fused(skip.permute(0, 2, 3, 1).contiguous().cuda(), low.permute(0, 2, 3, 1).contiguous().cuda(), pk["L.upc.wsk"], pk["L.upc.wup"],
+                       sh.cuda(), pk["L.upc.bias"], w3.shape[0])
+    return y, pw, pk
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 257, 251, 128, 125, 64, 64, 128, 64),      # up4 as the UNet runs it: odd in both directions (padding row and column)
+    (2, 128, 125, 64, 62, 128, 128, 256, 128),     # up3: even rows, a padding column; two workgroup rows of 64 channels
+    (3, 40, 70, 20, 35, 64, 32, 64, 64),           # no padding at all, ragged tile tails, C_up != C_skip
+    (1, 9, 33, 4, 16, 64, 64, 96, 192),            # tiny: a second tile row / column that is almost empty
+    (2, 64, 62, 32, 31, 256, 256, 512, 256),       # up2
+    (3, 32, 31, 16, 15, 512, 512, 1024, 512),      # up1
+])
+def test_upconv_fused_matches_the_reference_formulation(shape):
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd._lib import lib
+    from oracle.unet import relative_l1
+    B, H, W, Hl, Wl, Cs, Cu, Cl, Cout = shape
+    assert lib().mfpa_upconv_serves(H, W, Hl, Wl, Cs, Cl, Cout) == 1
+    g = torch.Generator().manual_seed(sum(shape))
+    args = _level(g, *shape)
+    want = _reference(*args)
+    y, pw, pk = _fused(*args)
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    rl1 = relative_l1(got, want)
+    worst = float((got - want).abs().max() / want.abs().max())
+    print(f"[upconv {shape}] relative L1 {rl1:.2e}, worst / max {worst:.2e}")
+    assert rl1 < 5e-6 and worst < 2e-5, (shape, rl1, worst)                       # bf16x3: ~2^-17 per operand
+    # border rows / columns separately (the bias classes and the zero padding of the low-resolution tensor)
+    for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, -2], np.s_[:, :, :, 0], np.s_[:, :, :, -1], np.s_[:, :, :, -2]):
+        assert relative_l1(got[sl], want[sl]) < 1e-5, (shape, sl)
+    y2, _, _ = _fused(*args)
+    assert torch.equal(y2, y)                                                     # deterministic
+    # the two-launch device path it replaces (same arithmetic family): both sit at rounding distance from the float64 reference
+    skip, low = args[0], args[1]
+    if Cu % 64:                                                                   # (mfpa_convT2x2 wants 64-channel output tiles)
+        return
+    u = K.convT2x2(low.permute(0, 2, 3, 1).contiguous().cuda(), K.split_bf16x3(pw["L.up.w"]), pw["L.up.b"], precision=1)
+    w = pw["L.conv.double_conv.0.w"]
+    two, _, _ = K.conv3x3_fused(skip.permute(0, 2, 3, 1).contiguous().cuda(), K.split_bf16x3(w), pw["L.conv.double_conv.0.scale"],
+                                pw["L.conv.double_conv.0.shift"], x1=u, precision=1)
+    assert relative_l1(two.cpu().permute(0, 3, 1, 2).double(), want) < 2e-5              # (it rounds `up` to float32 in between)
+
+
+def test_upconv_serves_and_rejects():
+    from musicfpaugment_amd._lib import lib
+    L = lib()
+    assert L.mfpa_upconv_serves(257, 251, 128, 125, 64, 128, 64) == 1
+    assert L.mfpa_upconv_serves(257, 251, 127, 125, 64, 128, 64) == 0        # three padding rows: not the reference's geometry
+    assert L.mfpa_upconv_serves(16, 15, 8, 7, 512, 1024, 512) == 0           # W <= 16
+    assert L.mfpa_upconv_serves(64, 62, 32, 31, 48, 512, 256) == 0           # Cs not a multiple of 32
+
+
+def test_unet_forward_with_and_without_the_fold_agree(golden):
+    """The whole eval forward with every decoder level folded (the product routing) against the same module with the fold switched off, on full-size
+    clips, and both against the oracle's fp32 forward (gate 1e-4)."""
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd import synth
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict, stress_state_dict
+    from oracle import stft as ostft
+    from oracle import unet as ou
+    wav = synth.batch(2, seed=77)
+    spec = ostft.spectrogram(wav)
+    x = torch.from_numpy(spec).float().unsqueeze(1)
+    for sd in (formula_state_dict(0), stress_state_dict("bn_spread", 0)):
+        with torch.no_grad():
+            want = ou.forward(x, sd)
+        outs = {}
+        for fold in (True, False):
+            K.FOLD_UP = fold
+            try:
+                m = UNet(1, 1, rate=0.05)
+                m.load_state_dict(sd)
+                m = m.cuda().eval()
+                m.precision = 1
+                pw = m.packed_weights()
+                assert (("up4.upc.wup" in pw) == fold)
+                outs[fold] = m(x.cuda()).cpu()
+            finally:
+                K.FOLD_UP = True
+        r_f, r_u = ou.relative_l1(outs[True], want), ou.relative_l1(outs[False], want)
+        d = ou.relative_l1(outs[True], outs[False])
+        print(f"[fold] vs oracle fp32: folded {r_f:.2e}, two-launch {r_u:.2e}; folded vs two-launch {d:.2e}")
+        assert r_f <= 1e-4 and r_u <= 1e-4 and d <= 5e-5
+        assert r_f <= 2.0 * r_u + 1e-6                                          # the fold must not eat into the gate's margin
