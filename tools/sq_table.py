@@ -7,7 +7,7 @@ print("| kernel | launches | µs | MFMA busy | clock GHz | parked | issue-stalle
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for k in a:
     r, r2 = a[k], b.get(k, {})
-    if not PREC1.search(k) and "conv_wd16_kernel" not in k and "conv_ws64_kernel" not in k:      # PREC 1 instantiations (and the bf16x3-only 16 x 16 x 32 kernel)
+    if not PREC1.search(k) and "conv_wd16_kernel" not in k and "conv_ws64_kernel" not in k and "conv_up_kernel" not in k:      # PREC 1 instantiations (and the bf16x3-only 16 x 16 x 32 kernel)
         continue
     wc, gui = r["SQ_WAVE_CYCLES"], r["GRBM_GUI_ACTIVE"] / 8
     mf = max(r2.get("SQ_INSTS_MFMA", 1), 1)
