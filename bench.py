@@ -143,9 +143,8 @@ def cpu_baseline(budget_s: float, seed: int):
         pass
     out = {"value": round(n / dt, 4), "unit": "clips/s", "cores": best_thr, "kind": "port",
            "one_thread_value": round(one_thread, 4), "host_cpu_count": ncpu, "host_cpu_model": model,
-           "sample": f"{n} synthetic 8 s clips in {dt:.1f} s, one at a time like the reference "
-                     f"(peak_extractor.py:236-311): numpy float64 STFT -> torch-CPU fp32 UNet forward (batch 1, "
-                     f"{best_thr} of {ncpu} host threads, calibrated) -> numpy log/high-pass + fwd/bwd prune"}
+           "sample": f"{n} synthetic 8 s clips in {dt:.1f} s, one at a time like the reference (oracle: numpy f64 STFT -> "
+                     f"torch-CPU fp32 UNet, batch 1, {best_thr} of {ncpu} threads -> numpy prune)"}
     # every core at work: one worker per core, started together (spawned before this process owns a GPU)
     workers = max(1, min(32, ncpu))
     wthr = max(1, ncpu // workers)
@@ -166,8 +165,7 @@ def cpu_baseline(budget_s: float, seed: int):
             p.join(timeout=30)
         out["all_core_value"] = round(sum(c / t for c, t in got), 4)
         out["all_core_cores"] = workers * wthr
-        out["all_core_sample"] = (f"{workers} worker processes x {wthr} threads, {sum(c for c, _ in got)} clips in "
-                                  f"{max(t for _, t in got):.1f} s, the same per-clip chain in every worker")
+        out["all_core_sample"] = f"{workers} workers x {wthr} threads, {sum(c for c, _ in got)} clips in {max(t for _, t in got):.1f} s, same chain"
     except Exception as e:                       # the batch-1 figure above stands on its own
         out["all_core_value"] = None
         out["all_core_sample"] = f"not measured: {type(e).__name__}: {e}"
@@ -756,9 +754,8 @@ def bench_infer(args, rank, world, dev, dist):
         differ = (got[1][0] != got[0][0]).sum()
         parity = {"rel_l1_bf16x3_vs_fp32": float(num / den), "gate": 1e-4, "masks_equal_frac": float(same),
                   "mask_cells_differing": int(differ), "peaks_fp32": int(got[0][0].sum()), "clips": int(got[0][0].shape[0]),
-                  "weights": "formula_state_dict(0); the stressed / trained families are gated in tests/test_gpu_unet.py",
-                  "note": "masks of the two ARITHMETIC variants (their spectrograms are ~2e-5 apart, so a near-tie may fall either way: a cell or "
-                          "two in 8 clips); on IDENTICAL spectrograms the peak sets are bit-exact (tests/test_gpu_fullsize.py)"}
+                  "note": "masks of the two ARITHMETIC variants (spectrograms ~2e-5 apart: a near-tie may fall either way); on IDENTICAL "
+                          "spectrograms the peak sets are bit-exact (tests/test_gpu_fullsize.py)"}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -795,8 +792,7 @@ def bench_infer(args, rank, world, dev, dist):
                    "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "peaks_last_step_rank0": total_peaks,
                    **({"batch_streams": len(hot._side)} if hot._side else {}),
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
-                   **({"why_256": "BASELINE configs[1]'s batch; the UNet runs in passes of <= 128 clips, so clips/s is the same at configs[2]'s 512 "
-                                  "(configs.config3_unet_forward_fp32_512 is that batch at the reference's fp32 arithmetic)"}
+                   **({"why_256": "BASELINE configs[1]'s batch; the UNet runs in passes of <= 128 clips: same clips/s at configs[2]'s 512"}
                       if net is not None and B == 256 and not getattr(args, "sub_config", False) else {})},
     }
 
@@ -814,7 +810,7 @@ def bench_infer(args, rank, world, dev, dist):
         if os.path.exists(pmc):      # HBM bytes per step from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             with open(pmc) as fh:    # (FETCH_SIZE x2 per MI355X_MICROARCH.md), scaled to this batch size
                 traffic = json.load(fh)["per_256_clip_step_bytes"] * B / 256.0
-            tsrc = f"profiles/{PMC_TRAFFIC_BF16X3} (offline PMC passes, bytes per step of all MFMA conv launches)"
+            tsrc = f"profiles/{PMC_TRAFFIC_BF16X3} (offline PMC passes)"
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                 # three bf16 MFMAs per executed product; the folded decoder levels execute fewer products than the algorithmic count
@@ -874,7 +870,10 @@ def bench_infer(args, rank, world, dev, dist):
         f32 = out["other_precision"] if oname == "fp32" else {"value": out["value"], "ms_per_step": out["ms_per_step"], "roofline": out.get("roofline")}
         out["value_fp32"], out["ms_per_step_fp32"] = f32["value"], f32["ms_per_step"]
         r32 = f32.get("roofline") or {}
-        out["roofline_fp32"] = {k: r32.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step")}
+        out["roofline_fp32"] = {k: r32.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "launches")}
+        out["roofline_fp32"]["kernel"] = "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (v_mfma_f32_32x32x2_f32; not folded)"
+        if oname == "fp32":
+            del out["other_precision"]            # (the same numbers, now first-class keys: the line stays under the driver's 8 KB)
     return out
 
 
@@ -1002,7 +1001,24 @@ def _compact(r):
     if isinstance(r.get("kernel_breakdown"), dict):
         out["kernel_breakdown"] = {k.split(" ")[0]: ({kk: vv for kk, vv in v.items() if kk in ("us", "GB_per_s")} if isinstance(v, dict) else None)
                                    for k, v in r["kernel_breakdown"].items() if k != "note"}
-    return out
+    if isinstance(out.get("roofline"), dict):
+        out["roofline"] = {k: v for k, v in out["roofline"].items() if k not in ("peak", "unit", "bound")}   # (the peak is the headline roofline's; fp32 entries say dtype f32: 157.3)
+    for k in ("wall_s_including_setup", "loss_last", "peaks_last_step_rank0", "clips_per_step_all_gpus"):
+        out.pop(k, None)
+    if out.get("parity_in_run") is not None:        # the headline's own parity_in_run is the same measurement
+        out.pop("parity_in_run")
+    return _no_prose(out)
+
+
+def _no_prose(o, limit=20):
+    """Nested entries keep numbers, booleans and short tags; sentences (strings longer than `limit`) go: they are in DESIGN.md section 4.  Floats to 6 significant digits."""
+    if isinstance(o, dict):
+        return {k: _no_prose(v, limit) for k, v in o.items() if not (isinstance(v, str) and len(v) > limit)}
+    if isinstance(o, (list, tuple)):
+        return [_no_prose(v, limit) for v in o]
+    if isinstance(o, float):
+        return float(f"{o:.6g}")
+    return o
 
 
 TRAIN_LINE_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline",
@@ -1273,8 +1289,7 @@ def main():
         nested = dist_configs(args, rank, world, dev, dist)        # every rank: the gradient all-reduce is a collective
     if rank == 0:
         result["dist_backend"] = ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None
-        result["device_sample"] = {"before": dev_before, "after": dev_after,
-                                   "note": "rocm-smi on rank 0's GPU just outside the timed region of the headline"}
+        result["device_sample"] = {"before": dev_before, "after": dev_after}      # rocm-smi on rank 0's GPU just outside the timed region
         try:
             from musicfpaugment_amd import ops_demucs
             result["persistent_lstm_fallbacks"] = int(getattr(ops_demucs, "persistent_lstm_fallbacks", 0))

@@ -1522,12 +1522,36 @@ template <int N> __device__ __forceinline__ void lfv_store(float* p, const LFV<N
 #pragma unroll
   for (int i = 0; i < N; ++i) p[i] = x.v[i]; }
 
+#ifndef MFPA_LSTM_WIDE_PUT
+#define MFPA_LSTM_WIDE_PUT 1      // round 6: a step's new h leaves the workgroup as 16-byte write-through stores (gathered through LDS) instead of one
+#endif                            // 4-byte (2-byte) agent-scope store per cell thread and half: narrow sc1 stores are one fabric write each (A/B builds: 0)
+#ifndef MFPA_LSTM_FAST_CELL
+#define MFPA_LSTM_FAST_CELL 1     // round 6: the cell's sigmoid / tanh on v_exp_f32 + v_rcp_f32 (absolute error ~1e-7) instead of the library expf / tanhf (A/B builds: 0)
+#endif
+__device__ __forceinline__ float lstm_sig(float x) {
+#if MFPA_LSTM_FAST_CELL
+  return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+#else
+  return 1.f / (1.f + expf(-x));
+#endif
+}
+__device__ __forceinline__ float lstm_tanh(float x) {
+#if MFPA_LSTM_FAST_CELL
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));       // e^{2x} -> inf: 1; -> 0: -1
+#else
+  return tanhf(x);
+#endif
+}
+
 template <int KS, int COH, int MS>          // k-steps of 16 per wave: H = 128 KS
 __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
   constexpr int SLAB = 32 * MS, UPT = MS, TPC = 16 / UPT;   // clips per workgroup; hidden units per cell thread; cell threads per clip
   typedef LFV<UPT> fv;
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   float* G = reinterpret_cast<float*>(lsm);                 // [QW][SLAB][QGLD]
+#if MFPA_LSTM_WIDE_PUT
+  char* const PS = lsm + (size_t)QW * SLAB * QGLD * sizeof(float);   // [SLAB][64 B]: the step's new h, split, on its way out
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int H = a.H;
@@ -1713,14 +1737,30 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
       fv hn, vi, vf, vg, vo, hs;
 #pragma unroll
       for (int k = 0; k < UPT; ++k) {
-        const float si = 1.f / (1.f + expf(-gs[0][k])), sf = 1.f / (1.f + expf(-gs[1][k])), so = 1.f / (1.f + expf(-gs[3][k]));
-        const float tg = tanhf(gs[2][k]);
+        const float si = lstm_sig(gs[0][k]), sf = lstm_sig(gs[1][k]), so = lstm_sig(gs[3][k]);
+        const float tg = lstm_tanh(gs[2][k]);
         c[k] = sf * c[k] + si * tg;
-        hn[k] = so * tanhf(c[k]);
+        hn[k] = so * lstm_tanh(c[k]);
         hs[k] = hn[k] + ad[k];
         vi[k] = si; vf[k] = sf; vg[k] = tg; vo[k] = so;
       }
+#if MFPA_LSTM_WIDE_PUT
+      {   // this thread's hi / lo halves into the workgroup's staging rows: [clip][16 units x bf16 hi | 16 units x bf16 lo]
+        char* ps = PS + clip * 64 + UPT * up * 2;
+        if (UPT == 2) {
+          const __bf16 h0 = (__bf16)hn[0], h1 = (__bf16)hn[UPT - 1];
+          const __bf16 l0 = (__bf16)(hn[0] - (float)h0), l1 = (__bf16)(hn[UPT - 1] - (float)h1);
+          *reinterpret_cast<unsigned*>(ps) = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+          *reinterpret_cast<unsigned*>(ps + 32) = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        } else {
+          const __bf16 h0 = (__bf16)hn[0];
+          *reinterpret_cast<unsigned short*>(ps) = __builtin_bit_cast(unsigned short, h0);
+          *reinterpret_cast<unsigned short*>(ps + 32) = __builtin_bit_cast(unsigned short, (__bf16)(hn[0] - (float)h0));
+        }
+      }
+#else
       put_split(a.hsplit + (size_t)(t & 1) * bufb, hn);
+#endif
       const size_t o = (size_t)m * ldh + (size_t)t * H + u0;
       lfv_store<UPT>(a.hseq + o, hn);
       if (a.xsum) lfv_store<UPT>(a.xsum + o, hs);
@@ -1733,7 +1773,27 @@ __global__ __launch_bounds__(64 * QW, 1) void lstm_seq_kernel(LstmSeqArgs a) {
         lfv_store<UPT>(a.cseq + o, c);
       }
     }
+#if MFPA_LSTM_WIDE_PUT
+    if (t + 1 < a.t1) {
+      // the slab's new h as 16-byte write-through (sc1) stores: thread j takes piece j & 3 (hi 0..7, hi 8..15, lo 0..7, lo 8..15) of clip j >> 2
+      __syncthreads();
+      if (tid < 4 * SLAB) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int sc = tid >> 2, piece = tid & 3;
+        const int sm = m0 + sc;
+        if (sm < a.B) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(PS + sc * 64 + piece * 16);
+          const int ug = grp * LU;
+          const unsigned off = (unsigned)((size_t)(t & 1) * bufb + (size_t)sm * rowb + (size_t)(ug >> 5) * 128 + (size_t)(ug & 31) * 2 + (size_t)(piece >> 1) * 64 +
+                                          (size_t)(piece & 1) * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v, hrsrc, off, 0, 16);
+        }
+      }
+      arrive();
+    }
+#else
     if (t + 1 < a.t1) arrive();                            // (its __syncthreads also frees the gate slabs for the next step)
+#endif
   }
   if (live && !a.train) lfv_store<UPT>(a.cstate + (size_t)m * H + u0, c);
 }
@@ -1990,7 +2050,7 @@ int mfpa_lstm_layer_seq(const float* whh_grouped, float* xp, float* hseq, float*
   hipStream_t st = mfpa_stream(stream);
   MFPA_HIP(hipMemsetAsync(work, 0, (size_t)LSTM_ERR_WORD * 4, st));          // the slab counters; the error word stays
   const unsigned grid = (unsigned)(((nslab * ngroups + 7) / 8) * 8);
-  const size_t lds = (size_t)QW * 32 * ms * QGLD * sizeof(float);
+  const size_t lds = (size_t)QW * 32 * ms * QGLD * sizeof(float) + (MFPA_LSTM_WIDE_PUT ? (size_t)32 * ms * 64 : 0);
   static const int coh = MFPA_EXP_ENV("MFPA_LSTM_COH", 1);   // 0: one L1 / L2 invalidate per step + cached loads (7.83 vs 7.58 ms for both layers of 256 clips)
 #define SEQ_LAUNCH(KS_)                                                                                                   \
   if (ms == 1) hipLaunchKernelGGL((lstm_seq_kernel<KS_, 1, 1>), dim3(grid), dim3(64 * QW), lds, st, a);                   \
