@@ -754,8 +754,7 @@ def bench_infer(args, rank, world, dev, dist):
         differ = (got[1][0] != got[0][0]).sum()
         parity = {"rel_l1_bf16x3_vs_fp32": float(num / den), "gate": 1e-4, "masks_equal_frac": float(same),
                   "mask_cells_differing": int(differ), "peaks_fp32": int(got[0][0].sum()), "clips": int(got[0][0].shape[0]),
-                  "note": "masks of the two ARITHMETIC variants (spectrograms ~2e-5 apart: a near-tie may fall either way); on IDENTICAL "
-                          "spectrograms the peak sets are bit-exact (tests/test_gpu_fullsize.py)"}
+                  "note": "masks of the two ARITHMETIC variants (~2e-5 apart: a near-tie may fall either way)"}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -792,7 +791,7 @@ def bench_infer(args, rank, world, dev, dist):
                    "clips_per_gpu_per_step": B, "clips_per_step_all_gpus": world * B, "peaks_last_step_rank0": total_peaks,
                    **({"batch_streams": len(hot._side)} if hot._side else {}),
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
-                   **({"why_256": "BASELINE configs[1]'s batch; the UNet runs in passes of <= 128 clips: same clips/s at configs[2]'s 512"}
+                   **({"why_256": "BASELINE configs[1]'s batch; UNet passes of <= 128 clips: same clips/s at 512"}
                       if net is not None and B == 256 and not getattr(args, "sub_config", False) else {})},
     }
 
@@ -803,7 +802,7 @@ def bench_infer(args, rank, world, dev, dist):
         if precision == "fp32":
             return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (v_mfma_f32_32x32x2_f32)",
+                    "kernel": "conv_mfma_kernel<PREC 0> (v_mfma_f32_32x32x2_f32) + conv_up_kernel<0> (decoder levels folded, v_mfma_f32_16x16x4_f32)",
                     "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
         traffic, tsrc = None, None
         pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_BF16X3)
@@ -816,7 +815,7 @@ def bench_infer(args, rank, world, dev, dist):
                 # three bf16 MFMAs per executed product; the folded decoder levels execute fewer products than the algorithmic count
                 "mfma_flops_issued_per_algorithmic_flop": round(3 * EXEC_RATIO, 3),
                 "mfma_issue_frac": round(3 * EXEC_RATIO * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                "kernel": "conv_wd16_kernel + conv_ws64_kernel + conv_up_kernel (decoder levels, transposed convolution folded in) + conv_mfma_kernel<PREC 1> (DESIGN.md 3.1)",
+                "kernel": "conv_wd16_kernel + conv_ws64_kernel + conv_up_kernel<1> (decoder levels, transposed convolution folded in); DESIGN.md 3.1",
                 "launches": tm.launches(), "kernel_ms_per_step": round(conv_ms / args.steps, 3)}
 
     if net is not None and timer.launches():
@@ -871,7 +870,7 @@ def bench_infer(args, rank, world, dev, dist):
         out["value_fp32"], out["ms_per_step_fp32"] = f32["value"], f32["ms_per_step"]
         r32 = f32.get("roofline") or {}
         out["roofline_fp32"] = {k: r32.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "launches")}
-        out["roofline_fp32"]["kernel"] = "conv_mfma_kernel<PREC 0> + convT_mfma_kernel<PREC 0> (v_mfma_f32_32x32x2_f32; not folded)"
+        out["roofline_fp32"]["kernel"] = "conv_mfma_kernel<PREC 0> (32x32x2_f32) + conv_up_kernel<0> (16x16x4_f32)"
         if oname == "fp32":
             del out["other_precision"]            # (the same numbers, now first-class keys: the line stays under the driver's 8 KB)
     return out
@@ -1309,7 +1308,10 @@ def main():
                 result["persistent_lstm_fallbacks"] = int(getattr(ops_demucs, "persistent_lstm_fallbacks", 0))
             except Exception:
                 pass
-        print(json.dumps(_sanitised(result), allow_nan=False), flush=True)
+        line = json.dumps(_sanitised(result), allow_nan=False)
+        if len(line) > 8000:
+            print(f"[bench] WARNING: the JSON line is {len(line)} bytes; the driver's record keeps about the last 8 KB", file=sys.stderr, flush=True)
+        print(line, flush=True)
     if dist is not None:
         if _STATUS.get("broken"):
             # a nested config failed on some rank: peers may still sit in a bucket all-reduce -- tearing the communicator down with a

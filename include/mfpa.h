@@ -317,7 +317,7 @@ int mfpa_conv_c1_layout(int H, int W);
  *   up = ConvTranspose2d(Cl, Cu, 2, 2)(low); pad to the skip's size; y = relu(bn(conv3x3(cat([skip, up]))))        (eval-mode BatchNorm)
  * as ONE launch that reads `skip` and `low` and never forms `up`: nothing non-linear sits between the two convolutions, so the up half is,
  * per output phase (Y & 1, X & 1), a 2 x 2 convolution of `low` with composite weights (exact algebra; float64 check:
- * tools/exp_phase_composite.py) plus a bias that depends only on the pixel's border class.  bf16x3 products like mfpa_conv_mfma(precision 1).
+ * tools/exp_phase_composite.py) plus a bias that depends only on the pixel's border class.  Products: bf16x3 or exact fp32 (`precision`).
  *   mfpa_upconv_pack (one-time, device): w3 [9][Cout][Cs + Cu] (tap = 3 ky + kx: mfpa_conv_mfma's fp32 kernel layout), wt [4][Cu][Cl]
  *     (mfpa_convT2x2's layout), bt (Cu), scale (Cout, the folded BatchNorm scale, or NULL) -> wc16 [16][Cout][Cl] float32, index
  *     ((py * 2 + px) * 2 + ty) * 2 + tx = phase (py, px), low-resolution tap (ty - 1 + py, tx - 1 + px), and bias_tab (4, 4, Cout) by
@@ -332,6 +332,9 @@ typedef struct mfpa_upconv_desc {
   const float* shift; const float* bias_tab;
   float* y;
   int B, H, W, Cs, Hl, Wl, Cl, Cout, relu;
+  int precision;                   /* 1: bf16x3 (w_skip / w_up = w_layout-2 fragment images); 0: exact fp32 products (v_mfma_f32_16x16x4_f32) on the
+                                    * FP32 fragment images [tap][Cin / 32][Cout / 16][piece 2][lane 64][4 floats], lane (g = l >> 4, c = l & 15) =
+                                    * output channel 16 t + c, input channels 32 chunk + 8 g + 4 piece .. + 3 */
 } mfpa_upconv_desc;
 int mfpa_upconv_fused(const mfpa_upconv_desc* d, void* stream);
 int mfpa_upconv_pack(const float* w3, const float* wt, const float* bt, const float* scale, int Cout, int Cs, int Cu, int Cl,

@@ -184,7 +184,7 @@ class UpconvDesc(ctypes.Structure):
     """mfpa_upconv_desc of include/mfpa.h."""
     _fields_ = [("skip", c_void_p), ("low", c_void_p), ("w_skip", c_void_p), ("w_up", c_void_p), ("shift", c_void_p), ("bias_tab", c_void_p),
                 ("y", c_void_p), ("B", c_int), ("H", c_int), ("W", c_int), ("Cs", c_int), ("Hl", c_int), ("Wl", c_int), ("Cl", c_int),
-                ("Cout", c_int), ("relu", c_int)]
+                ("Cout", c_int), ("relu", c_int), ("precision", c_int)]
 
 
 class ConvDesc(ctypes.Structure):

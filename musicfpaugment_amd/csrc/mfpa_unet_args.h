@@ -62,6 +62,7 @@ struct UpArgs {
   const float* bias_tab;   // (4, 4, Cout)
   float* y;                // (B,H,W,Cout)
   int B, H, W, Cs, Hl, Wl, Cl, Cout, relu;
+  int precision;           // 1: bf16x3 fragment images; 0: fp32 fragment images (exact fp32 products)
   int tiles_x, tiles_y;
 };
 __attribute__((visibility("hidden"))) int launch_conv_up(UpArgs& a, hipStream_t s);

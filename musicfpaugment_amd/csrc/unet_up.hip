@@ -79,6 +79,11 @@ __device__ __forceinline__ int tile_of(int b, int i, int G) {
 // bias class of an output row / column: which of the three taps along that axis fall inside the up-sampled extent [0, 2 n)
 __device__ __forceinline__ int bias_class(int v, int n2) { return v == 0 ? 0 : (v < n2 - 1 ? 1 : (v == n2 - 1 ? 2 : 3)); }
 
+// PREC 1: bf16x3 products (v_mfma_f32_16x16x32_bf16; operands split hi | lo while staged: planes [hi | lo][k-group]).
+// PREC 0: exact fp32 products (v_mfma_f32_16x16x4_f32, the reference's arithmetic): the stage's eight planes hold the eight 16-byte pieces
+// of a pixel's 32-channel chunk as they are (the loaders only copy), lane (p, g) takes channels 8 g .. 8 g + 7 (pieces 2 g, 2 g + 1) and the
+// eight k-steps of a chunk pair channel 8 g + s of the pixel with the same channel of the weight fragment.
+template <int PREC>
 __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -198,9 +203,14 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
       }
     };
     char* const wbase = smem + plane_off(0, aq >> 1) + pl * 16 + 8 * (aq & 1);
+    char* const wbase32 = smem + plane_off(aq >> 2, aq & 3) + pl * 16;       // PREC 0: piece aq of the pixel, as it is
     auto split_slot = [&](auto SET, auto IT, int stage_off) __attribute__((always_inline)) {
       constexpr int it = decltype(IT)::value, set = decltype(SET)::value;
       const f32x4 v = areg[set][it];
+      if constexpr (PREC == 0) {
+        *reinterpret_cast<f32x4*>(wbase32 + stage_off + it * PPI * 16) = v;
+        return;
+      }
       unsigned hi[2], lo[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -285,7 +295,8 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
   const int wm = wave & 1, wn = wave >> 1;                             // row parity (= the row phase py), channel half
   const int p = lane & 15, g = lane >> 4;
 
-  bf16x8 wq[4][2][2];                                                  // weight fragments: [set][16-channel tile][hi, lo]; the skip half rings sets 0..2
+  typedef typename std::conditional<PREC == 1, bf16x8, f32x4>::type frag_t;   // 16 bytes either way
+  frag_t wq[4][2][2];                                                  // weight fragments: [set][16-channel tile][hi, lo | piece 0, 1]; the skip half rings sets 0..2
                                                                        // (tap t in set t % 3, two taps ahead), the low half pairs (0, 1) / (2, 3) (one pair ahead)
   // weight fragments through raw buffer loads: descriptor in scalar registers, ONE vector offset (lane * 16) for every load, the (tap, chunk,
   // channel-tile) block offset in the instruction's scalar offset -- as 64-bit global pointers hipcc kept a register pair per prefetch
@@ -297,10 +308,10 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
   auto load_w_at = [&](__amdgpu_buffer_rsrc_t rs, unsigned blk, auto SLOT) __attribute__((always_inline)) {
     constexpr int slot = decltype(SLOT)::value;
     const int so = (int)__builtin_amdgcn_readfirstlane((int)(blk << 11));
-    wq[slot][0][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, so, 0));
-    wq[slot][0][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 1024, so, 0));
-    wq[slot][1][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 2048, so, 0));
-    wq[slot][1][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 3072, so, 0));
+    wq[slot][0][0] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, so, 0));
+    wq[slot][0][1] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 1024, so, 0));
+    wq[slot][1][0] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 2048, so, 0));
+    wq[slot][1][1] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 3072, so, 0));
   };
   auto load_w_skip = [&](int chunk, int tap, auto SLOT) __attribute__((always_inline)) {
     load_w_at(rs_skip, ((unsigned)tap * (unsigned)nsk + (unsigned)chunk) * wrow + wcol, SLOT);
@@ -310,20 +321,23 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
     const unsigned t16 = (unsigned)((wm * 2 + px) * 4 + pair);
     load_w_at(rs_up, (t16 * (unsigned)nup + (unsigned)chunk) * wrow + wcol, SLOT);
   };
-  struct XFrags { bf16x8 h[4], l[4]; };
+  struct XFrags { frag_t h[4], l[4]; };                                 // PREC 0: h = piece 2 g, l = piece 2 g + 1
   XFrags fx0, fx1;
   // fragment of group (j, px) -- tile rows 2 j + wm, columns 2 p + px:
   //   skip, tap (ta, tb): halo row 2 j + wm + ta, halo column 2 p + s with s = px + tb -> staged position (s & 1) * 17 + (s >> 1) + p
   //   low, pair (ty, tx): patch row j + ty + wm, patch column p + tx + px
-  const int xb_skip = (wm * HPW + p) * 16 + plane_off(0, g);
-  const int xb_up = (wm * LPW + p) * 16 + plane_off(0, g);
+  // PREC 1: plane (hi, g) and, HLS further, (lo, g); PREC 0: pieces 2 g and 2 g + 1 = planes (g >> 1, 2 (g & 1)) and the next one
+  const int pl0 = PREC == 1 ? plane_off(0, g) : plane_off(g >> 1, 2 * (g & 1));
+  constexpr int SECOND = PREC == 1 ? HLS : PLANE;                      // (planes 2 k and 2 k + 1 are PLANE apart: plane_off)
+  const int xb_skip = (wm * HPW + p) * 16 + pl0;
+  const int xb_up = (wm * LPW + p) * 16 + pl0;
   auto read_at = [&](XFrags& f, const char* base, auto STRIDE) __attribute__((always_inline)) {
     constexpr int stride = decltype(STRIDE)::value;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const char* r = base + j * stride;
-      f.l[j] = *reinterpret_cast<const bf16x8*>(r + HLS);
-      f.h[j] = *reinterpret_cast<const bf16x8*>(r);
+      f.l[j] = *reinterpret_cast<const frag_t*>(r + SECOND);
+      f.h[j] = *reinterpret_cast<const frag_t*>(r);
     }
   };
   auto read_skip = [&](XFrags& f, const char* stage, auto TAP, auto PX) __attribute__((always_inline)) {
@@ -340,8 +354,21 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = floatx4{0.f, 0.f, 0.f, 0.f};
   floatx4 initv[2];                                                    // the accumulators' start values: the output shift (the scale is in the weights)
-  auto mfma_half = [&](const XFrags& f, const bf16x8 (&w)[2][2], auto HALFI, auto FIRST) __attribute__((always_inline)) {
+  auto mfma_half = [&](const XFrags& f, const frag_t (&w)[2][2], auto HALFI, auto FIRST) __attribute__((always_inline)) {
     constexpr int half = decltype(HALFI)::value;
+    if constexpr (PREC == 0) {
+      // eight k-steps of four channels: step s = element s & 3 of piece s >> 2; an accumulator is touched every eighth instruction
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float wv = (s8 < 4 ? w[ct][0] : w[ct][1])[s8 & 3], xv = (s8 < 4 ? f.h[i] : f.l[i])[s8 & 3];
+            acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, (decltype(FIRST)::value && s8 == 0) ? initv[ct] : acc[ct][4 * half + i], 0, 0, 0);
+          }
+      return;
+    } else {
     // term-major (lo x hi, hi x lo, hi x hi), as in conv_ws64_kernel
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -356,8 +383,9 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[ct][4 * half + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct][0], f.h[i], acc[ct][4 * half + i], 0, 0, 0);
+    }
   };
-  constexpr int N_R = 8, N_M = 24, N_W = 4;                            // fragment reads / MFMAs of one half, weight loads of one set
+  constexpr int N_R = 8, N_M = PREC == 1 ? 24 : 64, N_W = 4;                            // fragment reads / MFMAs of one half, weight loads of one set
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   auto pin_half_with_loads = [&]() __attribute__((always_inline)) {   // MFMAs interleaved with the half's 8 fragment reads, then its 4 weight loads
@@ -559,7 +587,8 @@ int launch_conv_up(UpArgs& a, hipStream_t s) {
   unsigned gx = (unsigned)(cus > 0 ? cus : 256) / gy;
   if (gx < 1) gx = 1;
   if ((long long)gx > ntiles) gx = (unsigned)ntiles;
-  hipLaunchKernelGGL(conv_up_kernel, dim3(gx, gy), dim3(THREADS), lds, s, a);
+  if (a.precision == 0) hipLaunchKernelGGL(conv_up_kernel<0>, dim3(gx, gy), dim3(THREADS), lds, s, a);
+  else hipLaunchKernelGGL(conv_up_kernel<1>, dim3(gx, gy), dim3(THREADS), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
@@ -593,5 +622,7 @@ extern "C" int mfpa_upconv_fused(const mfpa_upconv_desc* d, void* stream) {
   mfpa_unet::UpArgs a{};
   a.skip = d->skip; a.low = d->low; a.w_skip = d->w_skip; a.w_up = d->w_up; a.shift = d->shift; a.bias_tab = d->bias_tab; a.y = d->y;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cs = d->Cs; a.Hl = d->Hl; a.Wl = d->Wl; a.Cl = d->Cl; a.Cout = d->Cout; a.relu = d->relu ? 1 : 0;
+  if (d->precision != 0 && d->precision != 1) return MFPA_EINVAL;
+  a.precision = d->precision;
   return mfpa_unet::launch_conv_up(a, mfpa_stream(stream));
 }

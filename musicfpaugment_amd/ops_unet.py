@@ -86,6 +86,15 @@ def split_bf16x3_frag(w: torch.Tensor, layout: int = 2) -> torch.Tensor:
     return img.view(torch.float32).reshape(t, co, ci)
 
 
+def frag_f32(w: torch.Tensor) -> torch.Tensor:
+    """Kernel-layout fp32 weights [taps][Cout][Cin] (Cout % 16 == 0, Cin % 32 == 0) -> the FP32 fragment image of mfpa_upconv_fused(precision 0)
+    (v_mfma_f32_16x16x4_f32): [tap][chunk = Cin / 32][Cout / 16][piece 2][lane 64][4 floats], lane (g = l >> 4, c = l & 15) = output channel
+    16 t + c, input channels 32 chunk + 8 g + 4 piece .. + 3.  Same shape and bytes as w."""
+    t, co, ci = w.shape
+    w7 = w.reshape(t, co // 16, 16, ci // 32, 4, 2, 4)                                # [t][ct16][c][chunk][g][piece][j]
+    return w7.permute(0, 3, 1, 5, 4, 2, 6).contiguous().reshape(t, co, ci)            # [t][chunk][ct16][piece][g][c][j]
+
+
 def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[str, torch.Tensor]:
     """precision 0: fp32 MFMA weights; 1: additionally pre-split (bf16x3) copies under '<name>.w3', and for the layers the
     "weights direct" kernels can take (128-channel output tiles, >= 64 input channels) the fragment-ordered image '<name>.wf'."""
@@ -122,7 +131,10 @@ def pack_unet_weights(sd: Dict[str, torch.Tensor], precision: int = 0) -> Dict[s
                     pw[k + "ff"] = (lay, split_bf16x3_frag(pw[k] * pw[k[:-2] + ".scale"][None, :, None], lay))
         if lay == 2 and FOLD_UP:
             for name in FOLD_UP_LEVELS:
-                pw.update(pack_upconv(pw, name))
+                pw.update(pack_upconv(pw, name, 1))
+    elif FOLD_UP and FOLD_UP_FP32:
+        for name in FOLD_UP_LEVELS:
+            pw.update(pack_upconv(pw, name, 0))
     return pw
 
 
@@ -131,7 +143,10 @@ FOLD_UP_LEVELS = ("up1", "up2", "up3", "up4")   # the decoder levels whose Up bl
                                                 # the two launches it replaces, 64 clips: +6 / +19 / +32 / +40 % (profiles/r06_upconv_levels.txt)
 
 
-def pack_upconv(pw: Dict[str, torch.Tensor], name: str) -> Dict[str, torch.Tensor]:
+FOLD_UP_FP32 = True           # the fp32 MFMA path (precision 0) folds too (mfpa_upconv_fused(precision 0)); False: A/B runs
+
+
+def pack_upconv(pw: Dict[str, torch.Tensor], name: str, precision: int = 1) -> Dict[str, torch.Tensor]:
     """Operands of mfpa_upconv_fused for decoder level `name` from the fp32 kernel-layout weights already in `pw`: the skip half of the
     level's first 3x3 convolution with the folded BatchNorm scale multiplied in (fragment image), the composite weights of its up half
     (ConvTranspose2d folded in: mfpa_upconv_pack on the device, float64 accumulation; fragment image as a 16-tap kernel) and the
@@ -148,17 +163,17 @@ def pack_upconv(pw: Dict[str, torch.Tensor], name: str) -> Dict[str, torch.Tenso
     tab = torch.empty((4, 4, Cout), dtype=torch.float32, device=w3.device)
     check(lib().mfpa_upconv_pack(ptr(w3), ptr(wt), ptr(bt), ptr(scale), Cout, Cs, Cu, Cl, ptr(wc), ptr(tab), stream()), "mfpa_upconv_pack")
     wsk = (w3[:, :, :Cs] * scale[None, :, None]).contiguous()
-    return {name + ".upc.wsk": split_bf16x3_frag(wsk, 2), name + ".upc.wup": split_bf16x3_frag(wc, 2), name + ".upc.bias": tab,
-            name + ".upc.shape": (Cs, Cl, Cout)}
+    img = (lambda w_: split_bf16x3_frag(w_, 2)) if precision == 1 else frag_f32
+    return {name + ".upc.wsk": img(wsk), name + ".upc.wup": img(wc), name + ".upc.bias": tab, name + ".upc.shape": (Cs, Cl, Cout)}
 
 
-def upconv_fused(skip, low, w_skip, w_up, shift, bias_tab, Cout, relu=True):
+def upconv_fused(skip, low, w_skip, w_up, shift, bias_tab, Cout, relu=True, precision=1):
     """One decoder level's up -> pad -> cat -> conv3x3 + BN + ReLU (training/unet.py:58-65) as one launch; see include/mfpa.h."""
     B, H, W, Cs = skip.shape
     _, Hl, Wl, Cl = low.shape
     y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=skip.device)
     d = UpconvDesc(skip=ptr(skip), low=ptr(low), w_skip=ptr(w_skip), w_up=ptr(w_up), shift=ptr(shift), bias_tab=ptr(bias_tab), y=ptr(y),
-                   B=B, H=H, W=W, Cs=Cs, Hl=Hl, Wl=Wl, Cl=Cl, Cout=Cout, relu=int(relu))
+                   B=B, H=H, W=W, Cs=Cs, Hl=Hl, Wl=Wl, Cl=Cl, Cout=Cout, relu=int(relu), precision=int(precision))
     t0 = _TIMER.start() if _TIMER is not None else None
     check(lib().mfpa_upconv_fused(ctypes.byref(d), stream()), "mfpa_upconv_fused")
     if t0 is not None:
@@ -361,7 +376,7 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
 
     def folds(name, H_, W_, Hl_, Wl_):
         """Does decoder level `name` run as mfpa_upconv_fused at this size?"""
-        if not (FOLD_UP and prec == 1 and name in FOLD_UP_LEVELS and (name + ".upc.wup") in pw):
+        if not (FOLD_UP and name in FOLD_UP_LEVELS and (name + ".upc.wup") in pw):
             return False
         cs, cl, co = pw[name + ".upc.shape"]
         return lib().mfpa_upconv_serves(H_, W_, Hl_, Wl_, cs, cl, co) == 1
@@ -409,7 +424,7 @@ def unet_forward_eval(pw: Dict[str, torch.Tensor], x32: Optional[torch.Tensor] =
         if folds(name, skip.shape[1], skip.shape[2], y.shape[1], y.shape[2]):
             # round 6: the level's transposed convolution folded into its first 3x3 convolution -- one launch, `up` never exists
             m = upconv_fused(skip, y, pw[name + ".upc.wsk"], pw[name + ".upc.wup"], pw[name + ".conv.double_conv.0.shift"],
-                             pw[name + ".upc.bias"], pw[name + ".upc.shape"][2])
+                             pw[name + ".upc.bias"], pw[name + ".upc.shape"][2], precision=prec)
             del skip
         else:
             u = convT2x2(y, pw[name + ".up.w" + sfx], pw[name + ".up.b"], precision=prec)

@@ -28,15 +28,15 @@ def _reference(skip, low, wt, bt, w3, sc, sh):
     return F.relu(z * sc.to(dd)[None, :, None, None] + sh.to(dd)[None, :, None, None])
 
 
-def _fused(skip, low, wt, bt, w3, sc, sh):
+def _fused(skip, low, wt, bt, w3, sc, sh, precision=1):
     from musicfpaugment_amd import ops_unet as K
     Cs = skip.shape[1]
     pw = {"L.conv.double_conv.0.w": K.pack_conv3x3(w3).cuda(), "L.up.w": K.pack_convT2x2(wt).cuda(), "L.up.b": bt.cuda(),
           "L.conv.double_conv.0.scale": sc.cuda(), "L.conv.double_conv.0.shift": sh.cuda()}
-    pk = K.pack_upconv(pw, "L")
+    pk = K.pack_upconv(pw, "L", precision)
     assert pk["L.upc.shape"] == (Cs, low.shape[1], w3.shape[0])
     y = K.upconv_fused(skip.permute(0, 2, 3, 1).contiguous().cuda(), low.permute(0, 2, 3, 1).contiguous().cuda(), pk["L.upc.wsk"], pk["L.upc.wup"],
-                       sh.cuda(), pk["L.upc.bias"], w3.shape[0])
+                       sh.cuda(), pk["L.upc.bias"], w3.shape[0], precision=precision)
     return y, pw, pk
 
 
@@ -68,6 +68,14 @@ def test_upconv_fused_matches_the_reference_formulation(shape):
         assert relative_l1(got[sl], want[sl]) < 1e-5, (shape, sl)
     y2, _, _ = _fused(*args)
     assert torch.equal(y2, y)                                                     # deterministic
+    # exact fp32 products (precision 0, v_mfma_f32_16x16x4_f32): the reference's arithmetic up to the order of the sums
+    y32, _, _ = _fused(*args, precision=0)
+    got32 = y32.cpu().permute(0, 3, 1, 2).double()
+    rl32 = relative_l1(got32, want)
+    print(f"[upconv {shape}] fp32 products: relative L1 {rl32:.2e}, worst / max {float((got32 - want).abs().max() / want.abs().max()):.2e}")
+    assert rl32 < 3e-6, (shape, rl32)                                             # (fp32 sums of up to 13 824 products)
+    for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+        assert relative_l1(got32[sl], want[sl]) < 5e-6, (shape, sl)
     # the two-launch device path it replaces (same arithmetic family): both sit at rounding distance from the float64 reference
     skip, low = args[0], args[1]
     if Cu % 64:                                                                   # (mfpa_convT2x2 wants 64-channel output tiles)
@@ -103,21 +111,54 @@ def test_unet_forward_with_and_without_the_fold_agree(golden):
     for sd in (formula_state_dict(0), stress_state_dict("bn_spread", 0)):
         with torch.no_grad():
             want = ou.forward(x, sd)
-        outs = {}
-        for fold in (True, False):
-            K.FOLD_UP = fold
-            try:
-                m = UNet(1, 1, rate=0.05)
-                m.load_state_dict(sd)
-                m = m.cuda().eval()
-                m.precision = 1
-                pw = m.packed_weights()
-                assert (("up4.upc.wup" in pw) == fold)
-                outs[fold] = m(x.cuda()).cpu()
-            finally:
-                K.FOLD_UP = True
-        r_f, r_u = ou.relative_l1(outs[True], want), ou.relative_l1(outs[False], want)
-        d = ou.relative_l1(outs[True], outs[False])
-        print(f"[fold] vs oracle fp32: folded {r_f:.2e}, two-launch {r_u:.2e}; folded vs two-launch {d:.2e}")
-        assert r_f <= 1e-4 and r_u <= 1e-4 and d <= 5e-5
-        assert r_f <= 2.0 * r_u + 1e-6                                          # the fold must not eat into the gate's margin
+        for prec, gate in ((1, 1e-4), (0, 1e-5)):
+            outs = {}
+            for fold in (True, False):
+                K.FOLD_UP = fold
+                try:
+                    m = UNet(1, 1, rate=0.05)
+                    m.load_state_dict(sd)
+                    m = m.cuda().eval()
+                    m.precision = prec
+                    pw = m.packed_weights()
+                    assert (("up4.upc.wup" in pw) == fold)
+                    outs[fold] = m(x.cuda()).cpu()
+                finally:
+                    K.FOLD_UP = True
+            r_f, r_u = ou.relative_l1(outs[True], want), ou.relative_l1(outs[False], want)
+            d = ou.relative_l1(outs[True], outs[False])
+            print(f"[fold, precision {prec}] vs oracle fp32: folded {r_f:.2e}, two-launch {r_u:.2e}; folded vs two-launch {d:.2e}")
+            assert r_f <= gate and r_u <= gate and d <= gate / 2
+            assert r_f <= 2.0 * r_u + 1e-6                                      # the fold must not eat into the gate's margin
+
+
+def test_committed_pmc_traffic_file_describes_the_current_routing():
+    """bench.py's `roofline.traffic` is the committed rocprofv3 --pmc measurement scaled by the batch (profiles/<bench.PMC_TRAFFIC_BF16X3>):
+    it must have been taken on THIS routing -- one 64-clip bf16x3 forward issues exactly the MFMA launches the file lists, with one
+    conv_up_kernel launch per folded decoder level and no transposed-convolution launch left."""
+    import json
+    import os
+    import bench
+    from musicfpaugment_amd import ops_unet as K
+    from musicfpaugment_amd.training.unet import UNet
+    from musicfpaugment_amd.training.weights import formula_state_dict
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", bench.PMC_TRAFFIC_BF16X3)))
+    m = UNet(1, 1, rate=0.05)
+    m.load_state_dict(formula_state_dict(0))
+    m = m.cuda().eval()
+    m.precision = 1
+    x = torch.rand(2, 1, 257, 251, device="cuda")
+    m(x)                                                                          # packs the weights
+    timer = K.KernelTimer()
+    K.set_timer(timer)
+    try:
+        m(x)
+    finally:
+        K.set_timer(None)
+    torch.cuda.synchronize()
+    assert timer.launches() == rec["launches"], (timer.launches(), rec["launches"])
+    per = rec["per_kernel"]
+    n_up = sum(v["launches"] for k, v in per.items() if "conv_up_kernel" in k)
+    assert n_up == len(K.FOLD_UP_LEVELS) and K.FOLD_UP
+    assert not any("convT" in k for k in per)
+    assert sum(v["launches"] for v in per.values()) == rec["launches"]

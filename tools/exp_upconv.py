@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--clips", type=int, default=64)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--levels", default="up4,up3,up2,up1")
+ap.add_argument("--precision", type=int, default=1, help="1 bf16x3 (default), 0 exact fp32 products")
 args = ap.parse_args()
 from musicfpaugment_amd import ops_unet as K
 from musicfpaugment_amd._lib import lib
@@ -43,19 +44,20 @@ for name in args.levels.split(","):
     sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
     sh = torch.randn(Cout, device="cuda", generator=g) * 0.1
     pw = {"L.conv.double_conv.0.w": w3, "L.up.w": wt, "L.up.b": bt, "L.conv.double_conv.0.scale": sc, "L.conv.double_conv.0.shift": sh}
-    w3s, wts = K.split_bf16x3(w3), K.split_bf16x3(wt)
-    wf = (2, K.split_bf16x3_frag(w3, 2))
-    wff = (2, K.split_bf16x3_frag(w3 * sc[None, :, None], 2))
-    t_ct = timed(lambda: K.convT2x2(low, wts, bt, precision=1))
-    u = K.convT2x2(low, wts, bt, precision=1)
-    t_cv = timed(lambda: K.conv3x3_fused(skip, w3s, sc, sh, x1=u, precision=1, wf=wf, wff=wff))
-    two = K.conv3x3_fused(skip, w3s, sc, sh, x1=u, precision=1, wf=wf, wff=wff)[0]
+    P = args.precision
+    w3s, wts = (K.split_bf16x3(w3), K.split_bf16x3(wt)) if P == 1 else (w3, wt)
+    wf = (2, K.split_bf16x3_frag(w3, 2)) if P == 1 else None
+    wff = (2, K.split_bf16x3_frag(w3 * sc[None, :, None], 2)) if P == 1 else None
+    t_ct = timed(lambda: K.convT2x2(low, wts, bt, precision=P))
+    u = K.convT2x2(low, wts, bt, precision=P)
+    t_cv = timed(lambda: K.conv3x3_fused(skip, w3s, sc, sh, x1=u, precision=P, wf=wf, wff=wff))
+    two = K.conv3x3_fused(skip, w3s, sc, sh, x1=u, precision=P, wf=wf, wff=wff)[0]
     del u
     line = f"{name}  {Cl:4d}->{Cu:3d} up, {Cs + Cu:4d}->{Cout:3d} @{H}x{W}   two {t_ct * 1e6:7.1f} + {t_cv * 1e6:7.1f} = {(t_ct + t_cv) * 1e6:7.1f}"
     tot2 += t_ct + t_cv
     if lib().mfpa_upconv_serves(H, W, Hl, Wl, Cs, Cl, Cout) == 1:
-        pk = K.pack_upconv(pw, "L")
-        fn = lambda: K.upconv_fused(skip, low, pk["L.upc.wsk"], pk["L.upc.wup"], sh, pk["L.upc.bias"], Cout)
+        pk = K.pack_upconv(pw, "L", P)
+        fn = lambda: K.upconv_fused(skip, low, pk["L.upc.wsk"], pk["L.upc.wup"], sh, pk["L.upc.bias"], Cout, precision=P)
         t_f = timed(fn)
         y = fn()
         diff = float((y - two).abs().max() / two.abs().max())
