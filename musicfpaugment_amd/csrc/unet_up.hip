@@ -71,8 +71,10 @@ constexpr int pin_read_slots(int slots, int left) {
   return used;
 }
 
-__device__ __forceinline__ int tile_of(int b, int i, int G) {
-  if ((G & 7) == 0) return i * G + (b & 7) * (G >> 3) + (b >> 3);       // the 32 workgroups of an XCD walk consecutive tiles
+__device__ __forceinline__ int tile_of(int b, int i, int G, int ngrp) {
+  // one channel group: walkers b and b + 8 share an XCD, and the 32 walkers of an XCD take consecutive tiles (their shared halo rows meet in its L2);
+  // several channel groups: walker b's XCD is fixed by its workgroup id as a whole -- plain order
+  if (ngrp == 1 && (G & 7) == 0) return i * G + (b & 7) * (G >> 3) + (b >> 3);
   return i * G + b;
 }
 
@@ -90,9 +92,14 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nsk = a.Cs / KC, nup = a.Cl / KC, nchunks = nsk + nup;
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
-  const int G = (int)gridDim.x;
-  const int n0 = (int)blockIdx.y * 64;
-  const int first_tile = tile_of((int)blockIdx.x, 0, G);
+  // one-dimensional grid, workgroup id = tile walker * (Cout / 64) + channel group: workgroup ids go to the XCDs round-robin, so with 8 (4, 2)
+  // channel groups every XCD serves ONE (two, four) of them and its 32 CUs stream the same slice of the weight images through that XCD's L2 --
+  // up1's images are 43 MB, eight slices of 5.4 MB (with the two-dimensional grid every XCD streamed all of them)
+  const int ngrp = a.Cout / 64;
+  const int G = (int)gridDim.x / ngrp;
+  const int wgx = (int)blockIdx.x / ngrp;
+  const int n0 = ((int)blockIdx.x % ngrp) * 64;
+  const int first_tile = tile_of(wgx, 0, G, ngrp);
   const int owned = first_tile < ntiles ? (ntiles - first_tile + G - 1) / G : 0;
 
   // LDS: [stage 0 | stage 1 | shift 64, bias table 16 x 64 | the epilogue's output tile 64 KB]
@@ -257,13 +264,13 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
     };
     // the chunk sequence of this workgroup: (tile i, chunk c), c fastest: the skip's chunks, then the low-resolution tensor's
     int qi = 0, qc = 0;
-    Tile TQ = make_tile(tile_of((int)blockIdx.x, 0, G));
+    Tile TQ = make_tile(tile_of(wgx, 0, G, ngrp));
     auto issue_next = [&](auto SET) __attribute__((always_inline)) {
       const Src S = make_src(TQ, qc);
       issue_all(S, TQ.ain, SET);
       if (++qc == nchunks) {
         qc = 0; ++qi;
-        if (qi < owned) TQ = make_tile(tile_of((int)blockIdx.x, qi, G));
+        if (qi < owned) TQ = make_tile(tile_of(wgx, qi, G, ngrp));
       }
     };
     using SET0 = std::integral_constant<int, 0>;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
       if (k + 2 < total) issue_next(ISSUE_SET);
       __builtin_amdgcn_sched_barrier(0);
       if (k + 1 < total) split_all(SPLIT_SET, par * STAGE, ((k + 1) % nchunks) < nsk);
-      if (k >= nchunks + 1 && (k - 1) % nchunks == 0) duty(tile_of((int)blockIdx.x, (k - 1) / nchunks - 1, G));
+      if (k >= nchunks + 1 && (k - 1) % nchunks == 0) duty(tile_of(wgx, (k - 1) / nchunks - 1, G, ngrp));
       __syncthreads();
       par ^= 1;
     };
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
       if (k + 1 < total) iteration(k + 1, SET0{}, SET1{});
     }
     __syncthreads();                                                   // the compute waves' final barrier: the last tile's output is in LDS
-    duty(tile_of((int)blockIdx.x, owned - 1, G));
+    duty(tile_of(wgx, owned - 1, G, ngrp));
     return;
   }
 
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
   __syncthreads();                                                     // stage 0 holds chunk 0 of the first tile; `epi` is written
   read_skip(fx0, smem, I0{}, I0{});
   for (int ti = 0; ti < owned; ++ti) {
-    int bx = __builtin_amdgcn_readfirstlane(tile_of((int)blockIdx.x, ti, G));
+    int bx = __builtin_amdgcn_readfirstlane(tile_of(wgx, ti, G, ngrp));
     const int tx = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty = bx % a.tiles_y;
     const int ey0 = ty * PH, ex0 = tx * PW;
@@ -571,6 +578,7 @@ bool conv_up_serves(int H, int W, int Hl, int Wl, int Cs, int Cl, int Cout) {
   if (4ull * H * W * Cs + 8ull * (W + 2) * (unsigned long long)Cs >= 0xfffffff0ull) return false;
   if (4ull * Hl * Wl * Cl + 8ull * (Wl + 2) * (unsigned long long)Cl >= 0xfffffff0ull) return false;
   if (4ull * H * W * Cout > 0xffffffffull) return false;
+  if (64ull * Cout * Cl >= 0x7fffffffull || 36ull * Cout * Cs >= 0x7fffffffull) return false;   // the weight images' buffer descriptors and 32-bit block offsets
   return true;
 }
 
@@ -587,8 +595,8 @@ int launch_conv_up(UpArgs& a, hipStream_t s) {
   unsigned gx = (unsigned)(cus > 0 ? cus : 256) / gy;
   if (gx < 1) gx = 1;
   if ((long long)gx > ntiles) gx = (unsigned)ntiles;
-  if (a.precision == 0) hipLaunchKernelGGL(conv_up_kernel<0>, dim3(gx, gy), dim3(THREADS), lds, s, a);
-  else hipLaunchKernelGGL(conv_up_kernel<1>, dim3(gx, gy), dim3(THREADS), lds, s, a);
+  if (a.precision == 0) hipLaunchKernelGGL(conv_up_kernel<0>, dim3(gx * gy), dim3(THREADS), lds, s, a);
+  else hipLaunchKernelGGL(conv_up_kernel<1>, dim3(gx * gy), dim3(THREADS), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
 }
