@@ -320,13 +320,18 @@ __global__ __launch_bounds__(THREADS, 1) void conv_up_kernel(UpArgs a) {
     wq[slot][1][0] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 2048, so, 0));
     wq[slot][1][1] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane + 3072, so, 0));
   };
+#ifdef MFPA_UP_WHOT            // timing-only variant (tools/: wrong results by design): every weight fragment comes from ONE block per wave, i.e. from L1
+#define MFPA_UP_WBLK(x) (wcol)
+#else
+#define MFPA_UP_WBLK(x) (x)
+#endif
   auto load_w_skip = [&](int chunk, int tap, auto SLOT) __attribute__((always_inline)) {
-    load_w_at(rs_skip, ((unsigned)tap * (unsigned)nsk + (unsigned)chunk) * wrow + wcol, SLOT);
+    load_w_at(rs_skip, MFPA_UP_WBLK(((unsigned)tap * (unsigned)nsk + (unsigned)chunk) * wrow + wcol), SLOT);
   };
   // composite image: "tap" index ((py * 2 + px) * 2 + ty) * 2 + tx, py = this wave's row parity
   auto load_w_up = [&](int chunk, int pair, int px, auto SLOT) __attribute__((always_inline)) {
     const unsigned t16 = (unsigned)((wm * 2 + px) * 4 + pair);
-    load_w_at(rs_up, (t16 * (unsigned)nup + (unsigned)chunk) * wrow + wcol, SLOT);
+    load_w_at(rs_up, MFPA_UP_WBLK((t16 * (unsigned)nup + (unsigned)chunk) * wrow + wcol), SLOT);
   };
   struct XFrags { frag_t h[4], l[4]; };                                 // PREC 0: h = piece 2 g, l = piece 2 g + 1
   XFrags fx0, fx1;

@@ -159,12 +159,21 @@ def pack_upconv(pw: Dict[str, torch.Tensor], name: str, precision: int = 1) -> D
     Cs = w3.shape[2] - Cu
     if not w3.is_cuda:
         return {}                                                  # (CPU-side packing: the fused launch is simply not offered)
-    wc = torch.empty((16, Cout, Cl), dtype=torch.float32, device=w3.device)
-    tab = torch.empty((4, 4, Cout), dtype=torch.float32, device=w3.device)
-    check(lib().mfpa_upconv_pack(ptr(w3), ptr(wt), ptr(bt), ptr(scale), Cout, Cs, Cu, Cl, ptr(wc), ptr(tab), stream()), "mfpa_upconv_pack")
+    wc, tab = upconv_pack_raw(w3, wt, bt, scale)
     wsk = (w3[:, :, :Cs] * scale[None, :, None]).contiguous()
     img = (lambda w_: split_bf16x3_frag(w_, 2)) if precision == 1 else frag_f32
     return {name + ".upc.wsk": img(wsk), name + ".upc.wup": img(wc), name + ".upc.bias": tab, name + ".upc.shape": (Cs, Cl, Cout)}
+
+
+def upconv_pack_raw(w3: torch.Tensor, wt: torch.Tensor, bt: torch.Tensor, scale: Optional[torch.Tensor]):
+    """mfpa_upconv_pack: kernel-layout w3 [9][Cout][Cs + Cu], wt [4][Cu][Cl], bt (Cu), scale (Cout) or None -> (composite weights (16, Cout, Cl),
+    border-class bias table (4, 4, Cout)), float32 (float64 accumulation on the device)."""
+    Cout, Cu, Cl = w3.shape[1], wt.shape[1], wt.shape[2]
+    Cs = w3.shape[2] - Cu
+    wc = torch.empty((16, Cout, Cl), dtype=torch.float32, device=w3.device)
+    tab = torch.empty((4, 4, Cout), dtype=torch.float32, device=w3.device)
+    check(lib().mfpa_upconv_pack(ptr(w3), ptr(wt), ptr(bt), ptr(scale), Cout, Cs, Cu, Cl, ptr(wc), ptr(tab), stream()), "mfpa_upconv_pack")
+    return wc, tab
 
 
 def upconv_fused(skip, low, w_skip, w_up, shift, bias_tab, Cout, relu=True, precision=1):

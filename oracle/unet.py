@@ -106,3 +106,76 @@ def forward_bf16x3_model(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.
         return forward(x, sd)
     finally:
         F.conv2d, F.conv_transpose2d = conv2d, conv_t
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the algebra behind mfpa_upconv_fused (csrc/unet_up.hip), restated on the CPU.  Up.forward (training/unet.py:58-65) is
+#     up = ConvTranspose2d(k 2, s 2)(low) + bt;  pad to the skip's size (diff // 2 in front);  z = conv3x3(cat([skip, up]), W3, padding 1)
+# and nothing non-linear sits between the two convolutions, so the `up` half of z is, per output phase (Y & 1, X & 1), a 2 x 2 convolution of
+# `low` with COMPOSITE weights plus a bias that depends only on which of the nine taps fall inside the up-sampled extent.  These functions are
+# test infrastructure: tests/test_oracle_upconv.py checks them against the reference formulation above in float64 (odd sizes, borders), and
+# tests/test_gpu_upconv.py checks the device's mfpa_upconv_pack against them.
+
+
+def upconv_composite(w3: torch.Tensor, wt: torch.Tensor, bt: torch.Tensor, scale: torch.Tensor = None):
+    """w3 (Cout, Cs + Cu, 3, 3) the level's first Conv2d weight, wt (Cl, Cu, 2, 2) / bt (Cu) the ConvTranspose2d's, scale (Cout) an optional
+    per-output-channel factor (the folded eval BatchNorm scale).  Returns float64
+      wc   (16, Cout, Cl): index ((py * 2 + px) * 2 + ty) * 2 + tx = output phase (py, px), low-resolution tap (ty - 1 + py, tx - 1 + px);
+      bias (4, 4, Cout):   by (row class, column class) of the output pixel -- 0: first row / column of the up-sampled extent (tap -1 outside),
+                           1: interior, 2: its last (tap +1 outside), 3: the padding row / column of an odd size (only tap -1 inside)."""
+    dd = torch.float64
+    w3, wt, bt = w3.to(dd), wt.to(dd), bt.to(dd)
+    Cout, Cu, Cl = w3.shape[0], wt.shape[1], wt.shape[0]
+    w3u = w3[:, w3.shape[1] - Cu:]                                        # (Cout, Cu, 3, 3): the half that multiplies `up`
+    wc = torch.zeros(16, Cout, Cl, dtype=dd)
+    for py in range(2):
+        for px in range(2):
+            for a in (-1, 0, 1):
+                for b in (-1, 0, 1):
+                    ry, rx = (py + a) // 2, (px + b) // 2                 # low-resolution offset of up-sampled pixel (Y + a, X + b) (floor division)
+                    ty, tx = ry + 1 - py, rx + 1 - px
+                    t16 = ((py * 2 + px) * 2 + ty) * 2 + tx
+                    wc[t16] += w3u[:, :, a + 1, b + 1] @ wt[:, :, (py + a) % 2, (px + b) % 2].T       # (Cout, Cu) @ (Cu, Cl)
+    inside = {0: (0, 1), 1: (-1, 0, 1), 2: (-1, 0), 3: (-1,)}
+    bias = torch.zeros(4, 4, Cout, dtype=dd)
+    for rc in range(4):
+        for cc in range(4):
+            for a in inside[rc]:
+                for b in inside[cc]:
+                    bias[rc, cc] += w3u[:, :, a + 1, b + 1] @ bt
+    if scale is not None:
+        wc = wc * scale.to(dd)[None, :, None]
+        bias = bias * scale.to(dd)[None, None, :]
+    return wc, bias
+
+
+def upconv_composite_forward(skip: torch.Tensor, low: torch.Tensor, w3: torch.Tensor, wc: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """z of the header comment from the composite operands (float64): conv3x3 of the skip half + the four-phase 2 x 2 convolution of `low` + the
+    border-class bias.  skip (B, Cs, H, W), low (B, Cl, Hl, Wl) with H - 2 Hl and W - 2 Wl in {0, 1}."""
+    dd = torch.float64
+    skip, low, w3 = skip.to(dd), low.to(dd), w3.to(dd)
+    B, Cs, H, W = skip.shape
+    Hl, Wl = low.shape[2], low.shape[3]
+    assert 0 <= H - 2 * Hl <= 1 and 0 <= W - 2 * Wl <= 1
+    z = F.conv2d(skip, w3[:, :Cs], padding=1)
+    lp = F.pad(low, [1, 1, 1, 1])                                         # zero padding of the low-resolution tensor = that of the up-sampled one
+    cls = lambda v, n2: 0 if v == 0 else (1 if v < n2 - 1 else (2 if v == n2 - 1 else 3))
+    rcls = torch.tensor([cls(y, 2 * Hl) for y in range(H)])
+    ccls = torch.tensor([cls(x, 2 * Wl) for x in range(W)])
+    z = z + bias[rcls][:, ccls].permute(2, 0, 1)[None]                    # (H, W, Cout) -> (1, Cout, H, W)
+    for py in range(2):
+        for px in range(2):
+            ys, xs = torch.arange(py, H, 2), torch.arange(px, W, 2)       # output pixels of this phase; low-resolution pixel (Y // 2, X // 2)
+            acc = 0
+            for ty in range(2):
+                for tx in range(2):
+                    t16 = ((py * 2 + px) * 2 + ty) * 2 + tx
+                    # padded low-resolution index of (Y // 2 + ty - 1 + py, X // 2 + tx - 1 + px): + 1 for the padding (a padding row / column
+                    # of the output maps one past the tensor: Y // 2 = Hl -> padded index Hl + ty + py <= Hl + 1 only when ty + py <= 1; beyond: zero)
+                    yi = (ys // 2 + ty + py).clamp(max=Hl + 1)
+                    xi = (xs // 2 + tx + px).clamp(max=Wl + 1)
+                    ok = ((ys // 2 + ty + py) <= Hl + 1)[:, None] & ((xs // 2 + tx + px) <= Wl + 1)[None, :]
+                    patch = lp[:, :, yi][:, :, :, xi] * ok[None, None].to(dd)
+                    acc = acc + torch.einsum("oc,bcyx->boyx", wc[t16], patch)
+            z[:, :, py::2, px::2] += acc
+    return z

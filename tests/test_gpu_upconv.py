@@ -162,3 +162,20 @@ def test_committed_pmc_traffic_file_describes_the_current_routing():
     assert n_up == len(K.FOLD_UP_LEVELS) and K.FOLD_UP
     assert not any("convT" in k for k in per)
     assert sum(v["launches"] for v in per.values()) == rec["launches"]
+
+
+def test_upconv_pack_matches_the_oracle_composite():
+    """mfpa_upconv_pack (device, float64 accumulation) against oracle.unet.upconv_composite (the CPU restatement tests/test_oracle_upconv.py pins
+    to the reference formulation): the 16 composite matrices and the 4 x 4 border-class bias table, with and without the folded scale."""
+    from musicfpaugment_amd import ops_unet as K
+    from oracle import unet as ou
+    g = torch.Generator().manual_seed(5)
+    for (Cs, Cu, Cl, Cout) in [(64, 64, 128, 64), (96, 32, 160, 128)]:
+        w3 = torch.randn(Cout, Cs + Cu, 3, 3, generator=g) / np.sqrt(9 * (Cs + Cu))
+        wt = torch.randn(Cl, Cu, 2, 2, generator=g) / np.sqrt(Cl)
+        bt = torch.randn(Cu, generator=g)
+        for sc in (None, torch.rand(Cout, generator=g) + 0.5):
+            want_wc, want_b = ou.upconv_composite(w3, wt, bt, sc)
+            wc, tab = K.upconv_pack_raw(K.pack_conv3x3(w3).cuda(), K.pack_convT2x2(wt).cuda(), bt.cuda(), None if sc is None else sc.cuda())
+            assert float((wc.cpu().double() - want_wc).abs().max()) <= 1e-7 * float(want_wc.abs().max())       # float32 rounding of a float64 sum
+            assert float((tab.cpu().double() - want_b).abs().max()) <= 1e-7 * float(want_b.abs().max())
