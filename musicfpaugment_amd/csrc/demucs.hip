@@ -592,7 +592,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_pipe_kernel(GemmArgs a) {
   };
   auto store = [&](int buf, const Stage& st) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store(As + buf * ASZ + (r0 + 64 * i) * HROW, st.a[i]);
+    for (int i = 0; i < 4; ++i) {
+#ifdef MFPA_GEMM_ACOPY   // timing-only variant (wrong results by design): the activation tile is COPIED into LDS as if it arrived already split
+      *reinterpret_cast<f32x4*>(As + buf * ASZ + (r0 + 64 * i) * HROW + 16 * q) = st.a[i];
+#else
+      split_store(As + buf * ASZ + (r0 + 64 * i) * HROW, st.a[i]);
+#endif
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (WSPLIT) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (r0 + 64 * i) * HROW + 16 * q) = st.b[i];
