@@ -179,3 +179,30 @@ def test_upconv_pack_matches_the_oracle_composite():
             wc, tab = K.upconv_pack_raw(K.pack_conv3x3(w3).cuda(), K.pack_convT2x2(wt).cuda(), bt.cuda(), None if sc is None else sc.cuda())
             assert float((wc.cpu().double() - want_wc).abs().max()) <= 1e-7 * float(want_wc.abs().max())       # float32 rounding of a float64 sum
             assert float((tab.cpu().double() - want_b).abs().max()) <= 1e-7 * float(want_b.abs().max())
+
+
+def test_upconv_fused_border_geometry_sweep():
+    """Every (rows mod 8, columns mod 32) tile-tail class and every padding combination (H - 2 Hl, W - 2 Wl in {0, 1}) on small images, both
+    arithmetic variants: 4 x 9 image sizes against the float64 reference formulation, whole tensor and the four border lines."""
+    from oracle.unet import relative_l1
+    g = torch.Generator().manual_seed(2024)
+    Cs, Cu, Cl, Cout = 64, 32, 32, 64
+    wt = torch.randn(Cl, Cu, 2, 2, generator=g) / np.sqrt(Cl)
+    bt = torch.randn(Cu, generator=g) * 0.5
+    w3 = torch.randn(Cout, Cs + Cu, 3, 3, generator=g) / np.sqrt(9 * (Cs + Cu))
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    sizes = [(8, 17), (9, 18), (10, 31), (15, 32), (16, 33), (17, 34), (23, 47), (24, 63), (25, 65)]
+    for (H, W) in sizes:
+        for (dy, dx) in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            if (H - dy) % 2 or (W - dx) % 2:
+                continue
+            Hl, Wl = (H - dy) // 2, (W - dx) // 2
+            skip = torch.randn(2, Cs, H, W, generator=g)
+            low = torch.randn(2, Cl, Hl, Wl, generator=g)
+            want = _reference(skip, low, wt, bt, w3, sc, sh)
+            for prec, tol in ((1, 6e-6), (0, 1e-6)):
+                y, _, _ = _fused(skip, low, wt, bt, w3, sc, sh, precision=prec)
+                got = y.cpu().permute(0, 3, 1, 2).double()
+                assert relative_l1(got, want) < tol, (H, W, Hl, Wl, prec)
+                for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+                    assert relative_l1(got[sl], want[sl]) < 3 * tol, (H, W, Hl, Wl, prec, sl)
