@@ -502,6 +502,8 @@ def bench_train(args, rank, world, dev, dist):
     from musicfpaugment_amd.ops_train import UNetTrainEngine
     from musicfpaugment_amd.training.unet import UNet
     from musicfpaugment_amd.training.weights import formula_state_dict
+    if getattr(args, "no_plain_convt", False):
+        ops_train.PLAIN_CONVT = False
     if getattr(args, "no_z16", False):
         ops_train.Z16_ACTIVATIONS = False
     if getattr(args, "no_fused_finish", False):
@@ -1164,6 +1166,7 @@ def build_parser():
                     "float32 (ops_train.POOL_BWD_FUSED = SKIP_GRAD_BF16 = False; A/B runs)")
     ap.add_argument("--no-batch-repack", action="store_true", help="train mode: one weight re-pack launch per convolution and use (ops_train.BATCH_REPACK = False; A/B runs)")
     ap.add_argument("--no-fused-finish", action="store_true", help="train mode: BatchNorm partial-sum finishes as separate launches (ops_train.FUSED_FINISH = False; A/B runs)")
+    ap.add_argument("--no-plain-convt", action="store_true", help="train mode (plain bf16): the transposed convolutions' forward / input gradient stay bf16x3 (ops_train.PLAIN_CONVT = False; A/B runs)")
     ap.add_argument("--no-z16", action="store_true", help="train mode (plain bf16): keep the activations in HBM as float32 (ops_train.Z16_ACTIVATIONS = False; A/B runs)")
     ap.add_argument("--augment", action="store_true", help="train mode: run the AugmentFP chain on the device inside every step")
     ap.add_argument("--wgrad", choices=["fp32", "bf16x3", "bf16"], default=None,

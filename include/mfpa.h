@@ -246,8 +246,10 @@ typedef struct mfpa_conv_desc {
   unsigned drop_seed, drop_thresh; /* training Dropout on source 0 after the affine+ReLU: keep element idx iff */
   float drop_scale;                /* hash(seed, idx) >= thresh (= rate * 2^32), scaled by 1/(1-rate); 0 = off  */
   int precision;                   /* 0 = fp32 MFMA; 1 = bf16x3 (w must then be in the pre-split row format);
-                                    * 2 = plain bf16 (w_layout 2 only: the same fragment-ordered image, of which only the hi halves are
-                                    *     read; one MFMA per product, relative error ~2^-9: the training step's "bf16 MFMA" arithmetic) */
+                                    * 2 = plain bf16 (mode 0: w_layout 2 only -- the same fragment-ordered image, of which only the hi halves are
+                                    *     read; one MFMA per product, relative error ~2^-9: the training step's "bf16 MFMA" arithmetic.  Round 6:
+                                    *     also mode 1 with bfloat16 I/O (x0_is_bf16 or y == NULL) and mode 2, on the ROW image of precision 1:
+                                    *     the transposed convolution of the training step and its input gradient use the hi halves only) */
   float* y_pool;                   /* mode 0, optional: MaxPool2d(2) of the output fused in the epilogue, (B,H/2,W/2,Cout) */
   const float* w1x1; float b1x1;   /* mode 0, Cout == 64, optional: OutConv 1x1 to one class fused in the epilogue:        */
   float* y1x1;                     /*   y1x1 (B,H,W) = sum_c out[..][c]*w1x1[c] + b1x1; y may then be NULL (not stored)    */

@@ -416,8 +416,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || conv_is_pipe(BN, PH,
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) b_base[nt] = (wn * (NT * 32) + nt * 32 + li) * LDK + 4 * lh;
 
+  // round 6: the plain-bf16 training step (mfpa_conv_desc.precision 2) runs the transposed convolution's INPUT GRADIENT (MODE 2) with one
+  // bf16 MFMA per product too -- the hi halves of the same staged operands; wave-uniform
+  const bool plain_hi = MODE == 2 && PREC == 1 && a.plain != 0;
   auto compute = [&](int tap_off, const float* Bs) __attribute__((always_inline)) {       // tap_off: LDS offset (floats) of the tap's shifted A fragments
     if (PREC == 1) {
+      if (MODE == 2 && plain_hi) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 ah[MT], bh[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) ah[mt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(As + a_base[mt] + tap_off) + 32 * s);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Bs + b_base[nt]) + 32 * s);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -2033,8 +2051,9 @@ int launch_wd16(ConvArgs& a, hipStream_t s) {
 // 4..32-iteration loop.  Here a workgroup keeps FOUR accumulator sets (one per tap) for 128 input pixels x 64 output
 // channels: the input chunk is staged once per 32 channels and its fragments are reused by all four taps; a wave owns
 // 32 pixels x 64 channels x 4 taps (128 accumulator VGPRs).  Two workgroups per CU overlap each other's staging.
-template <int PH, int PW, int PREC, bool IO16 = false>
+template <int PH, int PW, int PREC, bool IO16 = false, bool PLAIN = false>
 __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
+  static_assert(!PLAIN || (IO16 && PREC == 1), "the plain-bf16 form belongs to the training step's bf16-I/O instantiation");
   // IO16 (the plain-bf16 training step with its activations kept as bfloat16): the source and / or the output are bfloat16 tensors -- its
   // own instantiation, the inference kernels carry none of it
   constexpr int BM = PH * PW, BN = 64, NT = 2;
@@ -2118,7 +2137,7 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
         }
         char* row = reinterpret_cast<char*>(As + pix * LDK);
         *reinterpret_cast<bf16x4*>(row + 8 * q) = hi;
-        *reinterpret_cast<bf16x4*>(row + 64 + 8 * q) = lo;
+        if constexpr (!PLAIN) *reinterpret_cast<bf16x4*>(row + 64 + 8 * q) = lo;
         if (a.x0_bf16 != nullptr && blockIdx.y == 0) {                 // training forward: the activated input's bf16 copy (its weight gradient's operand)
           const int gy = y0 + pix / PW, gx = x0p + pix % PW;
           if (gy < a.H && gx < a.W)
@@ -2150,7 +2169,20 @@ __global__ __launch_bounds__(256, 2) void convT_mfma_kernel(ConvArgs a) {
     store(chunk);
     __syncthreads();
     if (chunk + 1 < nchunks) load(chunk + 1);          // lands during the MFMA block
-    if (PREC == 1) {
+    if constexpr (PLAIN) {
+      // round 6, the plain-bf16 training step (mfpa_conv_desc.precision 2): one bf16 MFMA per product on the hi halves, like its 3x3 convolutions
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(As + a_off) + 32 * s);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(Bs + (t * BN + nt * 32) * LDK + b_off) + 32 * s);
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t][nt], 0, 0, 0);
+          }
+      }
+    } else if constexpr (PREC == 1) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const char* ar = reinterpret_cast<const char*>(As + a_off) + 32 * s;
@@ -2255,8 +2287,10 @@ int launch_convT(ConvArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)PH * PW * LDK + 4 * (size_t)64 * LDK);
   dim3 grid((unsigned)((long long)a.tiles_x * a.tiles_y * a.B), (unsigned)(a.Cout / 64));
   if (a.in16 || a.y == nullptr) {
-    if constexpr (PREC == 1) hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC, true>), grid, dim3(256), lds, s, a);
-    else return MFPA_EINVAL;
+    if constexpr (PREC == 1) {
+      if (a.plain) hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC, true, true>), grid, dim3(256), lds, s, a);     // round 6: the plain-bf16 training step
+      else hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC, true>), grid, dim3(256), lds, s, a);
+    } else return MFPA_EINVAL;
   } else hipLaunchKernelGGL((convT_mfma_kernel<PH, PW, PREC>), grid, dim3(256), lds, s, a);
   MFPA_CHECK_LAUNCH();
   return MFPA_OK;
@@ -2608,12 +2642,15 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   if (d->precision < 0 || d->precision > 2) return MFPA_EINVAL;
   if (d->w_layout < 0 || d->w_layout > 2) return MFPA_EINVAL;
   if (d->w_layout != 0 && (d->mode != 0 || d->precision < 1)) return MFPA_EINVAL;
-  if (d->precision == 2 && d->w_layout != 2) return MFPA_EINVAL;         // plain bf16: conv_wd16_kernel only (it reads the hi halves of the same image)
+  // plain bf16: conv_wd16_kernel (mode 0: it reads the hi halves of the fragment image), or -- round 6 -- the transposed convolution of the training
+  // step and its input gradient (modes 1 / 2 on the row image: the hi halves of the staged operands)
+  if (d->precision == 2 && d->mode == 0 && d->w_layout != 2) return MFPA_EINVAL;
+  if (d->precision == 2 && d->mode == 1 && !(d->x0_is_bf16 || !d->y)) return MFPA_EINVAL;      // (its bf16-I/O instantiation carries the plain form)
   a.w_frag = d->w_layout;
   a.plain = d->precision == 2;
   // bfloat16 sources (both of them): the plain-bf16 conv_wd16_kernel (any on-load affine / dropout is applied in float32 and rounded once), or
   // the transposed convolution (mode 1)
-  if (d->x0_is_bf16 && !((d->precision == 2 && d->mode == 0 && ((d->C0 + d->C1) % 64) == 0 && !d->x1_bf16) || (d->mode == 1 && d->precision == 1)))
+  if (d->x0_is_bf16 && !((d->precision == 2 && d->mode == 0 && ((d->C0 + d->C1) % 64) == 0 && !d->x1_bf16) || (d->mode == 1 && d->precision >= 1)))
     return MFPA_EINVAL;
   if (d->x0_is_bf16 && (d->c1_x32 || d->c1_spec64)) return MFPA_EINVAL;
   a.in16 = d->x0_is_bf16 ? 1 : 0;
@@ -2621,11 +2658,11 @@ int mfpa_conv_mfma(const mfpa_conv_desc* d, void* stream) {
   const bool any_split = a.x0_split || a.x1_split || a.y_split || a.y_pool_split;
   if (any_split && (d->mode != 0 || d->precision != 1 || d->w_layout != 2 || (a.x1_split && d->C1 < 1) || (a.y_split && !d->y) || (a.y_pool_split && !d->y_pool) ||
                     (a.x0_split && (d->c1_x32 || d->c1_spec64)))) return MFPA_EINVAL;
-  if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision == 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
+  if (d->x0_bf16 != nullptr && !((d->w_layout == 2 || (d->mode == 1 && d->precision >= 1)) && d->x0)) return MFPA_EINVAL;   // conv_wd16_kernel's loader, or the bf16x3 transposed convolution's
   if (d->x1_bf16 != nullptr && (d->w_layout != 2 || !d->x1 || d->C1 < 1)) return MFPA_EINVAL;
   // y_bf16 with y: a bf16 copy beside the float32 output; y_bf16 WITHOUT y: the output exists as bfloat16 only (conv_wd16_kernel, or the
   // bf16x3 transposed convolution)
-  if (d->y_bf16 != nullptr && !(d->w_layout == 2 || (d->mode == 1 && d->precision == 1 && !d->y))) return MFPA_EINVAL;
+  if (d->y_bf16 != nullptr && !(d->w_layout == 2 || (d->mode == 1 && d->precision >= 1 && !d->y))) return MFPA_EINVAL;
   if (!d->y && d->y_bf16 && (d->y_pool || d->w1x1 || d->precision == 0)) return MFPA_EINVAL;
   a.x0_bf16 = reinterpret_cast<__bf16*>(d->x0_bf16);
   a.x1_bf16 = reinterpret_cast<__bf16*>(d->x1_bf16);

@@ -234,7 +234,9 @@ def conv_mfma(x0, w, Cout, *, mode=0, in_affine: Optional[Stats] = None, x1=None
                  H1=0 if x1 is None else x1.shape[1], W1=0 if x1 is None else x1.shape[2],
                  B=B, H=H, W=W, Cout=Cout, relu=int(relu), yH=0 if mode == 1 else oh, yW=0 if mode == 1 else ow,
                  mode=mode, drop_seed=_drop(in_affine)[0], drop_thresh=_drop(in_affine)[1],
-                 drop_scale=_drop(in_affine)[2], precision=2 if (plain and w_layout == 2 and mode == 0) else precision, w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part),
+                 drop_scale=_drop(in_affine)[2],
+                 precision=2 if (plain and ((w_layout == 2 and mode == 0) or (PLAIN_CONVT and (mode == 2 or (mode == 1 and (in16 or out_bf16)))))) else precision,
+                 w_layout=w_layout, x0_bf16=ptr(xb), x1_bf16=ptr(x1b), y_bf16=ptr(yb16), stats_part=ptr(part),
                  bwd_z=ptr(bwd_of[0]) if (bwd_of and part is not None) else 0,
                  bwd_scale=ptr(bwd_of[1].scale) if (bwd_of and part is not None) else 0,
                  bwd_shift=ptr(bwd_of[1].shift) if (bwd_of and part is not None) else 0,
@@ -259,6 +261,7 @@ SKIP_GRAD_BF16 = True       # plain-bf16 step with bf16 activations: the decoder
 BATCH_REPACK = True         # the convolutions' operand images (forward + input-gradient forms) re-made by ONE launch per step (PackCache); False: one launch each
 FUSED_FINISH = True         # single-GPU BatchNorm statistics / backward sums from row partials: the finish kernels read the block partials directly
                             # (mfpa_conv_stats_bn_finish, mfpa_bn_relu_bwd_from_part: 35 launches fewer per step, bit-identical; False: the separate calls)
+PLAIN_CONVT = True          # plain-bf16 step: the transposed convolutions' forward and input gradient with one bf16 MFMA per product too (round 6; False: bf16x3)
 DY16_MID = False            # True: a DoubleConv's inner gradient (dy of its first BatchNorm) too leaves its convolution as bfloat16 only -- built, tested, measured
                             # at -0.07 ms of 31.2 (those two kernels are not bound by these bytes): off
 Z16_ACTIVATIONS = True      # plain-bf16 step (precision 2 with bf16 weight gradients): the convolutions' raw outputs z, the pooled activations and the
