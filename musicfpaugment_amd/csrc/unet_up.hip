@@ -1,5 +1,5 @@
-// A decoder level's FIRST convolution with the transposed convolution folded into it (training/unet.py:41-65, inference, bf16x3 products on
-// v_mfma_f32_16x16x32_bf16).  Round 6.
+// A decoder level's FIRST convolution with the transposed convolution folded into it (training/unet.py:41-65, inference; bf16x3 products on
+// v_mfma_f32_16x16x32_bf16, or exact fp32 products on v_mfma_f32_16x16x4_f32: template parameter PREC).  Round 6.
 //
 // The reference computes   up = ConvTranspose2d(k 2, s 2)(low) + bt;  pad up to the skip's size;  y = relu(bn(conv3x3(cat([skip, up])))).
 // Nothing non-linear sits between the transposed convolution and the 3x3 convolution, so the `up` half of that convolution is, per output
